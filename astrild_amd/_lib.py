@@ -1,0 +1,88 @@
+"""ctypes binding of ``libastrild_hip.so`` (the C-ABI in ``include/astrild_hip.h``).
+
+There is NO CPU fallback: if the shared library is missing or fails to load
+the product path raises.  Build it with ``python -c "import __graft_entry__ as
+g; g.build()"`` or ``make -C astrild_amd/csrc``.
+"""
+import ctypes as ct
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libastrild_hip.so")
+
+F32, F64 = 0, 1
+WIN = {"ngp": 0, "nnb": 0, "nearest": 0, "cic": 1, "tsc": 2}
+FFT_R2C, FFT_C2R, FFT_C2C_FWD, FFT_C2C_INV = 0, 1, 2, 3
+ERR_WORKSPACE = -4
+
+
+class AstrildHipError(RuntimeError):
+    pass
+
+
+_vp, _sz, _i, _d, _u64 = ct.c_void_p, ct.c_size_t, ct.c_int, ct.c_double, ct.c_uint64
+
+# name -> (restype, argtypes); mirrors include/astrild_hip.h one to one
+SIGNATURES = {
+    "ast_version": (_i, []),
+    "ast_last_error": (ct.c_char_p, []),
+    "ast_fill": (_i, [_vp, _i, _sz, _d, _vp]),
+    "ast_divide": (_i, [_vp, _i, _sz, _d, _vp]),
+    "ast_synth_lattice_particles": (_i, [_vp, _i, _sz, _sz, _i, _d, _d, _u64, _u64, _vp]),
+    "ast_ngp_assign": (_i, [_vp, _vp, _vp, _vp, _i, _sz, _i, _vp, _vp, _vp, _vp]),
+    "ast_paint": (_i, [_i, _i, _vp, _vp, _sz, _i, _d, _d, _i, _i, _vp, _vp, _vp]),
+    "ast_paint_tiled_workspace_bytes": (_sz, [_sz, _i, _i]),
+    "ast_paint_tiled": (_i, [_i, _i, _vp, _vp, _sz, _i, _d, _d, _i, _i, _vp, _vp, _sz, _vp, _vp]),
+    "ast_accumulate": (_i, [_vp, _vp, _i, _sz, _vp]),
+    "ast_fft_plan_create": (_i, [ct.POINTER(_vp), _i, _i, _i, ct.POINTER(_sz), _sz, _d, _i]),
+    "ast_fft_plan_create_strided_1d": (_i, [ct.POINTER(_vp), _i, _i, _sz, _sz, _sz, _sz, _d]),
+    "ast_fft_plan_work_bytes": (_sz, [_vp]),
+    "ast_fft_exec": (_i, [_vp, _vp, _vp, _vp]),
+    "ast_fft_plan_destroy": (_i, [_vp]),
+    "ast_power_bin_1d": (_i, [_vp, _vp, _i, _i, _d, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ast_shell_filter": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ast_triple_product_sum": (_i, [_vp, _vp, _vp, _i, _sz, _vp, _vp]),
+    "ast_slab_pack": (_i, [_vp, _vp, _i, _sz, _sz, _sz, _i, _vp]),
+    "ast_slab_unpack": (_i, [_vp, _vp, _i, _sz, _sz, _sz, _i, _vp]),
+    "ast_kappa_stack": (_i, [_vp, _vp, _vp, _i, _sz, _i, _vp, _vp]),
+    "ast_lens_plan_create": (_i, [ct.POINTER(_vp), _i, _d]),
+    "ast_lens_plan_destroy": (_i, [_vp]),
+    "ast_kappa_to_alphas": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "ast_kappa_to_phi": (_i, [_vp, _vp, _vp, _vp]),
+    "kappa0_to_alphas": (None, [_vp, _i, _d, _vp, _vp]),
+    "kappa0_to_phi": (None, [_vp, _i, _d, _vp]),
+    "ast_smooth_plan_create": (_i, [ct.POINTER(_vp), _i]),
+    "ast_smooth_plan_destroy": (_i, [_vp]),
+    "ast_gaussian_smooth": (_i, [_vp, _vp, _d, _i, _vp]),
+    "ast_minmax": (_i, [_vp, _i, _sz, _vp, _vp]),
+    "ast_histogram": (_i, [_vp, _i, _sz, _d, _d, _i, _vp, _vp]),
+    "ast_add": (_i, [_vp, _vp, _vp, _i, _sz, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (cached).  Raises if it is not built — no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise AstrildHipError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()'). "
+                "astrild_amd has no CPU fallback."
+            )
+        handle = ct.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)     # AttributeError = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().ast_last_error().decode(errors="replace")
+        raise AstrildHipError(f"{what or 'libastrild_hip'} failed (code {rc}): {msg}")
+    return rc

@@ -1,0 +1,392 @@
+// a-7 / a-8 / a-9: Ray-Ramses kappa-map stack and the per-map pipeline
+// (kappa -> deflection / potential, Gaussian smoothing), fp64 like the
+// reference.
+//
+// kappa -> alpha replaces rays/skys/lib_so_cgls/{lensing_funcs,fft_convolve}.c:
+// the reference re-plans FFTW, rebuilds both kernels and transforms kappa
+// twice on every call (fft_convolve.c:64-65 via lensing_funcs.c:103-104).
+// Here a plan caches the three kernel spectra per (Nc, bsz); a call is one
+// zero-pad kernel, one r2c, and per output one fused multiply, one c2r and one
+// crop+scale kernel, all on (2Nc)^2 arrays resident in HBM.
+#include "ast_common.h"
+#include <cmath>
+#include <mutex>
+#include <vector>
+
+namespace {
+
+// ----------------------------------------------------------- kappa stack
+template <typename T>
+__global__ void __launch_bounds__(256)
+kappa_stack_kernel(const T* const* __restrict__ planes, const double* __restrict__ wnum,
+                   const double* __restrict__ wden, int nplanes, size_t count, T* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        T acc = (T)0;
+        for (int p = 0; p < nplanes; ++p) {
+            T v = planes[p][i];
+            if (wnum) v = (T)((double)v * wnum[p] / wden[p]);      // quantity * g(x_mid, x_s') / g(x_mid, x_s)
+            acc = p == 0 ? v : acc + v;                             // first = copy, then running +=
+        }
+        out[i] = acc;
+    }
+}
+
+// ------------------------------------------------ kappa -> alpha / phi
+__global__ void __launch_bounds__(256)
+zero_pad_kernel(const double* __restrict__ in, int nc, double* __restrict__ out) {
+    const size_t n2 = 2 * (size_t)nc, total = n2 * n2;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const size_t i = idx / n2, j = idx % n2;
+        out[idx] = (i < (size_t)nc && j < (size_t)nc) ? in[i * nc + j] : 0.0;   // zero_padding, lensing_funcs.c:8-19
+    }
+}
+
+// kernel_alphas_iso / kernel_phi_iso (lensing_funcs.c:45-83, 117-148) in closed
+// form: the quarter plane i, j <= Ncc/2 is evaluated, the rest mirrored with
+// the reference's parities.  which: 0 = alpha1, 1 = alpha2, 2 = phi.
+__global__ void __launch_bounds__(256)
+iso_kernel_build(int ncc, double dcell, int which, double* __restrict__ out) {
+    const size_t total = (size_t)ncc * ncc;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const int h = ncc / 2;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int i = (int)(idx / ncc), j = (int)(idx % ncc);
+        const int ii = i <= h ? i : ncc - i, jj = j <= h ? j : ncc - j;
+        const double x = (double)ii * dcell + 0.5 * dcell;
+        const double y = (double)jj * dcell + 0.5 * dcell;
+        const double r = sqrt(x * x + y * y);
+        double v = 0.0;
+        if (!(r > dcell * (double)ncc / 2.0)) {
+            if (which == 0) v = x / (M_PI * r * r);
+            else if (which == 1) v = y / (M_PI * r * r);
+            else v = 1.0 / M_PI * log(r);
+        }
+        if (which == 0 && i > h) v = -v;
+        if (which == 1 && j > h) v = -v;
+        out[idx] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+cmul_kernel(const double2* __restrict__ a, const double2* __restrict__ b, double2* __restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double2 x = a[i], y = b[i];
+        double2 r;
+        r.x = x.x * y.x - x.y * y.y;      // fft_convolve.c:75-78
+        r.y = x.x * y.y + x.y * y.x;
+        out[i] = r;
+    }
+}
+
+// corner_matrix (lensing_funcs.c:33-43) fused with out/(nx*ny)*dx*dy (fft_convolve.c:88)
+__global__ void __launch_bounds__(256)
+crop_scale_kernel(const double* __restrict__ in, int nc, double dsx, double* __restrict__ out) {
+    const size_t n2 = 2 * (size_t)nc, total = (size_t)nc * nc;
+    const double nn = (double)(n2 * n2);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const size_t i = idx / nc, j = idx % nc;
+        out[idx] = in[i * n2 + j] / nn * dsx * dsx;
+    }
+}
+
+// ------------------------------------------------------ Gaussian smoothing
+// exp(-0.5 * l^2 * (2 pi sigma)^2) on the half spectrum, then the 1/npix^2 of irfft2
+__global__ void __launch_bounds__(256)
+gauss_fft_filter_kernel(double2* __restrict__ spec, int npix, double sigma_px) {
+    const int nh = npix / 2 + 1;
+    const size_t total = (size_t)npix * nh;
+    const double two_pi_s = 2.0 * M_PI * sigma_px;
+    const double f2 = two_pi_s * two_pi_s;
+    const double inv = 1.0 / ((double)npix * (double)npix);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int i = (int)(idx / nh), j = (int)(idx % nh);
+        // fftfreq(n): 0..(n-1)//2 then negative; rfftfreq(n): 0..n//2
+        const int fi = i <= (npix - 1) / 2 ? i : i - npix;
+        const double ly = (double)fi / (double)npix, lx = (double)j / (double)npix;
+        const double l2 = lx * lx + ly * ly;
+        const double g = exp(-0.5 * l2 * f2) * inv;
+        double2 v = spec[idx];
+        v.x *= g;
+        v.y *= g;
+        spec[idx] = v;
+    }
+}
+
+// scipy.ndimage.correlate1d with a symmetric kernel, mode="reflect"
+// (d c b a | a b c d | d c b a), along `axis` of an npix x npix map.
+__device__ inline int reflect_idx(int i, int n) {
+    // half-sample symmetric extension, valid for any offset
+    const int period = 2 * n;
+    int m = i % period;
+    if (m < 0) m += period;
+    return m < n ? m : period - 1 - m;
+}
+
+__global__ void __launch_bounds__(256)
+gauss_real_pass_kernel(const double* __restrict__ in, double* __restrict__ out, int npix, int axis,
+                       const double* __restrict__ w, int radius) {
+    const size_t total = (size_t)npix * npix;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int i = (int)(idx / npix), j = (int)(idx % npix);
+        const int c = axis == 0 ? i : j;
+        auto at = [&](int k) -> double {
+            const int r = reflect_idx(k, npix);
+            return axis == 0 ? in[(size_t)r * npix + j] : in[(size_t)i * npix + r];
+        };
+        // ni_filters.c NI_Correlate1D symmetric branch: centre tap, then pairs
+        double acc = at(c) * w[radius];
+        for (int k = -radius; k < 0; ++k) acc += (at(c + k) + at(c - k)) * w[k + radius];
+        out[idx] = acc;
+    }
+}
+
+#define AST_FWD(call)                  \
+    do {                               \
+        int rc_ = (call);              \
+        if (rc_ != AST_OK) return rc_; \
+    } while (0)
+
+}  // namespace
+
+struct ast_lens_plan {
+    int nc = 0;
+    double bsz = 0.0;
+    ast_fft_plan* r2c = nullptr;
+    ast_fft_plan* c2r = nullptr;
+    double* pad = nullptr;        // (2nc)^2 real: padded kappa, then c2r output
+    double2* spec = nullptr;      // kappa spectrum
+    double2* prod = nullptr;      // product spectrum (c2r input, overwritten by rocFFT)
+    double2* kspec[3] = {nullptr, nullptr, nullptr};   // alpha1, alpha2, phi kernel spectra
+    bool kready[3] = {false, false, false};
+};
+
+struct ast_smooth_plan {
+    int npix = 0;
+    ast_fft_plan* r2c = nullptr;
+    ast_fft_plan* c2r = nullptr;
+    double2* spec = nullptr;
+    double* tmp = nullptr;
+    double* w_d = nullptr;
+    int w_cap = 0;
+    std::vector<double> w_h;
+};
+
+extern "C" int ast_kappa_stack(const void* const* planes, const double* wnum, const double* wden, int nplanes,
+                               size_t count, int dtype, void* out, void* stream) {
+    AST_CHECK_ARG(planes && out && nplanes >= 1);
+    AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
+    AST_CHECK_ARG((wnum == nullptr) == (wden == nullptr));
+    if (count == 0) return AST_OK;
+    unsigned g = ast::stream_grid(count, 256);
+    hipStream_t s = ast::as_stream(stream);
+    if (dtype == AST_F32)
+        kappa_stack_kernel<float><<<g, 256, 0, s>>>((const float* const*)planes, wnum, wden, nplanes, count, (float*)out);
+    else
+        kappa_stack_kernel<double><<<g, 256, 0, s>>>((const double* const*)planes, wnum, wden, nplanes, count, (double*)out);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+extern "C" int ast_lens_plan_destroy(ast_lens_plan* p) {
+    if (!p) return AST_OK;
+    ast_fft_plan_destroy(p->r2c);
+    ast_fft_plan_destroy(p->c2r);
+    if (p->pad) (void)hipFree(p->pad);
+    if (p->spec) (void)hipFree(p->spec);
+    if (p->prod) (void)hipFree(p->prod);
+    for (auto* k : p->kspec) if (k) (void)hipFree(k);
+    delete p;
+    return AST_OK;
+}
+
+extern "C" int ast_lens_plan_create(ast_lens_plan** out, int nc, double bsz) {
+    AST_CHECK_ARG(out != nullptr && nc >= 1 && nc <= 16384 && bsz > 0.0);
+    auto* p = new ast_lens_plan();
+    p->nc = nc;
+    p->bsz = bsz;
+    const size_t n2 = 2 * (size_t)nc, nh = n2 / 2 + 1;
+    const size_t lens[2] = {n2, n2};
+    int rc = ast_fft_plan_create(&p->r2c, AST_FFT_R2C, AST_F64, 2, lens, 1, 1.0, 0);
+    if (rc == AST_OK) rc = ast_fft_plan_create(&p->c2r, AST_FFT_C2R, AST_F64, 2, lens, 1, 1.0, 0);
+    if (rc != AST_OK) { ast_lens_plan_destroy(p); return rc; }
+    hipError_t e = hipMalloc(&p->pad, n2 * n2 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&p->spec, n2 * nh * sizeof(double2));
+    if (e == hipSuccess) e = hipMalloc(&p->prod, n2 * nh * sizeof(double2));
+    if (e != hipSuccess) {
+        ast::set_error("ast_lens_plan_create: hipMalloc -> %s", hipGetErrorString(e));
+        ast_lens_plan_destroy(p);
+        return AST_ERR_HIP;
+    }
+    *out = p;
+    return AST_OK;
+}
+
+// kernel spectrum `which`, built on first use and cached in the plan
+static int lens_kernel_spectrum(ast_lens_plan* p, int which, hipStream_t s) {
+    if (p->kready[which]) return AST_OK;
+    const size_t n2 = 2 * (size_t)p->nc, nh = n2 / 2 + 1;
+    if (!p->kspec[which]) AST_CHECK_HIP(hipMalloc(&p->kspec[which], n2 * nh * sizeof(double2)));
+    const double dsx = p->bsz / (double)p->nc;
+    iso_kernel_build<<<ast::stream_grid(n2 * n2, 256), 256, 0, s>>>((int)n2, dsx, which, p->pad);
+    AST_CHECK_LAUNCH();
+    AST_FWD(ast_fft_exec(p->r2c, p->pad, p->kspec[which], s));
+    p->kready[which] = true;
+    return AST_OK;
+}
+
+static int lens_convolve(ast_lens_plan* p, int which, double* out, hipStream_t s) {
+    const size_t n2 = 2 * (size_t)p->nc, nh = n2 / 2 + 1;
+    cmul_kernel<<<ast::stream_grid(n2 * nh, 256), 256, 0, s>>>(p->spec, p->kspec[which], p->prod, n2 * nh);
+    AST_CHECK_LAUNCH();
+    AST_FWD(ast_fft_exec(p->c2r, p->prod, p->pad, s));
+    crop_scale_kernel<<<ast::stream_grid((size_t)p->nc * p->nc, 256), 256, 0, s>>>(p->pad, p->nc, p->bsz / (double)p->nc, out);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+static int lens_forward(ast_lens_plan* p, const double* kappa, hipStream_t s) {
+    const size_t n2 = 2 * (size_t)p->nc;
+    zero_pad_kernel<<<ast::stream_grid(n2 * n2, 256), 256, 0, s>>>(kappa, p->nc, p->pad);
+    AST_CHECK_LAUNCH();
+    return ast_fft_exec(p->r2c, p->pad, p->spec, s);
+}
+
+extern "C" int ast_kappa_to_alphas(ast_lens_plan* p, const double* kappa, double* alpha1, double* alpha2, void* stream) {
+    AST_CHECK_ARG(p && kappa && alpha1 && alpha2);
+    hipStream_t s = ast::as_stream(stream);
+    AST_FWD(lens_kernel_spectrum(p, 0, s));
+    AST_FWD(lens_kernel_spectrum(p, 1, s));
+    AST_FWD(lens_forward(p, kappa, s));
+    AST_FWD(lens_convolve(p, 0, alpha1, s));
+    AST_FWD(lens_convolve(p, 1, alpha2, s));
+    return AST_OK;
+}
+
+extern "C" int ast_kappa_to_phi(ast_lens_plan* p, const double* kappa, double* phi, void* stream) {
+    AST_CHECK_ARG(p && kappa && phi);
+    hipStream_t s = ast::as_stream(stream);
+    AST_FWD(lens_kernel_spectrum(p, 2, s));
+    AST_FWD(lens_forward(p, kappa, s));
+    AST_FWD(lens_convolve(p, 2, phi, s));
+    return AST_OK;
+}
+
+// --- libglsg.so-compatible host entry points (lensing_funcs.h:5,7) ---
+namespace {
+std::mutex g_host_mutex;
+ast_lens_plan* g_host_plan = nullptr;
+
+int host_lens(double* kappa0, int nc, double bsz, double* o1, double* o2, bool phi) {
+    std::lock_guard<std::mutex> lock(g_host_mutex);
+    if (!g_host_plan || g_host_plan->nc != nc || g_host_plan->bsz != bsz) {
+        ast_lens_plan_destroy(g_host_plan);
+        g_host_plan = nullptr;
+        AST_FWD(ast_lens_plan_create(&g_host_plan, nc, bsz));
+    }
+    const size_t bytes = (size_t)nc * nc * sizeof(double);
+    double *k_d = nullptr, *a_d = nullptr, *b_d = nullptr;
+    hipError_t e = hipMalloc(&k_d, bytes);
+    if (e == hipSuccess) e = hipMalloc(&a_d, bytes);
+    if (e == hipSuccess && !phi) e = hipMalloc(&b_d, bytes);
+    int rc = AST_OK;
+    if (e != hipSuccess) {
+        ast::set_error("kappa0_to_%s: hipMalloc -> %s", phi ? "phi" : "alphas", hipGetErrorString(e));
+        rc = AST_ERR_HIP;
+    }
+    if (rc == AST_OK && hipMemcpy(k_d, kappa0, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = AST_ERR_HIP;
+    if (rc == AST_OK) rc = phi ? ast_kappa_to_phi(g_host_plan, k_d, a_d, nullptr)
+                               : ast_kappa_to_alphas(g_host_plan, k_d, a_d, b_d, nullptr);
+    if (rc == AST_OK && hipDeviceSynchronize() != hipSuccess) rc = AST_ERR_HIP;
+    if (rc == AST_OK && hipMemcpy(o1, a_d, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = AST_ERR_HIP;
+    if (rc == AST_OK && !phi && hipMemcpy(o2, b_d, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = AST_ERR_HIP;
+    if (k_d) (void)hipFree(k_d);
+    if (a_d) (void)hipFree(a_d);
+    if (b_d) (void)hipFree(b_d);
+    return rc;
+}
+}  // namespace
+
+extern "C" void kappa0_to_alphas(double* kappa0, int Nc, double bsz, double* alpha1, double* alpha2) {
+    // void like the original; a failure is fatal rather than silent garbage
+    if (host_lens(kappa0, Nc, bsz, alpha1, alpha2, false) != AST_OK) {
+        fprintf(stderr, "libastrild_hip: kappa0_to_alphas failed: %s\n", ast_last_error());
+        abort();
+    }
+}
+
+extern "C" void kappa0_to_phi(double* kappa0, int Nc, double bsz, double* phi) {
+    if (host_lens(kappa0, Nc, bsz, phi, nullptr, true) != AST_OK) {
+        fprintf(stderr, "libastrild_hip: kappa0_to_phi failed: %s\n", ast_last_error());
+        abort();
+    }
+}
+
+// ------------------------------------------------------------- smoothing
+extern "C" int ast_smooth_plan_destroy(ast_smooth_plan* p) {
+    if (!p) return AST_OK;
+    ast_fft_plan_destroy(p->r2c);
+    ast_fft_plan_destroy(p->c2r);
+    if (p->spec) (void)hipFree(p->spec);
+    if (p->tmp) (void)hipFree(p->tmp);
+    if (p->w_d) (void)hipFree(p->w_d);
+    delete p;
+    return AST_OK;
+}
+
+extern "C" int ast_smooth_plan_create(ast_smooth_plan** out, int npix) {
+    AST_CHECK_ARG(out != nullptr && npix >= 2 && npix <= 32768);
+    auto* p = new ast_smooth_plan();
+    p->npix = npix;
+    const size_t lens[2] = {(size_t)npix, (size_t)npix};
+    const size_t nh = npix / 2 + 1;
+    int rc = ast_fft_plan_create(&p->r2c, AST_FFT_R2C, AST_F64, 2, lens, 1, 1.0, 0);
+    if (rc == AST_OK) rc = ast_fft_plan_create(&p->c2r, AST_FFT_C2R, AST_F64, 2, lens, 1, 1.0, 0);
+    if (rc != AST_OK) { ast_smooth_plan_destroy(p); return rc; }
+    p->w_cap = 2 * 4 * npix + 1;
+    hipError_t e = hipMalloc(&p->spec, (size_t)npix * nh * sizeof(double2));
+    if (e == hipSuccess) e = hipMalloc(&p->tmp, (size_t)npix * npix * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&p->w_d, (size_t)p->w_cap * sizeof(double));
+    if (e != hipSuccess) {
+        ast::set_error("ast_smooth_plan_create: hipMalloc -> %s", hipGetErrorString(e));
+        ast_smooth_plan_destroy(p);
+        return AST_ERR_HIP;
+    }
+    *out = p;
+    return AST_OK;
+}
+
+extern "C" int ast_gaussian_smooth(ast_smooth_plan* p, double* img, double sigma_px, int mode, void* stream) {
+    AST_CHECK_ARG(p && img && sigma_px > 0.0 && (mode == 0 || mode == 1));
+    hipStream_t s = ast::as_stream(stream);
+    const int npix = p->npix;
+    if (mode == 0) {
+        const size_t nh = npix / 2 + 1;
+        AST_FWD(ast_fft_exec(p->r2c, img, p->spec, s));
+        gauss_fft_filter_kernel<<<ast::stream_grid((size_t)npix * nh, 256), 256, 0, s>>>(p->spec, npix, sigma_px);
+        AST_CHECK_LAUNCH();
+        return ast_fft_exec(p->c2r, p->spec, img, s);
+    }
+    // scipy.ndimage._filters._gaussian_kernel1d: radius = int(truncate*sigma + 0.5), truncate = 4
+    const int radius = (int)(4.0 * sigma_px + 0.5);
+    AST_CHECK_ARG(2 * radius + 1 <= p->w_cap);
+    p->w_h.assign(2 * radius + 1, 0.0);
+    double sum = 0.0;
+    const double sigma2 = sigma_px * sigma_px;
+    for (int k = -radius; k <= radius; ++k) {
+        p->w_h[k + radius] = std::exp(-0.5 / sigma2 * (double)(k * k));
+        sum += p->w_h[k + radius];
+    }
+    for (auto& v : p->w_h) v /= sum;
+    AST_CHECK_HIP(hipMemcpyAsync(p->w_d, p->w_h.data(), p->w_h.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    unsigned g = ast::stream_grid((size_t)npix * npix, 256);
+    gauss_real_pass_kernel<<<g, 256, 0, s>>>(img, p->tmp, npix, 0, p->w_d, radius);
+    gauss_real_pass_kernel<<<g, 256, 0, s>>>(p->tmp, img, npix, 1, p->w_d, radius);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}

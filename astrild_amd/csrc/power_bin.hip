@@ -1,0 +1,236 @@
+// a-5: FFTPower(mode="1d") k-shell binning of the half spectrum, plus the
+// shell filter / triple product of the FFT bispectrum estimator (a-10) and the
+// slab pack/unpack of the distributed transpose.
+//
+// Binning layout: one wave walks one (i0, i1) row of the spectrum with its 64
+// lanes along the contiguous half axis, so loads are coalesced and the shell
+// index is monotone across lanes.  Equal-shell runs are summed inside the wave
+// with a segmented shuffle reduction; only run heads touch the workgroup's
+// LDS shell table, which is flushed to HBM once per workgroup.
+#include "ast_common.h"
+
+namespace {
+
+__device__ inline int freq(int i, int n) { return i > n / 2 ? i - n : i; }
+
+__device__ inline int isqrt_i(long long v) {
+    int r = (int)sqrt((double)v);
+    while ((long long)r * r > v) --r;
+    while ((long long)(r + 1) * (r + 1) <= v) ++r;
+    return r;
+}
+
+template <typename C> struct cplx_traits;
+template <> struct cplx_traits<float2> { using real = float; };
+template <> struct cplx_traits<double2> { using real = double; };
+
+constexpr int MAX_SHELLS = 4096;  // nmesh <= 8192
+
+template <typename C>
+__global__ void __launch_bounds__(256)
+power_bin_kernel(const C* __restrict__ s1, const C* __restrict__ s2, int n, double pnorm, double kf,
+                 int i0_start, int i0_count, int i1_start, int i1_count,
+                 double* ksum, double* psum, unsigned long long* nmodes) {
+    extern __shared__ unsigned char smem[];
+    const int nb = n / 2 - 1;
+    const int nslots = nb + 2;                       // slot 0: below first edge, slot nb+1: beyond last
+    double* lk = reinterpret_cast<double*>(smem);
+    double* lp = lk + nslots;
+    unsigned long long* lm = reinterpret_cast<unsigned long long*>(lp + nslots);
+    for (int i = threadIdx.x; i < nslots; i += blockDim.x) { lk[i] = 0.0; lp[i] = 0.0; lm[i] = 0ull; }
+    __syncthreads();
+
+    const int nz = n / 2 + 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+    const long long nrows = (long long)i0_count * i1_count;
+    for (long long row = (long long)blockIdx.x * waves_per_block + wave; row < nrows;
+         row += (long long)gridDim.x * waves_per_block) {
+        const int a = (int)(row / i1_count), b = (int)(row % i1_count);
+        const int m0 = freq(i0_start + a, n), m1 = freq(i1_start + b, n);
+        const long long base = (long long)m0 * m0 + (long long)m1 * m1;
+        const C* r1 = s1 + (size_t)row * nz;
+        const C* r2 = s2 ? s2 + (size_t)row * nz : nullptr;
+        for (int z0 = 0; z0 < nz; z0 += 64) {
+            const int iz = z0 + lane;
+            int slot = nb + 1;
+            double pv = 0.0, kv = 0.0;
+            unsigned long long mv = 0;
+            if (iz < nz) {
+                const long long m2 = base + (long long)iz * iz;
+                const int sh = isqrt_i(m2);           // shell = sh - 1
+                slot = sh > nb ? nb + 1 : sh;         // sh == 0 (DC) -> slot 0
+                const C x = r1[iz];
+                const C y = r2 ? r2[iz] : x;
+                const double w = (iz > 0 && iz < n / 2) ? 2.0 : 1.0;
+                pv = w * ((double)x.x * (double)y.x + (double)x.y * (double)y.y);
+                kv = w * sqrt((double)m2);
+                mv = (unsigned long long)w;
+            }
+            // segmented reduction over runs of equal slot (slot is monotone in lane)
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int os = __shfl_down(slot, off, 64);
+                const double op = __shfl_down(pv, off, 64);
+                const double ok = __shfl_down(kv, off, 64);
+                const unsigned long long om = __shfl_down(mv, off, 64);
+                if (lane + off < 64 && os == slot) { pv += op; kv += ok; mv += om; }
+            }
+            const int prev = __shfl_up(slot, 1, 64);
+            if ((lane == 0 || prev != slot) && slot >= 1 && slot <= nb) {
+                atomicAdd(&lp[slot], pv);
+                atomicAdd(&lk[slot], kv);
+                atomicAdd(&lm[slot], mv);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+        const unsigned long long m = lm[i + 1];
+        if (m) {
+            atomicAdd(&psum[i], lp[i + 1] * pnorm);
+            atomicAdd(&ksum[i], lk[i + 1] * kf);
+            atomicAdd(&nmodes[i], m);
+        }
+    }
+}
+
+template <typename C>
+__global__ void __launch_bounds__(256)
+shell_filter_kernel(const C* __restrict__ in, C* __restrict__ out, int n, int shell,
+                    int i0_start, int i0_count, int i1_start, int i1_count) {
+    const int nz = n / 2 + 1;
+    const size_t total = (size_t)i0_count * i1_count * nz;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int iz = (int)(i % nz);
+        const size_t row = i / nz;
+        const int m0 = freq(i0_start + (int)(row / i1_count), n), m1 = freq(i1_start + (int)(row % i1_count), n);
+        const long long m2 = (long long)m0 * m0 + (long long)m1 * m1 + (long long)iz * iz;
+        const bool inside = isqrt_i(m2) - 1 == shell;
+        C v;
+        if (in) v = in[i]; else { v.x = 1; v.y = 0; }
+        if (!inside) { v.x = 0; v.y = 0; }
+        out[i] = v;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+triple_sum_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c, size_t n, double* out) {
+    double acc = 0.0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        acc += (double)a[i] * (double)b[i] * (double)c[i];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+// (n0, n1, n2) -> parts x (n0, n1/parts, n2)
+template <typename C, bool UNPACK>
+__global__ void __launch_bounds__(256)
+slab_pack_kernel(const C* __restrict__ in, C* __restrict__ out, size_t n0, size_t n1, size_t n2, int parts) {
+    const size_t c1 = n1 / parts;
+    const size_t total = n0 * n1 * n2;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t k = i % n2;
+        const size_t j = (i / n2) % n1;
+        const size_t a = i / (n2 * n1);
+        const size_t part = j / c1, jl = j % c1;
+        const size_t packed = ((part * n0 + a) * c1 + jl) * n2 + k;
+        if (UNPACK) out[i] = in[packed]; else out[packed] = in[i];
+    }
+}
+
+}  // namespace
+
+extern "C" int ast_power_bin_1d(const void* spec1, const void* spec2, int dtype, int nmesh, double boxsize,
+                                int i0_start, int i0_count, int i1_start, int i1_count,
+                                double* ksum, double* psum, long long* nmodes, void* stream) {
+    AST_CHECK_ARG(spec1 && ksum && psum && nmodes);
+    AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
+    AST_CHECK_ARG(nmesh >= 4 && nmesh % 2 == 0 && nmesh / 2 - 1 <= MAX_SHELLS && boxsize > 0.0);
+    AST_CHECK_ARG(i0_start >= 0 && i0_count >= 0 && i0_start + i0_count <= nmesh);
+    AST_CHECK_ARG(i1_start >= 0 && i1_count >= 0 && i1_start + i1_count <= nmesh);
+    const long long nrows = (long long)i0_count * i1_count;
+    if (nrows == 0) return AST_OK;
+    const int nb = nmesh / 2 - 1;
+    const size_t lds = (size_t)(nb + 2) * (2 * sizeof(double) + sizeof(unsigned long long));
+    const double kf = 2.0 * M_PI / boxsize;
+    const double pnorm = boxsize * boxsize * boxsize;
+    long long need = (nrows + 3) / 4;
+    unsigned g = (unsigned)(need > 2048 ? 2048 : need);
+    auto* nm = reinterpret_cast<unsigned long long*>(nmodes);
+    hipStream_t s = ast::as_stream(stream);
+    if (dtype == AST_F32)
+        power_bin_kernel<float2><<<g, 256, lds, s>>>((const float2*)spec1, (const float2*)spec2, nmesh, pnorm, kf,
+                                                      i0_start, i0_count, i1_start, i1_count, ksum, psum, nm);
+    else
+        power_bin_kernel<double2><<<g, 256, lds, s>>>((const double2*)spec1, (const double2*)spec2, nmesh, pnorm, kf,
+                                                       i0_start, i0_count, i1_start, i1_count, ksum, psum, nm);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+extern "C" int ast_shell_filter(const void* in, void* out, int dtype, int nmesh, int shell, int i0_start,
+                                int i0_count, int i1_start, int i1_count, void* stream) {
+    AST_CHECK_ARG(out != nullptr);
+    AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
+    AST_CHECK_ARG(nmesh >= 4 && nmesh % 2 == 0 && shell >= 0 && shell < nmesh / 2 - 1);
+    AST_CHECK_ARG(i0_start >= 0 && i0_count >= 0 && i0_start + i0_count <= nmesh);
+    AST_CHECK_ARG(i1_start >= 0 && i1_count >= 0 && i1_start + i1_count <= nmesh);
+    const size_t total = (size_t)i0_count * i1_count * (nmesh / 2 + 1);
+    if (total == 0) return AST_OK;
+    unsigned g = ast::stream_grid(total, 256);
+    hipStream_t s = ast::as_stream(stream);
+    if (dtype == AST_F32)
+        shell_filter_kernel<float2><<<g, 256, 0, s>>>((const float2*)in, (float2*)out, nmesh, shell, i0_start, i0_count, i1_start, i1_count);
+    else
+        shell_filter_kernel<double2><<<g, 256, 0, s>>>((const double2*)in, (double2*)out, nmesh, shell, i0_start, i0_count, i1_start, i1_count);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+extern "C" int ast_triple_product_sum(const void* a, const void* b, const void* c, int dtype, size_t count,
+                                      double* out, void* stream) {
+    AST_CHECK_ARG(a && b && c && out);
+    AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
+    if (count == 0) return AST_OK;
+    unsigned g = ast::stream_grid(count, 256);
+    hipStream_t s = ast::as_stream(stream);
+    if (dtype == AST_F32)
+        triple_sum_kernel<float><<<g, 256, 0, s>>>((const float*)a, (const float*)b, (const float*)c, count, out);
+    else
+        triple_sum_kernel<double><<<g, 256, 0, s>>>((const double*)a, (const double*)b, (const double*)c, count, out);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+template <bool UNPACK>
+static int slab_pack_impl(const void* in, void* out, int dtype, size_t n0, size_t n1, size_t n2, int parts, void* stream) {
+    AST_CHECK_ARG(in && out && in != out);
+    AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
+    AST_CHECK_ARG(parts >= 1 && n1 % (size_t)parts == 0);
+    const size_t total = n0 * n1 * n2;
+    if (total == 0) return AST_OK;
+    unsigned g = ast::stream_grid(total, 256);
+    hipStream_t s = ast::as_stream(stream);
+    if (dtype == AST_F32)
+        slab_pack_kernel<float2, UNPACK><<<g, 256, 0, s>>>((const float2*)in, (float2*)out, n0, n1, n2, parts);
+    else
+        slab_pack_kernel<double2, UNPACK><<<g, 256, 0, s>>>((const double2*)in, (double2*)out, n0, n1, n2, parts);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+extern "C" int ast_slab_pack(const void* in, void* out, int dtype, size_t n0, size_t n1, size_t n2, int parts, void* stream) {
+    return slab_pack_impl<false>(in, out, dtype, n0, n1, n2, parts, stream);
+}
+extern "C" int ast_slab_unpack(const void* in, void* out, int dtype, size_t n0, size_t n1, size_t n2, int parts, void* stream) {
+    return slab_pack_impl<true>(in, out, dtype, n0, n1, n2, parts, stream);
+}

@@ -1,0 +1,252 @@
+// Error state, fill / divide / add / accumulate streaming kernels, min-max and
+// histogram reductions, synthetic particle generator.
+#include "ast_common.h"
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+namespace ast {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace ast
+
+extern "C" int ast_version(void) { return 100; }
+extern "C" const char* ast_last_error(void) { return ast::g_err; }
+
+namespace {
+
+template <typename T>
+__global__ void fill_kernel(T* buf, size_t n, T v) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) buf[i] = v;
+}
+
+template <typename T>
+__global__ void divide_kernel(T* buf, size_t n, T d) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) buf[i] = buf[i] / d;
+}
+
+template <typename T>
+__global__ void add_kernel(const T* a, const T* b, T* out, size_t n) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = a[i] + b[i];
+}
+
+// 64-lane butterfly reductions
+__device__ inline double wave_min(double v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ inline double wave_max(double v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// order-preserving map double <-> uint64 so min/max can use integer atomics
+__device__ inline unsigned long long d2key(double d) {
+    unsigned long long u = (unsigned long long)__double_as_longlong(d);
+    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ inline double key2d(unsigned long long k) {
+    unsigned long long u = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+template <typename T>
+__global__ void minmax_kernel(const T* buf, size_t n, unsigned long long* keys) {
+    double lo = DBL_MAX, hi = -DBL_MAX;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double v = (double)buf[i];
+        lo = fmin(lo, v);
+        hi = fmax(hi, v);
+    }
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&keys[0], d2key(lo));
+        atomicMax(&keys[1], d2key(hi));
+    }
+}
+
+__global__ void minmax_init(unsigned long long* keys) {
+    keys[0] = ~0ull;
+    keys[1] = 0ull;
+}
+__global__ void minmax_finish(unsigned long long* keys) {
+    double lo = key2d(keys[0]), hi = key2d(keys[1]);
+    reinterpret_cast<double*>(keys)[0] = lo;
+    reinterpret_cast<double*>(keys)[1] = hi;
+}
+
+// np.histogram with uniform bins (numpy/lib/_histograms_impl.py fast path):
+//   f = (v - lo) * (nbins / (hi - lo));  idx = (int) f;  idx == nbins -> nbins-1;
+//   then numpy corrects against the float64 edges: v < edge[idx] -> idx-1,
+//   v >= edge[idx+1] && idx != nbins-1 -> idx+1.   edges = linspace(lo, hi, nbins+1).
+template <typename T, int MAXB>
+__global__ void hist_kernel(const T* buf, size_t n, double lo, double hi, int nbins,
+                            unsigned long long* counts) {
+    __shared__ unsigned int lh[MAXB];
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    const double norm = (double)nbins / (hi - lo);
+    const double step = (hi - lo) / (double)nbins;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double v = (double)buf[i];
+        if (!(v >= lo && v <= hi)) continue;
+        int idx = (int)((v - lo) * norm);
+        if (idx == nbins) idx = nbins - 1;
+        // numpy's linspace: edge[i] = lo + i*step (last forced to hi)
+        double e0 = lo + idx * step;
+        double e1 = (idx + 1 == nbins) ? hi : lo + (idx + 1) * step;
+        if (v < e0) idx -= 1;
+        else if (v >= e1 && idx != nbins - 1) idx += 1;
+        atomicAdd(&lh[idx], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x)
+        if (lh[i]) atomicAdd(&counts[i], (unsigned long long)lh[i]);
+}
+
+// ---- counter-based normal generator for the synthetic particle set ----
+__device__ inline uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+template <typename T>
+__global__ void synth_kernel(T* pos, size_t first, size_t count, int npside, double boxsize,
+                             double sigma, uint64_t seed, uint64_t shuffle_stride) {
+    const uint64_t n3 = (uint64_t)npside * npside * npside;
+    const double h = boxsize / npside;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += stride) {
+        uint64_t p = first + t;
+        uint64_t id = shuffle_stride ? (uint64_t)(((unsigned __int128)p * shuffle_stride) % n3) : p;
+        uint64_t k = id % npside, j = (id / npside) % npside, i = id / ((uint64_t)npside * npside);
+        double q[3] = {(i + 0.5) * h, (j + 0.5) * h, (k + 0.5) * h};
+        // two Box-Muller pairs give three normals
+        uint64_t a = mix64(seed ^ mix64(id * 4 + 0)), b = mix64(seed ^ mix64(id * 4 + 1));
+        uint64_t c = mix64(seed ^ mix64(id * 4 + 2)), d = mix64(seed ^ mix64(id * 4 + 3));
+        double u1 = ((a >> 11) + 1.0) * (1.0 / 9007199254740993.0);   // (0,1)
+        double u2 = (b >> 11) * (1.0 / 9007199254740992.0);
+        double u3 = ((c >> 11) + 1.0) * (1.0 / 9007199254740993.0);
+        double u4 = (d >> 11) * (1.0 / 9007199254740992.0);
+        double r1 = sqrt(-2.0 * log(u1)), r2 = sqrt(-2.0 * log(u3));
+        double s1, c1, s2, c2;
+        sincos(6.283185307179586 * u2, &s1, &c1);
+        sincos(6.283185307179586 * u4, &s2, &c2);
+        double xi[3] = {r1 * c1, r1 * s1, r2 * c2};
+        for (int dim = 0; dim < 3; ++dim) {
+            double x = q[dim] + sigma * xi[dim];
+            x -= floor(x / boxsize) * boxsize;
+            T xt = (T)x;
+            if (xt >= (T)boxsize) xt = (T)0;   // the cast may round up to L
+            pos[3 * t + dim] = xt;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ast_fill(void* buf, int dtype, size_t count, double value, void* stream) {
+    AST_CHECK_ARG(buf != nullptr || count == 0);
+    AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
+    if (count == 0) return AST_OK;
+    unsigned g = ast::stream_grid(count, 256);
+    if (dtype == AST_F32)
+        fill_kernel<float><<<g, 256, 0, ast::as_stream(stream)>>>((float*)buf, count, (float)value);
+    else
+        fill_kernel<double><<<g, 256, 0, ast::as_stream(stream)>>>((double*)buf, count, value);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+extern "C" int ast_divide(void* buf, int dtype, size_t count, double divisor, void* stream) {
+    AST_CHECK_ARG(buf != nullptr || count == 0);
+    AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
+    if (count == 0) return AST_OK;
+    unsigned g = ast::stream_grid(count, 256);
+    if (dtype == AST_F32)
+        divide_kernel<float><<<g, 256, 0, ast::as_stream(stream)>>>((float*)buf, count, (float)divisor);
+    else
+        divide_kernel<double><<<g, 256, 0, ast::as_stream(stream)>>>((double*)buf, count, divisor);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+extern "C" int ast_add(const void* a, const void* b, void* out, int dtype, size_t count, void* stream) {
+    AST_CHECK_ARG((a && b && out) || count == 0);
+    AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
+    if (count == 0) return AST_OK;
+    unsigned g = ast::stream_grid(count, 256);
+    if (dtype == AST_F32)
+        add_kernel<float><<<g, 256, 0, ast::as_stream(stream)>>>((const float*)a, (const float*)b, (float*)out, count);
+    else
+        add_kernel<double><<<g, 256, 0, ast::as_stream(stream)>>>((const double*)a, (const double*)b, (double*)out, count);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+extern "C" int ast_accumulate(void* dst, const void* src, int dtype, size_t count, void* stream) {
+    return ast_add(dst, src, dst, dtype, count, stream);
+}
+
+extern "C" int ast_minmax(const void* buf, int dtype, size_t count, double* out, void* stream) {
+    AST_CHECK_ARG(buf && out && count > 0);
+    AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
+    hipStream_t s = ast::as_stream(stream);
+    auto* keys = reinterpret_cast<unsigned long long*>(out);
+    minmax_init<<<1, 1, 0, s>>>(keys);
+    unsigned g = ast::stream_grid(count, 256);
+    if (dtype == AST_F32)
+        minmax_kernel<float><<<g, 256, 0, s>>>((const float*)buf, count, keys);
+    else
+        minmax_kernel<double><<<g, 256, 0, s>>>((const double*)buf, count, keys);
+    minmax_finish<<<1, 1, 0, s>>>(keys);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+extern "C" int ast_histogram(const void* buf, int dtype, size_t count, double lo, double hi, int nbins,
+                             long long* counts, void* stream) {
+    AST_CHECK_ARG(buf && counts);
+    AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
+    AST_CHECK_ARG(nbins > 0 && nbins <= 4096);
+    AST_CHECK_ARG(hi > lo);
+    if (count == 0) return AST_OK;
+    unsigned g = ast::stream_grid(count, 256);
+    auto* c = reinterpret_cast<unsigned long long*>(counts);
+    if (dtype == AST_F32)
+        hist_kernel<float, 4096><<<g, 256, 0, ast::as_stream(stream)>>>((const float*)buf, count, lo, hi, nbins, c);
+    else
+        hist_kernel<double, 4096><<<g, 256, 0, ast::as_stream(stream)>>>((const double*)buf, count, lo, hi, nbins, c);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+extern "C" int ast_synth_lattice_particles(void* pos, int dtype, size_t first, size_t count, int npside,
+                                           double boxsize, double sigma, uint64_t seed,
+                                           uint64_t shuffle_stride, void* stream) {
+    AST_CHECK_ARG(pos != nullptr || count == 0);
+    AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
+    AST_CHECK_ARG(npside > 0 && boxsize > 0);
+    AST_CHECK_ARG(first + count <= (size_t)npside * npside * npside);
+    if (count == 0) return AST_OK;
+    unsigned g = ast::stream_grid(count, 256);
+    if (dtype == AST_F32)
+        synth_kernel<float><<<g, 256, 0, ast::as_stream(stream)>>>((float*)pos, first, count, npside, boxsize, sigma, seed, shuffle_stride);
+    else
+        synth_kernel<double><<<g, 256, 0, ast::as_stream(stream)>>>((double*)pos, first, count, npside, boxsize, sigma, seed, shuffle_stride);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}

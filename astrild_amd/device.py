@@ -1,0 +1,229 @@
+"""HBM-resident building blocks of the hot path, one Python call per C-ABI entry.
+
+PyTorch-ROCm tensors are used only as device-memory holders (allocation,
+streams, lifetime); every computation is a call into ``libastrild_hip.so``.
+Arrays follow the reference's layouts: grids are ``(N, N, N)`` C order with
+axis 0 slowest (``value_map[x, y, z]``, power_spectrum_3d.py:142-148), particle
+positions ``(Np, 3)`` like pmesh's ``paint`` (stats_subfind.py:125-131).
+"""
+import ctypes as ct
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import F32, F64, check
+
+_REAL = {torch.float32: F32, torch.float64: F64}
+_CPLX = {torch.complex64: F32, torch.complex128: F64}
+_TO_CPLX = {torch.float32: torch.complex64, torch.float64: torch.complex128}
+_TO_REAL = {torch.complex64: torch.float32, torch.complex128: torch.float64}
+
+
+def device():
+    if not torch.cuda.is_available():
+        raise _lib.AstrildHipError("astrild_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                                   "there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream():
+    return ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return None if t is None else ct.c_void_p(t.data_ptr())
+
+
+def as_device(a, dtype=None):
+    """numpy / torch -> contiguous CUDA tensor (the H2D hop of the Python API)."""
+    if isinstance(a, torch.Tensor):
+        t = a.to(device=device(), dtype=dtype or a.dtype)
+    else:
+        arr = np.ascontiguousarray(a)
+        t = torch.from_numpy(arr).to(device=device(), dtype=dtype)
+    return t.contiguous()
+
+
+def real_code(t):
+    try:
+        return _REAL[t.dtype]
+    except KeyError:
+        raise TypeError(f"expected float32/float64 tensor, got {t.dtype}") from None
+
+
+# ------------------------------------------------------------------ FFT plans
+class FFTPlan:
+    """Owns one rocFFT plan created through the C-ABI."""
+
+    def __init__(self, kind, dtype_code, lengths, batch=1, scale=1.0, inplace=False, strided=None):
+        self.handle = ct.c_void_p()
+        L = _lib.lib()
+        if strided is None:
+            arr = (ct.c_size_t * len(lengths))(*[int(v) for v in lengths])
+            check(L.ast_fft_plan_create(ct.byref(self.handle), kind, dtype_code, len(lengths), arr,
+                                        int(batch), float(scale), int(bool(inplace))), "ast_fft_plan_create")
+        else:
+            length, stride, dist = strided
+            check(L.ast_fft_plan_create_strided_1d(ct.byref(self.handle), kind, dtype_code, int(length),
+                                                   int(stride), int(batch), int(dist), float(scale)),
+                  "ast_fft_plan_create_strided_1d")
+
+    @property
+    def work_bytes(self):
+        return int(_lib.lib().ast_fft_plan_work_bytes(self.handle))
+
+    def execute(self, src, dst=None):
+        check(_lib.lib().ast_fft_exec(self.handle, ptr(src), ptr(dst), stream()), "ast_fft_exec")
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.lib().ast_fft_plan_destroy(self.handle)
+                self.handle = ct.c_void_p()
+        except Exception:
+            pass
+
+
+_plan_cache = {}
+
+
+def fft_plan(kind, dtype_code, lengths, batch=1, scale=1.0, inplace=False, strided=None):
+    key = (torch.cuda.current_device(), kind, dtype_code, tuple(lengths), batch, scale, inplace, strided)
+    p = _plan_cache.get(key)
+    if p is None:
+        p = _plan_cache[key] = FFTPlan(kind, dtype_code, lengths, batch, scale, inplace, strided)
+    return p
+
+
+def clear_plan_cache():
+    _plan_cache.clear()
+
+
+# ------------------------------------------------------------ mass assignment
+def ngp_assign(x, y, z, values, npar, dtype=torch.float64):
+    """``value_map[(npar*x).astype(int), ...] = values`` with last-write-wins
+    (PowerSpectrum3D._read_data, power_spectrum_3d.py:142-148)."""
+    x, y, z, values = (as_device(a, dtype) for a in (x, y, z, values))
+    n = int(npar)
+    grid = torch.empty((n, n, n), dtype=dtype, device=device())
+    owner = torch.empty(n * n * n, dtype=torch.int32, device=device())
+    dropped = torch.zeros(1, dtype=torch.int64, device=device())
+    check(_lib.lib().ast_ngp_assign(ptr(x), ptr(y), ptr(z), ptr(values), real_code(grid), x.numel(), n,
+                                    ptr(grid), ptr(owner), ptr(dropped), stream()), "ast_ngp_assign")
+    nd = int(dropped.item())
+    if nd:
+        raise IndexError(f"{nd} particles have coordinates outside [0, 1) (numpy would raise too)")
+    return grid
+
+
+def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="auto",
+          x_start=0, nx_alloc=None, check_dropped=True):
+    """pmesh ``ParticleMesh.paint(pos, mass=, resampler=)`` on the GPU.
+
+    pos: (Np, 3) CUDA tensor (float32/float64); mass: (Np,) or None.
+    Returns the accumulated grid ``(nx_alloc, nmesh, nmesh)`` in pos.dtype.
+    method: "direct" (global float atomics), "tiled" (LDS tiles) or "auto".
+    """
+    L = _lib.lib()
+    n = int(nmesh)
+    nx = n if nx_alloc is None else int(nx_alloc)
+    assert pos.is_cuda and pos.dim() == 2 and pos.shape[1] == 3 and pos.is_contiguous()
+    code = real_code(pos)
+    if mass is not None:
+        assert mass.is_cuda and mass.dtype == pos.dtype and mass.numel() == pos.shape[0] and mass.is_contiguous()
+    if out is None:
+        out = torch.zeros((nx, n, n), dtype=pos.dtype, device=pos.device)
+    else:
+        assert out.is_cuda and out.dtype == pos.dtype and out.numel() == nx * n * n and out.is_contiguous()
+    win = _lib.WIN[window.lower()]
+    npart = pos.shape[0]
+    dropped = torch.zeros(1, dtype=torch.int64, device=pos.device)
+    ws_bytes = 0
+    if method in ("auto", "tiled") and win != 0 and npart < 2**32 - 1:
+        ws_bytes = int(L.ast_paint_tiled_workspace_bytes(npart, n, nx))
+    if method == "tiled" and ws_bytes == 0:
+        raise _lib.AstrildHipError("tiled paint needs a CIC/TSC window and nmesh a multiple of 32")
+    use_tiled = ws_bytes > 0 and (method == "tiled" or npart >= 65536)
+    if use_tiled:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pos.device)
+        check(L.ast_paint_tiled(win, code, ptr(pos), ptr(mass), npart, n, float(boxsize), float(scale),
+                                int(x_start), nx, ptr(out), ptr(ws), ws_bytes, ptr(dropped), stream()),
+              "ast_paint_tiled")
+    else:
+        check(L.ast_paint(win, code, ptr(pos), ptr(mass), npart, n, float(boxsize), float(scale),
+                          int(x_start), nx, ptr(out), ptr(dropped), stream()), "ast_paint")
+    if check_dropped:
+        nd = int(dropped.item())
+        if nd:
+            raise _lib.AstrildHipError(f"{nd} deposits fell outside the grid buffer "
+                                       f"(x_start={x_start}, nx_alloc={nx})")
+    return out
+
+
+def synth_lattice_particles(npside, nmesh, boxsize, seed=20240601, sigma_cells=0.5, shuffle=False,
+                            dtype=torch.float32, first=0, count=None):
+    """Synthetic particle set of SURVEY.md §8(d), generated directly in HBM."""
+    n3 = int(npside) ** 3
+    count = n3 - first if count is None else int(count)
+    pos = torch.empty((count, 3), dtype=dtype, device=device())
+    stride = 0
+    if shuffle:
+        stride = 2654435761 % n3            # odd -> coprime with power-of-two n3; checked below otherwise
+        while np.gcd(stride, n3) != 1:
+            stride += 1
+    check(_lib.lib().ast_synth_lattice_particles(ptr(pos), real_code(pos), int(first), count, int(npside),
+                                                 float(boxsize), float(sigma_cells) * boxsize / nmesh,
+                                                 int(seed), int(stride), stream()), "ast_synth_lattice_particles")
+    return pos
+
+
+# ---------------------------------------------------------------- 3D spectra
+def r2c(field, out=None):
+    """pmesh-normalised forward transform: ``rfftn(field) / Ng`` (rocFFT, 3D R2C)."""
+    assert field.is_cuda and field.dim() == 3 and field.is_contiguous()
+    n0, n1, n2 = field.shape
+    code = real_code(field)
+    if out is None:
+        out = torch.empty((n0, n1, n2 // 2 + 1), dtype=_TO_CPLX[field.dtype], device=field.device)
+    plan = fft_plan(_lib.FFT_R2C, code, (n0, n1, n2), 1, 1.0 / (n0 * n1 * n2), False)
+    plan.execute(field, out)
+    return out
+
+
+def power_bin_1d(spec1, spec2, nmesh, boxsize, i0=None, i1=None, sums=None):
+    """Shell sums (ksum, psum, nmodes) of a block of the half spectrum (device tensors)."""
+    n = int(nmesh)
+    nb = n // 2 - 1
+    i0 = (0, n) if i0 is None else i0
+    i1 = (0, n) if i1 is None else i1
+    assert spec1.is_cuda and spec1.is_contiguous() and spec1.numel() == i0[1] * i1[1] * (n // 2 + 1)
+    code = _CPLX[spec1.dtype]
+    if spec2 is not None:
+        assert spec2.dtype == spec1.dtype and spec2.numel() == spec1.numel() and spec2.is_contiguous()
+    if sums is None:
+        dev = spec1.device
+        sums = (torch.zeros(nb, dtype=torch.float64, device=dev), torch.zeros(nb, dtype=torch.float64, device=dev),
+                torch.zeros(nb, dtype=torch.int64, device=dev))
+    ksum, psum, nmodes = sums
+    check(_lib.lib().ast_power_bin_1d(ptr(spec1), ptr(spec2), code, n, float(boxsize), int(i0[0]), int(i0[1]),
+                                      int(i1[0]), int(i1[1]), ptr(ksum), ptr(psum), ptr(nmodes), stream()),
+          "ast_power_bin_1d")
+    return sums
+
+
+def finish_power(ksum, psum, nmodes):
+    """k = ksum/N, P = psum/N on the host; empty shells are NaN like nbodykit's 0/0."""
+    ks, ps, nm = (t.cpu().numpy() for t in (ksum, psum, nmodes))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return {"k": ks / nm, "power": ps / nm, "modes": nm, "shotnoise": 0.0}
+
+
+def fftpower_1d(field1, boxsize, field2=None):
+    """``FFTPower(first, mode="1d", kmin=2*pi/L[, second])`` for in-memory grids
+    (nbodykit call sites: power_spectrum_3d.py:189-224, stats_subfind.py:142-150)."""
+    n = field1.shape[0]
+    assert tuple(field1.shape) == (n, n, n) and n % 2 == 0
+    s1 = r2c(field1)
+    s2 = None if field2 is None else r2c(field2)
+    return finish_power(*power_bin_1d(s1, s2, n, boxsize))

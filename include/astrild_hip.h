@@ -1,0 +1,253 @@
+/*
+ * astrild_hip.h — C-ABI of libastrild_hip.so, the MI355X (gfx950) drop-in for
+ * the numerics underneath astrild's post-processing hot path.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes; no exceptions cross the boundary.
+ *   - Every pointer named *_d / documented "device" is HBM (hipMalloc'd, or
+ *     the data_ptr() of a PyTorch-ROCm tensor used as a memory holder).
+ *   - The caller owns every buffer.  Plans own only their rocFFT work area.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); the
+ *     call enqueues work on it and returns without synchronising, unless the
+ *     doc says "synchronous".
+ *   - Return value: AST_OK (0) or a negative AST_ERR_*; ast_last_error()
+ *     returns a thread-local message for the last failure.
+ *   - dtype: AST_F32 / AST_F64 selects the element type of particle and grid
+ *     buffers (spectra are the matching interleaved complex type).
+ *
+ * Each entry cites the reference interface it replaces (paths relative to
+ * /root/reference/src/astrild/).
+ */
+#ifndef ASTRILD_HIP_H
+#define ASTRILD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AST_OK 0
+#define AST_ERR_ARG (-1)
+#define AST_ERR_HIP (-2)
+#define AST_ERR_ROCFFT (-3)
+#define AST_ERR_WORKSPACE (-4)
+
+#define AST_F32 0
+#define AST_F64 1
+
+#define AST_WIN_NGP 0
+#define AST_WIN_CIC 1
+#define AST_WIN_TSC 2
+
+#define AST_FFT_R2C 0 /* real forward  */
+#define AST_FFT_C2R 1 /* real inverse  */
+#define AST_FFT_C2C_FWD 2
+#define AST_FFT_C2C_INV 3
+
+int ast_version(void);
+const char* ast_last_error(void);
+
+/* ---------------------------------------------------------------- utility */
+
+/* buf[i] = value, i < count. */
+int ast_fill(void* buf_d, int dtype, size_t count, double value, void* stream);
+
+/* buf[i] /= divisor (IEEE division, bit-exact with numpy).  Replaces
+ * SkyUtils.convert_code_to_phy_units (rays/skys/sky_utils.py:318-339:
+ * kappa/shear/deflt / c^2, isw_rs / c^3) and the `/ dx**3` of
+ * particles/hutils/stats_subfind.py:132. */
+int ast_divide(void* buf_d, int dtype, size_t count, double divisor, void* stream);
+
+/* Synthetic "Gaussian-random" particle set of SURVEY.md §8(d), generated in
+ * HBM: lattice point q = (i+1/2, j+1/2, k+1/2) L/npside (k fastest) plus
+ * sigma * N(0,1) per component, wrapped into [0, L).  Counter-based
+ * generator keyed by (seed, particle index, component); particles
+ * [first, first+count) of the lattice are written to pos_d as (count, 3).
+ * `shuffle_stride` != 0 visits the lattice in the order
+ * p -> (p * shuffle_stride) mod npside^3 (a fixed permutation when the
+ * stride is coprime with npside^3): the scatter-unfriendly ordering.
+ * Bench / test plumbing, not part of the reference. */
+int ast_synth_lattice_particles(void* pos_d, int dtype, size_t first, size_t count,
+                                int npside, double boxsize, double sigma,
+                                uint64_t seed, uint64_t shuffle_stride, void* stream);
+
+/* ----------------------------------------------- a-1 / a-2: mass assignment */
+
+/* NGP scatter-ASSIGN with numpy's last-write-wins semantics.  Replaces
+ * PowerSpectrum3D._read_data, power_spectra/power_spectrum_3d.py:142-148:
+ *     idx = (npar * coord).astype(int);  value_map[(x, y, z)] = values
+ * x_d, y_d, z_d, values_d: np elements each (DataFrame columns, SoA).
+ * grid_d: npar^3 elements, C order (axis 0 slowest); zero-filled by the call.
+ * owner_d: npar^3 uint32 scratch.  np must be < 2^32 - 1.  Coordinates must
+ * lie in [0, 1) like the reference requires (numpy would raise IndexError
+ * otherwise); out-of-range particles are counted in *dropped_d (device
+ * uint64, may be NULL) and skipped. */
+int ast_ngp_assign(const void* x_d, const void* y_d, const void* z_d, const void* values_d,
+                   int dtype, size_t np, int npar, void* grid_d, uint32_t* owner_d,
+                   unsigned long long* dropped_d, void* stream);
+
+/* Mass-weighted scatter-ADD with a separable NGP / CIC / TSC window.
+ * Replaces pmesh ParticleMesh(Nmesh=[n]*3, BoxSize=L).paint(pos, mass=,
+ * resampler=) as called at particles/hutils/stats_subfind.py:130-131 (and the
+ * window='TSC' meshes of power_spectrum_3d.py:197-212).
+ *   pos_d:  (np, 3) AoS, box units; any real value wraps periodically.
+ *   mass_d: np elements or NULL (unit mass).
+ *   scale:  every deposit is multiplied by it (1/dx^3 folds the division of
+ *           stats_subfind.py:132 into the paint; 1.0 = pmesh behaviour).
+ *   grid_d: ACCUMULATED into (caller zero-fills).  It holds nx_alloc planes
+ *           of nmesh x nmesh cells: buffer plane p is global axis-0 plane
+ *           (x_start + p) mod nmesh.  Single GPU: x_start = 0,
+ *           nx_alloc = nmesh.  Slab-decomposed: the rank's owned planes plus
+ *           its ghost planes.  Deposits falling outside the buffer are
+ *           counted in *dropped_d (device uint64, may be NULL) and skipped.
+ * Index/fraction arithmetic is float64 for both dtypes; the accumulation is
+ * in `dtype` with hardware atomics (sum order is not reproducible). */
+int ast_paint(int window, int dtype, const void* pos_d, const void* mass_d, size_t np,
+              int nmesh, double boxsize, double scale, int x_start, int nx_alloc,
+              void* grid_d, unsigned long long* dropped_d, void* stream);
+
+/* Same result as ast_paint, for the CIC/TSC windows, through LDS-resident
+ * grid tiles: particles are run-length grouped by the tile of their base
+ * cell (no particle data is moved), each workgroup accumulates one tile in
+ * LDS and flushes it once.  workspace_d must hold
+ * ast_paint_tiled_workspace_bytes(np, nmesh, nx_alloc) bytes. */
+size_t ast_paint_tiled_workspace_bytes(size_t np, int nmesh, int nx_alloc);
+int ast_paint_tiled(int window, int dtype, const void* pos_d, const void* mass_d, size_t np,
+                    int nmesh, double boxsize, double scale, int x_start, int nx_alloc,
+                    void* grid_d, void* workspace_d, size_t workspace_bytes,
+                    unsigned long long* dropped_d, void* stream);
+
+/* dst[i] += src[i] — ghost-plane fold after a slab paint. */
+int ast_accumulate(void* dst_d, const void* src_d, int dtype, size_t count, void* stream);
+
+/* ------------------------------------------------------------- a-4: FFTs */
+
+typedef struct ast_fft_plan ast_fft_plan;
+
+/* rocFFT plan.  lengths[] are in C (row-major) order, slowest axis first,
+ * like numpy shapes.  Real transforms keep the half spectrum on the LAST
+ * axis (lengths[rank-1]/2+1 complex values).  `scale` multiplies every
+ * output element (1/Ng gives pmesh's r2c normalisation used by nbodykit
+ * FFTPower, power_spectrum_3d.py:189-195).  Contiguous layouts.  The plan
+ * allocates its rocFFT work buffer with hipMalloc. */
+int ast_fft_plan_create(ast_fft_plan** plan, int kind, int dtype, int rank,
+                        const size_t* lengths, size_t batch, double scale, int inplace);
+
+/* Complex 1-D transforms of length `length` with element stride `stride`,
+ * `batch` of them `dist` elements apart (in place) — the axis-0 pass of the
+ * slab-decomposed 3D FFT. */
+int ast_fft_plan_create_strided_1d(ast_fft_plan** plan, int kind, int dtype, size_t length,
+                                   size_t stride, size_t batch, size_t dist, double scale);
+
+size_t ast_fft_plan_work_bytes(const ast_fft_plan* plan);
+int ast_fft_exec(ast_fft_plan* plan, void* in_d, void* out_d, void* stream);
+int ast_fft_plan_destroy(ast_fft_plan* plan);
+
+/* ---------------------------------------------- a-5: k-shell power binning */
+
+/* FFTPower(mode="1d", dk = kmin = 2 pi / L) shell sums over a block of the
+ * half spectrum.  Replaces nbodykit project_to_basis as reached from
+ * power_spectrum_3d.py:189-224 and stats_subfind.py:142-150.
+ *   spec1_d, spec2_d: interleaved complex, dims (i0_count, i1_count,
+ *       nmesh/2+1), C order, holding pmesh-normalised delta_k (spec2_d NULL =
+ *       auto spectrum).  Global integer frequencies of the first two axes
+ *       start at i0_start / i1_start (single GPU: 0, nmesh, 0, nmesh).
+ *   ksum_d, psum_d (double) and nmodes_d (int64), nmesh/2-1 bins each, are
+ *       ACCUMULATED into (caller zero-fills):  sum w |k|,
+ *       sum w Re(d1 conj(d2)) L^3,  sum w,  with Hermitian weight w = 2 for
+ *       0 < i2 < nmesh/2 else 1.  Shell of a mode: isqrt(|m|^2) - 1 in exact
+ *       integer arithmetic; the DC mode and |m| >= nmesh/2 are dropped.
+ *   k = ksum/nmodes, P = psum/nmodes is left to the caller so that slab
+ *       partials can be summed first. */
+int ast_power_bin_1d(const void* spec1_d, const void* spec2_d, int dtype, int nmesh,
+                     double boxsize, int i0_start, int i0_count, int i1_start, int i1_count,
+                     double* ksum_d, double* psum_d, long long* nmodes_d, void* stream);
+
+/* --------------------------------------------------- a-10: bispectrum */
+
+/* out = in * 1[shell(m) == shell] (or just the indicator when in_d is NULL)
+ * over the same spectrum block layout as ast_power_bin_1d. */
+int ast_shell_filter(const void* in_d, void* out_d, int dtype, int nmesh, int shell,
+                     int i0_start, int i0_count, int i1_start, int i1_count, void* stream);
+
+/* *out_d += sum_i a[i] * b[i] * c[i]  (double accumulator, device). */
+int ast_triple_product_sum(const void* a_d, const void* b_d, const void* c_d, int dtype,
+                           size_t count, double* out_d, void* stream);
+
+/* ------------------------------------------------- slab transpose helpers */
+
+/* Pack the (n0, n1, n2) complex block so that the n1 axis is split into
+ * `parts` equal chunks, each stored contiguously as (n0, n1/parts, n2):
+ * the send layout of the slab all-to-all.  unpack is the inverse for the
+ * receive side: `parts` blocks of (n0, n1, n2) -> one (parts*n0, n1, n2)
+ * array is already contiguous, so only pack is needed on the way out and
+ * this inverse on the way back (c2r). */
+int ast_slab_pack(const void* in_d, void* out_d, int dtype, size_t n0, size_t n1, size_t n2,
+                  int parts, void* stream);
+int ast_slab_unpack(const void* in_d, void* out_d, int dtype, size_t n0, size_t n1, size_t n2,
+                    int parts, void* stream);
+
+/* ------------------------------------------------------ a-7: kappa stack */
+
+/* out[i] = sum_p planes[p][i] * wnum[p] / wden[p], added in plane order
+ * p = 0..nplanes-1 exactly like the reference's running `+=`
+ * (rays/rayramses.py:224-232, simcoll.py:322-336) with the lensing-kernel
+ * re-weighting quantity * g(x_mid, x_s') / g(x_mid, x_s) of
+ * rayramses.py:306-312 / simcoll.py:424-430.  planes_d: device array of
+ * nplanes device pointers; wnum_d / wden_d: device doubles or NULL (no
+ * re-weighting).  fp64 results are bit-identical to numpy. */
+int ast_kappa_stack(const void* const* planes_d, const double* wnum_d, const double* wden_d,
+                    int nplanes, size_t count, int dtype, void* out_d, void* stream);
+
+/* --------------------------------------- a-8 / a-9: per-map kappa pipeline */
+
+typedef struct ast_lens_plan ast_lens_plan;
+
+/* Plan for kappa -> (alpha1, alpha2) / phi on an nc x nc map of side bsz
+ * [rad]: owns the (2nc)^2 rocFFT plans, the padded work arrays and the cached
+ * spectra of the isotropic kernels of lensing_funcs.c:45-83,117-148. */
+int ast_lens_plan_create(ast_lens_plan** plan, int nc, double bsz);
+int ast_lens_plan_destroy(ast_lens_plan* plan);
+/* Device-pointer variants (fp64, C-contiguous nc*nc). */
+int ast_kappa_to_alphas(ast_lens_plan* plan, const double* kappa_d, double* alpha1_d,
+                        double* alpha2_d, void* stream);
+int ast_kappa_to_phi(ast_lens_plan* plan, const double* kappa_d, double* phi_d, void* stream);
+
+/* libglsg.so-compatible entry points (rays/skys/lib_so_cgls/lensing_funcs.h:5,7;
+ * bound by ctypes at rays/skys/sky_utils.py:402-435): HOST pointers,
+ * caller-allocated outputs, synchronous, void return like the original. */
+void kappa0_to_alphas(double* kappa0, int Nc, double bsz, double* alpha1, double* alpha2);
+void kappa0_to_phi(double* kappa0, int Nc, double bsz, double* phi);
+
+typedef struct ast_smooth_plan ast_smooth_plan;
+
+/* Gaussian smoothing of an npix x npix fp64 map (Filters.gaussian,
+ * rays/utils/filters.py:181-225 -> lenstools ConvergenceMap.smooth):
+ *   mode 0 "gaussianFFT": irfft2(exp(-0.5 l^2 (2 pi sigma_px)^2) rfft2(img)),
+ *          l from (r)fftfreq(npix) — periodic.
+ *   mode 1 "gaussian": separable real-space kernel, reflect boundary,
+ *          truncate 4 sigma (scipy.ndimage.gaussian_filter).
+ * In place on img_d. */
+int ast_smooth_plan_create(ast_smooth_plan** plan, int npix);
+int ast_smooth_plan_destroy(ast_smooth_plan* plan);
+int ast_gaussian_smooth(ast_smooth_plan* plan, double* img_d, double sigma_px, int mode,
+                        void* stream);
+
+/* min and max of a buffer -> out_d[0], out_d[1] (double, device). */
+int ast_minmax(const void* buf_d, int dtype, size_t count, double* out_d, void* stream);
+
+/* np.histogram(data, bins=nbins, range=(lo, hi)) counts: uniform bins,
+ * right-most bin closed (SkyArray.pdf, rays/skys/sky_array.py:428-433).
+ * counts_d (int64, nbins) is ACCUMULATED into. */
+int ast_histogram(const void* buf_d, int dtype, size_t count, double lo, double hi, int nbins,
+                  long long* counts_d, void* stream);
+
+/* out[i] = a[i] + b[i]  (add_galaxy_shape_noise, sky_array.py:693-706). */
+int ast_add(const void* a_d, const void* b_d, void* out_d, int dtype, size_t count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASTRILD_HIP_H */

@@ -1,0 +1,192 @@
+"""GPU parity: HIP mass assignment + rocFFT + shell binning vs the oracle.
+
+Tolerances: indices / mode counts / NGP assignment bit-exact; fp64 floats
+1e-12 (sum order only); fp32 floats 1e-6 relative (north_star tolerance).
+"""
+import numpy as np
+import pytest
+
+from oracle import mesh as omesh, fftpower as offt
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev(hip):
+    from astrild_amd import device
+    torch.cuda.set_device(0)
+    return device
+
+
+def _tt(dtype):
+    return torch.float32 if dtype == np.float32 else torch.float64
+
+
+@pytest.mark.parametrize("method", ["direct", "tiled"])
+@pytest.mark.parametrize("window", ["ngp", "cic", "tsc"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_paint_random_particles_with_mass(dev, method, window, dtype):
+    if method == "tiled" and window == "ngp":
+        pytest.skip("tiled path is CIC/TSC only")
+    rng = np.random.default_rng(11)
+    n, L, npart = 64, 250.0, 70000
+    pos = rng.uniform(-0.3 * L, 1.3 * L, size=(npart, 3)).astype(dtype)   # wraps on both sides
+    mass = rng.uniform(0.5, 2.0, size=npart).astype(dtype)
+    got = dev.paint(dev.as_device(pos), dev.as_device(mass), n, L, window, method=method).cpu().numpy()
+    ref = omesh.paint(pos, mass, n, L, window)
+    tol = 1e-12 if dtype == np.float64 else 2e-6
+    np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * ref.max())
+    assert got.sum(dtype=np.float64) == pytest.approx(mass.sum(dtype=np.float64), rel=1e-6)
+
+
+@pytest.mark.parametrize("method", ["direct", "tiled"])
+@pytest.mark.parametrize("window", ["cic", "tsc"])
+def test_paint_lattice_particles_natural_and_shuffled(dev, method, window):
+    n, L = 64, 1000.0
+    for shuffle in (False, True):
+        pos = omesh.lattice_particles(n, n, L, seed=20240601, shuffle=shuffle, dtype=np.float32)
+        got = dev.paint(dev.as_device(pos), None, n, L, window, method=method).cpu().numpy()
+        ref = omesh.paint(pos, None, n, L, window)
+        np.testing.assert_allclose(got, ref, rtol=2e-6, atol=2e-6)
+
+
+def test_paint_scale_folds_cell_volume(dev):
+    rng = np.random.default_rng(3)
+    n, L = 32, 500.0
+    pos = rng.uniform(0, L, size=(5000, 3))
+    dx = L / n
+    got = dev.paint(dev.as_device(pos), None, n, L, "tsc", scale=1.0 / dx**3, method="direct").cpu().numpy()
+    ref = omesh.paint(pos, None, n, L, "tsc") / dx**3          # stats_subfind.py:131-132
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12 * ref.max())
+
+
+@pytest.mark.parametrize("method", ["direct", "tiled"])
+@pytest.mark.parametrize("window", ["cic", "tsc"])
+def test_paint_slab_buffer_with_ghost_planes(dev, method, window):
+    # rank owning planes [16, 32) of a 64-grid, one ghost plane each side
+    rng = np.random.default_rng(5)
+    n, L = 64, 64.0
+    pos = rng.uniform(0, L, size=(40000, 3))
+    s = pos[:, 0] * (n / L)
+    base = np.floor(s) if window == "cic" else np.floor(s + 0.5)
+    own = (base >= 16) & (base < 32)
+    mine = np.ascontiguousarray(pos[own])
+    x_start, nx_alloc = 15, 18
+    got = dev.paint(dev.as_device(mine), None, n, L, window, method=method,
+                    x_start=x_start, nx_alloc=nx_alloc).cpu().numpy()
+    ref = omesh.paint(mine, None, n, L, window)[x_start:x_start + nx_alloc]
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
+    # a particle outside the buffer must be reported, not silently lost
+    with pytest.raises(Exception):
+        dev.paint(dev.as_device(pos), None, n, L, window, method=method, x_start=x_start, nx_alloc=nx_alloc)
+
+
+def test_paint_empty_and_single_particle(dev):
+    n, L = 32, 32.0
+    empty = torch.empty((0, 3), dtype=torch.float64, device="cuda")
+    assert float(dev.paint(empty, None, n, L, "cic", method="direct").abs().sum()) == 0.0
+    one = np.array([[31.25, 0.5, 3.0]])
+    got = dev.paint(dev.as_device(one), None, n, L, "cic", method="tiled").cpu().numpy()
+    np.testing.assert_array_equal(got, omesh.paint(one, None, n, L, "cic"))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_ngp_assign_bit_exact_last_write_wins(dev, dtype):
+    rng = np.random.default_rng(9)
+    npar, npart = 32, 120000                       # ~3.7 particles per cell: many duplicates
+    x, y, z = (rng.uniform(0, 1, npart).astype(dtype) for _ in range(3))
+    x[x >= 1] = 0
+    y[y >= 1] = 0
+    z[z >= 1] = 0
+    v = rng.standard_normal(npart).astype(dtype)
+    got = dev.ngp_assign(x, y, z, v, npar, dtype=_tt(dtype)).cpu().numpy()
+    ref = omesh.ngp_assign(x, y, z, v, npar)
+    np.testing.assert_array_equal(got.astype(np.float64), ref)
+    with pytest.raises(IndexError):
+        dev.ngp_assign(np.array([1.5]), np.array([0.1]), np.array([0.1]), np.array([1.0]), 8)
+
+
+@pytest.mark.parametrize("n", [16, 32, 64])
+def test_mode_counts_and_k_bit_exact(dev, n):
+    f = torch.zeros((n, n, n), dtype=torch.float64, device="cuda")
+    res = dev.fftpower_1d(f, 123.0)
+    ref = offt.fftpower_1d(np.zeros((n, n, n)), 123.0)
+    np.testing.assert_array_equal(res["modes"], ref["modes"])
+    np.testing.assert_array_equal(res["modes"], offt.brute_force_mode_counts(n))
+    np.testing.assert_allclose(res["k"], ref["k"], rtol=1e-14)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-12), (np.float32, 1e-6)])
+def test_fftpower_white_noise_field(dev, dtype, tol):
+    rng = np.random.default_rng(21)
+    n, L = 64, 200.0
+    f = (1.0 + 0.3 * rng.standard_normal((n, n, n))).astype(dtype)
+    res = dev.fftpower_1d(dev.as_device(f), L)
+    ref = offt.fftpower_1d(f, L)
+    np.testing.assert_array_equal(res["modes"], ref["modes"])
+    np.testing.assert_allclose(res["k"], ref["k"], rtol=1e-14)
+    np.testing.assert_allclose(res["power"], ref["power"].real, rtol=tol)
+
+
+def test_fftpower_cross_spectrum(dev):
+    rng = np.random.default_rng(22)
+    n, L = 32, 50.0
+    f1 = rng.standard_normal((n, n, n))
+    f2 = 0.5 * f1 + rng.standard_normal((n, n, n))
+    res = dev.fftpower_1d(dev.as_device(f1), L, dev.as_device(f2))
+    ref = offt.fftpower_1d(f1, L, f2)
+    np.testing.assert_allclose(res["power"], ref["power"].real, rtol=1e-11, atol=1e-12 * abs(ref["power"]).max())
+
+
+def test_plane_wave_known_answer(dev):
+    n, L, A = 32, 100.0, 0.3
+    x = np.arange(n) / n
+    m = (2, -3, 4)
+    f = 5.0 + A * np.cos(2 * np.pi * (m[0] * x[:, None, None] + m[1] * x[None, :, None] + m[2] * x[None, None, :]))
+    res = dev.fftpower_1d(dev.as_device(f), L)
+    shell = int(np.floor(np.sqrt(29))) - 1
+    exp = np.zeros(n // 2 - 1)
+    exp[shell] = 2 * (A * A / 4) * L**3 / res["modes"][shell]
+    np.testing.assert_allclose(res["power"], exp, atol=1e-9 * L**3)
+
+
+@pytest.mark.parametrize("method", ["direct", "tiled"])
+def test_pipeline_cic_pk_lattice_fp32_vs_oracle(dev, method):
+    # configs[0]-shaped: 64^3 here to keep the oracle in seconds; same code path as 128^3
+    n, L = 64, 1000.0
+    pos = omesh.lattice_particles(n, n, L, dtype=np.float32)
+    grid = dev.paint(dev.as_device(pos), None, n, L, "cic", method=method)
+    res = dev.fftpower_1d(grid, L)
+    ref = offt.fftpower_1d(omesh.paint(pos, None, n, L, "cic"), L)
+    np.testing.assert_array_equal(res["modes"], ref["modes"])
+    # fp32 grid + fp32 FFT: measured deviation is reported in DESIGN.md; cold-lattice low-k
+    # shells carry ~1e-5 of the Nyquist power, so compare against the spectrum's peak
+    np.testing.assert_allclose(res["power"], ref["power"].real, rtol=1e-4, atol=1e-6 * ref["power"].real.max())
+
+
+def test_pipeline_cic_pk_fp64_tight(dev):
+    n, L = 64, 1000.0
+    pos = omesh.lattice_particles(n, n, L, seed=7)
+    grid = dev.paint(dev.as_device(pos), None, n, L, "cic", method="tiled")
+    res = dev.fftpower_1d(grid, L)
+    ref = offt.fftpower_1d(omesh.paint(pos, None, n, L, "cic"), L)
+    np.testing.assert_array_equal(res["modes"], ref["modes"])
+    np.testing.assert_allclose(res["power"], ref["power"].real, rtol=1e-9)
+
+
+def test_synthetic_generator_statistics(dev):
+    n, L = 64, 1000.0
+    pos = dev.synth_lattice_particles(n, n, L, seed=1, dtype=torch.float64).cpu().numpy()
+    g = (np.arange(n) + 0.5) * (L / n)
+    q = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
+    d = pos - q
+    d -= L * np.round(d / L)
+    sigma = 0.5 * L / n
+    assert abs(d.mean()) < 4 * sigma / np.sqrt(d.size)
+    assert d.std() == pytest.approx(sigma, rel=5e-3)
+    assert pos.min() >= 0 and pos.max() < L
+    sh = dev.synth_lattice_particles(n, n, L, seed=1, shuffle=True, dtype=torch.float64).cpu().numpy()
+    # same multiset of particles, different order
+    np.testing.assert_allclose(np.sort(sh[:, 0]), np.sort(pos[:, 0]), rtol=0, atol=0)
+    assert not np.array_equal(sh, pos)
