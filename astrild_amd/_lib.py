@@ -26,6 +26,8 @@ _vp, _sz, _i, _d, _u64 = ct.c_void_p, ct.c_size_t, ct.c_int, ct.c_double, ct.c_u
 SIGNATURES = {
     "ast_version": (_i, []),
     "ast_last_error": (ct.c_char_p, []),
+    "ast_profile_enable": (_i, [_i]),
+    "ast_profile_report": (_i, [ct.c_char_p, _sz]),
     "ast_fill": (_i, [_vp, _i, _sz, _d, _vp]),
     "ast_divide": (_i, [_vp, _i, _sz, _d, _vp]),
     "ast_synth_lattice_particles": (_i, [_vp, _i, _sz, _sz, _i, _d, _d, _u64, _u64, _vp]),
@@ -72,6 +74,10 @@ def lib():
                 "(python -c 'import __graft_entry__ as g; g.build()'). "
                 "astrild_amd has no CPU fallback."
             )
+        # torch ships its own libamdhip64 / librocfft; load it FIRST so this library
+        # binds to the same HIP runtime instance that owns the tensors' memory and
+        # streams (two runtimes in one process do not share devices or pointers).
+        import torch  # noqa: F401
         handle = ct.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)     # AttributeError = header/library mismatch

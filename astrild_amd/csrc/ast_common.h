@@ -20,7 +20,18 @@ inline unsigned stream_grid(size_t work_items, unsigned block) {
     return (unsigned)(need > 2048 ? 2048 : need);
 }
 
+// Optional per-launch HIP-event timing (ast_profile_enable): a scope records an
+// event pair on the launch stream; ast_profile_report aggregates by name.
+struct ProfScope {
+    ProfScope(const char* name, hipStream_t s);
+    ~ProfScope();
+    int slot;
+    hipStream_t stream;
+};
+
 }  // namespace ast
+
+#define AST_PROF(name, stream) ast::ProfScope ast_prof_scope_(name, stream)
 
 #define AST_CHECK_ARG(cond)                                              \
     do {                                                                 \

@@ -132,6 +132,7 @@ extern "C" int ast_fft_exec(ast_fft_plan* plan, void* in, void* out, void* strea
     AST_CHECK_FFT(rocfft_execution_info_set_stream(plan->info, stream));
     void* ib[1] = {in};
     void* ob[1] = {out};
+    AST_PROF("rocfft_execute", ast::as_stream(stream));
     AST_CHECK_FFT(rocfft_execute(plan->plan, ib, plan->inplace ? nullptr : ob, plan->info));
     return AST_OK;
 }

@@ -185,6 +185,7 @@ extern "C" int ast_kappa_stack(const void* const* planes, const double* wnum, co
     if (count == 0) return AST_OK;
     unsigned g = ast::stream_grid(count, 256);
     hipStream_t s = ast::as_stream(stream);
+    AST_PROF("kappa_stack", s);
     if (dtype == AST_F32)
         kappa_stack_kernel<float><<<g, 256, 0, s>>>((const float* const*)planes, wnum, wden, nplanes, count, (float*)out);
     else
@@ -242,9 +243,13 @@ static int lens_kernel_spectrum(ast_lens_plan* p, int which, hipStream_t s) {
 
 static int lens_convolve(ast_lens_plan* p, int which, double* out, hipStream_t s) {
     const size_t n2 = 2 * (size_t)p->nc, nh = n2 / 2 + 1;
-    cmul_kernel<<<ast::stream_grid(n2 * nh, 256), 256, 0, s>>>(p->spec, p->kspec[which], p->prod, n2 * nh);
+    {
+        AST_PROF("lens.cmul", s);
+        cmul_kernel<<<ast::stream_grid(n2 * nh, 256), 256, 0, s>>>(p->spec, p->kspec[which], p->prod, n2 * nh);
+    }
     AST_CHECK_LAUNCH();
     AST_FWD(ast_fft_exec(p->c2r, p->prod, p->pad, s));
+    AST_PROF("lens.crop_scale", s);
     crop_scale_kernel<<<ast::stream_grid((size_t)p->nc * p->nc, 256), 256, 0, s>>>(p->pad, p->nc, p->bsz / (double)p->nc, out);
     AST_CHECK_LAUNCH();
     return AST_OK;
@@ -252,7 +257,10 @@ static int lens_convolve(ast_lens_plan* p, int which, double* out, hipStream_t s
 
 static int lens_forward(ast_lens_plan* p, const double* kappa, hipStream_t s) {
     const size_t n2 = 2 * (size_t)p->nc;
-    zero_pad_kernel<<<ast::stream_grid(n2 * n2, 256), 256, 0, s>>>(kappa, p->nc, p->pad);
+    {
+        AST_PROF("lens.zero_pad", s);
+        zero_pad_kernel<<<ast::stream_grid(n2 * n2, 256), 256, 0, s>>>(kappa, p->nc, p->pad);
+    }
     AST_CHECK_LAUNCH();
     return ast_fft_exec(p->r2c, p->pad, p->spec, s);
 }
@@ -368,7 +376,10 @@ extern "C" int ast_gaussian_smooth(ast_smooth_plan* p, double* img, double sigma
     if (mode == 0) {
         const size_t nh = npix / 2 + 1;
         AST_FWD(ast_fft_exec(p->r2c, img, p->spec, s));
-        gauss_fft_filter_kernel<<<ast::stream_grid((size_t)npix * nh, 256), 256, 0, s>>>(p->spec, npix, sigma_px);
+        {
+            AST_PROF("smooth.gauss_filter", s);
+            gauss_fft_filter_kernel<<<ast::stream_grid((size_t)npix * nh, 256), 256, 0, s>>>(p->spec, npix, sigma_px);
+        }
         AST_CHECK_LAUNCH();
         return ast_fft_exec(p->c2r, p->spec, img, s);
     }

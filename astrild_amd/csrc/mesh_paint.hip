@@ -10,44 +10,12 @@
 // positions the product x * (n/L) would otherwise lose ~1e-4 of a cell at
 // n = 1024, which shows up at the 1e-4 level in low-k power of cold lattices.
 #include "ast_common.h"
+#include "paint_window.h"
 
 namespace {
 
-template <int W> struct Window;
-template <> struct Window<1> {   // NGP: support 1, left 0, shift 0.5
-    __device__ static inline void eval(double s, long long& i0, double* w) {
-        i0 = (long long)floor(s + 0.5);
-        w[0] = 1.0;
-    }
-};
-template <> struct Window<2> {   // CIC
-    __device__ static inline void eval(double s, long long& i0, double* w) {
-        double fl = floor(s);
-        double f = s - fl;
-        i0 = (long long)fl;
-        double a = 1.0 - f, b = f, sum = a + b;
-        w[0] = a / sum;
-        w[1] = b / sum;
-    }
-};
-template <> struct Window<3> {   // TSC
-    __device__ static inline void eval(double s, long long& i0, double* w) {
-        double ic = floor(s + 0.5);
-        double d = s - ic;
-        i0 = (long long)ic - 1;
-        double hm = 0.5 - d, hp = 0.5 + d;
-        double a = 0.5 * (hm * hm), b = 0.75 - d * d, c = 0.5 * (hp * hp);
-        double sum = (a + b) + c;
-        w[0] = a / sum;
-        w[1] = b / sum;
-        w[2] = c / sum;
-    }
-};
-
-__device__ inline int wrap(long long i, int n) {
-    long long r = i % n;
-    return (int)(r < 0 ? r + n : r);
-}
+using ast::Window;
+using ast::wrap;
 
 template <typename T, int W>
 __global__ void __launch_bounds__(256)
@@ -60,9 +28,9 @@ paint_direct_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_
         double sx = (double)pos[3 * p + 0] * inv_dx;
         double sy = (double)pos[3 * p + 1] * inv_dx;
         double sz = (double)pos[3 * p + 2] * inv_dx;
-        double m = (mass ? (double)mass[p] : 1.0) * scale;
+        const T m = (T)((mass ? (double)mass[p] : 1.0) * scale);
         long long ix0, iy0, iz0;
-        double wx[W], wy[W], wz[W];
+        T wx[W], wy[W], wz[W];
         Window<W>::eval(sx, ix0, wx);
         Window<W>::eval(sy, iy0, wy);
         Window<W>::eval(sz, iz0, wz);
@@ -81,13 +49,13 @@ paint_direct_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_
                 ++ndrop;
                 continue;
             }
-            double ma = m * wx[a];
+            const T ma = m * wx[a];
 #pragma unroll
             for (int b = 0; b < W; ++b) {
-                double mab = ma * wy[b];
+                const T mab = ma * wy[b];
                 T* row = grid + ((size_t)px * n + jy[b]) * n;
 #pragma unroll
-                for (int c = 0; c < W; ++c) atomicAdd(row + jz[c], (T)(mab * wz[c]));
+                for (int c = 0; c < W; ++c) atomicAdd(row + jz[c], mab * wz[c]);
             }
         }
     }
@@ -136,6 +104,7 @@ int launch_paint(int window, const T* pos, const T* mass, size_t np, int n, doub
                  hipStream_t s) {
     const double inv_dx = (double)n / boxsize;
     unsigned g = ast::stream_grid(np, 256);
+    AST_PROF("paint_direct", s);
     switch (window) {
         case AST_WIN_NGP:
             paint_direct_kernel<T, 1><<<g, 256, 0, s>>>(pos, mass, np, n, inv_dx, scale, x_start, nx_alloc, grid, dropped);
@@ -185,6 +154,7 @@ extern "C" int ast_ngp_assign(const void* x, const void* y, const void* z, const
     if (np == 0) return AST_OK;
     AST_CHECK_ARG(x && y && z && values);
     unsigned g = ast::stream_grid(np, 256);
+    AST_PROF("ngp_assign", s);
     if (dtype == AST_F32) {
         ngp_owner_kernel<float><<<g, 256, 0, s>>>((const float*)x, (const float*)y, (const float*)z, np, npar, owner, dropped);
         ngp_write_kernel<float><<<g, 256, 0, s>>>((const float*)x, (const float*)y, (const float*)z, (const float*)values, np, npar, owner, (float*)grid);

@@ -4,58 +4,32 @@
 // MI355X (MI355X_MICROARCH.md "Global float atomics"), so the deposit is
 // restructured so that all 8 / 27 updates of a particle land in LDS:
 //
-//   A  run scan   one thread per particle (coalesced position loads): tile id
-//                 of its base cell; inside each wave, consecutive particles
-//                 with the same tile form a run {tile, first particle, length}.
-//                 Only run heads allocate a slot and bump the tile's run count.
-//                 No particle data is moved or copied.
-//   B  scan       exclusive prefix sum of the per-tile run counts.
-//   C  bucket     runs are written tile-major.
-//   D  deposit    one workgroup per tile: zero an LDS tile (+ window halo),
-//                 each wave walks runs of this tile (a run is a contiguous
-//                 piece of the particle array, so the loads stay coalesced),
-//                 ds_add_f32/f64 into LDS, one flush of the tile to HBM.
+//   A1 count   one thread per particle (coalesced position loads): tile id of
+//              its base cell.  Inside a wave, consecutive particles of the same
+//              tile form a run; only the run head bumps the tile's particle
+//              count (one atomic per run, not per particle).
+//   B  scan    exclusive prefix sum of the per-tile counts.
+//   A2 fill    same walk; the run head reserves `len` slots of the tile's
+//              segment of a particle-INDEX list and the run's lanes write
+//              their 4-byte indices there (coalesced for coherent input).
+//              Particle data itself is never moved.
+//   D  deposit one workgroup per tile: zero an LDS tile (+ window halo), walk
+//              the tile's index segment with all 256 lanes, gather positions,
+//              ds_add_f32/f64 into LDS, flush the tile to HBM once.
 //
 // Spatially coherent input (lattice / Morton / slab ordered snapshots) gives
-// long runs and the run list is tiny; fully shuffled input degrades to one run
-// per particle — still correct, and no slower than a key-value sort would be.
+// long runs: few atomics in A1/A2 and coalesced gathers in D.  Fully shuffled
+// input degrades to one run per particle — still correct.
 #include "ast_common.h"
+#include "paint_window.h"
+#include <cstdlib>
 
 namespace {
 
+using ast::Window;
+using ast::wrap;
+
 constexpr int TX = 8, TY = 8, TZ = 32;   // owned cells per tile
-
-template <int W> struct Win;
-template <> struct Win<2> {
-    static constexpr int LO = 0;
-    __device__ static inline void eval(double s, long long& i0, double* w) {
-        double fl = floor(s);
-        double f = s - fl;
-        i0 = (long long)fl;
-        double a = 1.0 - f, b = f, sum = a + b;
-        w[0] = a / sum;
-        w[1] = b / sum;
-    }
-};
-template <> struct Win<3> {
-    static constexpr int LO = 1;
-    __device__ static inline void eval(double s, long long& i0, double* w) {
-        double ic = floor(s + 0.5);
-        double d = s - ic;
-        i0 = (long long)ic - 1;
-        double hm = 0.5 - d, hp = 0.5 + d;
-        double a = 0.5 * (hm * hm), b = 0.75 - d * d, c = 0.5 * (hp * hp);
-        double sum = (a + b) + c;
-        w[0] = a / sum;
-        w[1] = b / sum;
-        w[2] = c / sum;
-    }
-};
-
-__device__ inline int wrapi(long long i, int n) {
-    long long r = i % n;
-    return (int)(r < 0 ? r + n : r);
-}
 
 struct TileGeom {
     int n, x_start, nx_alloc;
@@ -66,53 +40,71 @@ struct TileGeom {
 // base cell (window centre for TSC, lower corner for CIC) -> tile id, or
 // 0xffffffff when the base plane is outside the buffer.
 template <typename T, int W>
-__device__ inline uint32_t tile_of(const T* pos, size_t p, const TileGeom& g) {
-    long long i0;
-    double w[W];
-    Win<W>::eval((double)pos[3 * p + 0] * g.inv_dx, i0, w);
-    int bx = wrapi(i0 + Win<W>::LO, g.n) - g.x_start;
+__device__ inline uint32_t tile_of(T x, T y, T z, const TileGeom& g) {
+    int bx = wrap(ast::base_cell<W>((double)x * g.inv_dx), g.n) - g.x_start;
     if (bx < 0) bx += g.n;
     if (bx >= g.nx_alloc) return 0xffffffffu;
-    Win<W>::eval((double)pos[3 * p + 1] * g.inv_dx, i0, w);
-    int by = wrapi(i0 + Win<W>::LO, g.n);
-    Win<W>::eval((double)pos[3 * p + 2] * g.inv_dx, i0, w);
-    int bz = wrapi(i0 + Win<W>::LO, g.n);
+    const int by = wrap(ast::base_cell<W>((double)y * g.inv_dx), g.n);
+    const int bz = wrap(ast::base_cell<W>((double)z * g.inv_dx), g.n);
     return (uint32_t)(((bx / TX) * g.nty + by / TY) * g.ntz + bz / TZ);
 }
 
-// run entry: tile (25 bits) | length (7 bits, 1..64 stored as len-1... 6 bits + spare) | first particle (32 bits)
-__device__ inline uint64_t pack_run(uint32_t tile, uint32_t len, uint32_t start) {
-    return ((uint64_t)tile << 39) | ((uint64_t)(len - 1) << 32) | start;
+// Run structure of one wave's 64 consecutive particles.
+struct WaveRuns {
+    bool head;       // this lane starts a run
+    int len;         // run length (valid on head lanes)
+    int head_lane;   // lane of the head of the run this lane belongs to (live lanes)
+};
+
+__device__ inline WaveRuns wave_runs(uint32_t key, bool live, int lane) {
+    WaveRuns r;
+    const uint32_t prev = __shfl_up(key, 1, 64);
+    r.head = live && (lane == 0 || prev != key);
+    const unsigned long long hmask = __ballot(r.head);
+    const unsigned long long dmask = __ballot(!live);
+    const unsigned long long above = ~((2ull << lane) - 1ull);           // bits > lane (lane 63: none)
+    const unsigned long long stop = (hmask | dmask) & above;
+    const int end = stop ? __ffsll((long long)stop) - 1 : 64;
+    r.len = end - lane;
+    const unsigned long long at_or_below = hmask & ~above;
+    r.head_lane = at_or_below ? 63 - __clzll((long long)at_or_below) : 0;
+    return r;
 }
 
-template <typename T, int W>
+constexpr int IDX_UNROLL = 4;   // particles per thread per trip: keeps 12 loads in flight
+
+template <typename T, int W, bool FILL>
 __global__ void __launch_bounds__(256)
-run_scan_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint64_t* __restrict__ runs,
-                unsigned long long* __restrict__ nruns, uint32_t* __restrict__ tile_count,
-                unsigned long long* dropped) {
+tile_index_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t* __restrict__ tile_count,
+                  const uint32_t* __restrict__ tile_off, uint32_t* __restrict__ tile_fill,
+                  uint32_t* __restrict__ index, unsigned long long* dropped) {
     const int lane = threadIdx.x & 63;
-    const size_t nchunks = (np + 255) / 256;
-    for (size_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        const size_t p = chunk * 256 + threadIdx.x;
-        const bool valid = p < np;
-        uint32_t key = valid ? tile_of<T, W>(pos, p, g) : 0xffffffffu;
-        const bool live = key != 0xffffffffu;
-        const uint32_t prev = __shfl_up(key, 1, 64);
-        const bool head = live && (lane == 0 || prev != key);
-        // a run ends where the next head starts or at the first dead lane
-        const unsigned long long hmask = __ballot(head);
-        const unsigned long long dmask = __ballot(!live);
-        if (valid && !live && dropped) atomicAdd(dropped, 1ull);
-        if (hmask == 0) continue;
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(nruns, (unsigned long long)__popcll(hmask));
-        base = __shfl(base, 0, 64);
-        if (head) {
-            const unsigned long long stop = (hmask | dmask) & ~((2ull << lane) - 1ull);  // bits above lane
-            const int end = stop ? __ffsll((long long)stop) - 1 : 64;
-            const unsigned long long below = hmask & ((1ull << lane) - 1ull);
-            runs[base + __popcll(below)] = pack_run(key, (uint32_t)(end - lane), (uint32_t)p);
-            atomicAdd(&tile_count[key], 1u);
+    const size_t per_trip = 256 * IDX_UNROLL;
+    const size_t ntrips = (np + per_trip - 1) / per_trip;
+    for (size_t trip = blockIdx.x; trip < ntrips; trip += gridDim.x) {
+        T x[IDX_UNROLL], y[IDX_UNROLL], z[IDX_UNROLL];
+#pragma unroll
+        for (int u = 0; u < IDX_UNROLL; ++u) {
+            const size_t p = trip * per_trip + (size_t)u * 256 + threadIdx.x;
+            if (p < np) { x[u] = pos[3 * p + 0]; y[u] = pos[3 * p + 1]; z[u] = pos[3 * p + 2]; }
+            else { x[u] = y[u] = z[u] = (T)0; }
+        }
+#pragma unroll
+        for (int u = 0; u < IDX_UNROLL; ++u) {
+            const size_t p = trip * per_trip + (size_t)u * 256 + threadIdx.x;
+            const bool valid = p < np;
+            const uint32_t key = valid ? tile_of<T, W>(x[u], y[u], z[u], g) : 0xffffffffu;
+            const bool live = key != 0xffffffffu;
+            const WaveRuns r = wave_runs(key, live, lane);
+            if (!FILL) {
+                if (r.head) atomicAdd(&tile_count[key], (uint32_t)r.len);
+                if (valid && !live && dropped) atomicAdd(dropped, 1ull);
+            } else {
+                uint32_t base = 0;
+                if (r.head) base = tile_off[key] + atomicAdd(&tile_fill[key], (uint32_t)r.len);
+                base = __shfl(base, r.head_lane, 64);
+                if (live) index[base + (uint32_t)(lane - r.head_lane)] = (uint32_t)p;
+            }
         }
     }
 }
@@ -140,7 +132,7 @@ scan_blocks_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, 
 }
 
 __global__ void __launch_bounds__(256)
-scan_sums_kernel(uint32_t* block_sums, uint32_t nblocks, uint32_t* total_out) {
+scan_sums_kernel(uint32_t* block_sums, uint32_t nblocks) {
     // single workgroup, serial over 256-wide strips (nblocks <= 32768)
     __shared__ uint32_t carry, wsum[4];
     if (threadIdx.x == 0) carry = 0;
@@ -161,7 +153,6 @@ scan_sums_kernel(uint32_t* block_sums, uint32_t nblocks, uint32_t* total_out) {
         if (threadIdx.x == 255) carry = woff + inc;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total_out = carry;
 }
 
 __global__ void __launch_bounds__(256)
@@ -172,94 +163,95 @@ scan_add_kernel(uint32_t* out, const uint32_t* __restrict__ block_sums, uint32_t
     for (int i = 0; i < 4; ++i) if (base + i < n) out[base + i] += add;
 }
 
-__global__ void __launch_bounds__(256)
-bucket_runs_kernel(const uint64_t* __restrict__ runs, const unsigned long long* __restrict__ nruns,
-                   const uint32_t* __restrict__ tile_off, uint32_t* __restrict__ tile_fill,
-                   uint64_t* __restrict__ sorted) {
-    const unsigned long long nr = *nruns;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nr; i += stride) {
-        const uint64_t r = runs[i];
-        const uint32_t tile = (uint32_t)(r >> 39);
-        const uint32_t slot = tile_off[tile] + atomicAdd(&tile_fill[tile], 1u);
-        sorted[slot] = r;
-    }
-}
-
 template <typename T, int W>
 __global__ void __launch_bounds__(256)
 tile_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileGeom g, double scale,
-                    const uint64_t* __restrict__ sorted, const uint32_t* __restrict__ tile_off,
+                    const uint32_t* __restrict__ index, const uint32_t* __restrict__ tile_off,
                     const uint32_t* __restrict__ tile_count, T* __restrict__ grid,
-                    unsigned long long* dropped) {
+                    unsigned long long* dropped, int ablate) {
     constexpr int LX = TX + W - 1, LY = TY + W - 1, LZ = TZ + W - 1;
-    constexpr int LO = Win<W>::LO;
-    __shared__ T tile[LX * LY * LZ];
+    constexpr int LO = Window<W>::LO;
+    // ds_add_f32 retires ~0.33 lanes/clk/CU on gfx950 against ~7 for ds_add_f64
+    // (scripts/micro/lds_atomics.hip), so the LDS tile accumulates in double for
+    // both grid dtypes and is rounded to T once, at the flush.
+    __shared__ double tile[LX * LY * LZ];
     const uint32_t t = blockIdx.x;
-    const uint32_t nr = tile_count[t];
-    if (nr == 0) return;                       // uniform for the workgroup
-    const uint32_t r0 = tile_off[t];
-    for (int i = threadIdx.x; i < LX * LY * LZ; i += 256) tile[i] = (T)0;
+    const uint32_t cnt = tile_count[t];
+    if (cnt == 0) return;                       // uniform for the workgroup
+    const uint32_t off = tile_off[t];
+    for (int i = threadIdx.x; i < LX * LY * LZ; i += 256) tile[i] = 0.0;
     __syncthreads();
 
     const int tz = t % g.ntz, ty = (t / g.ntz) % g.nty, tx = t / (g.ntz * g.nty);
     const int ox = tx * TX, oy = ty * TY, oz = tz * TZ;   // owned origin (buffer plane / global y, z)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t r = wave; r < nr; r += 4) {
-        const uint64_t run = sorted[r0 + r];
-        const uint32_t start = (uint32_t)run;
-        const int len = (int)((run >> 32) & 0x7f) + 1;
-        if (lane < len) {
-            const size_t p = (size_t)start + lane;
+    constexpr int U = 4;
+    for (uint32_t i0 = 0; i0 < cnt; i0 += 256 * U) {
+        T px[U], py[U], pz[U], pm[U];
+        bool on[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t i = i0 + u * 256 + threadIdx.x;
+            on[u] = i < cnt;
+            const size_t p = on[u] ? index[off + i] : 0;
+            px[u] = on[u] ? pos[3 * p + 0] : (T)0;
+            py[u] = on[u] ? pos[3 * p + 1] : (T)0;
+            pz[u] = on[u] ? pos[3 * p + 2] : (T)0;
+            pm[u] = (on[u] && mass) ? mass[p] : (T)1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!on[u]) continue;
             long long ix0, iy0, iz0;
-            double wx[W], wy[W], wz[W];
-            Win<W>::eval((double)pos[3 * p + 0] * g.inv_dx, ix0, wx);
-            Win<W>::eval((double)pos[3 * p + 1] * g.inv_dx, iy0, wy);
-            Win<W>::eval((double)pos[3 * p + 2] * g.inv_dx, iz0, wz);
-            int bx = wrapi(ix0 + LO, g.n) - g.x_start;
+            T wx[W], wy[W], wz[W];
+            Window<W>::eval((double)px[u] * g.inv_dx, ix0, wx);
+            Window<W>::eval((double)py[u] * g.inv_dx, iy0, wy);
+            Window<W>::eval((double)pz[u] * g.inv_dx, iz0, wz);
+            int bx = wrap(ix0 + LO, g.n) - g.x_start;
             if (bx < 0) bx += g.n;
-            const int lx = bx - ox;                               // 0..TX-1 by construction of the run
-            const int ly = wrapi(iy0 + LO, g.n) - oy;
-            const int lz = wrapi(iz0 + LO, g.n) - oz;
-            const double m = (mass ? (double)mass[p] : 1.0) * scale;
+            const int lx = bx - ox;                               // 0..TX-1 by construction of the index
+            const int ly = wrap(iy0 + LO, g.n) - oy;
+            const int lz = wrap(iz0 + LO, g.n) - oz;
+            const T m = (T)((double)pm[u] * scale);
 #pragma unroll
             for (int a = 0; a < W; ++a) {
-                const double ma = m * wx[a];
+                const T ma = m * wx[a];
 #pragma unroll
                 for (int b = 0; b < W; ++b) {
-                    const double mab = ma * wy[b];
-                    T* row = &tile[((lx + a) * LY + (ly + b)) * LZ + lz];
+                    const T mab = ma * wy[b];
+                    double* row = &tile[((lx + a) * LY + (ly + b)) * LZ + lz];
 #pragma unroll
-                    for (int c = 0; c < W; ++c) atomicAdd(row + c, (T)(mab * wz[c]));
+                    for (int c = 0; c < W; ++c) {
+                        if (ablate & 2) { T v = mab * wz[c]; asm volatile("" ::"v"(v), "v"(row)); }
+                        else atomicAdd(row + c, (double)(mab * wz[c]));
+                    }
                 }
             }
         }
     }
     __syncthreads();
+    if (ablate & 1) return;
 
     // flush: LDS cell (a, b, c) is buffer plane ox + a - LO, global (oy + b - LO, oz + c - LO)
     unsigned long long ndrop = 0;
     for (int i = threadIdx.x; i < LX * LY * LZ; i += 256) {
-        const T v = tile[i];
+        const T v = (T)tile[i];
         if (v == (T)0) continue;
         const int c = i % LZ, b = (i / LZ) % LY, a = i / (LZ * LY);
         int px = ox + a - LO;
-        if (g.nx_alloc == g.n) px = wrapi(px, g.n);
+        if (g.nx_alloc == g.n) px = wrap(px, g.n);
         else if (px < 0 || px >= g.nx_alloc) { ++ndrop; continue; }
-        const int gy = wrapi(oy + b - LO, g.n), gz = wrapi(oz + c - LO, g.n);
+        const int gy = wrap(oy + b - LO, g.n), gz = wrap(oz + c - LO, g.n);
         atomicAdd(&grid[((size_t)px * g.n + gy) * g.n + gz], v);
     }
     if (dropped && ndrop) atomicAdd(dropped, ndrop);
 }
 
 struct Workspace {
-    unsigned long long* nruns;      // [0] run counter, [1] scan total (as u32)
     uint32_t* tile_count;
-    uint32_t* tile_off;
     uint32_t* tile_fill;
+    uint32_t* tile_off;
     uint32_t* block_sums;
-    uint64_t* runs;
-    uint64_t* sorted;
+    uint32_t* index;
     size_t bytes;
 };
 
@@ -269,13 +261,11 @@ Workspace carve(void* base, size_t np, uint32_t ntiles) {
     Workspace w;
     size_t off = 0;
     auto take = [&](size_t bytes) { void* p = (char*)base + off; off += align256(bytes); return p; };
-    w.nruns = (unsigned long long*)take(64);
     w.tile_count = (uint32_t*)take((size_t)ntiles * 4);
     w.tile_fill = (uint32_t*)take((size_t)ntiles * 4);
     w.tile_off = (uint32_t*)take((size_t)ntiles * 4);
     w.block_sums = (uint32_t*)take((size_t)((ntiles + 1023) / 1024 + 1) * 4);
-    w.runs = (uint64_t*)take(np * 8);
-    w.sorted = (uint64_t*)take(np * 8);
+    w.index = (uint32_t*)take(np * 4);
     w.bytes = off;
     return w;
 }
@@ -288,7 +278,7 @@ bool tiled_geometry(int nmesh, int nx_alloc, TileGeom& g, uint32_t& ntiles) {
     g.nty = nmesh / TY;
     g.ntz = nmesh / TZ;
     const unsigned long long nt = (unsigned long long)g.ntx * g.nty * g.ntz;
-    if (nt >= (1ull << 25)) return false;
+    if (nt >= (1ull << 31)) return false;
     ntiles = (uint32_t)nt;
     return true;
 }
@@ -297,18 +287,28 @@ template <typename T, int W>
 int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntiles, double scale, T* grid,
               void* workspace, unsigned long long* dropped, hipStream_t s) {
     Workspace w = carve(workspace, np, ntiles);
-    // counters, tile_count, tile_fill are contiguous at the front of the workspace
-    const size_t zero_bytes = (size_t)((char*)w.tile_off - (char*)w.nruns);
-    AST_CHECK_HIP(hipMemsetAsync(w.nruns, 0, zero_bytes, s));
-    const size_t nchunks = (np + 255) / 256;
-    unsigned ga = (unsigned)(nchunks > 8192 ? 8192 : nchunks);
-    run_scan_kernel<T, W><<<ga, 256, 0, s>>>(pos, np, g, w.runs, w.nruns, w.tile_count, dropped);
+    // tile_count and tile_fill are contiguous at the front of the workspace
+    AST_CHECK_HIP(hipMemsetAsync(w.tile_count, 0, (size_t)((char*)w.tile_off - (char*)w.tile_count), s));
+    const size_t ntrips = (np + 256 * IDX_UNROLL - 1) / (256 * IDX_UNROLL);
+    const unsigned ga = (unsigned)(ntrips > 16384 ? 16384 : ntrips);
+    {
+        AST_PROF("paint_tiled.count", s);
+        tile_index_kernel<T, W, false><<<ga, 256, 0, s>>>(pos, np, g, w.tile_count, nullptr, nullptr, nullptr, dropped);
+    }
     const uint32_t nblk = (ntiles + 1023) / 1024;
-    scan_blocks_kernel<<<nblk, 256, 0, s>>>(w.tile_count, w.tile_off, w.block_sums, ntiles);
-    scan_sums_kernel<<<1, 256, 0, s>>>(w.block_sums, nblk, (uint32_t*)(w.nruns + 1));
-    scan_add_kernel<<<nblk, 256, 0, s>>>(w.tile_off, w.block_sums, ntiles);
-    bucket_runs_kernel<<<2048, 256, 0, s>>>(w.runs, w.nruns, w.tile_off, w.tile_fill, w.sorted);
-    tile_deposit_kernel<T, W><<<ntiles, 256, 0, s>>>(pos, mass, g, scale, w.sorted, w.tile_off, w.tile_count, grid, dropped);
+    {
+        AST_PROF("paint_tiled.scan", s);
+        scan_blocks_kernel<<<nblk, 256, 0, s>>>(w.tile_count, w.tile_off, w.block_sums, ntiles);
+        scan_sums_kernel<<<1, 256, 0, s>>>(w.block_sums, nblk);
+        scan_add_kernel<<<nblk, 256, 0, s>>>(w.tile_off, w.block_sums, ntiles);
+    }
+    {
+        AST_PROF("paint_tiled.fill", s);
+        tile_index_kernel<T, W, true><<<ga, 256, 0, s>>>(pos, np, g, nullptr, w.tile_off, w.tile_fill, w.index, nullptr);
+    }
+    AST_PROF("paint_tiled.deposit", s);
+    tile_deposit_kernel<T, W><<<ntiles, 256, 0, s>>>(pos, mass, g, scale, w.index, w.tile_off, w.tile_count, grid, dropped,
+                                                     getenv("AST_PAINT_ABLATE") ? atoi(getenv("AST_PAINT_ABLATE")) : 0);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
@@ -337,7 +337,7 @@ extern "C" int ast_paint_tiled(int window, int dtype, const void* pos, const voi
     TileGeom g;
     uint32_t ntiles = 0;
     if (!tiled_geometry(nmesh, nx_alloc, g, ntiles)) {
-        ast::set_error("ast_paint_tiled: nmesh must be a multiple of %d with fewer than 2^25 tiles", TZ);
+        ast::set_error("ast_paint_tiled: nmesh must be a multiple of %d", TZ);
         return AST_ERR_ARG;
     }
     g.x_start = x_start;

@@ -3,10 +3,10 @@
 // slab pack/unpack of the distributed transpose.
 //
 // Binning layout: one wave walks one (i0, i1) row of the spectrum with its 64
-// lanes along the contiguous half axis, so loads are coalesced and the shell
-// index is monotone across lanes.  Equal-shell runs are summed inside the wave
-// with a segmented shuffle reduction; only run heads touch the workgroup's
-// LDS shell table, which is flushed to HBM once per workgroup.
+// lanes along the contiguous half axis, so loads are coalesced; lanes add into
+// the workgroup's LDS shell table, which is flushed to HBM once per workgroup.
+// The data-independent sums (sum w|k|, sum w) come from a separate geometry
+// kernel so the data pass carries one LDS atomic per mode instead of three.
 #include "ast_common.h"
 
 namespace {
@@ -14,9 +14,10 @@ namespace {
 __device__ inline int freq(int i, int n) { return i > n / 2 ? i - n : i; }
 
 __device__ inline int isqrt_i(long long v) {
-    int r = (int)sqrt((double)v);
-    while ((long long)r * r > v) --r;
-    while ((long long)(r + 1) * (r + 1) <= v) ++r;
+    // |m|^2 <= 3 * 4096^2 < 2^26: the float sqrt is within 1 of the integer root
+    int r = (int)__fsqrt_rn((float)v);
+    if ((long long)r * r > v) --r;
+    if ((long long)(r + 1) * (r + 1) <= v) ++r;
     return r;
 }
 
@@ -26,18 +27,18 @@ template <> struct cplx_traits<double2> { using real = double; };
 
 constexpr int MAX_SHELLS = 4096;  // nmesh <= 8192
 
+// Data pass: psum only.  One wave per (i0, i1) row, lanes along the contiguous
+// half axis (coalesced 8/16-byte loads); every lane adds its weighted power
+// straight into the workgroup's LDS shell table (ds_add_f64), which is flushed
+// to HBM once per workgroup.  Along a row the shell index moves by at most one
+// per mode, so same-address conflicts inside a wave stay short.
 template <typename C>
 __global__ void __launch_bounds__(256)
-power_bin_kernel(const C* __restrict__ s1, const C* __restrict__ s2, int n, double pnorm, double kf,
-                 int i0_start, int i0_count, int i1_start, int i1_count,
-                 double* ksum, double* psum, unsigned long long* nmodes) {
-    extern __shared__ unsigned char smem[];
+power_bin_kernel(const C* __restrict__ s1, const C* __restrict__ s2, int n, double pnorm,
+                 int i0_start, int i0_count, int i1_start, int i1_count, double* psum) {
+    extern __shared__ double lp[];
     const int nb = n / 2 - 1;
-    const int nslots = nb + 2;                       // slot 0: below first edge, slot nb+1: beyond last
-    double* lk = reinterpret_cast<double*>(smem);
-    double* lp = lk + nslots;
-    unsigned long long* lm = reinterpret_cast<unsigned long long*>(lp + nslots);
-    for (int i = threadIdx.x; i < nslots; i += blockDim.x) { lk[i] = 0.0; lp[i] = 0.0; lm[i] = 0ull; }
+    for (int i = threadIdx.x; i < nb + 2; i += blockDim.x) lp[i] = 0.0;
     __syncthreads();
 
     const int nz = n / 2 + 1;
@@ -52,44 +53,55 @@ power_bin_kernel(const C* __restrict__ s1, const C* __restrict__ s2, int n, doub
         const long long base = (long long)m0 * m0 + (long long)m1 * m1;
         const C* r1 = s1 + (size_t)row * nz;
         const C* r2 = s2 ? s2 + (size_t)row * nz : nullptr;
-        for (int z0 = 0; z0 < nz; z0 += 64) {
-            const int iz = z0 + lane;
-            int slot = nb + 1;
-            double pv = 0.0, kv = 0.0;
-            unsigned long long mv = 0;
-            if (iz < nz) {
-                const long long m2 = base + (long long)iz * iz;
-                const int sh = isqrt_i(m2);           // shell = sh - 1
-                slot = sh > nb ? nb + 1 : sh;         // sh == 0 (DC) -> slot 0
-                const C x = r1[iz];
-                const C y = r2 ? r2[iz] : x;
-                const double w = (iz > 0 && iz < n / 2) ? 2.0 : 1.0;
-                pv = w * ((double)x.x * (double)y.x + (double)x.y * (double)y.y);
-                kv = w * sqrt((double)m2);
-                mv = (unsigned long long)w;
-            }
-            // segmented reduction over runs of equal slot (slot is monotone in lane)
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int os = __shfl_down(slot, off, 64);
-                const double op = __shfl_down(pv, off, 64);
-                const double ok = __shfl_down(kv, off, 64);
-                const unsigned long long om = __shfl_down(mv, off, 64);
-                if (lane + off < 64 && os == slot) { pv += op; kv += ok; mv += om; }
-            }
-            const int prev = __shfl_up(slot, 1, 64);
-            if ((lane == 0 || prev != slot) && slot >= 1 && slot <= nb) {
-                atomicAdd(&lp[slot], pv);
-                atomicAdd(&lk[slot], kv);
-                atomicAdd(&lm[slot], mv);
-            }
+        for (int iz = lane; iz < nz; iz += 64) {
+            const int sh = isqrt_i(base + (long long)iz * iz);   // shell = sh - 1; sh == 0 is the DC mode
+            if (sh < 1 || sh > nb) continue;
+            const C x = r1[iz];
+            const C y = r2 ? r2[iz] : x;
+            const double w = (iz > 0 && iz < n / 2) ? 2.0 : 1.0;
+            atomicAdd(&lp[sh], w * ((double)x.x * (double)y.x + (double)x.y * (double)y.y));
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+        const double v = lp[i + 1];
+        if (v != 0.0) atomicAdd(&psum[i], v * pnorm);
+    }
+}
+
+// Geometry pass: sum w |k| and sum w per shell depend only on the lattice block,
+// not on the data; callers cache them per (nmesh, L, block).
+__global__ void __launch_bounds__(256)
+shell_geometry_kernel(int n, double kf, int i0_start, int i0_count, int i1_start, int i1_count,
+                      double* ksum, unsigned long long* nmodes) {
+    extern __shared__ double lk[];
+    const int nb = n / 2 - 1;
+    unsigned long long* lm = reinterpret_cast<unsigned long long*>(lk + nb + 2);
+    for (int i = threadIdx.x; i < nb + 2; i += blockDim.x) { lk[i] = 0.0; lm[i] = 0ull; }
+    __syncthreads();
+    const int nz = n / 2 + 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+    const long long nrows = (long long)i0_count * i1_count;
+    for (long long row = (long long)blockIdx.x * waves_per_block + wave; row < nrows;
+         row += (long long)gridDim.x * waves_per_block) {
+        const int a = (int)(row / i1_count), b = (int)(row % i1_count);
+        const int m0 = freq(i0_start + a, n), m1 = freq(i1_start + b, n);
+        const long long base = (long long)m0 * m0 + (long long)m1 * m1;
+        for (int iz = lane; iz < nz; iz += 64) {
+            const long long m2 = base + (long long)iz * iz;
+            const int sh = isqrt_i(m2);
+            if (sh < 1 || sh > nb) continue;
+            const unsigned long long w = (iz > 0 && iz < n / 2) ? 2ull : 1ull;
+            atomicAdd(&lk[sh], (double)w * sqrt((double)m2));
+            atomicAdd(&lm[sh], w);
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nb; i += blockDim.x) {
         const unsigned long long m = lm[i + 1];
         if (m) {
-            atomicAdd(&psum[i], lp[i + 1] * pnorm);
             atomicAdd(&ksum[i], lk[i + 1] * kf);
             atomicAdd(&nmodes[i], m);
         }
@@ -152,7 +164,9 @@ slab_pack_kernel(const C* __restrict__ in, C* __restrict__ out, size_t n0, size_
 extern "C" int ast_power_bin_1d(const void* spec1, const void* spec2, int dtype, int nmesh, double boxsize,
                                 int i0_start, int i0_count, int i1_start, int i1_count,
                                 double* ksum, double* psum, long long* nmodes, void* stream) {
-    AST_CHECK_ARG(spec1 && ksum && psum && nmodes);
+    AST_CHECK_ARG((spec1 && psum) || (!spec1 && !spec2 && !psum));
+    AST_CHECK_ARG((ksum == nullptr) == (nmodes == nullptr));
+    AST_CHECK_ARG(psum || ksum);
     AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
     AST_CHECK_ARG(nmesh >= 4 && nmesh % 2 == 0 && nmesh / 2 - 1 <= MAX_SHELLS && boxsize > 0.0);
     AST_CHECK_ARG(i0_start >= 0 && i0_count >= 0 && i0_start + i0_count <= nmesh);
@@ -160,19 +174,27 @@ extern "C" int ast_power_bin_1d(const void* spec1, const void* spec2, int dtype,
     const long long nrows = (long long)i0_count * i1_count;
     if (nrows == 0) return AST_OK;
     const int nb = nmesh / 2 - 1;
-    const size_t lds = (size_t)(nb + 2) * (2 * sizeof(double) + sizeof(unsigned long long));
     const double kf = 2.0 * M_PI / boxsize;
     const double pnorm = boxsize * boxsize * boxsize;
-    long long need = (nrows + 3) / 4;
-    unsigned g = (unsigned)(need > 2048 ? 2048 : need);
-    auto* nm = reinterpret_cast<unsigned long long*>(nmodes);
+    const long long need = (nrows + 3) / 4;
+    const unsigned g = (unsigned)(need > 4096 ? 4096 : need);
     hipStream_t s = ast::as_stream(stream);
-    if (dtype == AST_F32)
-        power_bin_kernel<float2><<<g, 256, lds, s>>>((const float2*)spec1, (const float2*)spec2, nmesh, pnorm, kf,
-                                                      i0_start, i0_count, i1_start, i1_count, ksum, psum, nm);
-    else
-        power_bin_kernel<double2><<<g, 256, lds, s>>>((const double2*)spec1, (const double2*)spec2, nmesh, pnorm, kf,
-                                                       i0_start, i0_count, i1_start, i1_count, ksum, psum, nm);
+    if (psum) {
+        AST_PROF("power_bin", s);
+        const size_t lds = (size_t)(nb + 2) * sizeof(double);
+        if (dtype == AST_F32)
+            power_bin_kernel<float2><<<g, 256, lds, s>>>((const float2*)spec1, (const float2*)spec2, nmesh, pnorm,
+                                                          i0_start, i0_count, i1_start, i1_count, psum);
+        else
+            power_bin_kernel<double2><<<g, 256, lds, s>>>((const double2*)spec1, (const double2*)spec2, nmesh, pnorm,
+                                                           i0_start, i0_count, i1_start, i1_count, psum);
+    }
+    if (ksum) {
+        AST_PROF("shell_geometry", s);
+        const size_t lds = (size_t)(nb + 2) * (sizeof(double) + sizeof(unsigned long long));
+        shell_geometry_kernel<<<g, 256, lds, s>>>(nmesh, kf, i0_start, i0_count, i1_start, i1_count, ksum,
+                                                   reinterpret_cast<unsigned long long*>(nmodes));
+    }
     AST_CHECK_LAUNCH();
     return AST_OK;
 }

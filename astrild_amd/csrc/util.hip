@@ -4,6 +4,8 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 namespace ast {
 static thread_local char g_err[512] = "";
@@ -13,7 +15,61 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+namespace {
+struct ProfRec { const char* name; hipEvent_t a, b; };
+std::mutex g_prof_mutex;
+std::vector<ProfRec> g_prof;
+bool g_prof_on = false;
+}  // namespace
+
+ProfScope::ProfScope(const char* name, hipStream_t s) : slot(-1), stream(s) {
+    if (!g_prof_on) return;
+    ProfRec r{name, nullptr, nullptr};
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, s);
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    g_prof.push_back(r);
+    slot = (int)g_prof.size() - 1;
+}
+ProfScope::~ProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    if (slot < (int)g_prof.size()) (void)hipEventRecord(g_prof[slot].b, stream);
+}
+
 }  // namespace ast
+
+extern "C" int ast_profile_enable(int on) {
+    std::lock_guard<std::mutex> lock(ast::g_prof_mutex);
+    for (auto& r : ast::g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    ast::g_prof.clear();
+    ast::g_prof_on = on != 0;
+    return AST_OK;
+}
+
+extern "C" int ast_profile_report(char* buf, size_t cap) {
+    AST_CHECK_ARG(buf != nullptr && cap > 0);
+    std::lock_guard<std::mutex> lock(ast::g_prof_mutex);
+    struct Agg { const char* name; int calls; double ms; };
+    std::vector<Agg> agg;
+    for (auto& r : ast::g_prof) {
+        if (hipEventSynchronize(r.b) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        bool found = false;
+        for (auto& a : agg) if (strcmp(a.name, r.name) == 0) { a.calls++; a.ms += ms; found = true; break; }
+        if (!found) agg.push_back({r.name, 1, ms});
+    }
+    size_t off = 0;
+    buf[0] = 0;
+    for (auto& a : agg) {
+        int n = snprintf(buf + off, cap - off, "%s,%d,%.6f\n", a.name, a.calls, a.ms);
+        if (n < 0 || (size_t)n >= cap - off) break;
+        off += (size_t)n;
+    }
+    return AST_OK;
+}
 
 extern "C" int ast_version(void) { return 100; }
 extern "C" const char* ast_last_error(void) { return ast::g_err; }

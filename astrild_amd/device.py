@@ -52,6 +52,21 @@ def real_code(t):
         raise TypeError(f"expected float32/float64 tensor, got {t.dtype}") from None
 
 
+def profile_enable(on=True):
+    check(_lib.lib().ast_profile_enable(int(bool(on))), "ast_profile_enable")
+
+
+def profile_report():
+    """{launch site: (calls, total_ms)} measured with HIP events on the launch stream."""
+    buf = ct.create_string_buffer(1 << 16)
+    check(_lib.lib().ast_profile_report(buf, len(buf)), "ast_profile_report")
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, calls, ms = line.rsplit(",", 2)
+        out[name] = (int(calls), float(ms))
+    return out
+
+
 # ------------------------------------------------------------------ FFT plans
 class FFTPlan:
     """Owns one rocFFT plan created through the C-ABI."""
@@ -191,25 +206,44 @@ def r2c(field, out=None):
     return out
 
 
-def power_bin_1d(spec1, spec2, nmesh, boxsize, i0=None, i1=None, sums=None):
+_geom_cache = {}
+
+
+def shell_geometry(nmesh, boxsize, i0=None, i1=None):
+    """(sum w|k|, sum w) per shell of a spectrum block — data independent, cached."""
+    n = int(nmesh)
+    i0 = (0, n) if i0 is None else tuple(i0)
+    i1 = (0, n) if i1 is None else tuple(i1)
+    key = (torch.cuda.current_device(), n, float(boxsize), i0, i1)
+    hit = _geom_cache.get(key)
+    if hit is None:
+        nb = n // 2 - 1
+        ksum = torch.zeros(nb, dtype=torch.float64, device=device())
+        nmodes = torch.zeros(nb, dtype=torch.int64, device=device())
+        check(_lib.lib().ast_power_bin_1d(None, None, F64, n, float(boxsize), int(i0[0]), int(i0[1]),
+                                          int(i1[0]), int(i1[1]), ptr(ksum), None, ptr(nmodes), stream()),
+              "ast_power_bin_1d[geometry]")
+        hit = _geom_cache[key] = (ksum, nmodes)
+    return hit
+
+
+def power_bin_1d(spec1, spec2, nmesh, boxsize, i0=None, i1=None, psum=None):
     """Shell sums (ksum, psum, nmodes) of a block of the half spectrum (device tensors)."""
     n = int(nmesh)
     nb = n // 2 - 1
-    i0 = (0, n) if i0 is None else i0
-    i1 = (0, n) if i1 is None else i1
+    i0 = (0, n) if i0 is None else tuple(i0)
+    i1 = (0, n) if i1 is None else tuple(i1)
     assert spec1.is_cuda and spec1.is_contiguous() and spec1.numel() == i0[1] * i1[1] * (n // 2 + 1)
     code = _CPLX[spec1.dtype]
     if spec2 is not None:
         assert spec2.dtype == spec1.dtype and spec2.numel() == spec1.numel() and spec2.is_contiguous()
-    if sums is None:
-        dev = spec1.device
-        sums = (torch.zeros(nb, dtype=torch.float64, device=dev), torch.zeros(nb, dtype=torch.float64, device=dev),
-                torch.zeros(nb, dtype=torch.int64, device=dev))
-    ksum, psum, nmodes = sums
+    if psum is None:
+        psum = torch.zeros(nb, dtype=torch.float64, device=spec1.device)
+    ksum, nmodes = shell_geometry(n, boxsize, i0, i1)
     check(_lib.lib().ast_power_bin_1d(ptr(spec1), ptr(spec2), code, n, float(boxsize), int(i0[0]), int(i0[1]),
-                                      int(i1[0]), int(i1[1]), ptr(ksum), ptr(psum), ptr(nmodes), stream()),
+                                      int(i1[0]), int(i1[1]), None, ptr(psum), None, stream()),
           "ast_power_bin_1d")
-    return sums
+    return ksum, psum, nmodes
 
 
 def finish_power(ksum, psum, nmodes):

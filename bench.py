@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py — particles/s through the hot path: mass assignment (CIC) + 3D R2C FFT
++ FFTPower shell binning, inputs resident in HBM (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]        # N=1: one process
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = zero the grid, paint all particles, forward FFT, shell-bin P(k).
+N=1 workload: 1024^3 synthetic lattice+Gaussian particles on a
+1024^3 grid, fp32.  N>1: the same 1024^3 problem slab-decomposed along axis 0
+(strong scaling; one RCCL all-to-all per step for the slab transpose).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ngrid", type=int, default=1024)
+    ap.add_argument("--npside", type=int, default=0, help="particle lattice side (default = ngrid)")
+    ap.add_argument("--window", default="cic", choices=["cic", "tsc"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--order", default="natural", choices=["natural", "shuffled"])
+    ap.add_argument("--method", default="auto", choices=["auto", "tiled", "direct"])
+    ap.add_argument("--cpu-sample", type=int, default=512, help="lattice side of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--kappa", type=int, default=1, help="also time the kappa-map pipeline (1/0)")
+    return ap.parse_args()
+
+
+def cpu_baseline(sample, window, boxsize):
+    """The oracle (numpy port of the reference's CPU path: pmesh-convention paint,
+    rfftn, FFTPower binning; float64 like the reference) on a bounded sample of the
+    workload: sample^3 particles on a sample^3 grid, single thread."""
+    from oracle import mesh as omesh, fftpower as offt
+    pos = omesh.lattice_particles(sample, sample, boxsize, seed=20240601)
+    t0 = time.perf_counter()
+    grid = omesh.paint(pos, None, sample, boxsize, window)
+    t1 = time.perf_counter()
+    offt.fftpower_1d(grid, boxsize)
+    t2 = time.perf_counter()
+    n = pos.shape[0]
+    return {
+        "value": n / (t2 - t0), "unit": "particles/s", "cores": 1, "kind": "port",
+        "sample": f"{sample}^3 particles on a {sample}^3 grid, float64, numpy bincount paint {t1 - t0:.2f}s + "
+                  f"numpy rfftn/shell binning {t2 - t1:.2f}s; host has {os.cpu_count()} logical cores",
+    }
+
+
+def kappa_leg(dev, steps, warmup):
+    """64 planes x 4096^2 fp64 -> stack -> Gaussian FFT smoothing -> kappa->alpha (config D)."""
+    from astrild_amd import lensing
+    return lensing.bench_kappa_pipeline(nplanes=64, npix=4096, steps=max(2, min(steps, 5)), warmup=min(warmup, 2))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from astrild_amd import device as dev
+    n = args.ngrid
+    npside = args.npside or n
+    L = 1000.0
+    tdt = torch.float32 if args.dtype == "f32" else torch.float64
+    esz = 4 if args.dtype == "f32" else 8
+    npart_total = npside ** 3
+
+    if world == 1:
+        pos = dev.synth_lattice_particles(npside, n, L, seed=20240601, shuffle=(args.order == "shuffled"), dtype=tdt)
+        grid = torch.empty((n, n, n), dtype=tdt, device="cuda")
+        spec = torch.empty((n, n, n // 2 + 1), dtype=torch.complex64 if args.dtype == "f32" else torch.complex128,
+                           device="cuda")
+        psum = torch.zeros(n // 2 - 1, dtype=torch.float64, device="cuda")
+        dev.shell_geometry(n, L)          # data independent, cached like the FFT plan
+
+        def step():
+            grid.zero_()
+            dev.paint(pos, None, n, L, args.window, out=grid, method=args.method, check_dropped=False)
+            dev.r2c(grid, out=spec)
+            psum.zero_()
+            return dev.power_bin_1d(spec, None, n, L, psum=psum)
+    else:
+        from astrild_amd import slab
+        pipe = slab.SlabPowerPipeline(n, L, npside, window=args.window, dtype=tdt, seed=20240601,
+                                      shuffle=(args.order == "shuffled"))
+        step = pipe.step
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    dev.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sums = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = dev.profile_report()
+    dev.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = npart_total / (elapsed / args.steps)
+
+    # sanity: the spectrum that was timed is a real one (finite, positive at Nyquist-ish k)
+    res = dev.finish_power(*sums)
+    assert np.isfinite(res["power"]).all() and res["power"][-1] > 0
+
+    # ---- roofline per logical stage: SURVEY.md §8(d) algorithmic bytes / HIP-event time ----
+    npart_rank = npart_total / world
+    ng_rank = n ** 3 / world
+    stage_sites = {
+        "paint": [k for k in prof if k.startswith("paint")],
+        "fft": [k for k in prof if k.startswith("rocfft") or k.startswith("slab.")],
+        "power_bin": [k for k in prof if k == "power_bin"],
+    }
+    stage_bytes = {
+        "paint": npart_rank * 3 * esz + ng_rank * esz,       # read positions once, write the grid once
+        "fft": 3 * 2 * ng_rank * esz,                         # 3 axis passes x (read + write)
+        "power_bin": ng_rank * esz,                           # half spectrum read once (~esz B per real cell)
+    }
+    stages = {}
+    for name, sites in stage_sites.items():
+        ms = sum(prof[s][1] for s in sites) / args.steps
+        if ms > 0:
+            gbs = stage_bytes[name] / ms / 1e6
+            stages[name] = {"ms": round(ms, 4), "alg_GB": round(stage_bytes[name] / 1e9, 3),
+                            "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                            "kernels": {s: round(prof[s][1] / args.steps, 4) for s in sites}}
+    dom = max(stages, key=lambda k: stages[k]["ms"])
+    roofline = {
+        "bound": "hbm", "kernel": f"{dom} stage ({'+'.join(stage_sites[dom])})",
+        "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": stages[dom]["frac"], "traffic": None,
+        "end_to_end": {"alg_GB": round(sum(stage_bytes.values()) / 1e9, 3),
+                       "GBps": round(sum(stage_bytes.values()) * world / (ms_per_step * 1e6), 1),
+                       "frac": round(sum(stage_bytes.values()) * world / (ms_per_step * 1e6) / (HBM_PEAK_GBS * world), 4)},
+        "stages": stages,
+    }
+
+    out = {
+        "metric": "particles/sec CIC+3D-FFT P(k) on 1024^3 grid" if n == 1024 and args.window == "cic"
+                  else f"particles/sec {args.window.upper()}+3D-FFT P(k) on {n}^3 grid",
+        "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{npside}^3 lattice+Gaussian(0.5 cell) particles ({args.order} order) -> "
+                               f"{args.window.upper()} paint on {n}^3 grid -> 3D R2C -> FFTPower 1d shells",
+                   "ngrid": n, "nparticles": npart_total, "boxsize": L,
+                   "parallelism": "single GPU" if world == 1 else f"axis-0 slabs x{world}, RCCL all-to-all transpose"},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1:
+        if args.cpu_sample:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.window, L)
+        if args.kappa:
+            try:
+                del pos, grid, spec
+                torch.cuda.empty_cache()
+                out["kappa"] = kappa_leg(dev, args.steps, args.warmup)
+            except ImportError:
+                pass
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

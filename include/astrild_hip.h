@@ -49,6 +49,13 @@ extern "C" {
 int ast_version(void);
 const char* ast_last_error(void);
 
+/* Per-launch HIP-event timing for bench.py's roofline leg: while enabled every
+ * kernel launch site records an event pair on its stream.  ast_profile_report
+ * synchronises them and writes one "name,calls,total_ms" line per site into
+ * buf (NUL terminated).  ast_profile_enable(0/1) also clears the records. */
+int ast_profile_enable(int on);
+int ast_profile_report(char* buf, size_t cap);
+
 /* ---------------------------------------------------------------- utility */
 
 /* buf[i] = value, i < count. */
@@ -160,7 +167,10 @@ int ast_fft_plan_destroy(ast_fft_plan* plan);
  *       0 < i2 < nmesh/2 else 1.  Shell of a mode: isqrt(|m|^2) - 1 in exact
  *       integer arithmetic; the DC mode and |m| >= nmesh/2 are dropped.
  *   k = ksum/nmodes, P = psum/nmodes is left to the caller so that slab
- *       partials can be summed first. */
+ *       partials can be summed first.
+ *   ksum_d / nmodes_d depend only on (nmesh, L, block), not on the data: pass
+ *       both NULL to skip them (callers cache them), or spec1_d = psum_d = NULL
+ *       to compute only them. */
 int ast_power_bin_1d(const void* spec1_d, const void* spec2_d, int dtype, int nmesh,
                      double boxsize, int i0_start, int i0_count, int i1_start, int i1_count,
                      double* ksum_d, double* psum_d, long long* nmodes_d, void* stream);
