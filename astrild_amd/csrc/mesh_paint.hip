@@ -15,35 +15,34 @@
 namespace {
 
 using ast::Window;
-using ast::wrap;
 
 template <typename T, int W>
 __global__ void __launch_bounds__(256)
 paint_direct_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t np, int n,
                     double inv_dx, double scale, int x_start, int nx_alloc, T* __restrict__ grid,
                     unsigned long long* dropped) {
+    constexpr int LO = Window<W>::LO;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     unsigned long long ndrop = 0;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += stride) {
-        double sx = (double)pos[3 * p + 0] * inv_dx;
-        double sy = (double)pos[3 * p + 1] * inv_dx;
-        double sz = (double)pos[3 * p + 2] * inv_dx;
+        double fx, fy, fz;
+        const int bx = ast::locate<W>((double)pos[3 * p + 0] * inv_dx, n, fx);
+        const int by = ast::locate<W>((double)pos[3 * p + 1] * inv_dx, n, fy);
+        const int bz = ast::locate<W>((double)pos[3 * p + 2] * inv_dx, n, fz);
         const T m = (T)((mass ? (double)mass[p] : 1.0) * scale);
-        long long ix0, iy0, iz0;
         T wx[W], wy[W], wz[W];
-        Window<W>::eval(sx, ix0, wx);
-        Window<W>::eval(sy, iy0, wy);
-        Window<W>::eval(sz, iz0, wz);
+        Window<W>::weights(fx, wx);
+        Window<W>::weights(fy, wy);
+        Window<W>::weights(fz, wz);
         int jy[W], jz[W];
 #pragma unroll
         for (int a = 0; a < W; ++a) {
-            jy[a] = wrap(iy0 + a, n);
-            jz[a] = wrap(iz0 + a, n);
+            jy[a] = ast::wrap1(by - LO + a, n);
+            jz[a] = ast::wrap1(bz - LO + a, n);
         }
 #pragma unroll
         for (int a = 0; a < W; ++a) {
-            int gx = wrap(ix0 + a, n);
-            int px = gx - x_start;
+            int px = ast::wrap1(bx - LO + a, n) - x_start;
             if (px < 0) px += n;
             if (px >= nx_alloc) {
                 ++ndrop;

@@ -27,9 +27,13 @@
 namespace {
 
 using ast::Window;
-using ast::wrap;
 
-constexpr int TX = 8, TY = 8, TZ = 32;   // owned cells per tile
+#ifndef TILE_TX
+#define TILE_TX 8
+#define TILE_TY 8
+#define TILE_TZ 32
+#endif
+constexpr int TX = TILE_TX, TY = TILE_TY, TZ = TILE_TZ;   // owned cells per tile
 
 struct TileGeom {
     int n, x_start, nx_alloc;
@@ -41,11 +45,12 @@ struct TileGeom {
 // 0xffffffff when the base plane is outside the buffer.
 template <typename T, int W>
 __device__ inline uint32_t tile_of(T x, T y, T z, const TileGeom& g) {
-    int bx = wrap(ast::base_cell<W>((double)x * g.inv_dx), g.n) - g.x_start;
+    double f;
+    int bx = ast::locate<W>((double)x * g.inv_dx, g.n, f) - g.x_start;
     if (bx < 0) bx += g.n;
     if (bx >= g.nx_alloc) return 0xffffffffu;
-    const int by = wrap(ast::base_cell<W>((double)y * g.inv_dx), g.n);
-    const int bz = wrap(ast::base_cell<W>((double)z * g.inv_dx), g.n);
+    const int by = ast::locate<W>((double)y * g.inv_dx, g.n, f);
+    const int bz = ast::locate<W>((double)z * g.inv_dx, g.n, f);
     return (uint32_t)(((bx / TX) * g.nty + by / TY) * g.ntz + bz / TZ);
 }
 
@@ -71,42 +76,94 @@ __device__ inline WaveRuns wave_runs(uint32_t key, bool live, int lane) {
     return r;
 }
 
-constexpr int IDX_UNROLL = 4;   // particles per thread per trip: keeps 12 loads in flight
+constexpr int IDX_UNROLL = 4;      // particles per thread per trip: keeps 12 loads in flight
+constexpr int AGG_TRIPS = 8;       // trips of 1024 particles between flushes of the LDS table
+constexpr int AGG_SLOTS = 256;     // direct-mapped by (tile id & 255)
+constexpr uint32_t SLOT_EMPTY = 0xffffffffu;
+constexpr uint32_t CODE_DONE = 0xffffffffu;
 
+// Both passes walk the particle array in contiguous intervals of 8192 particles
+// per workgroup.  Global atomics are the bottleneck of a naive version (one per
+// run: ~2/3 of the kernel time), so run heads first combine into a small
+// direct-mapped LDS table keyed by tile id; the table is flushed once per
+// interval with ONE global atomic per distinct tile.  Runs whose slot is taken by
+// another tile fall back to a global atomic of their own.  In the FILL pass the
+// final position of a particle is only known after the flush, so each thread
+// parks (slot, offset-in-interval) codes of its 32 particles in LDS meanwhile.
 template <typename T, int W, bool FILL>
 __global__ void __launch_bounds__(256)
 tile_index_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t* __restrict__ tile_count,
                   const uint32_t* __restrict__ tile_off, uint32_t* __restrict__ tile_fill,
-                  uint32_t* __restrict__ index, unsigned long long* dropped) {
-    const int lane = threadIdx.x & 63;
+                  uint32_t* __restrict__ index, unsigned long long* dropped, int ablate) {
+    __shared__ uint32_t skey[AGG_SLOTS], scnt[AGG_SLOTS], sbase[AGG_SLOTS];
+    __shared__ uint32_t codes[FILL ? AGG_TRIPS * IDX_UNROLL : 1][256];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    skey[tid] = SLOT_EMPTY;
+    scnt[tid] = 0;
+    __syncthreads();
     const size_t per_trip = 256 * IDX_UNROLL;
-    const size_t ntrips = (np + per_trip - 1) / per_trip;
-    for (size_t trip = blockIdx.x; trip < ntrips; trip += gridDim.x) {
-        T x[IDX_UNROLL], y[IDX_UNROLL], z[IDX_UNROLL];
+    const size_t per_interval = per_trip * AGG_TRIPS;
+    const size_t nintervals = (np + per_interval - 1) / per_interval;
+    unsigned long long ndrop = 0;
+    for (size_t interval = blockIdx.x; interval < nintervals; interval += gridDim.x) {
+        const size_t p0 = interval * per_interval;
+        for (int trip = 0; trip < AGG_TRIPS; ++trip) {
+            T x[IDX_UNROLL], y[IDX_UNROLL], z[IDX_UNROLL];
 #pragma unroll
-        for (int u = 0; u < IDX_UNROLL; ++u) {
-            const size_t p = trip * per_trip + (size_t)u * 256 + threadIdx.x;
-            if (p < np) { x[u] = pos[3 * p + 0]; y[u] = pos[3 * p + 1]; z[u] = pos[3 * p + 2]; }
-            else { x[u] = y[u] = z[u] = (T)0; }
-        }
+            for (int u = 0; u < IDX_UNROLL; ++u) {
+                const size_t p = p0 + (size_t)trip * per_trip + (size_t)u * 256 + tid;
+                if (p < np) { x[u] = pos[3 * p + 0]; y[u] = pos[3 * p + 1]; z[u] = pos[3 * p + 2]; }
+                else { x[u] = y[u] = z[u] = (T)0; }
+            }
 #pragma unroll
-        for (int u = 0; u < IDX_UNROLL; ++u) {
-            const size_t p = trip * per_trip + (size_t)u * 256 + threadIdx.x;
-            const bool valid = p < np;
-            const uint32_t key = valid ? tile_of<T, W>(x[u], y[u], z[u], g) : 0xffffffffu;
-            const bool live = key != 0xffffffffu;
-            const WaveRuns r = wave_runs(key, live, lane);
-            if (!FILL) {
-                if (r.head) atomicAdd(&tile_count[key], (uint32_t)r.len);
-                if (valid && !live && dropped) atomicAdd(dropped, 1ull);
-            } else {
-                uint32_t base = 0;
-                if (r.head) base = tile_off[key] + atomicAdd(&tile_fill[key], (uint32_t)r.len);
-                base = __shfl(base, r.head_lane, 64);
-                if (live) index[base + (uint32_t)(lane - r.head_lane)] = (uint32_t)p;
+            for (int u = 0; u < IDX_UNROLL; ++u) {
+                const size_t p = p0 + (size_t)trip * per_trip + (size_t)u * 256 + tid;
+                const bool valid = p < np;
+                const uint32_t key = valid ? tile_of<T, W>(x[u], y[u], z[u], g) : 0xffffffffu;
+                const bool live = key != 0xffffffffu;
+                if (valid && !live) ++ndrop;
+                const WaveRuns r = wave_runs(key, live, lane);
+                bool hit = false;
+                uint32_t val = 0;               // hit: slot << 16 | offset in the interval; miss: global slot
+                if (r.head) {
+                    const uint32_t slot = key & (AGG_SLOTS - 1);
+                    const uint32_t old = atomicCAS(&skey[slot], SLOT_EMPTY, key);
+                    hit = old == SLOT_EMPTY || old == key;
+                    if (hit) val = (slot << 16) | atomicAdd(&scnt[slot], (uint32_t)r.len);
+                    else if (!FILL) atomicAdd(&tile_count[key], (uint32_t)r.len);
+                    else val = tile_off[key] + atomicAdd(&tile_fill[key], (uint32_t)r.len);
+                }
+                if (FILL) {
+                    const int hitb = __shfl((int)hit, r.head_lane, 64);
+                    const uint32_t valb = __shfl(val, r.head_lane, 64) + (uint32_t)(lane - r.head_lane);
+                    uint32_t code = CODE_DONE;
+                    if (live) {
+                        if (hitb) code = valb;
+                        else index[valb] = (uint32_t)p;
+                    }
+                    codes[trip * IDX_UNROLL + u][tid] = code;
+                }
             }
         }
+        __syncthreads();
+        if (skey[tid] != SLOT_EMPTY) {
+            if (!FILL) atomicAdd(&tile_count[skey[tid]], scnt[tid]);
+            else sbase[tid] = tile_off[skey[tid]] + atomicAdd(&tile_fill[skey[tid]], scnt[tid]);
+        }
+        __syncthreads();
+        if (FILL) {
+#pragma unroll 4
+            for (int j = 0; j < AGG_TRIPS * IDX_UNROLL; ++j) {
+                const uint32_t c = codes[j][tid];
+                if (c != CODE_DONE) index[sbase[c >> 16] + (c & 0xffffu)] = (uint32_t)(p0 + (size_t)j * 256 + tid);
+            }
+        }
+        skey[tid] = SLOT_EMPTY;
+        scnt[tid] = 0;
+        __syncthreads();
     }
+    if (!FILL && dropped && ndrop) atomicAdd(dropped, ndrop);
 }
 
 // ---- exclusive scan of tile_count (3 kernels, 1024 items per block) ----
@@ -184,7 +241,10 @@ tile_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileG
 
     const int tz = t % g.ntz, ty = (t / g.ntz) % g.nty, tx = t / (g.ntz * g.nty);
     const int ox = tx * TX, oy = ty * TY, oz = tz * TZ;   // owned origin (buffer plane / global y, z)
-    constexpr int U = 4;
+#ifndef DEP_U
+#define DEP_U 4
+#endif
+    constexpr int U = DEP_U;
     for (uint32_t i0 = 0; i0 < cnt; i0 += 256 * U) {
         T px[U], py[U], pz[U], pm[U];
         bool on[U];
@@ -201,16 +261,16 @@ tile_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileG
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (!on[u]) continue;
-            long long ix0, iy0, iz0;
-            T wx[W], wy[W], wz[W];
-            Window<W>::eval((double)px[u] * g.inv_dx, ix0, wx);
-            Window<W>::eval((double)py[u] * g.inv_dx, iy0, wy);
-            Window<W>::eval((double)pz[u] * g.inv_dx, iz0, wz);
-            int bx = wrap(ix0 + LO, g.n) - g.x_start;
+            double fx, fy, fz;
+            int bx = ast::locate<W>((double)px[u] * g.inv_dx, g.n, fx) - g.x_start;
             if (bx < 0) bx += g.n;
             const int lx = bx - ox;                               // 0..TX-1 by construction of the index
-            const int ly = wrap(iy0 + LO, g.n) - oy;
-            const int lz = wrap(iz0 + LO, g.n) - oz;
+            const int ly = ast::locate<W>((double)py[u] * g.inv_dx, g.n, fy) - oy;
+            const int lz = ast::locate<W>((double)pz[u] * g.inv_dx, g.n, fz) - oz;
+            T wx[W], wy[W], wz[W];
+            Window<W>::weights(fx, wx);
+            Window<W>::weights(fy, wy);
+            Window<W>::weights(fz, wz);
             const T m = (T)((double)pm[u] * scale);
 #pragma unroll
             for (int a = 0; a < W; ++a) {
@@ -238,9 +298,9 @@ tile_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileG
         if (v == (T)0) continue;
         const int c = i % LZ, b = (i / LZ) % LY, a = i / (LZ * LY);
         int px = ox + a - LO;
-        if (g.nx_alloc == g.n) px = wrap(px, g.n);
+        if (g.nx_alloc == g.n) px = ast::wrap1(px, g.n);
         else if (px < 0 || px >= g.nx_alloc) { ++ndrop; continue; }
-        const int gy = wrap(oy + b - LO, g.n), gz = wrap(oz + c - LO, g.n);
+        const int gy = ast::wrap1(oy + b - LO, g.n), gz = ast::wrap1(oz + c - LO, g.n);
         atomicAdd(&grid[((size_t)px * g.n + gy) * g.n + gz], v);
     }
     if (dropped && ndrop) atomicAdd(dropped, ndrop);
@@ -287,13 +347,15 @@ template <typename T, int W>
 int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntiles, double scale, T* grid,
               void* workspace, unsigned long long* dropped, hipStream_t s) {
     Workspace w = carve(workspace, np, ntiles);
+    const int abl = getenv("AST_PAINT_ABLATE") ? atoi(getenv("AST_PAINT_ABLATE")) : 0;
     // tile_count and tile_fill are contiguous at the front of the workspace
     AST_CHECK_HIP(hipMemsetAsync(w.tile_count, 0, (size_t)((char*)w.tile_off - (char*)w.tile_count), s));
-    const size_t ntrips = (np + 256 * IDX_UNROLL - 1) / (256 * IDX_UNROLL);
-    const unsigned ga = (unsigned)(ntrips > 16384 ? 16384 : ntrips);
+    const size_t per_interval = (size_t)256 * IDX_UNROLL * AGG_TRIPS;
+    const size_t nintervals = (np + per_interval - 1) / per_interval;
+    const unsigned ga = (unsigned)(nintervals > 8192 ? 8192 : nintervals);
     {
         AST_PROF("paint_tiled.count", s);
-        tile_index_kernel<T, W, false><<<ga, 256, 0, s>>>(pos, np, g, w.tile_count, nullptr, nullptr, nullptr, dropped);
+        tile_index_kernel<T, W, false><<<ga, 256, 0, s>>>(pos, np, g, w.tile_count, nullptr, nullptr, nullptr, dropped, abl);
     }
     const uint32_t nblk = (ntiles + 1023) / 1024;
     {
@@ -304,11 +366,10 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
     }
     {
         AST_PROF("paint_tiled.fill", s);
-        tile_index_kernel<T, W, true><<<ga, 256, 0, s>>>(pos, np, g, nullptr, w.tile_off, w.tile_fill, w.index, nullptr);
+        tile_index_kernel<T, W, true><<<ga, 256, 0, s>>>(pos, np, g, nullptr, w.tile_off, w.tile_fill, w.index, nullptr, abl);
     }
     AST_PROF("paint_tiled.deposit", s);
-    tile_deposit_kernel<T, W><<<ntiles, 256, 0, s>>>(pos, mass, g, scale, w.index, w.tile_off, w.tile_count, grid, dropped,
-                                                     getenv("AST_PAINT_ABLATE") ? atoi(getenv("AST_PAINT_ABLATE")) : 0);
+    tile_deposit_kernel<T, W><<<ntiles, 256, 0, s>>>(pos, mass, g, scale, w.index, w.tile_off, w.tile_count, grid, dropped, abl);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }

@@ -10,36 +10,48 @@
 
 namespace ast {
 
+// Rare paths kept out of line so the hot loops stay small: particles more than
+// one box length outside [0, L), or beyond the int32 range in grid units.
+__device__ __noinline__ inline int wrap_slow_i(int i, int n) {
+    int r = i % n;
+    return r < 0 ? r + n : r;
+}
+__device__ __noinline__ inline int wrap_slow_d(double fl, int n) {
+    double r = fl - floor(fl / (double)n) * (double)n;    // in [0, n] up to rounding
+    int i = (int)r;
+    if (i >= n) i -= n;
+    if (i < 0) i += n;
+    return i;
+}
+
+// periodic wrap of an index that is at most one period out of range
+__device__ inline int wrap1(int i, int n) {
+    if (i < 0) i += n;
+    if (i >= n) i -= n;
+    return i;
+}
+
+// Window<W>: support W, base cell = the cell the particle is assigned to
+// (CIC: lower corner floor(s); NGP/TSC: nearest grid point floor(s + 1/2)),
+// stencil = base - LO .. base - LO + W - 1.
 template <int W> struct Window;
 
-template <> struct Window<1> {              // NGP: support 1, left 0, shift 0.5
+template <> struct Window<1> {
     static constexpr int LO = 0;
-    template <typename R>
-    __device__ static inline void eval(double s, long long& i0, R* w) {
-        i0 = (long long)floor(s + 0.5);
-        w[0] = (R)1;
-    }
+    template <typename R> __device__ static inline void weights(double, R* w) { w[0] = (R)1; }
 };
-
-template <> struct Window<2> {              // CIC: leftmost = floor(s)
-    static constexpr int LO = 0;            // base cell = leftmost + LO
-    template <typename R>
-    __device__ static inline void eval(double s, long long& i0, R* w) {
-        const double fl = floor(s);
-        const R f = (R)(s - fl);
-        i0 = (long long)fl;
+template <> struct Window<2> {
+    static constexpr int LO = 0;
+    template <typename R> __device__ static inline void weights(double frac, R* w) {
+        const R f = (R)frac;              // in [0, 1)
         w[0] = (R)1 - f;
         w[1] = f;
     }
 };
-
-template <> struct Window<3> {              // TSC: centre = floor(s + 1/2), leftmost = centre - 1
+template <> struct Window<3> {
     static constexpr int LO = 1;
-    template <typename R>
-    __device__ static inline void eval(double s, long long& i0, R* w) {
-        const double ic = floor(s + 0.5);
-        const R d = (R)(s - ic);
-        i0 = (long long)ic - 1;
+    template <typename R> __device__ static inline void weights(double frac, R* w) {
+        const R d = (R)frac;              // in [-1/2, 1/2)
         const R hm = (R)0.5 - d, hp = (R)0.5 + d;
         w[0] = (R)0.5 * (hm * hm);
         w[1] = (R)0.75 - d * d;
@@ -47,20 +59,18 @@ template <> struct Window<3> {              // TSC: centre = floor(s + 1/2), lef
     }
 };
 
-// base cell only (tile keys); the weights are dead code here
+// s = x * n/L  ->  base cell wrapped into [0, n) and the offset s - floor(..)
 template <int W>
-__device__ inline long long base_cell(double s) {
-    return W == 3 ? (long long)floor(s + 0.5) : (W == 2 ? (long long)floor(s) : (long long)floor(s + 0.5));
-}
-
-// periodic wrap; in-box particles take the branch-free fast path (a 64-bit
-// modulo is a ~100-instruction software routine on the GPU)
-__device__ inline int wrap(long long i, int n) {
-    if ((unsigned long long)i < (unsigned long long)n) return (int)i;
-    if (i < 0 && i >= -(long long)n) return (int)(i + n);
-    if (i >= n && i < 2ll * n) return (int)(i - n);
-    long long r = i % n;
-    return (int)(r < 0 ? r + n : r);
+__device__ inline int locate(double s, int n, double& frac) {
+    const double fl = floor(W == 2 ? s : s + 0.5);
+    frac = s - fl;
+    if (fabs(fl) < 1073741824.0) {
+        const int i = (int)fl;
+        if ((unsigned)i < (unsigned)n) return i;
+        if (i >= -n && i < 2 * n) return wrap1(i, n);
+        return wrap_slow_i(i, n);
+    }
+    return wrap_slow_d(fl, n);
 }
 
 }  // namespace ast

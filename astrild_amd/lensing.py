@@ -1,0 +1,236 @@
+"""HBM-resident kappa-map operations.
+
+Thin wrappers over the C-ABI: plane stack with lensing-kernel re-weighting,
+unit conversion, Gaussian smoothing, kappa -> deflection / potential, PDF
+histogram.  fp64 like the reference; torch tensors are memory holders only.
+"""
+import ctypes as ct
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import F64, check
+from .device import as_device, device, ptr, real_code, stream
+
+
+# ------------------------------------------------------------------ a-7 stack
+def kernel_function(x, x_s):
+    """g(x, x_s) = (x_s - x) * x / x_s  (rayramses.py:315-326, simcoll.py:432-443)."""
+    return (x_s - x) * x / x_s
+
+
+def translate_redshift_weights(x_near, x_far, x_src, x_src_shift):
+    """(numerator, denominator) of the re-weighting of rayramses.py:269-312:
+    quantity * g(x_mid, x_s') / g(x_mid, x_s) with x_mid = (x_far + x_near)/2 and the
+    clamp x_s' = x_far when the next snapshot lies beyond the shifted source."""
+    x_near, x_far = np.asarray(x_near, dtype=np.float64), np.asarray(x_far, dtype=np.float64)
+    x_shift = np.where(x_far > x_src_shift, x_far, x_src_shift)
+    x_mid = 0.5 * (x_far + x_near)
+    return kernel_function(x_mid, x_shift), kernel_function(x_mid, x_src)
+
+
+def kappa_stack(planes, wnum=None, wden=None, out=None):
+    """out = sum_p planes[p] * wnum[p] / wden[p] in plane order (first = copy, then
+    running +=), like rayramses.py:224-232 / simcoll.py:322-336.
+
+    planes: list of equal-shape CUDA tensors (or one (P, ...) tensor)."""
+    if isinstance(planes, torch.Tensor):
+        planes = [planes[p] for p in range(planes.shape[0])]
+    assert len(planes) >= 1
+    first = planes[0]
+    code = real_code(first)
+    for t in planes:
+        assert t.is_cuda and t.is_contiguous() and t.dtype == first.dtype and t.shape == first.shape
+    ptrs = torch.tensor([t.data_ptr() for t in planes], dtype=torch.int64, device=first.device)
+    if out is None:
+        out = torch.empty_like(first)
+    wn = wd = None
+    if wnum is not None:
+        wn = as_device(np.asarray(wnum, dtype=np.float64))
+        wd = as_device(np.asarray(wden, dtype=np.float64))
+        assert wn.numel() == len(planes) == wd.numel()
+    check(_lib.lib().ast_kappa_stack(ptr(ptrs), ptr(wn), ptr(wd), len(planes), first.numel(), code, ptr(out),
+                                     stream()), "ast_kappa_stack")
+    return out
+
+
+# ------------------------------------------------------------- a-8 per-map ops
+C_LIGHT_KMS = 299792.458       # astropy.constants.c.to("km/s").value (sky_utils.py:17)
+
+
+def convert_code_to_phy_units(quantity, t):
+    """In place: / c^2 for shear/deflt/kappa_2, / c^3 for isw_rs (sky_utils.py:318-339)."""
+    if quantity in ["shear_x", "shear_y", "deflt_x", "deflt_y", "kappa_2"]:
+        div = C_LIGHT_KMS ** 2
+    elif quantity in ["isw_rs"]:
+        div = C_LIGHT_KMS ** 3
+    else:
+        return t
+    check(_lib.lib().ast_divide(ptr(t), real_code(t), t.numel(), div, stream()), "ast_divide")
+    return t
+
+
+class _Plan:
+    _create = _destroy = None
+
+    def __init__(self, *args):
+        self.handle = ct.c_void_p()
+        check(getattr(_lib.lib(), self._create)(ct.byref(self.handle), *args), self._create)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                getattr(_lib.lib(), self._destroy)(self.handle)
+                self.handle = ct.c_void_p()
+        except Exception:
+            pass
+
+
+class LensPlan(_Plan):
+    """kappa -> (alpha1, alpha2) / phi for an nc x nc map of side bsz [rad]; caches
+    the kernel spectra of lensing_funcs.c:45-83,117-148 on the device."""
+    _create, _destroy = "ast_lens_plan_create", "ast_lens_plan_destroy"
+
+    def __init__(self, nc, bsz):
+        super().__init__(int(nc), float(bsz))
+        self.nc = int(nc)
+
+    def alphas(self, kappa):
+        assert kappa.is_cuda and kappa.dtype == torch.float64 and kappa.numel() == self.nc ** 2
+        kappa = kappa.contiguous()
+        a1, a2 = torch.empty_like(kappa), torch.empty_like(kappa)
+        check(_lib.lib().ast_kappa_to_alphas(self.handle, ptr(kappa), ptr(a1), ptr(a2), stream()),
+              "ast_kappa_to_alphas")
+        return a1, a2
+
+    def phi(self, kappa):
+        assert kappa.is_cuda and kappa.dtype == torch.float64 and kappa.numel() == self.nc ** 2
+        kappa = kappa.contiguous()
+        out = torch.empty_like(kappa)
+        check(_lib.lib().ast_kappa_to_phi(self.handle, ptr(kappa), ptr(out), stream()), "ast_kappa_to_phi")
+        return out
+
+
+class SmoothPlan(_Plan):
+    _create, _destroy = "ast_smooth_plan_create", "ast_smooth_plan_destroy"
+
+    def __init__(self, npix):
+        super().__init__(int(npix))
+        self.npix = int(npix)
+
+    def gaussian(self, img, sigma_px, kind="gaussianFFT"):
+        """In place.  kind: "gaussianFFT" (periodic) or "gaussian" (real space,
+        reflect, truncate 4) — lenstools ConvergenceMap.smooth's two branches."""
+        assert img.is_cuda and img.dtype == torch.float64 and img.numel() == self.npix ** 2 and img.is_contiguous()
+        mode = {"gaussianFFT": 0, "gaussian": 1}[kind]
+        check(_lib.lib().ast_gaussian_smooth(self.handle, ptr(img), float(sigma_px), mode, stream()),
+              "ast_gaussian_smooth")
+        return img
+
+
+_lens_plans, _smooth_plans = {}, {}
+
+
+def lens_plan(nc, bsz):
+    key = (torch.cuda.current_device(), int(nc), float(bsz))
+    if key not in _lens_plans:
+        _lens_plans.clear()          # one resident plan: the spectra are 3 x 0.5 GB at nc = 4096
+        _lens_plans[key] = LensPlan(nc, bsz)
+    return _lens_plans[key]
+
+
+def smooth_plan(npix):
+    key = (torch.cuda.current_device(), int(npix))
+    if key not in _smooth_plans:
+        _smooth_plans[key] = SmoothPlan(npix)
+    return _smooth_plans[key]
+
+
+def minmax(t):
+    out = torch.empty(2, dtype=torch.float64, device=t.device)
+    check(_lib.lib().ast_minmax(ptr(t), real_code(t), t.numel(), ptr(out), stream()), "ast_minmax")
+    lo, hi = out.cpu().numpy()
+    return float(lo), float(hi)
+
+
+def histogram(t, nbins, range=None, density=False):
+    """np.histogram(t, bins=nbins, range=, density=) -> (values, bin_edges) as numpy."""
+    nbins = int(nbins)
+    lo, hi = minmax(t) if range is None else (float(range[0]), float(range[1]))
+    if lo == hi:                      # numpy widens a degenerate range by +-0.5
+        lo, hi = lo - 0.5, hi + 0.5
+    counts = torch.zeros(nbins, dtype=torch.int64, device=t.device)
+    check(_lib.lib().ast_histogram(ptr(t), real_code(t), t.numel(), lo, hi, nbins, ptr(counts), stream()),
+          "ast_histogram")
+    counts = counts.cpu().numpy()
+    edges = np.linspace(lo, hi, nbins + 1)
+    if density:
+        return counts / np.diff(edges) / counts.sum(), edges
+    return counts, edges
+
+
+def add(a, b, out=None):
+    out = torch.empty_like(a) if out is None else out
+    check(_lib.lib().ast_add(ptr(a), ptr(b), ptr(out), real_code(a), a.numel(), stream()), "ast_add")
+    return out
+
+
+# ------------------------------------------------- synthetic planes + bench leg
+def synth_kappa_planes(nplanes, npix, seed0=4242, rms=0.01, dtype=torch.float64):
+    """Gaussian random fields with P(l) ~ (l + l0)^-2, one per plane.
+    Generated with torch's FFT as bench plumbing (inputs are not part of the path)."""
+    planes = []
+    fy = torch.fft.fftfreq(npix, device="cuda", dtype=torch.float64)[:, None]
+    fx = torch.fft.rfftfreq(npix, device="cuda", dtype=torch.float64)[None, :]
+    amp = 1.0 / (torch.sqrt(fx * fx + fy * fy) * npix + 10.0)
+    for p in range(nplanes):
+        g = torch.Generator(device="cuda").manual_seed(seed0 + p)
+        white = torch.randn((npix, npix), generator=g, device="cuda", dtype=torch.float64)
+        f = torch.fft.irfft2(torch.fft.rfft2(white) * amp, s=(npix, npix))
+        planes.append((f * (rms / f.std())).to(dtype).contiguous())
+    return planes
+
+
+def bench_kappa_pipeline(nplanes=64, npix=4096, steps=3, warmup=1, theta_deg=20.0, sigma_arcmin=1.0):
+    """kappa-maps/s at npix^2 for one full map: stack nplanes planes (weighted) ->
+    / c^2 -> Gaussian FFT smoothing -> kappa -> (alpha1, alpha2) -> 100-bin PDF."""
+    from . import device as dev
+    planes = synth_kappa_planes(nplanes, npix)
+    mid = (np.arange(nplanes) + 0.5) * (1000.0 / nplanes)
+    wnum, wden = translate_redshift_weights(mid - 7.8125, mid + 7.8125, 1100.0, 1000.0)
+    bsz = np.deg2rad(theta_deg)
+    lp = lens_plan(npix, bsz)
+    sp = smooth_plan(npix)
+    sigma_px = sigma_arcmin / 60.0 * npix / theta_deg
+    out = torch.empty_like(planes[0])
+
+    def step():
+        kappa_stack(planes, wnum, wden, out=out)
+        convert_code_to_phy_units("kappa_2", out)
+        sp.gaussian(out, sigma_px, "gaussianFFT")
+        a1, a2 = lp.alphas(out)
+        return histogram(out, 100, density=True), a1, a2
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    dev.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    prof = dev.profile_report()
+    dev.profile_enable(False)
+    stack_ms = prof.get("kappa_stack", (0, 0.0))[1] / steps
+    stack_bytes = (nplanes + 1) * npix * npix * 8
+    return {
+        "metric": f"kappa-maps/s at {npix}^2 ({nplanes}-plane weighted stack + smoothing + kappa->alpha + PDF, fp64)",
+        "value": 1.0 / dt, "unit": "maps/s", "ms_per_map": dt * 1e3,
+        "stack": {"ms": round(stack_ms, 4), "alg_GB": round(stack_bytes / 1e9, 3),
+                  "GBps": round(stack_bytes / stack_ms / 1e6, 1) if stack_ms else None,
+                  "frac": round(stack_bytes / stack_ms / 1e6 / 8000.0, 4) if stack_ms else None},
+        "kernels_ms": {k: round(v[1] / steps, 4) for k, v in prof.items()},
+    }

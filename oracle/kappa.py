@@ -1,0 +1,219 @@
+"""Oracle: Ray-Ramses kappa-map stack and the per-map pipeline (numpy, float64).
+
+TEST INFRASTRUCTURE — see oracle/__init__.py.  Paths below are relative to
+/root/reference/src/astrild/.
+
+Pinned by the reference's own known-answer tests (values restated as data in
+tests/golden/reference_known_answers.json; checked in tests/test_oracle_kappa.py):
+  * kappa0_to_alphas      <- tests/unit/rays/skys/test_skyutils.py:113-125
+  * NFW dT / alpha maps   <- tests/unit/rays/skys/test_skyutils.py:43-95
+  * unit conversion       <- tests/unit/rays/skys/test_skyutils.py:97-111
+  * Gaussian smoothing    <- tests/unit/rays/utils/test_filters.py:47-55
+The reference C library (rays/skys/lib_so_cgls/*.c) is NOT built here: it needs
+fftw3.h / libfftw3, which this image lacks, and stand-ins are not allowed, so it
+is "unbuildable"; the numpy restatement below is pinned by the test values
+instead.  The plane stack itself has no reference test (parity unpinned); it
+is plain sequential IEEE addition and is compared bit for bit.
+"""
+import numpy as np
+from scipy import ndimage
+
+C_LIGHT_KMS = 299792.458      # astropy c.to("km/s").value, rays/skys/sky_utils.py:17
+GCM2 = 4.785e-20              # G/c^2 [Mpc/M_sun], rays/skys/sky_utils.py:19
+
+
+# ----------------------------------------------------------------- a-7 stack
+def kernel_function(x, x_s):
+    """g = (x_s - x) * x / x_s — rays/rayramses.py:315-326, simcoll.py:432-443."""
+    return (x_s - x) * x / x_s
+
+
+def translate_redshift(quantity, x_near, x_far, x_src, x_src_shift):
+    """rays/rayramses.py:269-312 with comoving distances already evaluated
+    (the reference calls astropy's cosmology.comoving_distance for them)."""
+    x_shift = x_far if x_far > x_src_shift else x_src_shift
+    x_mid = 0.5 * (x_far + x_near)
+    return quantity * kernel_function(x_mid, x_shift) / kernel_function(x_mid, x_src)
+
+
+def kappa_stack(planes, x_near=None, x_far=None, x_src=None, x_src_shift=None):
+    """Running sum in plane order: first plane copied, then ``sum = sum + plane``
+    (rays/rayramses.py:224-232; simcoll.py:322-336), each plane optionally
+    re-weighted first."""
+    total = None
+    for p, plane in enumerate(planes):
+        q = np.asarray(plane, dtype=np.float64)
+        if x_near is not None:
+            q = translate_redshift(q, x_near[p], x_far[p], x_src, x_src_shift)
+        total = q.copy() if total is None else total + q
+    return total
+
+
+# --------------------------------------------------------------- a-8 per map
+def convert_code_to_phy_units(quantity, values):
+    """rays/skys/sky_utils.py:318-339."""
+    values = np.asarray(values, dtype=np.float64)
+    if quantity in ["shear_x", "shear_y", "deflt_x", "deflt_y", "kappa_2"]:
+        return values / C_LIGHT_KMS ** 2
+    if quantity in ["isw_rs"]:
+        return values / C_LIGHT_KMS ** 3
+    return values
+
+
+def rays_to_map(values):
+    """rays/skyio.py:32-48: the sort key is arange, so this is a row-major reshape."""
+    npix = int(np.sqrt(len(values)))
+    return np.asarray(values, dtype=np.float64)[: npix * npix].reshape(npix, npix).copy()
+
+
+def gaussian_smooth(img, theta_deg, sigma_arcmin, kind=None):
+    """Filters.gaussian (rays/utils/filters.py:181-225) -> lenstools
+    ConvergenceMap.smooth: sigma_px = sigma * npix / theta; <500 px real space
+    (scipy gaussian_filter: reflect, truncate 4), else FFT (periodic)."""
+    img = np.asarray(img, dtype=np.float64)
+    npix = img.shape[0]
+    sigma_px = (sigma_arcmin / 60.0) * npix / theta_deg
+    if kind is None:
+        kind = "gaussian" if npix < 500 else "gaussianFFT"
+    if kind == "gaussian":
+        return ndimage.gaussian_filter(img, sigma=sigma_px)
+    lx = np.fft.rfftfreq(npix)
+    ly = np.fft.fftfreq(npix)
+    l2 = lx[None, :] ** 2 + ly[:, None] ** 2
+    return np.fft.irfft2(np.exp(-0.5 * l2 * (2 * np.pi * sigma_px) ** 2) * np.fft.rfft2(img), s=img.shape)
+
+
+def fwhm_to_sigma(fwhm):
+    return fwhm / (2 * np.sqrt(2 * np.log(2)))      # rays/utils/filters.py:256-257
+
+
+def galaxy_shape_noise(npix, rnd_seed):
+    """rays/skys/sky_array.py:665-690: sigma_pix is hard-coded to 0.007."""
+    rg = np.random.Generator(np.random.PCG64(rnd_seed))
+    return rg.normal(loc=0, scale=0.007, size=[npix, npix])
+
+
+def pdf(img, nbins):
+    """rays/skys/sky_array.py:428-433."""
+    return np.histogram(img, bins=nbins, density=True)
+
+
+# ----------------------------------------------------- a-9 kappa -> alpha, phi
+def _iso_kernel(ncc, dcell, which):
+    """kernel_alphas_iso / kernel_phi_iso, rays/skys/lib_so_cgls/lensing_funcs.c:45-83,117-148."""
+    h = ncc // 2
+    idx = np.arange(ncc)
+    folded = np.where(idx <= h, idx, ncc - idx)
+    x = (folded * dcell + 0.5 * dcell)[:, None] * np.ones((1, ncc))
+    y = (folded * dcell + 0.5 * dcell)[None, :] * np.ones((ncc, 1))
+    r = np.sqrt(x * x + y * y)
+    inside = ~(r > dcell * ncc / 2.0)
+    if which == 0:
+        k = np.where(inside, x / (np.pi * r * r), 0.0)
+        k = np.where((idx > h)[:, None], -k, k)
+    elif which == 1:
+        k = np.where(inside, y / (np.pi * r * r), 0.0)
+        k = np.where((idx > h)[None, :], -k, k)
+    else:
+        k = np.where(inside, np.log(r) / np.pi, 0.0)
+    return k
+
+
+def _convolve_corner(kappa0, kernel, nc, dsx):
+    """zero_padding + convolve_fft + corner_matrix (lensing_funcs.c:8-43, fft_convolve.c:48-95)."""
+    n2 = 2 * nc
+    pad = np.zeros((n2, n2))
+    pad[:nc, :nc] = kappa0
+    full = np.fft.irfft2(np.fft.rfft2(pad) * np.fft.rfft2(kernel), s=(n2, n2)) * (n2 * n2)   # FFTW c2r is unnormalised
+    return (full / (n2 * n2) * dsx * dsx)[:nc, :nc]
+
+
+def kappa0_to_alphas(kappa0, nc, bsz):
+    """lensing_funcs.c:86-115.  Returns (alpha1, alpha2) in the C argument order."""
+    kappa0 = np.asarray(kappa0, dtype=np.float64).reshape(nc, nc)
+    dsx = bsz / nc
+    a1 = _convolve_corner(kappa0, _iso_kernel(2 * nc, dsx, 0), nc, dsx)
+    a2 = _convolve_corner(kappa0, _iso_kernel(2 * nc, dsx, 1), nc, dsx)
+    return a1, a2
+
+
+def kappa0_to_phi(kappa0, nc, bsz):
+    """lensing_funcs.c:151-173."""
+    kappa0 = np.asarray(kappa0, dtype=np.float64).reshape(nc, nc)
+    dsx = bsz / nc
+    return _convolve_corner(kappa0, _iso_kernel(2 * nc, dsx, 2), nc, dsx)
+
+
+def general_gaussian(m, p, sig):
+    """scipy.signal.general_gaussian (removed from scipy.signal's top level):
+    exp(-0.5 * |n/sig|^(2p)), n = arange(m) - (m-1)/2.  Input of the reference's
+    kappa->alpha test fixture (test_skyutils.py:35-40)."""
+    n = np.arange(m) - (m - 1.0) / 2.0
+    return np.exp(-0.5 * np.abs(n / sig) ** (2 * p))
+
+
+# ---------------------------------------------------- f-2 NFW stamps (next row)
+def nfw_deflection_angle_map(theta_200c, m_200c, c_200c, angu_diam_dist, npix=100, extent=1,
+                             direction=(0,), suppress=False, suppression_r=1):
+    """rays/skys/sky_utils.py:214-282 (Baxter et al. 2015, Sec. 3.2)."""
+    assert np.sum(direction) <= 1
+    r200 = np.tan(theta_200c * np.pi / 180) * angu_diam_dist
+    edges = np.linspace(0, 2 * r200 * extent, npix) - r200 * extent
+    tx, ty = np.meshgrid(edges, edges)
+    rr = np.sqrt(tx ** 2 + ty ** 2)
+    amp = m_200c * c_200c ** 2 / (np.log(1 + c_200c) - c_200c / (1 + c_200c)) / 4.0 / np.pi
+    const = 16 * np.pi * GCM2 * amp / c_200c / r200
+    x = (rr / (r200 / c_200c)).astype(complex)
+    with np.errstate(all="ignore"):
+        f = np.true_divide(1, x) * (np.log(x / 2) + 2 / np.sqrt(1 - x ** 2)
+                                    * np.arctanh(np.sqrt(np.true_divide(1 - x, 1 + x))))
+        out = np.zeros((npix, npix), dtype=complex)
+        for d in direction:
+            out += const * np.true_divide(tx if d == 0 else ty, rr) * f
+    out = np.nan_to_num(out, copy=False, nan=0.0, posinf=0.0, neginf=0.0)
+    if suppress:
+        out *= np.exp(-(rr / (suppression_r * r200)) ** 3)
+    out = out.real.copy()
+    out[abs(out) > 100] = 0.0
+    return out
+
+
+def nfw_temperature_perturbation_map(theta_200c, m_200c, c_200c, vel, angu_diam_dist, npix=100, extent=1,
+                                     direction=(0, 1), suppress=False, suppression_r=1):
+    """rays/skys/sky_utils.py:176-211 (moving-lens / Birkinshaw-Gull effect)."""
+    dt = np.zeros((npix, npix))
+    for d in direction:
+        a = nfw_deflection_angle_map(theta_200c, m_200c, c_200c, angu_diam_dist, npix, extent, [d],
+                                     suppress, suppression_r)
+        dt += -a * vel[d] / C_LIGHT_KMS
+    return dt
+
+
+def add_patch_to_map(limg, simg, cen_pix):
+    """rays/skys/sky_utils.py:140-173: add a stamp, clipped at the map boundary."""
+    rad = int(len(simg) / 2)
+    xe = np.arange(cen_pix[0] - rad, cen_pix[0] + rad + 1)
+    ye = np.arange(cen_pix[1] - rad, cen_pix[1] + rad + 1)
+    xok = (0 <= xe) & (xe < len(limg))
+    yok = (0 <= ye) & (ye < len(limg))
+    limg[ye[yok].min(): ye[yok].max() + 1, xe[xok].min(): xe[xok].max() + 1] += simg[np.ix_(yok, xok)]
+    return limg
+
+
+def analytic_halo_signal_map(halo_cat, extent, direction, suppress, suppression_r, npix, signal):
+    """rays/skys/sky_utils.py:79-137 for a catalogue dict of equal-length arrays."""
+    out = np.zeros((npix, npix))
+    for i in range(len(halo_cat["m200"])):
+        stamp_npix = int(2 * halo_cat["r200_pix"][i] * extent) + 1
+        dist = halo_cat["Dc"][i] * 0.6774
+        if signal == "dT":
+            stamp = nfw_temperature_perturbation_map(
+                halo_cat["r200_deg"][i], halo_cat["m200"][i], halo_cat["c_NFW"][i],
+                [halo_cat["theta1_tv"][i], halo_cat["theta2_tv"][i]], dist, stamp_npix, extent, direction,
+                suppress, suppression_r)
+        else:
+            stamp = nfw_deflection_angle_map(
+                halo_cat["r200_deg"][i], halo_cat["m200"][i], halo_cat["c_NFW"][i], dist, stamp_npix, extent,
+                direction, suppress, suppression_r)
+        out = add_patch_to_map(out, stamp, (halo_cat["theta1_pix"][i], halo_cat["theta2_pix"][i]))
+    return out

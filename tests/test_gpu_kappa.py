@@ -1,0 +1,195 @@
+"""GPU parity for the kappa-map path through the
+C-ABI, against the oracle and the reference's own known-answer values.
+
+Tolerances: plane stack and unit conversion fp64 bit-exact (sequential IEEE ops);
+histogram counts bit-exact; FFT-based results 1e-6 relative to the map's peak
+(north_star tolerance), in practice ~1e-13.
+"""
+import ctypes as ct
+import json
+import os
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from oracle import kappa as ok
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))
+
+
+@pytest.fixture(scope="module")
+def lens(hip):
+    from astrild_amd import lensing
+    torch.cuda.set_device(0)
+    return lensing
+
+
+@pytest.fixture(scope="module")
+def dev(hip):
+    from astrild_amd import device
+    return device
+
+
+def test_stack_unweighted_bit_exact(lens, dev):
+    rng = np.random.default_rng(0)
+    planes = [rng.standard_normal((96, 96)) * 10.0 ** rng.integers(-3, 3) for _ in range(17)]
+    got = lens.kappa_stack([dev.as_device(p) for p in planes]).cpu().numpy()
+    assert np.array_equal(got, ok.kappa_stack(planes))
+
+
+def test_stack_weighted_bit_exact_with_source_clamp(lens, dev):
+    rng = np.random.default_rng(1)
+    P = 12
+    planes = [rng.standard_normal((64, 64)) for _ in range(P)]
+    x_near = np.arange(P) * 83.3
+    x_far = x_near + 83.3
+    x_src, x_shift = 1100.0, 700.0          # planes beyond 700 get the x_far clamp
+    wn, wd = lens.translate_redshift_weights(x_near, x_far, x_src, x_shift)
+    got = lens.kappa_stack([dev.as_device(p) for p in planes], wn, wd).cpu().numpy()
+    ref = ok.kappa_stack(planes, x_near, x_far, x_src, x_shift)
+    assert np.array_equal(got, ref)
+
+
+def test_stack_fp32_and_single_plane(lens, dev):
+    rng = np.random.default_rng(2)
+    planes = [rng.standard_normal((32, 32)).astype(np.float32) for _ in range(5)]
+    got = lens.kappa_stack([dev.as_device(p) for p in planes]).cpu().numpy()
+    ref = planes[0].copy()
+    for p in planes[1:]:
+        ref = ref + p
+    assert np.array_equal(got, ref)
+    one = lens.kappa_stack([dev.as_device(planes[0])]).cpu().numpy()
+    assert np.array_equal(one, planes[0])
+
+
+def test_unit_conversion_bit_exact_and_reference_values(lens, dev):
+    g = GOLD["unit_conversion"]
+    for case in g["cases"]:
+        t = dev.as_device(np.full(10, g["c_light_km_s"] ** case["power"]))
+        assert lens.convert_code_to_phy_units(case["quantity"], t).cpu().numpy()[0] == g["expected"]
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal(1000) * 1e9
+    got = lens.convert_code_to_phy_units("kappa_2", dev.as_device(v.copy())).cpu().numpy()
+    assert np.array_equal(got, ok.convert_code_to_phy_units("kappa_2", v))
+
+
+def test_kappa_to_alphas_reference_known_answer_via_host_abi(hip):
+    # the libglsg.so-compatible entry point, bound exactly like sky_utils.py:402-419
+    g = GOLD["kappa_to_alphas"]
+    gg = ok.general_gaussian(100, 1, 10)
+    kappa = np.array(np.outer(gg, gg), dtype=ct.c_double)
+    npix = g["npix"]
+    a1 = np.zeros((npix, npix), dtype=ct.c_double)
+    a2 = np.zeros((npix, npix), dtype=ct.c_double)
+    fn = hip.kappa0_to_alphas
+    fn.argtypes = [np.ctypeslib.ndpointer(dtype=ct.c_double), ct.c_int, ct.c_double,
+                   np.ctypeslib.ndpointer(dtype=ct.c_double), np.ctypeslib.ndpointer(dtype=ct.c_double)]
+    fn(kappa, npix, np.deg2rad(g["opening_angle_deg"]), a1, a2)
+    e = g["alpha_1"]
+    npt.assert_almost_equal(a1.min(), e["min"], decimal=e["decimal"])
+    npt.assert_almost_equal(a1.mean(), e["mean"], decimal=e["decimal"])
+    npt.assert_almost_equal(a1.max(), e["max"], decimal=e["decimal"])
+    r1, r2 = ok.kappa0_to_alphas(kappa, npix, np.deg2rad(g["opening_angle_deg"]))
+    npt.assert_allclose(a1, r1, rtol=0, atol=1e-6 * abs(r1).max())
+    npt.assert_allclose(a2, r2, rtol=0, atol=1e-6 * abs(r2).max())
+    # phi through the host ABI too
+    phi = np.zeros((npix, npix), dtype=ct.c_double)
+    fp = hip.kappa0_to_phi
+    fp.argtypes = [np.ctypeslib.ndpointer(dtype=ct.c_double), ct.c_int, ct.c_double,
+                   np.ctypeslib.ndpointer(dtype=ct.c_double)]
+    fp(kappa, npix, np.deg2rad(g["opening_angle_deg"]), phi)
+    rp = ok.kappa0_to_phi(kappa, npix, np.deg2rad(g["opening_angle_deg"]))
+    npt.assert_allclose(phi, rp, rtol=0, atol=1e-6 * abs(rp).max())
+
+
+@pytest.mark.parametrize("nc", [16, 100, 256])
+def test_lens_plan_device_variants_vs_oracle(lens, dev, nc):
+    rng = np.random.default_rng(nc)
+    kappa = rng.standard_normal((nc, nc)) * 0.01
+    bsz = np.deg2rad(3.0)
+    plan = lens.LensPlan(nc, bsz)
+    kd = dev.as_device(kappa)
+    a1, a2 = plan.alphas(kd)
+    phi = plan.phi(kd)
+    a1b, _ = plan.alphas(kd)                       # cached kernel spectra: second call identical
+    r1, r2 = ok.kappa0_to_alphas(kappa, nc, bsz)
+    rp = ok.kappa0_to_phi(kappa, nc, bsz)
+    npt.assert_allclose(a1.cpu().numpy(), r1, rtol=0, atol=1e-10 * abs(r1).max())
+    npt.assert_allclose(a2.cpu().numpy(), r2, rtol=0, atol=1e-10 * abs(r2).max())
+    npt.assert_allclose(phi.cpu().numpy(), rp, rtol=0, atol=1e-10 * abs(rp).max())
+    assert torch.equal(a1, a1b)
+
+
+def test_gaussian_real_space_reference_known_answer(lens, dev):
+    g = GOLD["nfw_halo"]
+    halo = {k: np.array(v) for k, v in g["halo"].items()}
+    dt = ok.analytic_halo_signal_map(halo, g["extent"], g["direction"], g["suppress"], g["suppression_R"],
+                                     g["npix"], "dT")
+    gs = GOLD["gaussian_smoothing"]
+    plan = lens.SmoothPlan(g["npix"])
+    for case in gs["cases"]:
+        sigma_px = ok.fwhm_to_sigma(case["fwhm_arcmin"]) / 60.0 * g["npix"] / gs["theta_deg"]
+        img = dev.as_device(dt.copy())
+        plan.gaussian(img, sigma_px, "gaussian")
+        got = img.cpu().numpy()
+        npt.assert_almost_equal(got.max() * 1e8, case["max_times_1e8"], decimal=case["decimal"])
+        ref = ok.gaussian_smooth(dt, gs["theta_deg"], ok.fwhm_to_sigma(case["fwhm_arcmin"]), kind="gaussian")
+        npt.assert_allclose(got, ref, rtol=0, atol=1e-12 * abs(ref).max())
+
+
+@pytest.mark.parametrize("npix", [64, 501, 512])
+def test_gaussian_fft_branch_vs_oracle(lens, dev, npix):
+    rng = np.random.default_rng(npix)
+    img = rng.standard_normal((npix, npix))
+    theta, sig = 5.0, 1.7
+    sigma_px = sig / 60.0 * npix / theta
+    t = dev.as_device(img.copy())
+    lens.SmoothPlan(npix).gaussian(t, sigma_px, "gaussianFFT")
+    ref = ok.gaussian_smooth(img, theta, sig, kind="gaussianFFT")
+    npt.assert_allclose(t.cpu().numpy(), ref, rtol=0, atol=1e-12 * abs(ref).max())
+
+
+def test_gaussian_real_space_small_map_large_kernel(lens, dev):
+    # kernel radius larger than the map: exercises repeated reflection
+    rng = np.random.default_rng(7)
+    img = rng.standard_normal((24, 24))
+    t = dev.as_device(img.copy())
+    lens.SmoothPlan(24).gaussian(t, 9.0, "gaussian")
+    from scipy import ndimage
+    npt.assert_allclose(t.cpu().numpy(), ndimage.gaussian_filter(img, 9.0), rtol=0, atol=1e-13)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_histogram_counts_bit_exact_and_pdf(lens, dev, dtype):
+    rng = np.random.default_rng(5)
+    img = (rng.standard_normal((300, 300)) * 0.02).astype(dtype)
+    t = dev.as_device(img)
+    lo, hi = lens.minmax(t)
+    assert lo == img.min() and hi == img.max()
+    for nbins in (1, 7, 100, 1000):
+        counts, edges = lens.histogram(t, nbins)
+        rc, re = np.histogram(img.astype(np.float64), bins=nbins)
+        assert np.array_equal(counts, rc)
+        npt.assert_allclose(edges, re, rtol=1e-15, atol=0)
+    vals, _ = lens.histogram(t, 50, density=True)
+    rv, _ = ok.pdf(img.astype(np.float64), 50)
+    npt.assert_allclose(vals, rv, rtol=1e-13)
+    c2, _ = lens.histogram(t, 10, range=(-0.01, 0.03))
+    assert np.array_equal(c2, np.histogram(img.astype(np.float64), bins=10, range=(-0.01, 0.03))[0])
+
+
+def test_histogram_values_on_bin_edges(lens, dev):
+    # values exactly on edges: left-closed bins, right-most bin closed
+    img = np.array([0.0, 0.1, 0.2, 0.3, 0.5, 0.7, 1.0, 1.0, 0.9999999999999999, 0.30000000000000004])
+    counts, _ = lens.histogram(dev.as_device(img), 10)
+    assert np.array_equal(counts, np.histogram(img, bins=10)[0])
+
+
+def test_add_galaxy_shape_noise(lens, dev):
+    kap = np.random.default_rng(1).standard_normal((64, 64)) * 0.01
+    gsn = ok.galaxy_shape_noise(64, 34077)
+    got = lens.add(dev.as_device(kap), dev.as_device(gsn)).cpu().numpy()
+    assert np.array_equal(got, kap + gsn)

@@ -1,0 +1,122 @@
+"""Pins the oracle's rays sub-path against the reference's own known-answer
+test values (tests/golden/reference_known_answers.json).  CPU only."""
+import json
+import os
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from oracle import kappa as ok
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))
+
+
+def _halo():
+    g = GOLD["nfw_halo"]
+    return {k: np.array(v) for k, v in g["halo"].items()}, g
+
+
+@pytest.fixture(scope="module")
+def dt_map():
+    halo, g = _halo()
+    return ok.analytic_halo_signal_map(halo, g["extent"], g["direction"], g["suppress"], g["suppression_R"],
+                                       g["npix"], "dT")
+
+
+def test_nfw_dT_map_matches_reference_test(dt_map):
+    e = GOLD["nfw_halo"]["dT"]
+    assert np.unravel_index(dt_map.argmax(), dt_map.shape) == tuple(e["argmax"])
+    npt.assert_almost_equal(dt_map.min(), e["min"], decimal=e["decimals"]["min"])
+    npt.assert_almost_equal(dt_map.mean(), e["mean"], decimal=e["decimals"]["mean"])
+    npt.assert_almost_equal(dt_map.max(), e["max"], decimal=e["decimals"]["max"])
+
+
+def test_nfw_alpha_map_matches_reference_test():
+    halo, g = _halo()
+    m = ok.analytic_halo_signal_map(halo, g["extent"], g["direction"], g["suppress"], g["suppression_R"],
+                                    g["npix"], "alpha")
+    e = g["alpha"]
+    assert np.unravel_index(m.argmax(), m.shape) == tuple(e["argmax"])
+    npt.assert_almost_equal(m.min(), e["min"], decimal=e["decimals"]["min"])
+    npt.assert_almost_equal(m.mean(), e["mean"], decimal=e["decimals"]["mean"])
+    npt.assert_almost_equal(m.max(), e["max"], decimal=e["decimals"]["max"])
+
+
+def test_kappa0_to_alphas_matches_reference_test():
+    g = GOLD["kappa_to_alphas"]
+    gg = ok.general_gaussian(100, 1, 10)
+    a1, a2 = ok.kappa0_to_alphas(np.outer(gg, gg), g["npix"], np.deg2rad(g["opening_angle_deg"]))
+    e = g["alpha_1"]
+    npt.assert_almost_equal(a1.min(), e["min"], decimal=e["decimal"])
+    npt.assert_almost_equal(a1.mean(), e["mean"], decimal=e["decimal"])
+    npt.assert_almost_equal(a1.max(), e["max"], decimal=e["decimal"])
+    # the input is symmetric under transposition, so alpha2 must be alpha1 transposed
+    npt.assert_allclose(a2, a1.T, rtol=1e-12, atol=1e-15)
+
+
+def test_gaussian_smoothing_matches_reference_test(dt_map):
+    g = GOLD["gaussian_smoothing"]
+    for case in g["cases"]:
+        sm = ok.gaussian_smooth(dt_map, g["theta_deg"], ok.fwhm_to_sigma(case["fwhm_arcmin"]))
+        npt.assert_almost_equal(sm.max() * 1e8, case["max_times_1e8"], decimal=case["decimal"])
+
+
+def test_unit_conversion_matches_reference_test():
+    g = GOLD["unit_conversion"]
+    assert ok.C_LIGHT_KMS == g["c_light_km_s"]
+    for case in g["cases"]:
+        v = ok.convert_code_to_phy_units(case["quantity"], [g["c_light_km_s"] ** case["power"]] * 10)
+        assert v[0] == g["expected"]
+
+
+def test_phi_and_alpha_are_consistent():
+    # alpha ~ grad(phi) up to the half-pixel offset the kernels are sampled with
+    # ((i + 1/2) * dsx, lensing_funcs.c:52-53): loose finite-difference check only
+    nc, bsz = 64, 0.1
+    x = np.arange(nc) - nc / 2 + 0.5
+    kap = np.exp(-0.5 * (x[:, None] ** 2 + x[None, :] ** 2) / 4.0 ** 2)
+    a1, a2 = ok.kappa0_to_alphas(kap, nc, bsz)
+    phi = ok.kappa0_to_phi(kap, nc, bsz)
+    d = bsz / nc
+    sl = slice(8, -8)
+    for grad, alpha in ((np.gradient(phi, d, axis=0), a1), (np.gradient(phi, d, axis=1), a2)):
+        err = np.sqrt(np.mean((grad[sl, sl] - alpha[sl, sl]) ** 2)) / np.sqrt(np.mean(alpha[sl, sl] ** 2))
+        assert err < 0.15
+        assert np.corrcoef(grad[sl, sl].ravel(), alpha[sl, sl].ravel())[0, 1] > 0.99
+
+
+def test_fft_and_real_space_smoothing_agree_in_the_interior():
+    rng = np.random.default_rng(0)
+    img = np.zeros((256, 256))
+    img[96:160, 96:160] = rng.standard_normal((64, 64))
+    a = ok.gaussian_smooth(img, 1.0, 0.6, kind="gaussian")
+    b = ok.gaussian_smooth(img, 1.0, 0.6, kind="gaussianFFT")
+    npt.assert_allclose(a, b, atol=2e-4 * abs(a).max())      # real-space kernel is truncated at 4 sigma
+
+
+def test_stack_is_sequential_sum_and_weights():
+    rng = np.random.default_rng(1)
+    planes = [rng.standard_normal((8, 8)) for _ in range(5)]
+    tot = ok.kappa_stack(planes)
+    ref = planes[0].copy()
+    for p in planes[1:]:
+        ref = ref + p
+    assert np.array_equal(tot, ref)
+    xn = np.array([0.0, 100, 200, 300, 400]); xf = xn + 100
+    w = ok.kappa_stack(planes, xn, xf, 1100.0, 450.0)
+    # last plane lies beyond the shifted source: x_s' is clamped to x_far
+    g = ok.kernel_function
+    exp = sum(p * g(0.5 * (a + b), max(b, 450.0) if b > 450.0 else 450.0) / g(0.5 * (a + b), 1100.0)
+              for p, a, b in zip(planes, xn, xf))
+    npt.assert_allclose(w, exp, rtol=1e-13)
+
+
+def test_gsn_and_pdf_and_reshape():
+    g = ok.galaxy_shape_noise(64, 34077)
+    assert g.shape == (64, 64) and abs(g.std() - 0.007) < 3e-4
+    assert np.array_equal(g, ok.galaxy_shape_noise(64, 34077))
+    vals, edges = ok.pdf(g, 50)
+    assert len(vals) == 50 and np.isclose((vals * np.diff(edges)).sum(), 1.0)
+    v = np.arange(16.0)
+    assert np.array_equal(ok.rays_to_map(v), v.reshape(4, 4))
