@@ -110,7 +110,7 @@ shell_geometry_kernel(int n, double kf, int i0_start, int i0_count, int i1_start
 
 template <typename C>
 __global__ void __launch_bounds__(256)
-shell_filter_kernel(const C* __restrict__ in, C* __restrict__ out, int n, int shell,
+shell_filter_kernel(const C* __restrict__ in, C* __restrict__ out, int n, long long lo2, long long hi2,
                     int i0_start, int i0_count, int i1_start, int i1_count) {
     const int nz = n / 2 + 1;
     const size_t total = (size_t)i0_count * i1_count * nz;
@@ -120,7 +120,7 @@ shell_filter_kernel(const C* __restrict__ in, C* __restrict__ out, int n, int sh
         const size_t row = i / nz;
         const int m0 = freq(i0_start + (int)(row / i1_count), n), m1 = freq(i1_start + (int)(row % i1_count), n);
         const long long m2 = (long long)m0 * m0 + (long long)m1 * m1 + (long long)iz * iz;
-        const bool inside = isqrt_i(m2) - 1 == shell;
+        const bool inside = m2 >= lo2 && m2 < hi2;
         C v;
         if (in) v = in[i]; else { v.x = 1; v.y = 0; }
         if (!inside) { v.x = 0; v.y = 0; }
@@ -199,21 +199,23 @@ extern "C" int ast_power_bin_1d(const void* spec1, const void* spec2, int dtype,
     return AST_OK;
 }
 
-extern "C" int ast_shell_filter(const void* in, void* out, int dtype, int nmesh, int shell, int i0_start,
+extern "C" int ast_shell_filter(const void* in, void* out, int dtype, int nmesh, int m_lo, int m_hi, int i0_start,
                                 int i0_count, int i1_start, int i1_count, void* stream) {
     AST_CHECK_ARG(out != nullptr);
     AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
-    AST_CHECK_ARG(nmesh >= 4 && nmesh % 2 == 0 && shell >= 0 && shell < nmesh / 2 - 1);
+    AST_CHECK_ARG(nmesh >= 4 && nmesh % 2 == 0 && m_lo >= 0 && m_hi > m_lo);
+    const long long lo2 = (long long)m_lo * m_lo, hi2 = (long long)m_hi * m_hi;
     AST_CHECK_ARG(i0_start >= 0 && i0_count >= 0 && i0_start + i0_count <= nmesh);
     AST_CHECK_ARG(i1_start >= 0 && i1_count >= 0 && i1_start + i1_count <= nmesh);
     const size_t total = (size_t)i0_count * i1_count * (nmesh / 2 + 1);
     if (total == 0) return AST_OK;
     unsigned g = ast::stream_grid(total, 256);
     hipStream_t s = ast::as_stream(stream);
+    AST_PROF("shell_filter", s);
     if (dtype == AST_F32)
-        shell_filter_kernel<float2><<<g, 256, 0, s>>>((const float2*)in, (float2*)out, nmesh, shell, i0_start, i0_count, i1_start, i1_count);
+        shell_filter_kernel<float2><<<g, 256, 0, s>>>((const float2*)in, (float2*)out, nmesh, lo2, hi2, i0_start, i0_count, i1_start, i1_count);
     else
-        shell_filter_kernel<double2><<<g, 256, 0, s>>>((const double2*)in, (double2*)out, nmesh, shell, i0_start, i0_count, i1_start, i1_count);
+        shell_filter_kernel<double2><<<g, 256, 0, s>>>((const double2*)in, (double2*)out, nmesh, lo2, hi2, i0_start, i0_count, i1_start, i1_count);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
@@ -225,6 +227,7 @@ extern "C" int ast_triple_product_sum(const void* a, const void* b, const void* 
     if (count == 0) return AST_OK;
     unsigned g = ast::stream_grid(count, 256);
     hipStream_t s = ast::as_stream(stream);
+    AST_PROF("triple_product_sum", s);
     if (dtype == AST_F32)
         triple_sum_kernel<float><<<g, 256, 0, s>>>((const float*)a, (const float*)b, (const float*)c, count, out);
     else

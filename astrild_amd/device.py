@@ -261,3 +261,76 @@ def fftpower_1d(field1, boxsize, field2=None):
     s1 = r2c(field1)
     s2 = None if field2 is None else r2c(field2)
     return finish_power(*power_bin_1d(s1, s2, n, boxsize))
+
+
+# ----------------------------------------------------------------- bispectrum
+def c2r(spec, shape, out=None):
+    """Unnormalised inverse of :func:`r2c`'s layout: sum_k spec_k e^{ikx} (rocFFT C2R;
+    the input spectrum is used as scratch)."""
+    n0, n1, n2 = shape
+    code = _CPLX[spec.dtype]
+    if out is None:
+        out = torch.empty(shape, dtype=_TO_REAL[spec.dtype], device=spec.device)
+    fft_plan(_lib.FFT_C2R, code, (n0, n1, n2), 1, 1.0, False).execute(spec, out)
+    return out
+
+
+def shell_filter(spec, nmesh, m_lo, m_hi, out=None, i0=None, i1=None, dtype=None):
+    """out = spec * 1[m_lo <= |m| < m_hi]; spec=None writes the bare indicator."""
+    n = int(nmesh)
+    i0 = (0, n) if i0 is None else tuple(i0)
+    i1 = (0, n) if i1 is None else tuple(i1)
+    if out is None:
+        cd = spec.dtype if spec is not None else dtype
+        out = torch.empty((i0[1], i1[1], n // 2 + 1), dtype=cd, device=device())
+    check(_lib.lib().ast_shell_filter(ptr(spec), ptr(out), _CPLX[out.dtype], n, int(m_lo), int(m_hi),
+                                      int(i0[0]), int(i0[1]), int(i1[0]), int(i1[1]), stream()),
+          "ast_shell_filter")
+    return out
+
+
+def triple_product_sum(a, b, c):
+    out = torch.zeros(1, dtype=torch.float64, device=a.device)
+    check(_lib.lib().ast_triple_product_sum(ptr(a), ptr(b), ptr(c), real_code(a), a.numel(), ptr(out), stream()),
+          "ast_triple_product_sum")
+    return out
+
+
+_tri_cache = {}
+
+
+def bispectrum(field, boxsize, edges, triangles):
+    """FFT (Scoccimarro) bispectrum estimator on integer-|m| shells [edges[i], edges[i+1]).
+
+    Returns dict(B, ntri, k) with one entry per (i, j, l) in ``triangles``; ntri is
+    the exact integer count of closed triangles.  The reference's Bispectrum3D has
+    no bispectrum arithmetic (bispectrum_3d.py:165-215 computes P(k)); this is the
+    estimator its docstring cites (:42-44).
+    """
+    n = field.shape[0]
+    assert tuple(field.shape) == (n, n, n) and n % 2 == 0
+    edges = [int(e) for e in edges]
+    triangles = [tuple(int(v) for v in t) for t in triangles]
+    used = sorted({s for t in triangles for s in t})
+    spec = r2c(field)
+    scratch = torch.empty_like(spec)
+    dfields, ifields = {}, {}
+    key = (torch.cuda.current_device(), n, tuple(edges), tuple(triangles), field.dtype)
+    ntri = _tri_cache.get(key)
+    for s in used:
+        shell_filter(spec, n, edges[s], edges[s + 1], out=scratch)
+        dfields[s] = c2r(scratch, (n, n, n))
+        if ntri is None:
+            shell_filter(None, n, edges[s], edges[s + 1], out=scratch)
+            ifields[s] = c2r(scratch, (n, n, n))
+    nums = [triple_product_sum(dfields[i], dfields[j], dfields[l]) for (i, j, l) in triangles]
+    if ntri is None:
+        dens = [triple_product_sum(ifields[i], ifields[j], ifields[l]) for (i, j, l) in triangles]
+        ntri = np.rint(torch.cat(dens).cpu().numpy() / float(n) ** 3).astype(np.int64)
+        _tri_cache[key] = ntri
+    num = torch.cat(nums).cpu().numpy()
+    kf = 2.0 * np.pi / boxsize
+    kmid = np.array([[kf * 0.5 * (edges[s] + edges[s + 1]) for s in t] for t in triangles])
+    with np.errstate(invalid="ignore", divide="ignore"):
+        b = float(boxsize) ** 6 * num / (ntri * float(n) ** 3)
+    return {"B": b, "ntri": ntri, "k": kmid}

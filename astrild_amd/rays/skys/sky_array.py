@@ -1,0 +1,205 @@
+"""``SkyArray`` (src/astrild/rays/skys/sky_array.py) for the kappa-map hot path:
+unit conversion + reshape, PDF, filters, galaxy shape noise, kappa -> deflection,
+crop / division / merge.  ``self.data`` holds numpy arrays like the reference;
+the arithmetic runs on the GPU through libastrild_hip.so.
+
+Not carried over (out of scope or "next"): NFW halo painting
+constructors, wl_peak_counts (lenstools), create_cmb (broken in the reference,
+sky_array.py:735-739), resize (skimage)."""
+import copy
+from typing import Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import pandas as pd
+
+from ... import lensing
+from ...device import as_device
+from ..skyio import SkyIO
+from ..utils.filters import Filters
+from .sky_utils import SkyUtils
+
+
+class SkyArrayWarning(BaseException):
+    pass
+
+
+class SkyArray:
+    def __init__(self, skymap: np.ndarray, opening_angle: float, quantity: str, dirs: Dict[str, str],
+                 map_file: Optional[str] = None):
+        self.data = {"orig": skymap}
+        self._npix = skymap.shape[0]
+        self._opening_angle = opening_angle
+        self.quantity = quantity
+        self.dirs = dirs
+        self.map_file = map_file
+
+    @classmethod
+    def from_file(cls, map_file: str, opening_angle: float, quantity: str, dir_in: str,
+                  npix: Optional[int] = None, convert_unit: bool = True) -> "SkyArray":
+        assert map_file, "There is no file being pointed at"
+        file_extension = map_file.split(".")[-1]
+        if file_extension == "h5":
+            map_df = pd.read_hdf(map_file, key="df")
+            return cls.from_dataframe(map_df, opening_angle, quantity, dir_in, map_file, npix, convert_unit)
+        elif file_extension == "npy":
+            return cls.from_array(np.load(map_file), opening_angle, quantity, dir_in, map_file)
+        raise SkyArrayWarning(f"file type .{file_extension} is not supported")
+
+    @classmethod
+    def from_dataframe(cls, map_df: pd.DataFrame, opening_angle: float, quantity: str, dir_in: str,
+                       map_file: str, npix: Optional[int] = None, convert_unit: bool = True) -> "SkyArray":
+        """sky_array.py:138-164."""
+        if convert_unit:
+            map_df = SkyUtils.convert_code_to_phy_units(quantity, map_df)
+        map_array = SkyIO.transform_RayRamsesOutput_to_NumpyNdarray(map_df[quantity].values)
+        return cls.from_array(map_array, opening_angle, quantity, dir_in, map_file)
+
+    @classmethod
+    def from_array(cls, map_array: np.ndarray, opening_angle: float, quantity: str, dir_in: str,
+                   map_file: Optional[str] = None) -> "SkyArray":
+        assert map_array.shape[0] == map_array.shape[1]
+        return cls(map_array, opening_angle, quantity, {"sim": dir_in}, map_file)
+
+    @property
+    def npix(self) -> int:
+        return self._npix
+
+    @property
+    def opening_angle(self) -> float:
+        return self._opening_angle
+
+    def pdf(self, nbins: int, of: str = "orig") -> dict:
+        """np.histogram(data, bins=nbins, density=True)  (sky_array.py:428-433)."""
+        _pdf = {}
+        t = as_device(np.ascontiguousarray(self.data[of], dtype=np.float64))
+        _pdf["values"], _pdf["bins"] = lensing.histogram(t, nbins, density=True)
+        return _pdf
+
+    def crop(self, xlimit, ylimit, of: Optional[str] = None, img: Optional[np.ndarray] = None,
+             rtn: bool = False, orig_data: str = None) -> Union[np.ndarray, None]:
+        """sky_array.py:498-540."""
+        if of:
+            assert of in list(self.data.keys()), "Map does not exist."
+            img = self.data[of]
+        img = self._manage_img_data(img, orig_data)
+        xlimit = np.asarray(xlimit)
+        ylimit = np.asarray(ylimit)
+        if np.diff(xlimit) != np.diff(ylimit):
+            raise SkyArrayWarning("The whole class is currently designed for square images.")
+        if isinstance(xlimit[0], (float, np.floating)):
+            _npix = img.shape[0]
+            xlimit = (_npix * xlimit / 100).astype(int)
+            ylimit = (_npix * ylimit / 100).astype(int)
+        zoom = img[xlimit[0]: xlimit[1], ylimit[0]: ylimit[1]]
+        if rtn:
+            return zoom
+        self.data[of] = zoom
+        self._opening_angle = self._opening_angle * abs(np.diff(xlimit)) / self._npix
+        self._npix = zoom.shape[0]
+
+    def division(self, ntiles: int, of: Optional[str] = None, img: Optional[np.ndarray] = None,
+                 rtn: bool = False, orig_data: str = None) -> Union[List[np.ndarray], None]:
+        """sky_array.py:543-580."""
+        if of:
+            img = self.data[of]
+        img = self._manage_img_data(img, orig_data)
+        npix = img.shape[0]
+        edges = list(np.arange(0, npix, npix / ntiles)) + [npix]
+        edges = np.array([edges[idx: idx + 2] for idx in range(len(edges) - 1)]).astype(int)
+        tiles = np.asarray([self.crop(xlim, ylim, img=img, rtn=True) for xlim in edges for ylim in edges])
+        if rtn:
+            return tiles
+        self.tiles = tiles
+        self._tile_npix = tiles[0].shape[0]
+        self._tile_opening_angle = self._opening_angle * self._tile_npix / self._npix
+
+    def merge(self, tiles: np.ndarray, rtn: bool = False) -> Union[np.ndarray, None]:
+        """sky_array.py:583-601."""
+        ntiles = len(tiles)
+        nrows = int(np.sqrt(ntiles))
+        img = np.vstack([np.hstack(tiles[r * nrows: (r + 1) * nrows]) for r in range(nrows)])
+        if rtn:
+            return img
+        self.data["merged"] = img
+
+    def substract_mean(self, of: Optional[str] = None, img: Optional[np.ndarray] = None, rtn: bool = False,
+                       orig_data: str = None) -> Union[np.ndarray, None]:
+        if of:
+            assert of in list(self.data.keys()), "Map does not exist."
+            img = self.data[of]
+        img = self._manage_img_data(img, orig_data)
+        img -= np.mean(img)
+        if rtn:
+            return img
+        self.data[of] = img
+
+    def filter(self, filter_dsc: dict, on: Optional[str] = None, img: Optional[np.ndarray] = None,
+               rtn: bool = False, orig_data: str = None) -> Union[np.ndarray, None]:
+        """Apply the kernels of ``filter_dsc`` in order (sky_array.py:623-662);
+        each entry is dispatched by name into :class:`Filters`."""
+        if on:
+            assert on in list(self.data.keys()), "Map does not exist."
+            img = self.data[on]
+            map_name = [on]
+        else:
+            map_name = [""]
+        img = self._manage_img_data(img, orig_data)
+        for filter_name, args in filter_dsc.items():
+            args = dict(args)
+            if rtn is False:
+                map_name.append(args.pop("abbrev"))
+            else:
+                args.pop("abbrev", None)
+            fct = getattr(Filters, filter_name)
+            img = fct(img, self._opening_angle, **args)
+        if rtn:
+            return img
+        self.data[("_").join(map_name)] = img
+
+    def create_galaxy_shape_noise(self, std: float, ngal: float, rnd_seed: Optional[int] = None) -> None:
+        """sky_array.py:665-690.  sigma_pix is hard-coded to 0.007 in the reference
+        (:680; ``std``/``ngal`` are ignored there too).  The draw is numpy's own
+        Generator(PCG64(seed)).normal — the same library call the reference makes —
+        so a seeded map is bit-identical to astrild's."""
+        std_pix = 0.007
+        if rnd_seed is None:
+            self.data["gsn"] = np.random.normal(loc=0, scale=std_pix, size=[self._npix, self._npix])
+        else:
+            rg = np.random.Generator(np.random.PCG64(rnd_seed))
+            self.data["gsn"] = rg.normal(loc=0, scale=std_pix, size=[self._npix, self._npix])
+
+    def add_galaxy_shape_noise(self, on: str = "orig") -> np.ndarray:
+        """sky_array.py:693-706."""
+        if "kappa" in self.quantity:
+            a = as_device(np.ascontiguousarray(self.data["orig"], dtype=np.float64))
+            b = as_device(np.ascontiguousarray(self.data["gsn"], dtype=np.float64))
+            self.data["orig_gsn"] = lensing.add(a, b).cpu().numpy()
+            return self.data["orig_gsn"]
+        raise SkyArrayWarning(f"GSN should not be added to {self.quantity}")
+
+    def convert_convergence_to_deflection(self, on: Optional[str] = None, img: Optional[np.ndarray] = None,
+                                          npix: Optional[int] = None, opening_angle: Optional[float] = None,
+                                          rtn: bool = True, orig_data: str = None
+                                          ) -> Tuple[np.ndarray, np.ndarray]:
+        """sky_array.py:780-817.  Returns (alpha_2, alpha_1) — the reference's order."""
+        assert self.quantity in ["kappa_1", "kappa_2"], "Deflection angle can only be calculated from the kappa map"
+        if on:
+            img = self.data[on]
+        img = self._manage_img_data(img, orig_data)
+        if npix is None:
+            npix = self._npix
+        if opening_angle is None:
+            opening_angle = self._opening_angle
+        alpha_1, alpha_2 = SkyUtils.convert_convergence_to_deflection_ctypes(img, npix, opening_angle)
+        if rtn:
+            return alpha_2, alpha_1
+        self.data["defltx"] = alpha_2
+        self.data["deflty"] = alpha_1
+
+    @staticmethod
+    def _manage_img_data(img: np.ndarray, orig_data: str = None) -> np.ndarray:
+        if orig_data == "shallow":
+            return copy.copy(img)
+        elif orig_data == "deep":
+            return copy.deepcopy(img)
+        return img

@@ -177,9 +177,15 @@ int ast_power_bin_1d(const void* spec1_d, const void* spec2_d, int dtype, int nm
 
 /* --------------------------------------------------- a-10: bispectrum */
 
-/* out = in * 1[shell(m) == shell] (or just the indicator when in_d is NULL)
- * over the same spectrum block layout as ast_power_bin_1d. */
-int ast_shell_filter(const void* in_d, void* out_d, int dtype, int nmesh, int shell,
+/* The reference's Bispectrum3D computes P(k) (bispectra/bispectrum_3d.py:165-215);
+ * these two kernels carry the FFT (Scoccimarro) estimator its docstring cites
+ * (:42-44): delta_i(x) = IFFT[delta_k 1(k in shell i)], I_i(x) = IFFT[1(k in i)],
+ * B(i,j,l) = L^6 sum_x d_i d_j d_l / sum_x I_i I_j I_l.
+ *
+ * out = in * 1[m_lo <= |m| < m_hi] (or just the indicator when in_d is NULL),
+ * exact integer comparison of |m|^2, over the same spectrum block layout as
+ * ast_power_bin_1d. */
+int ast_shell_filter(const void* in_d, void* out_d, int dtype, int nmesh, int m_lo, int m_hi,
                      int i0_start, int i0_count, int i1_start, int i1_count, void* stream);
 
 /* *out_d += sum_i a[i] * b[i] * c[i]  (double accumulator, device). */

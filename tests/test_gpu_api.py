@@ -1,0 +1,256 @@
+"""GPU: the astrild-named Python API (PowerSpectrum3D, Bispectrum3D, SubFind, SkyMap /
+SkyArray / SkyUtils / Filters, RayRamses, SimulationCollection) against the oracle."""
+import os
+import types
+
+import numpy as np
+import numpy.testing as npt
+import pandas as pd
+import pytest
+
+from oracle import bispectrum as ob, fftpower as offt, kappa as ok, mesh as omesh
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+class FakeSimulation:
+    """The attributes PowerSpectrum3D touches on astrild.simulation.Simulation."""
+
+    def __init__(self, tmp, n, boxsize, files):
+        self.boxsize, self.domain_level, self.npar = boxsize, n, n
+        self.dirs = {"out": str(tmp) + "/"}
+        self._files = files
+        self.dir_nrs = sorted(files)
+
+    def get_file_nrs(self, file_dsc, path, which):
+        return sorted(self._files)
+
+    def get_file_paths(self, file_dsc, path, which):
+        return [self._files[k] for k in sorted(self._files)]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dev(hip):
+    torch.cuda.set_device(0)
+
+
+def test_power_spectrum_3d_compute_auto_and_cross(tmp_path):
+    from astrild_amd.power_spectra import PowerSpectrum3D
+    rng = np.random.default_rng(0)
+    n, L = 32, 250.0
+    grids = {3: rng.standard_normal((n, n, n)) + 2.0, 7: rng.standard_normal((n, n, n))}
+    files = {}
+    for nr, g in grids.items():
+        files[nr] = str(tmp_path / f"grid_{nr:03d}.npy")
+        np.save(files[nr], g)
+    sim = FakeSimulation(tmp_path, n, L, files)
+    ps = PowerSpectrum3D("particles", sim)
+    pk = ps.compute(["rho"], [{"path": "x", "root": "grid", "extension": "npy"}], save=False)
+    for nr, g in grids.items():
+        k, p = offt.power_spectrum_3d(g, L)
+        npt.assert_allclose(pk["k"][f"snap_{nr}"], k, rtol=1e-12)
+        npt.assert_allclose(pk["P"][f"snap_{nr}"], p, rtol=1e-10)
+    # cross spectrum branch (power_spectrum_3d.py:197-222)
+    k, p = ps._power_spectrum_3d(grids[3], grids[7])
+    kr, pr = offt.power_spectrum_3d(grids[3], L, grids[7])
+    npt.assert_allclose(p, pr, rtol=1e-9, atol=1e-12 * abs(pr).max())
+    with pytest.raises(BaseException):
+        ps._power_spectrum_3d(np.zeros((8, 8, 8)))
+
+
+def test_power_spectrum_3d_read_data_ngp_assign(tmp_path, monkeypatch):
+    from astrild_amd.power_spectra import PowerSpectrum3D, power_spectrum_3d as mod
+    rng = np.random.default_rng(1)
+    n = 16
+    df = pd.DataFrame({"x": rng.uniform(0, 1, 9000), "y": rng.uniform(0, 1, 9000), "z": rng.uniform(0, 1, 9000),
+                       "rho": rng.standard_normal(9000)})
+    monkeypatch.setattr(mod.pd, "read_hdf", lambda path, key=None: df)       # PyTables is not installed here
+    sim = FakeSimulation(tmp_path, n, 100.0, {})
+    grid = PowerSpectrum3D("particles", sim)._read_data("fields.h5", "rho")
+    ref = omesh.ngp_assign(df.x.values, df.y.values, df.z.values, df.rho.values, n)
+    assert np.array_equal(grid.cpu().numpy(), ref)
+
+
+def test_power_spectrum_3d_fp32_mode(tmp_path):
+    from astrild_amd.power_spectra import PowerSpectrum3D
+    rng = np.random.default_rng(2)
+    n, L = 64, 500.0
+    g = (1.0 + 0.5 * rng.standard_normal((n, n, n))).astype(np.float32)
+    ps = PowerSpectrum3D("particles", FakeSimulation(tmp_path, n, L, {}))
+    ps.dtype = torch.float32
+    k, p = ps._power_spectrum_3d(g)
+    kr, pr = offt.power_spectrum_3d(g, L)
+    npt.assert_allclose(p, pr, rtol=1e-6)
+
+
+def test_subfind_power_spectrum_tsc():
+    from astrild_amd.particles.hutils import SubFind
+    rng = np.random.default_rng(3)
+    nobj, nbins, box = 20000, 32, 62.0
+    h = 0.6774
+    snap = types.SimpleNamespace(
+        cat={"SubhaloPos": rng.uniform(0, box * 1e3 / h, (nobj, 3)), "SubhaloMass": rng.uniform(1, 50, nobj)},
+        header=types.SimpleNamespace(hubble=h, boxsize=box * 1e3),
+    )
+    k, p = SubFind.power_spectrum(snap, nbins=nbins, boxsize=box)
+    pos = snap.cat["SubhaloPos"] * h / 1e3
+    mass = snap.cat["SubhaloMass"] * h / 1e10
+    grid = omesh.paint(pos, mass, nbins, box, "tsc") / (box / nbins) ** 3
+    kr, pr = offt.power_spectrum_3d(grid, box)
+    npt.assert_allclose(k, kr, rtol=1e-12)
+    npt.assert_allclose(p, pr, rtol=1e-9)
+
+
+@pytest.mark.parametrize("n,width", [(16, 1), (32, 3)])
+def test_bispectrum_3d_vs_oracle(tmp_path, n, width):
+    from astrild_amd.bispectra import Bispectrum3D
+    rng = np.random.default_rng(n)
+    L = 80.0
+    f = rng.standard_normal((n, n, n))
+    f = f + 0.4 * f ** 2
+    bs = Bispectrum3D("particles", FakeSimulation(tmp_path, n, L, {}))
+    edges = ob.shell_edges(n, width=width)
+    nsh = len(edges) - 1
+    tri = [(i, j, l) for i in range(nsh) for j in range(i, nsh) for l in range(j, nsh)]
+    res = bs._bispectrum_3d(f, shell_width=width, triangles=tri)
+    b, ntri = ob.bispectrum_fft(f, L, edges, tri)
+    assert np.array_equal(res["ntri"], np.rint(ntri).astype(np.int64))     # integer triangle counts: exact
+    ok_ = res["ntri"] > 0
+    npt.assert_allclose(res["B"][ok_], b[ok_], rtol=1e-8, atol=1e-9 * np.nanmax(abs(b)))
+    # second call reuses the cached triangle counts
+    res2 = bs._bispectrum_3d(f, shell_width=width, triangles=tri)
+    npt.assert_allclose(res2["B"][ok_], res["B"][ok_], rtol=1e-12)
+    # the inherited P(k) behaviour of the reference class is kept
+    k, p = bs._power_spectrum_3d(f)
+    kr, pr = offt.power_spectrum_3d(f, L)
+    npt.assert_allclose(p, pr, rtol=1e-10)
+
+
+def test_bispectrum_brute_force_tiny(tmp_path):
+    from astrild_amd.bispectra import Bispectrum3D
+    n, L = 8, 10.0
+    f = np.random.default_rng(5).standard_normal((n, n, n)) ** 2
+    bs = Bispectrum3D("particles", FakeSimulation(tmp_path, n, L, {}))
+    edges = ob.shell_edges(n)
+    tri = [(0, 0, 0), (0, 1, 1), (1, 1, 2), (0, 1, 2), (2, 2, 2)]
+    res = bs._bispectrum_3d(f, triangles=tri)
+    bb, nb = ob.bispectrum_brute_force(f, L, edges, tri)
+    assert np.array_equal(res["ntri"], nb)
+    npt.assert_allclose(res["B"][nb > 0], bb[nb > 0], rtol=1e-9)
+
+
+def _kappa_frame(npix, seed=0):
+    rng = np.random.default_rng(seed)
+    c2, c3 = ok.C_LIGHT_KMS ** 2, ok.C_LIGHT_KMS ** 3
+    return pd.DataFrame({"kappa_2": rng.standard_normal(npix * npix) * 0.02 * c2,
+                         "isw_rs": rng.standard_normal(npix * npix) * 1e-6 * c3})
+
+
+def test_skymap_skyarray_pipeline():
+    from astrild_amd.rays import SkyMap
+    npix, theta = 128, 10.0
+    df = _kappa_frame(npix)
+    raw = df["kappa_2"].values.copy()
+    sky = SkyMap.from_dataframe(npix, theta, "kappa_2", "/tmp/", df.copy(), "Ray_maps_zrange_0.08_0.90.h5")
+    assert sky.npix == npix and sky.opening_angle == theta
+    ref_map = ok.rays_to_map(ok.convert_code_to_phy_units("kappa_2", raw))
+    assert np.array_equal(sky.data["orig"], ref_map)                      # unit conversion + reshape: bit-exact
+    # pdf
+    pdf = sky.pdf(50)
+    rv, re = ok.pdf(ref_map, 50)
+    npt.assert_allclose(pdf["values"], rv, rtol=1e-13)
+    npt.assert_allclose(pdf["bins"], re, rtol=1e-15)
+    # galaxy shape noise: same numpy PCG64 stream as the reference
+    sky.create_galaxy_shape_noise(0.4, 40.0, rnd_seed=34077)
+    assert np.array_equal(sky.data["gsn"], ok.galaxy_shape_noise(npix, 34077))
+    assert np.array_equal(sky.add_galaxy_shape_noise(), ref_map + sky.data["gsn"])
+    # filter dispatch by name, smoothing real-space branch (< 500 px)
+    sky.filter({"gaussian": {"theta_i": 2.5, "abbrev": "smooth"}}, on="orig_gsn")
+    ref_s = ok.gaussian_smooth(ref_map + sky.data["gsn"], theta, 2.5)
+    npt.assert_allclose(sky.data["orig_gsn_smooth"], ref_s, rtol=0, atol=1e-12 * abs(ref_s).max())
+    hp = sky.filter({"gaussian_high_pass": {"fwhm_i": 6.0, "abbrev": "hp"}}, on="orig", rtn=True)
+    npt.assert_allclose(hp, ref_map - ok.gaussian_smooth(ref_map, theta, ok.fwhm_to_sigma(6.0)),
+                        rtol=0, atol=1e-12 * abs(ref_map).max())
+    # kappa -> deflection: returns (alpha_2, alpha_1) like sky_array.py:813-817
+    ax, ay = sky.convert_convergence_to_deflection(on="orig")
+    r1, r2 = ok.kappa0_to_alphas(ref_map, npix, np.deg2rad(theta))
+    npt.assert_allclose(ax, r2, rtol=0, atol=1e-10 * abs(r2).max())
+    npt.assert_allclose(ay, r1, rtol=0, atol=1e-10 * abs(r1).max())
+    # crop / division / merge round trip
+    tiles = sky.division(4, of="orig", rtn=True)
+    assert tiles.shape == (16, 32, 32)
+    assert np.array_equal(sky.merge(tiles, rtn=True), sky.data["orig"])
+    with pytest.raises(BaseException):
+        SkyMap.from_array(ref_map, npix, theta, "isw_rs", "/tmp/").add_galaxy_shape_noise()
+
+
+def test_filters_gaussian_fft_branch_large_map():
+    from astrild_amd.rays.utils import Filters
+    rng = np.random.default_rng(4)
+    img = rng.standard_normal((512, 512))
+    got = Filters.gaussian(img, 20.0, theta_i=3.0)
+    ref = ok.gaussian_smooth(img, 20.0, 3.0)             # >= 500 px -> FFT branch
+    npt.assert_allclose(got, ref, rtol=0, atol=1e-12 * abs(ref).max())
+    assert Filters.sigma_to_fwhm(Filters.fwhm_to_sigma(1.0)) == pytest.approx(1.0)
+    with pytest.raises(ValueError):
+        Filters.gaussian(img, 20.0)
+
+
+class FlatCosmology:
+    """comoving_distance(z) = 3000 z [Mpc]: enough to exercise the re-weighting."""
+
+    def comoving_distance(self, z):
+        return 3000.0 * z
+
+
+def _ray_table():
+    idx = pd.MultiIndex.from_tuples([(1, 1), (1, 2), (1, 3), (2, 1), (2, 2)], names=["box_nr", "snap_nr"])
+    return pd.DataFrame({"redshift": [0.05, 0.10, 0.15, 0.20, 0.25]}, index=idx)
+
+
+def test_rayramses_sum_snapshots_plain_and_reweighted():
+    from astrild_amd.rays import RayRamses
+    npix = 64
+    frames = {(b, r): _kappa_frame(npix, seed=10 * b + r) for (b, r) in _ray_table().index}
+
+    class MemRay(RayRamses):
+        def _load_ray_map(self, ray_file):
+            box = int(ray_file.split("box")[1].split("/")[0])
+            ray = int(ray_file.split("output")[1].split(".")[0])
+            return frames[(box, ray)].copy()
+
+    rr = MemRay({"lc": "/lc/"}, cosmology=FlatCosmology(), ray_info_df=_ray_table())
+    out = rr.sum_snapshots(None, ["kappa_2", "isw_rs"], [], {"z": [0.07, 0.22], "box": [0], "ray": [0]})
+    sel = [(1, 2), (1, 3), (2, 1)]
+    for col in ("kappa_2", "isw_rs"):
+        assert np.array_equal(out[col].values, ok.kappa_stack([frames[s][col].values for s in sel]))
+    # whole light-cone with the source moved from z=0.4 to z=0.22: kappa_2 re-weighted, isw_rs not
+    rr = MemRay({"lc": "/lc/"}, cosmology=FlatCosmology(), ray_info_df=_ray_table())
+    out = rr.sum_snapshots(None, ["kappa_2", "isw_rs"], ["kappa_2"], {"z": [], "box": [0], "ray": [0]},
+                           z_src=0.4, z_src_shift=0.22)
+    zs = _ray_table()["redshift"].values
+    z_next = np.append(zs[1:], zs[-1])
+    ref = ok.kappa_stack([frames[s]["kappa_2"].values for s in _ray_table().index],
+                         3000.0 * zs, 3000.0 * z_next, 3000.0 * 0.4, 3000.0 * 0.22)
+    assert np.array_equal(out["kappa_2"].values, ref)
+    assert np.array_equal(out["isw_rs"].values, ok.kappa_stack([frames[s]["isw_rs"].values for s in _ray_table().index]))
+
+
+def test_simulation_collection_sum_npy_planes(tmp_path):
+    from astrild_amd.simcoll import SimulationCollection
+    rng = np.random.default_rng(8)
+    planes, sims = {}, {}
+    for box in (1, 2):
+        d = tmp_path / f"box{box}"
+        d.mkdir()
+        sims[f"box{box}"] = types.SimpleNamespace(dirs={"sim": str(d) + "/"},
+                                                  file_dsc={"root": "kappa2_maps", "extension": "npy"})
+        for ray in ((1, 2, 3) if box == 1 else (1, 2)):
+            planes[(box, ray)] = rng.standard_normal((48, 48))
+            np.save(d / f"kappa2_maps_output0000{ray}.npy", planes[(box, ray)])
+    sc = SimulationCollection(_ray_table(), sims)
+    tot = sc.sum_raytracing_snapshots(None, ["kappa_2"], [], {"z": [], "box": [0], "ray": [0]},
+                                      rm_ray={1: [2]})
+    order = [(1, 1), (1, 3), (2, 1), (2, 2)]
+    assert np.array_equal(tot, ok.kappa_stack([planes[o] for o in order]))
