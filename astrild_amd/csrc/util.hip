@@ -182,12 +182,12 @@ __device__ inline uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
 template <typename T>
 __global__ void synth_kernel(T* pos, size_t first, size_t count, int npside, double boxsize,
                              double sigma, uint64_t seed, uint64_t shuffle_stride) {
-    const uint64_t n3 = (uint64_t)npside * npside * npside;
     const double h = boxsize / npside;
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += stride) {
-        uint64_t p = first + t;
-        uint64_t id = shuffle_stride ? (uint64_t)(((unsigned __int128)p * shuffle_stride) % n3) : p;
+        // shuffled order permutes the particles INSIDE [first, first + count), so a rank's
+        // range keeps holding its own lattice planes
+        uint64_t id = first + (shuffle_stride ? (uint64_t)(((unsigned __int128)t * shuffle_stride) % count) : t);
         uint64_t k = id % npside, j = (id / npside) % npside, i = id / ((uint64_t)npside * npside);
         double q[3] = {(i + 0.5) * h, (j + 0.5) * h, (k + 0.5) * h};
         // two Box-Muller pairs give three normals

@@ -183,9 +183,9 @@ def synth_lattice_particles(npside, nmesh, boxsize, seed=20240601, sigma_cells=0
     count = n3 - first if count is None else int(count)
     pos = torch.empty((count, 3), dtype=dtype, device=device())
     stride = 0
-    if shuffle:
-        stride = 2654435761 % n3            # odd -> coprime with power-of-two n3; checked below otherwise
-        while np.gcd(stride, n3) != 1:
+    if shuffle and count > 1:
+        stride = 2654435761 % count or 1
+        while np.gcd(stride, count) != 1:
             stride += 1
     check(_lib.lib().ast_synth_lattice_particles(ptr(pos), real_code(pos), int(first), count, int(npside),
                                                  float(boxsize), float(sigma_cells) * boxsize / nmesh,

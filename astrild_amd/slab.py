@@ -1,0 +1,165 @@
+"""Slab-decomposed 3D pipeline: paint -> FFT -> P(k) over P GPUs of one node.
+
+The grid is split along axis 0 (the slowest axis of ``value_map[x, y, z]``; what
+BASELINE.json calls z-slabs): rank r owns planes [r*N/P, (r+1)*N/P).  One process
+per GPU, ``torch.distributed`` over RCCL/xGMI (backend "nccl").  Per step:
+
+  1. paint the rank's particles into its slab buffer (owned planes + ghost planes);
+  2. ghost fold: ghost planes go to the two ring neighbours and are added into
+     their owned planes (grouped send/recv, N^2 elements per plane);
+  3. batched 2D R2C over (y, z) of the owned planes;
+  4. pack + ONE all-to-all: rank r keeps ky in [r*N/P, (r+1)*N/P) for ALL x.  With
+     point-to-point xGMI every GPU talks to its 7 peers at once, so all 7 links
+     carry 1/P^2 of the spectrum each (67 MB per pair at 1024^3 fp32, P = 8);
+  5. strided 1D C2C along x (1/Ng folded into this pass);
+  6. shell binning of the local (N, N/P, N/2+1) block, then one all-reduce of the
+     N/2-1 shell sums (4 KB).
+
+The collective logic is independent of where the local arithmetic runs: it talks
+to an ``ops`` object.  ``HipSlabOps`` (the product) calls libastrild_hip.so; the
+CPU tests inject a numpy double to exercise steps 2, 4 and 6 over gloo.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class HipSlabOps:
+    """Local arithmetic on the GPU through the C-ABI."""
+
+    def __init__(self, dtype=torch.float32):
+        from . import device as dev
+        self.dev = dev
+        self.dtype = dtype
+        self.cdtype = torch.complex64 if dtype == torch.float32 else torch.complex128
+        self.device = dev.device()
+
+    def zeros(self, shape, dtype=None):
+        return torch.zeros(shape, dtype=dtype or self.dtype, device=self.device)
+
+    def empty(self, shape, dtype=None):
+        return torch.empty(shape, dtype=dtype or self.dtype, device=self.device)
+
+    def paint(self, pos, mass, n, boxsize, window, out, x_start, nx_alloc, check=False):
+        out.zero_()
+        return self.dev.paint(pos, mass, n, boxsize, window, out=out, x_start=x_start, nx_alloc=nx_alloc,
+                              check_dropped=check)
+
+    def add_into(self, dst, src):
+        from ._lib import check, lib
+        check(lib().ast_accumulate(self.dev.ptr(dst), self.dev.ptr(src), self.dev.real_code(dst), dst.numel(),
+                                   self.dev.stream()), "ast_accumulate")
+
+    def fft2d_planes(self, planes, out):
+        nloc, n1, n2 = planes.shape
+        code = self.dev.real_code(planes)
+        self.dev.fft_plan(0, code, (n1, n2), nloc, 1.0, False).execute(planes, out)      # AST_FFT_R2C
+        return out
+
+    def pack(self, spec, out, parts):
+        from ._lib import check, lib
+        n0, n1, n2 = spec.shape
+        check(lib().ast_slab_pack(self.dev.ptr(spec), self.dev.ptr(out), 0 if spec.dtype == torch.complex64 else 1,
+                                  n0, n1, n2, parts, self.dev.stream()), "ast_slab_pack")
+        return out
+
+    def fft1d_axis0(self, block, scale):
+        n0, n1, n2 = block.shape
+        code = 0 if block.dtype == torch.complex64 else 1
+        plan = self.dev.fft_plan(2, code, (n0,), n1 * n2, scale, True, strided=(n0, n1 * n2, 1))   # AST_FFT_C2C_FWD
+        plan.execute(block, None)
+        return block
+
+    def shell_geometry(self, n, boxsize, i0, i1):
+        return self.dev.shell_geometry(n, boxsize, i0, i1)
+
+    def power_bin(self, block, n, boxsize, i0, i1, psum):
+        psum.zero_()
+        self.dev.power_bin_1d(block, None, n, boxsize, i0, i1, psum=psum)
+        return psum
+
+    def synth(self, npside, n, boxsize, seed, shuffle, first, count):
+        return self.dev.synth_lattice_particles(npside, n, boxsize, seed=seed, shuffle=shuffle, dtype=self.dtype,
+                                                first=first, count=count)
+
+
+def ghost_fold(buf, nloc, gl, gh, ops, group=None):
+    """Step 2.  buf: (gl + nloc + gh, N, N) with the owned planes in the middle.
+    Lower ghosts belong to rank r-1 (its top gl planes), upper ghosts to rank r+1
+    (its bottom gh planes); both are sent and the incoming ones are added."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    left, right = (rank - 1) % world, (rank + 1) % world
+    lower = buf[:gl].contiguous()
+    upper = buf[gl + nloc:].contiguous()
+    from_right = torch.empty_like(lower)       # right neighbour's lower ghosts -> my top planes
+    from_left = torch.empty_like(upper)        # left neighbour's upper ghosts -> my bottom planes
+    reqs = dist.batch_isend_irecv([
+        dist.P2POp(dist.isend, lower, left, group),
+        dist.P2POp(dist.isend, upper, right, group),
+        dist.P2POp(dist.irecv, from_right, right, group),
+        dist.P2POp(dist.irecv, from_left, left, group),
+    ])
+    for q in reqs:
+        q.wait()
+    owned = buf[gl: gl + nloc]
+    ops.add_into(owned[nloc - gl:], from_right)
+    ops.add_into(owned[:gh], from_left)
+    return owned
+
+
+class SlabPowerPipeline:
+    """CIC/TSC + slab FFT + P(k) for the synthetic lattice workload of bench.py."""
+
+    def __init__(self, n, boxsize, npside, window="cic", dtype=torch.float32, seed=20240601, shuffle=False,
+                 ghost=4, ops=None, group=None, pos=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        P = self.world
+        if n % P or npside % P:
+            raise ValueError(f"grid {n} and particle lattice {npside} must be divisible by the number of ranks {P}")
+        self.n, self.L, self.window = n, float(boxsize), window
+        self.ops = ops or HipSlabOps(dtype)
+        self.nloc = n // P
+        self.nz = n // 2 + 1
+        # particles jitter across slab boundaries: ghost planes take base cells up to
+        # `ghost` planes outside, plus the window's own reach of one plane
+        self.gl = self.gh = ghost + 1
+        if self.nloc + self.gl + self.gh > n:
+            raise ValueError("slab too thin for the ghost zone")
+        self.x_start = (self.rank * self.nloc - self.gl) % n
+        self.nx_alloc = self.nloc + self.gl + self.gh
+        ppr = npside ** 3 // P
+        self.pos = pos if pos is not None else self.ops.synth(npside, n, self.L, seed, shuffle, self.rank * ppr, ppr)
+        o = self.ops
+        self.buf = o.empty((self.nx_alloc, n, n))
+        self.spec2d = o.empty((self.nloc, n, self.nz), o.cdtype)
+        self.packed = o.empty((P, self.nloc, self.nloc, self.nz), o.cdtype)
+        self.block = o.empty((n, self.nloc, self.nz), o.cdtype)
+        self.psum = o.zeros((n // 2 - 1,), torch.float64)
+        self.i0 = (0, n)
+        self.i1 = (self.rank * self.nloc, self.nloc)
+        ksum, nmodes = o.shell_geometry(n, self.L, self.i0, self.i1)
+        self.ksum, self.nmodes = ksum.clone(), nmodes.clone()
+        dist.all_reduce(self.ksum, group=group)
+        dist.all_reduce(self.nmodes, group=group)
+
+    def paint(self, check=False):
+        """check=True synchronises and raises if a deposit fell outside the ghost zone."""
+        self.ops.paint(self.pos, None, self.n, self.L, self.window, self.buf, self.x_start, self.nx_alloc, check)
+        return ghost_fold(self.buf, self.nloc, self.gl, self.gh, self.ops, self.group)
+
+    def forward_fft(self, owned):
+        o = self.ops
+        o.fft2d_planes(owned, self.spec2d)
+        o.pack(self.spec2d, self.packed, self.world)
+        # complex payload moved as (re, im) pairs of the real dtype: every c10d backend takes that
+        dist.all_to_all_single(torch.view_as_real(self.block), torch.view_as_real(self.packed), group=self.group)
+        return o.fft1d_axis0(self.block, 1.0 / float(self.n) ** 3)
+
+    def step(self, check=False):
+        block = self.forward_fft(self.paint(check))
+        self.ops.power_bin(block, self.n, self.L, self.i0, self.i1, self.psum)
+        dist.all_reduce(self.psum, group=self.group)
+        return self.ksum, self.psum, self.nmodes

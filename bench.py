@@ -108,6 +108,7 @@ def main():
         from astrild_amd import slab
         pipe = slab.SlabPowerPipeline(n, L, npside, window=args.window, dtype=tdt, seed=20240601,
                                       shuffle=(args.order == "shuffled"))
+        pipe.step(check=True)             # once, untimed: no deposit may fall outside the ghost zone
         step = pipe.step
 
     def barrier():

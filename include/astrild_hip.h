@@ -72,9 +72,9 @@ int ast_divide(void* buf_d, int dtype, size_t count, double divisor, void* strea
  * sigma * N(0,1) per component, wrapped into [0, L).  Counter-based
  * generator keyed by (seed, particle index, component); particles
  * [first, first+count) of the lattice are written to pos_d as (count, 3).
- * `shuffle_stride` != 0 visits the lattice in the order
- * p -> (p * shuffle_stride) mod npside^3 (a fixed permutation when the
- * stride is coprime with npside^3): the scatter-unfriendly ordering.
+ * `shuffle_stride` != 0 writes them in the order
+ * t -> first + (t * shuffle_stride) mod count (a fixed permutation of the range
+ * when the stride is coprime with count): the scatter-unfriendly ordering.
  * Bench / test plumbing, not part of the reference. */
 int ast_synth_lattice_particles(void* pos_d, int dtype, size_t first, size_t count,
                                 int npside, double boxsize, double sigma,

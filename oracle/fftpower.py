@@ -88,6 +88,28 @@ def project_1d(p3d_half, n, boxsize, binning="integer"):
     return ksum, psum, modes
 
 
+def project_block(p3d_block, n, boxsize, i0_start, i1_start):
+    """Shell sums of a (c0, c1, n//2+1) block of the half spectrum whose first two
+    axes start at global indices i0_start / i1_start (integer binning) — the
+    per-rank piece of a slab-decomposed spectrum."""
+    nb = n // 2 - 1
+    kf = 2.0 * np.pi / boxsize
+    c0, c1, nz = p3d_block.shape
+    assert nz == n // 2 + 1
+    m0 = _freq_int(n)[i0_start:i0_start + c0]
+    m1 = _freq_int(n)[i1_start:i1_start + c1]
+    mz = np.arange(nz)
+    m2 = (m0[:, None, None] ** 2 + m1[None, :, None] ** 2 + mz[None, None, :] ** 2).astype(np.int64)
+    w = np.where((mz > 0) & (mz < n // 2), 2, 1)[None, None, :] * np.ones_like(m2)
+    b = isqrt_array(m2) - 1
+    ok = (b >= 0) & (b < nb)
+    ww = w[ok].astype(np.float64)
+    ksum = np.bincount(b[ok], weights=ww * kf * np.sqrt(m2[ok].astype(np.float64)), minlength=nb)
+    psum = np.bincount(b[ok], weights=ww * p3d_block[ok].real, minlength=nb)
+    modes = np.bincount(b[ok], weights=ww, minlength=nb).astype(np.int64)
+    return ksum, psum, modes
+
+
 def fftpower_1d(field1, boxsize, field2=None, binning="integer"):
     """``FFTPower(first, mode="1d", kmin=2*pi/L[, second])`` on in-memory grids.
 
