@@ -38,6 +38,8 @@ SIGNATURES = {
     "ast_accumulate": (_i, [_vp, _vp, _i, _sz, _vp]),
     "ast_fft_plan_create": (_i, [ct.POINTER(_vp), _i, _i, _i, ct.POINTER(_sz), _sz, _d, _i]),
     "ast_fft_plan_create_strided_1d": (_i, [ct.POINTER(_vp), _i, _i, _sz, _sz, _sz, _sz, _d]),
+    "ast_fft_plan_create_general": (_i, [ct.POINTER(_vp), _i, _i, _i, ct.POINTER(_sz), ct.POINTER(_sz),
+                                        ct.POINTER(_sz), _sz, _sz, _sz, _d, _i]),
     "ast_fft_plan_work_bytes": (_sz, [_vp]),
     "ast_fft_exec": (_i, [_vp, _vp, _vp, _vp]),
     "ast_fft_plan_destroy": (_i, [_vp]),

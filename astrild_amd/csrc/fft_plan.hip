@@ -124,6 +124,46 @@ extern "C" int ast_fft_plan_create_strided_1d(ast_fft_plan** out, int kind, int 
     return AST_OK;
 }
 
+extern "C" int ast_fft_plan_create_general(ast_fft_plan** out, int kind, int dtype, int rank, const size_t* lengths,
+                                           const size_t* in_strides, const size_t* out_strides, size_t batch,
+                                           size_t in_dist, size_t out_dist, double scale, int inplace) {
+    AST_CHECK_ARG(out != nullptr && lengths != nullptr && in_strides != nullptr && out_strides != nullptr);
+    AST_CHECK_ARG(kind >= AST_FFT_R2C && kind <= AST_FFT_C2C_INV);
+    AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
+    AST_CHECK_ARG(rank >= 1 && rank <= 3 && batch >= 1);
+    ensure_setup();
+    size_t rl[3], ris[3], ros[3];
+    for (int i = 0; i < rank; ++i) {
+        rl[i] = lengths[rank - 1 - i];
+        ris[i] = in_strides[rank - 1 - i];
+        ros[i] = out_strides[rank - 1 - i];
+    }
+    auto* p = new ast_fft_plan();
+    p->inplace = inplace != 0;
+    rocfft_plan_description desc = nullptr;
+    AST_CHECK_FFT(rocfft_plan_description_create(&desc));
+    if (scale != 1.0) AST_CHECK_FFT(rocfft_plan_description_set_scale_factor(desc, scale));
+    rocfft_array_type it = rocfft_array_type_complex_interleaved, ot = rocfft_array_type_complex_interleaved;
+    if (kind == AST_FFT_R2C) { it = rocfft_array_type_real; ot = rocfft_array_type_hermitian_interleaved; }
+    if (kind == AST_FFT_C2R) { it = rocfft_array_type_hermitian_interleaved; ot = rocfft_array_type_real; }
+    AST_CHECK_FFT(rocfft_plan_description_set_data_layout(desc, it, ot, nullptr, nullptr, rank, ris, in_dist,
+                                                          rank, ros, out_dist));
+    rocfft_status st = rocfft_plan_create(&p->plan, inplace ? rocfft_placement_inplace : rocfft_placement_notinplace,
+                                          kind_to_type(kind),
+                                          dtype == AST_F32 ? rocfft_precision_single : rocfft_precision_double,
+                                          (size_t)rank, rl, batch, desc);
+    rocfft_plan_description_destroy(desc);
+    if (st != rocfft_status_success) {
+        delete p;
+        ast::set_error("ast_fft_plan_create_general: rocfft_plan_create -> rocfft_status %d", (int)st);
+        return AST_ERR_ROCFFT;
+    }
+    int rc = finish_plan(p);
+    if (rc != AST_OK) { ast_fft_plan_destroy(p); return rc; }
+    *out = p;
+    return AST_OK;
+}
+
 extern "C" size_t ast_fft_plan_work_bytes(const ast_fft_plan* plan) { return plan ? plan->work_bytes : 0; }
 
 extern "C" int ast_fft_exec(ast_fft_plan* plan, void* in, void* out, void* stream) {

@@ -161,10 +161,18 @@ def main():
                             "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
                             "kernels": {s: round(prof[s][1] / args.steps, 4) for s in sites}}
     dom = max(stages, key=lambda k: stages[k]["ms"])
+    # HBM traffic of the dominant stage from the PMC passes of the same command (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE in separate runs, gfx950 x2 read correction; profiles/r01_pmc_traffic.json says how)
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if dom == "paint" and world == 1 and n == 1024 and npside == 1024 and args.window == "cic" \
+            and args.dtype == "f32" and args.order == "natural" and os.path.isfile(pmc_file):
+        traffic = json.load(open(pmc_file)).get("paint_stage_corrected_GB_per_step")
+        traffic = None if traffic is None else traffic * 1e9
     roofline = {
         "bound": "hbm", "kernel": f"{dom} stage ({'+'.join(stage_sites[dom])})",
         "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": stages[dom]["frac"], "traffic": None,
+        "frac": stages[dom]["frac"], "traffic": traffic,
         "end_to_end": {"alg_GB": round(sum(stage_bytes.values()) / 1e9, 3),
                        "GBps": round(sum(stage_bytes.values()) * world / (ms_per_step * 1e6), 1),
                        "frac": round(sum(stage_bytes.values()) * world / (ms_per_step * 1e6) / (HBM_PEAK_GBS * world), 4)},

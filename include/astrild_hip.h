@@ -148,6 +148,12 @@ int ast_fft_plan_create(ast_fft_plan** plan, int kind, int dtype, int rank,
 int ast_fft_plan_create_strided_1d(ast_fft_plan** plan, int kind, int dtype, size_t length,
                                    size_t stride, size_t batch, size_t dist, double scale);
 
+/* General strided layout: strides (in elements of the respective array, real or
+ * complex) are given per axis in the same C order as lengths[]. */
+int ast_fft_plan_create_general(ast_fft_plan** plan, int kind, int dtype, int rank, const size_t* lengths,
+                                const size_t* in_strides, const size_t* out_strides, size_t batch,
+                                size_t in_dist, size_t out_dist, double scale, int inplace);
+
 size_t ast_fft_plan_work_bytes(const ast_fft_plan* plan);
 int ast_fft_exec(ast_fft_plan* plan, void* in_d, void* out_d, void* stream);
 int ast_fft_plan_destroy(ast_fft_plan* plan);

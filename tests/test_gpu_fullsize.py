@@ -1,0 +1,114 @@
+"""GPU, BASELINE.json sizes: size-independent properties of the hot path where the
+oracle is too slow — mass conservation, Parseval, direct-vs-tiled and
+natural-vs-shuffled agreement, fp32-vs-fp64 agreement, linearity of the stack,
+mean preservation of the periodic smoothing, histogram totals."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev(hip):
+    from astrild_amd import device
+    torch.cuda.set_device(0)
+    return device
+
+
+@pytest.mark.parametrize("n", [512, 1024])
+def test_cic_pk_pipeline_properties_at_baseline_size(dev, n):
+    L = 1000.0
+    pos = dev.synth_lattice_particles(n, n, L, seed=20240601, dtype=torch.float32)
+    npart = pos.shape[0]
+    grid = dev.paint(pos, None, n, L, "cic", method="tiled")
+    # (1) mass conservation: sum(grid) == Np (fp64 reduction of an fp32 grid)
+    total = float(grid.sum(dtype=torch.float64))
+    assert total == pytest.approx(npart, rel=1e-7)
+    assert float(grid.min()) >= 0.0
+    # (2) Parseval: sum_modes w |delta_k|^2 == <f^2>
+    spec = dev.r2c(grid)
+    w = torch.full((n // 2 + 1,), 2.0, dtype=torch.float64, device="cuda")
+    w[0] = w[-1] = 1.0
+    lhs = float(((spec.real.double() ** 2 + spec.imag.double() ** 2) * w).sum())
+    rhs = float((grid.double() ** 2).mean())
+    assert lhs == pytest.approx(rhs, rel=2e-6)
+    # (3) shell sums: every mode of the half lattice inside the Nyquist sphere is counted once
+    ks, ps, nm = dev.power_bin_1d(spec, None, n, L)
+    res = dev.finish_power(ks, ps, nm)
+    assert int(nm.sum()) > 0 and np.isfinite(res["power"]).all() and (res["power"] > 0).all()
+    kf = 2 * np.pi / L
+    assert np.all(res["k"] >= kf * np.arange(1, n // 2)) and np.all(res["k"] < kf * np.arange(2, n // 2 + 1))
+    # DC excluded: total shell power < total power
+    assert float(ps.sum()) / L ** 3 < lhs
+    del spec
+    # (4) direct (global atomics) and tiled (LDS) paints agree
+    if n == 512:
+        g2 = dev.paint(pos, None, n, L, "cic", method="direct")
+        assert float((g2 - grid).abs().max()) < 5e-6
+        del g2
+    # (5) shuffled order gives the same grid (same multiset of particles)
+    pos_s = dev.synth_lattice_particles(n, n, L, seed=20240601, dtype=torch.float32, shuffle=True)
+    g3 = dev.paint(pos_s, None, n, L, "cic", method="tiled")
+    assert float((g3 - grid).abs().max()) < 5e-6
+    del g3, pos_s
+    # (6) fp32 pipeline against the fp64 pipeline on the same fp32 positions
+    if n == 512:
+        g64 = dev.paint(pos.double(), None, n, L, "cic", method="tiled")
+        r64 = dev.fftpower_1d(g64, L)
+        r32 = dev.finish_power(ks, ps, nm)
+        assert np.array_equal(r64["modes"], r32["modes"])
+        # high-k shells (white, well above fp32 FFT round-off): north_star tolerance
+        np.testing.assert_allclose(r32["power"][n // 8:], r64["power"][n // 8:], rtol=1e-6)
+        # cold-lattice low-k shells carry ~1e-5 of the peak power: compare against the peak
+        np.testing.assert_allclose(r32["power"], r64["power"], rtol=0, atol=1e-6 * r64["power"].max())
+
+
+def test_tsc_mass_conservation_and_translation_at_512(dev):
+    n, L = 512, 1000.0
+    pos = dev.synth_lattice_particles(n, n, L, seed=7, dtype=torch.float32)
+    g = dev.paint(pos, None, n, L, "tsc", method="tiled")
+    assert float(g.sum(dtype=torch.float64)) == pytest.approx(pos.shape[0], rel=1e-7)
+    # integer-cell translation (exact in fp32 for this box: 3 cells = 5.859375)
+    shift = torch.tensor([3 * L / n, 5 * L / n, 17 * L / n], dtype=torch.float32, device="cuda")
+    moved = torch.remainder(pos + shift, L)
+    g2 = dev.paint(moved.contiguous(), None, n, L, "tsc", method="tiled")
+    ref = torch.roll(g, shifts=(3, 5, 17), dims=(0, 1, 2))
+    # positions were re-rounded to fp32 after the shift: agreement at the input's own resolution
+    assert float((g2 - ref).abs().max()) < 2e-3
+    assert float((g2 - ref).abs().mean()) < 2e-5
+
+
+def test_kappa_stack_and_pipeline_properties_at_4096(hip, dev):
+    from astrild_amd import lensing
+    npix, P = 4096, 64
+    planes = lensing.synth_kappa_planes(P, npix)
+    tot = lensing.kappa_stack(planes)
+    # stack == torch's own sequential sum, bit for bit (fp64 IEEE adds in plane order)
+    ref = planes[0].clone()
+    for p in planes[1:]:
+        ref += p
+    assert torch.equal(tot, ref)
+    # linearity in the weights: stack(2*w) == 2*stack(w) exactly (power-of-two scaling)
+    wn, wd = np.linspace(0.5, 1.5, P), np.full(P, 0.75)
+    a = lensing.kappa_stack(planes, wn, wd)
+    b = lensing.kappa_stack(planes, 2 * wn, wd)
+    assert torch.equal(b, 2 * a)
+    del planes, ref, b
+    # periodic Gaussian smoothing preserves the mean and reduces the variance
+    m0, v0 = float(a.mean()), float(a.var())
+    sm = a.clone()
+    lensing.smooth_plan(npix).gaussian(sm, 3.4, "gaussianFFT")
+    assert float(sm.mean()) == pytest.approx(m0, rel=1e-9, abs=1e-15)
+    assert float(sm.var()) < v0
+    # histogram totals
+    counts, edges = lensing.histogram(sm, 200)
+    assert counts.sum() == npix * npix and len(edges) == 201
+    # kappa -> alpha is linear and vanishes for a zero map
+    plan = lensing.lens_plan(npix, np.deg2rad(20.0))
+    a1, a2 = plan.alphas(sm)
+    b1, b2 = plan.alphas(2 * sm)
+    scale = float(a1.abs().max())
+    assert float((b1 - 2 * a1).abs().max()) < 1e-12 * scale
+    z1, z2 = plan.alphas(torch.zeros_like(sm))
+    assert float(z1.abs().max()) == 0.0 and float(z2.abs().max()) == 0.0
