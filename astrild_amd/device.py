@@ -133,12 +133,13 @@ def ngp_assign(x, y, z, values, npar, dtype=torch.float64):
 
 
 def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="auto",
-          x_start=0, nx_alloc=None, check_dropped=True):
+          x_start=0, nx_alloc=None, check_dropped=True, accumulate=None):
     """pmesh ``ParticleMesh.paint(pos, mass=, resampler=)`` on the GPU.
 
     pos: (Np, 3) CUDA tensor (float32/float64); mass: (Np,) or None.
-    Returns the accumulated grid ``(nx_alloc, nmesh, nmesh)`` in pos.dtype.
+    Returns the grid ``(nx_alloc, nmesh, nmesh)`` in pos.dtype.
     method: "direct" (global float atomics), "tiled" (LDS tiles) or "auto".
+    accumulate: add into ``out`` (default when ``out`` is given) or zero it first.
     """
     L = _lib.lib()
     n = int(nmesh)
@@ -147,10 +148,8 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     code = real_code(pos)
     if mass is not None:
         assert mass.is_cuda and mass.dtype == pos.dtype and mass.numel() == pos.shape[0] and mass.is_contiguous()
-    if out is None:
-        out = torch.zeros((nx, n, n), dtype=pos.dtype, device=pos.device)
-    else:
-        assert out.is_cuda and out.dtype == pos.dtype and out.numel() == nx * n * n and out.is_contiguous()
+    if accumulate is None:
+        accumulate = out is not None
     win = _lib.WIN[window.lower()]
     npart = pos.shape[0]
     dropped = torch.zeros(1, dtype=torch.int64, device=pos.device)
@@ -160,6 +159,12 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     if method == "tiled" and ws_bytes == 0:
         raise _lib.AstrildHipError("tiled paint needs a CIC/TSC window and nmesh a multiple of 32")
     use_tiled = ws_bytes > 0 and (method == "tiled" or npart >= 65536)
+    if out is None:
+        out = torch.zeros((nx, n, n), dtype=pos.dtype, device=pos.device)
+    else:
+        assert out.is_cuda and out.dtype == pos.dtype and out.numel() == nx * n * n and out.is_contiguous()
+        if not accumulate:
+            out.zero_()
     if use_tiled:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pos.device)
         check(L.ast_paint_tiled(win, code, ptr(pos), ptr(mass), npart, n, float(boxsize), float(scale),

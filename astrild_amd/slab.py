@@ -41,9 +41,8 @@ class HipSlabOps:
         return torch.empty(shape, dtype=dtype or self.dtype, device=self.device)
 
     def paint(self, pos, mass, n, boxsize, window, out, x_start, nx_alloc, check=False):
-        out.zero_()
         return self.dev.paint(pos, mass, n, boxsize, window, out=out, x_start=x_start, nx_alloc=nx_alloc,
-                              check_dropped=check)
+                              check_dropped=check, accumulate=False)
 
     def add_into(self, dst, src):
         from ._lib import check, lib

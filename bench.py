@@ -99,8 +99,8 @@ def main():
         dev.shell_geometry(n, L)          # data independent, cached like the FFT plan
 
         def step():
-            grid.zero_()
-            dev.paint(pos, None, n, L, args.window, out=grid, method=args.method, check_dropped=False)
+            dev.paint(pos, None, n, L, args.window, out=grid, method=args.method, check_dropped=False,
+                      accumulate=False)       # zero-fill + paint
             dev.r2c(grid, out=spec)
             psum.zero_()
             return dev.power_bin_1d(spec, None, n, L, psum=psum)

@@ -82,6 +82,26 @@ def test_paint_slab_buffer_with_ghost_planes(dev, method, window):
         dev.paint(dev.as_device(pos), None, n, L, window, method=method, x_start=x_start, nx_alloc=nx_alloc)
 
 
+@pytest.mark.parametrize("method", ["direct", "tiled"])
+def test_paint_accumulate_and_overwrite_modes(dev, method):
+    rng = np.random.default_rng(17)
+    n, L = 64, 100.0
+    pos = dev.as_device(rng.uniform(0, L, size=(80000, 3)))
+    ref = omesh.paint(pos.cpu().numpy(), None, n, L, "cic")
+    out = torch.full((n, n, n), 7.0, dtype=torch.float64, device="cuda")
+    dev.paint(pos, None, n, L, "cic", out=out, method=method)                      # out given -> accumulate
+    np.testing.assert_allclose(out.cpu().numpy(), ref + 7.0, rtol=1e-12)
+    dev.paint(pos, None, n, L, "cic", out=out, method=method, accumulate=False)    # overwrite: garbage in `out` is fine
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-12, atol=1e-13)
+    dev.paint(pos, None, n, L, "cic", out=out, method=method, accumulate=True)
+    np.testing.assert_allclose(out.cpu().numpy(), 2 * ref, rtol=1e-12, atol=1e-13)
+    # sparse input: most tiles are empty and must still be cleared in overwrite mode
+    few = dev.as_device(rng.uniform(0, L, size=(70000, 3)) * np.array([0.05, 1.0, 1.0]))
+    out.fill_(3.0)
+    dev.paint(few, None, n, L, "tsc", out=out, method=method, accumulate=False)
+    np.testing.assert_allclose(out.cpu().numpy(), omesh.paint(few.cpu().numpy(), None, n, L, "tsc"), rtol=1e-12, atol=1e-13)
+
+
 def test_paint_empty_and_single_particle(dev):
     n, L = 32, 32.0
     empty = torch.empty((0, 3), dtype=torch.float64, device="cuda")
