@@ -1,0 +1,303 @@
+// a-4, hand-written: LDS-tiled power-of-two FFT passes for the 3D R2C transform
+// (fp32, N in {256, 512, 1024}).
+//
+// rocFFT's 3D R2C at 1024^3 runs six kernels (two of them transposes) and moves
+// ~2.1x the algorithmic bytes (profiles/r01_pmc_traffic.json).  Here the
+// transform is exactly three passes, each reading and writing the array once:
+//
+//   z  rows_r2c_kernel     contiguous real rows -> half-spectrum rows (N real ->
+//                          N/2 complex FFT + the even/odd split, all in LDS)
+//   y  strided_c2c_kernel  for every x-plane: columns of 16 adjacent kz, N long
+//   x  strided_c2c_kernel  same kernel, element stride N * (N/2+1)
+//
+// Each workgroup does a length-N transform of a tile of C columns as
+// N = R1 * R2: R1-point FFTs in registers straight from global memory, twiddle,
+// ONE round trip through LDS, R2-point FFTs in registers, store.  Loads/stores
+// are C * 8 B = 128 B contiguous per row of the tile; every thread keeps R1 (R2)
+// independent 8-byte loads in flight.
+#include "ast_common.h"
+#include <cmath>
+#include <mutex>
+#include <vector>
+
+namespace {
+
+// cos / sin (2 pi k / 32), k = 0..15
+__device__ constexpr float kCos32[16] = {
+    1.0f, 0.9807852804032304f, 0.9238795325112867f, 0.8314696123025452f, 0.7071067811865476f,
+    0.5555702330196023f, 0.38268343236508984f, 0.19509032201612833f, 0.0f, -0.1950903220161282f,
+    -0.3826834323650897f, -0.555570233019602f, -0.7071067811865475f, -0.8314696123025453f,
+    -0.9238795325112867f, -0.9807852804032304f};
+__device__ constexpr float kSin32[16] = {
+    0.0f, 0.19509032201612825f, 0.3826834323650898f, 0.5555702330196022f, 0.7071067811865475f,
+    0.8314696123025452f, 0.9238795325112867f, 0.9807852804032304f, 1.0f, 0.9807852804032304f,
+    0.9238795325112867f, 0.8314696123025455f, 0.7071067811865476f, 0.5555702330196022f,
+    0.3826834323650899f, 0.1950903220161286f};
+
+__device__ inline float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ inline float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ inline float2 cmul(float2 a, float2 w) {
+    return make_float2(fmaf(a.x, w.x, -a.y * w.y), fmaf(a.x, w.y, a.y * w.x));
+}
+
+constexpr int bitrev(int v, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((v >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
+
+// In-register forward FFT of R points, decimation in frequency.  On return X[k]
+// sits in v[bitrev(k)].  Fully unrolled: every index and twiddle is a constant.
+template <int R>
+__device__ inline void fft_reg(float2 (&v)[R]) {
+#pragma unroll
+    for (int h = R / 2; h >= 1; h /= 2) {
+#pragma unroll
+        for (int blk = 0; blk < R; blk += 2 * h) {
+#pragma unroll
+            for (int j = 0; j < h; ++j) {
+                const float2 a = v[blk + j], b = v[blk + j + h];
+                v[blk + j] = cadd(a, b);
+                const float2 d = csub(a, b);
+                const int t = j * (16 / h);              // W_{2h}^j = W_32^{j * 32 / (2h)}
+                if (t == 0) v[blk + j + h] = d;
+                else if (t == 8) v[blk + j + h] = make_float2(d.y, -d.x);         // * (-i)
+                else v[blk + j + h] = cmul(d, make_float2(kCos32[t], -kSin32[t]));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------ strided C2C pass
+// data[b * batch_stride + k * elem_stride + c], k < N = R1*R2, c < ncols (contiguous).
+template <int R1, int R2, int C>
+__global__ void __launch_bounds__(C * (R1 > R2 ? R1 : R2))
+strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, size_t elem_stride,
+                   size_t ncols, size_t batch_stride, unsigned tiles_per_batch, float scale) {
+    constexpr int N = R1 * R2;
+    constexpr int NT = C * (R1 > R2 ? R1 : R2);
+    extern __shared__ float2 lds[];
+    float2* Y = lds;                 // [n2][k1][c]
+    float2* tw = lds + N * C;        // exp(-2 pi i m / N)
+    for (int i = threadIdx.x; i < N; i += NT) tw[i] = tw_g[i];
+
+    const unsigned tile = blockIdx.x % tiles_per_batch, b = blockIdx.x / tiles_per_batch;
+    const size_t c0 = (size_t)tile * C;
+    const int c = threadIdx.x % C, sub = threadIdx.x / C;
+    const bool col_ok = c0 + c < ncols;
+    float2* base = data + (size_t)b * batch_stride + c0 + c;
+
+    {                                                 // stage 1: task (c, n2 = sub)
+        const bool task1 = sub < R2;
+        float2 v[R1];
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1)
+            v[n1] = (col_ok && task1) ? base[(size_t)(n1 * R2 + sub) * elem_stride] : make_float2(0.f, 0.f);
+        fft_reg<R1>(v);
+        __syncthreads();                              // twiddle table is in LDS
+        if (task1) {
+#pragma unroll
+            for (int k1 = 0; k1 < R1; ++k1) {
+                float2 y = v[bitrev(k1, ilog2(R1))];
+                if (k1 != 0) y = cmul(y, tw[sub * k1]);
+                Y[(sub * R1 + k1) * C + c] = y;
+            }
+        }
+    }
+    __syncthreads();
+    if (sub < R1) {                                   // stage 2: task (c, k1 = sub)
+        float2 u[R2];
+#pragma unroll
+        for (int n2 = 0; n2 < R2; ++n2) u[n2] = Y[(n2 * R1 + sub) * C + c];
+        fft_reg<R2>(u);
+        if (col_ok) {
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) {
+                float2 x = u[bitrev(k2, ilog2(R2))];
+                x.x *= scale;
+                x.y *= scale;
+                base[(size_t)(sub + R1 * k2) * elem_stride] = x;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------- contiguous-row R2C pass
+// in: nrows rows of N = 2*M reals (pitch in_pitch reals); out: rows of M+1 complex.
+// M = R1*R2.  One workgroup transforms C rows.
+template <int R1, int R2, int C>
+__global__ void __launch_bounds__(C * R2)
+rows_r2c_kernel(const float* __restrict__ in, float2* __restrict__ out, const float2* __restrict__ tw_g,
+                size_t nrows, size_t in_pitch, size_t out_pitch, float scale) {
+    constexpr int M = R1 * R2, N = 2 * M;
+    constexpr int NT = C * R2;
+    constexpr int R2P = R2 + 1;
+    constexpr int MP = M + 1;
+    extern __shared__ float2 lds[];
+    float2* Y = lds;                     // stage buffer [r][k1][n2] (padded), then Z[r][k]
+    float2* tw = lds + C * (R1 * R2P > MP ? R1 * R2P : MP);     // exp(-2 pi i m / N), m < N
+    for (int i = threadIdx.x; i < N; i += NT) tw[i] = tw_g[i];
+
+    const size_t row0 = (size_t)blockIdx.x * C;
+    const int n2 = threadIdx.x % R2, r = threadIdx.x / R2;        // stage-1 task (r, n2)
+    const bool row_ok = row0 + r < nrows;
+    {
+        const float2* zin = reinterpret_cast<const float2*>(in + (row0 + r) * in_pitch);   // z[j] = x[2j] + i x[2j+1]
+        float2 v[R1];
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) v[n1] = row_ok ? zin[n1 * R2 + n2] : make_float2(0.f, 0.f);
+        fft_reg<R1>(v);
+        __syncthreads();
+#pragma unroll
+        for (int k1 = 0; k1 < R1; ++k1) {
+            float2 y = v[bitrev(k1, ilog2(R1))];
+            if (k1 != 0) y = cmul(y, tw[2 * n2 * k1]);            // W_M = W_N^2
+            Y[(r * R1 + k1) * R2P + n2] = y;
+        }
+    }
+    __syncthreads();
+    float2 u[R2];
+    const int k1 = threadIdx.x % R1, r2 = threadIdx.x / R1;       // stage-2 task (r2, k1): C*R1 of the C*R2 threads
+    const bool task2 = r2 < C;
+    if (task2) {
+#pragma unroll
+        for (int j = 0; j < R2; ++j) u[j] = Y[(r2 * R1 + k1) * R2P + j];
+        fft_reg<R2>(u);
+    }
+    __syncthreads();                                              // everyone has read Y: reuse it as Z[r][k]
+    if (task2) {
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) Y[r2 * MP + k1 + R1 * k2] = u[bitrev(k2, ilog2(R2))];
+    }
+    __syncthreads();
+    // even/odd split: X[k] = (Zk + conj(Zm))/2 - i w^k (Zk - conj(Zm))/2, m = M - k, w = e^{-2 pi i / N}
+    for (int i = threadIdx.x; i < C * (M / 2 + 1); i += NT) {
+        const int rr = i / (M / 2 + 1), k = i % (M / 2 + 1);
+        if (row0 + rr >= nrows) continue;
+        const float2 zk = Y[rr * MP + k];
+        const float2 zm = Y[rr * MP + ((M - k) & (M - 1))];
+        float2* orow = out + (row0 + rr) * out_pitch;
+        if (k == 0) {
+            orow[0] = make_float2((zk.x + zk.y) * scale, 0.f);
+            orow[M] = make_float2((zk.x - zk.y) * scale, 0.f);
+            continue;
+        }
+        const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));      // (Zk + conj Zm)/2
+        const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));      // (Zk - conj Zm)/2
+        const float2 w = tw[k];
+        const float2 t = cmul(o, w);                                                    // w^k * o
+        // X[k] = e - i t ;  X[M-k] = conj(e) - i * conj(w^k)... = conj(e + i t)
+        orow[k] = make_float2((e.x + t.y) * scale, (e.y - t.x) * scale);
+        orow[M - k] = make_float2((e.x - t.y) * scale, (-e.y - t.x) * scale);
+    }
+}
+
+// ------------------------------------------------------------------ host side
+struct TwiddleCache {
+    std::mutex m;
+    std::vector<std::pair<std::pair<int, int>, float2*>> tabs;   // (device, N) -> table
+    float2* get(int n) {
+        std::lock_guard<std::mutex> lock(m);
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+        for (auto& t : tabs) if (t.first.first == dev && t.first.second == n) return t.second;
+        std::vector<float2> h(n);
+        for (int i = 0; i < n; ++i) {
+            const double a = -2.0 * M_PI * (double)i / (double)n;
+            h[i] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+        float2* d = nullptr;
+        if (hipMalloc(&d, n * sizeof(float2)) != hipSuccess) return nullptr;
+        if (hipMemcpy(d, h.data(), n * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        tabs.push_back({{dev, n}, d});
+        return d;
+    }
+} g_tw;
+
+template <int R1, int R2, int C>
+int launch_c2c(float2* data, const float2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride,
+               float scale, hipStream_t s) {
+    constexpr int N = R1 * R2, NT = C * (R1 > R2 ? R1 : R2);
+    const size_t lds = (size_t)(N * C + N) * sizeof(float2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&strided_c2c_kernel<R1, R2, C>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const size_t tiles = (ncols + C - 1) / C;
+    AST_CHECK_ARG(tiles * batch < 0x7fffffffull);
+    strided_c2c_kernel<R1, R2, C><<<(unsigned)(tiles * batch), NT, lds, s>>>(data, tw, elem_stride, ncols, batch_stride,
+                                                                            (unsigned)tiles, scale);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+template <int R1, int R2, int C>
+int launch_r2c(const float* in, float2* out, const float2* tw, size_t nrows, size_t in_pitch, size_t out_pitch,
+               float scale, hipStream_t s) {
+    constexpr int M = R1 * R2, N = 2 * M, NT = C * R2;
+    constexpr int BUF = C * (R1 * (R2 + 1) > M + 1 ? R1 * (R2 + 1) : M + 1);
+    const size_t lds = (size_t)(BUF + N) * sizeof(float2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rows_r2c_kernel<R1, R2, C>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const size_t blocks = (nrows + C - 1) / C;
+    AST_CHECK_ARG(blocks < 0x7fffffffull);
+    rows_r2c_kernel<R1, R2, C><<<(unsigned)blocks, NT, lds, s>>>(in, out, tw, nrows, in_pitch, out_pitch, scale);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+}  // namespace
+
+extern "C" int ast_fft_tile_supported(int dtype, size_t n) {
+    return dtype == AST_F32 && (n == 256 || n == 512 || n == 1024) ? 1 : 0;
+}
+
+extern "C" int ast_fft_tile_c2c(void* data, int dtype, size_t n, size_t elem_stride, size_t ncols, size_t batch,
+                                size_t batch_stride, double scale, void* stream) {
+    AST_CHECK_ARG(data != nullptr && ncols >= 1 && batch >= 1 && elem_stride >= ncols);
+    AST_CHECK_ARG(ast_fft_tile_supported(dtype, n));
+    const float2* tw = g_tw.get((int)n);
+    if (!tw) { ast::set_error("ast_fft_tile_c2c: twiddle table allocation failed"); return AST_ERR_HIP; }
+    hipStream_t s = ast::as_stream(stream);
+    AST_PROF("fft_tile.c2c", s);
+    float2* d = (float2*)data;
+    if (n == 1024) return launch_c2c<32, 32, 16>(d, tw, elem_stride, ncols, batch, batch_stride, (float)scale, s);
+    if (n == 512) return launch_c2c<16, 32, 16>(d, tw, elem_stride, ncols, batch, batch_stride, (float)scale, s);
+    return launch_c2c<16, 16, 16>(d, tw, elem_stride, ncols, batch, batch_stride, (float)scale, s);
+}
+
+extern "C" int ast_fft_tile_rows_r2c(const void* in, void* out, int dtype, size_t n, size_t nrows, size_t in_pitch,
+                                     size_t out_pitch, double scale, void* stream) {
+    AST_CHECK_ARG(in != nullptr && out != nullptr && in != out && nrows >= 1);
+    AST_CHECK_ARG(ast_fft_tile_supported(dtype, n));
+    AST_CHECK_ARG(in_pitch >= n && in_pitch % 2 == 0 && out_pitch >= n / 2 + 1);
+    const float2* tw = g_tw.get((int)n);
+    if (!tw) { ast::set_error("ast_fft_tile_rows_r2c: twiddle table allocation failed"); return AST_ERR_HIP; }
+    hipStream_t s = ast::as_stream(stream);
+    AST_PROF("fft_tile.rows_r2c", s);
+    const float* i = (const float*)in;
+    float2* o = (float2*)out;
+    if (n == 1024) return launch_r2c<16, 32, 16>(i, o, tw, nrows, in_pitch, out_pitch, (float)scale, s);
+    if (n == 512) return launch_r2c<16, 16, 16>(i, o, tw, nrows, in_pitch, out_pitch, (float)scale, s);
+    return launch_r2c<8, 16, 16>(i, o, tw, nrows, in_pitch, out_pitch, (float)scale, s);
+}
+
+// The three passes of an (n, n, n) real -> (n, n, n/2+1) half-spectrum transform,
+// delta_k = scale * sum_x f e^{-ikx}.  `out` is also the work array (y, x passes in place).
+extern "C" int ast_fft_tile_r2c_3d(const void* in, void* out, int dtype, size_t n, double scale, void* stream) {
+    AST_CHECK_ARG(in != nullptr && out != nullptr);
+    AST_CHECK_ARG(ast_fft_tile_supported(dtype, n));
+    const size_t nz = n / 2 + 1;
+    int rc = ast_fft_tile_rows_r2c(in, out, dtype, n, n * n, n, nz, 1.0, stream);                   // z
+    if (rc != AST_OK) return rc;
+    rc = ast_fft_tile_c2c(out, dtype, n, nz, nz, n, n * nz, 1.0, stream);                          // y, per x-plane
+    if (rc != AST_OK) return rc;
+    return ast_fft_tile_c2c(out, dtype, n, n * nz, n * nz, 1, 0, scale, stream);                    // x
+}

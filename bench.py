@@ -144,7 +144,7 @@ def main():
     ng_rank = n ** 3 / world
     stage_sites = {
         "paint": [k for k in prof if k.startswith("paint")],
-        "fft": [k for k in prof if k.startswith("rocfft") or k.startswith("slab.")],
+        "fft": [k for k in prof if k.startswith("rocfft") or k.startswith("fft_tile") or k.startswith("slab.")],
         "power_bin": [k for k in prof if k == "power_bin"],
     }
     stage_bytes = {

@@ -158,6 +158,21 @@ size_t ast_fft_plan_work_bytes(const ast_fft_plan* plan);
 int ast_fft_exec(ast_fft_plan* plan, void* in_d, void* out_d, void* stream);
 int ast_fft_plan_destroy(ast_fft_plan* plan);
 
+/* Hand-written LDS-tiled FFT passes (fp32, n in {256, 512, 1024}): the 3D R2C as
+ * exactly three passes over the array (rocFFT's plan at 1024^3 runs six kernels
+ * and moves ~2x the bytes).  Same results as the rocFFT plans above to fp32
+ * round-off; callers fall back to rocFFT when ast_fft_tile_supported() is 0.
+ *   ast_fft_tile_c2c: in-place forward transforms of length n over
+ *       data[b*batch_stride + k*elem_stride + c], c < ncols contiguous columns.
+ *   ast_fft_tile_rows_r2c: nrows contiguous real rows of n -> n/2+1 complex.
+ *   ast_fft_tile_r2c_3d: (n,n,n) real -> (n,n,n/2+1), out = scale * sum f e^{-ikx}. */
+int ast_fft_tile_supported(int dtype, size_t n);
+int ast_fft_tile_c2c(void* data_d, int dtype, size_t n, size_t elem_stride, size_t ncols, size_t batch,
+                     size_t batch_stride, double scale, void* stream);
+int ast_fft_tile_rows_r2c(const void* in_d, void* out_d, int dtype, size_t n, size_t nrows, size_t in_pitch,
+                          size_t out_pitch, double scale, void* stream);
+int ast_fft_tile_r2c_3d(const void* in_d, void* out_d, int dtype, size_t n, double scale, void* stream);
+
 /* ---------------------------------------------- a-5: k-shell power binning */
 
 /* FFTPower(mode="1d", dk = kmin = 2 pi / L) shell sums over a block of the
