@@ -49,9 +49,22 @@ class HipSlabOps:
         check(lib().ast_accumulate(self.dev.ptr(dst), self.dev.ptr(src), self.dev.real_code(dst), dst.numel(),
                                    self.dev.stream()), "ast_accumulate")
 
+    def _tile_ok(self, code, n):
+        from ._lib import lib
+        return bool(lib().ast_fft_tile_supported(code, n))
+
     def fft2d_planes(self, planes, out):
+        from ._lib import check, lib
         nloc, n1, n2 = planes.shape
         code = self.dev.real_code(planes)
+        if n1 == n2 and self._tile_ok(code, n1):
+            # hand-written passes: z rows (R2C) then y columns of every local plane
+            nz = n2 // 2 + 1
+            check(lib().ast_fft_tile_rows_r2c(self.dev.ptr(planes), self.dev.ptr(out), code, n2, nloc * n1, n2, nz,
+                                              1.0, self.dev.stream()), "ast_fft_tile_rows_r2c")
+            check(lib().ast_fft_tile_c2c(self.dev.ptr(out), code, n1, nz, nz, nloc, n1 * nz, 1.0, self.dev.stream()),
+                  "ast_fft_tile_c2c")
+            return out
         self.dev.fft_plan(0, code, (n1, n2), nloc, 1.0, False).execute(planes, out)      # AST_FFT_R2C
         return out
 
@@ -63,8 +76,13 @@ class HipSlabOps:
         return out
 
     def fft1d_axis0(self, block, scale):
+        from ._lib import check, lib
         n0, n1, n2 = block.shape
         code = 0 if block.dtype == torch.complex64 else 1
+        if self._tile_ok(code, n0):
+            check(lib().ast_fft_tile_c2c(self.dev.ptr(block), code, n0, n1 * n2, n1 * n2, 1, 0, scale,
+                                         self.dev.stream()), "ast_fft_tile_c2c")
+            return block
         plan = self.dev.fft_plan(2, code, (n0,), n1 * n2, scale, True, strided=(n0, n1 * n2, 1))   # AST_FFT_C2C_FWD
         plan.execute(block, None)
         return block
