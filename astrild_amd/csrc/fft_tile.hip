@@ -71,16 +71,33 @@ __device__ inline void fft_reg(float2 (&v)[R]) {
 
 // ------------------------------------------------------------ strided C2C pass
 // data[b * batch_stride + k * elem_stride + c], k < N = R1*R2, c < ncols (contiguous).
-template <int R1, int R2, int C>
+// POWER = true is the last (x) pass of the 3D transform fused with FFTPower's shell
+// binning: batch index = ky, column = kz, row = kx; instead of storing delta_k each
+// thread adds w |delta_k|^2 of its modes into the workgroup's LDS shell table, which
+// is written out as one row of `partial` ([workgroup][shell], summed by
+// shell_partials_reduce_kernel in a fixed order).  The spectrum never goes back to HBM.
+__device__ inline int tile_isqrt(int v) {
+    int r = (int)__fsqrt_rn((float)v);
+    if (r * r > v) --r;
+    if ((r + 1) * (r + 1) <= v) ++r;
+    return r;
+}
+
+template <int R1, int R2, int C, bool POWER>
 __global__ void __launch_bounds__(C * (R1 > R2 ? R1 : R2))
 strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, size_t elem_stride,
-                   size_t ncols, size_t batch_stride, unsigned tiles_per_batch, float scale) {
+                   size_t ncols, size_t batch_stride, unsigned tiles_per_batch, float scale,
+                   double* __restrict__ partial) {
     constexpr int N = R1 * R2;
     constexpr int NT = C * (R1 > R2 ? R1 : R2);
+    constexpr int NB = N / 2 - 1;    // shells when POWER
     extern __shared__ float2 lds[];
     float2* Y = lds;                 // [n2][k1][c]
     float2* tw = lds + N * C;        // exp(-2 pi i m / N)
+    double* shell = reinterpret_cast<double*>(lds + N * C + N);     // [NB + 1] when POWER
     for (int i = threadIdx.x; i < N; i += NT) tw[i] = tw_g[i];
+    if (POWER)
+        for (int i = threadIdx.x; i <= NB; i += NT) shell[i] = 0.0;
 
     const unsigned tile = blockIdx.x % tiles_per_batch, b = blockIdx.x / tiles_per_batch;
     const size_t c0 = (size_t)tile * C;
@@ -106,12 +123,12 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
         }
     }
     __syncthreads();
+    float2 u[R2];
     if (sub < R1) {                                   // stage 2: task (c, k1 = sub)
-        float2 u[R2];
 #pragma unroll
         for (int n2 = 0; n2 < R2; ++n2) u[n2] = Y[(n2 * R1 + sub) * C + c];
         fft_reg<R2>(u);
-        if (col_ok) {
+        if (col_ok && !POWER) {
 #pragma unroll
             for (int k2 = 0; k2 < R2; ++k2) {
                 float2 x = u[bitrev(k2, ilog2(R2))];
@@ -121,6 +138,41 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
             }
         }
     }
+    if (POWER && col_ok && sub < R1) {
+        // one ds_add_f64 per mode; merging a wave's equal-shell lanes first (ballot + cross-lane
+        // adds) measured slower: 16 kz x 4 kx lanes rarely share one shell
+        const int kz = (int)(c0 + c);
+        const int ky = (int)b > N / 2 ? (int)b - N : (int)b;
+        const int m2yz = ky * ky + kz * kz;
+        const float w = (kz > 0 && kz < N / 2) ? 2.0f : 1.0f;
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) {
+            const float2 x = u[bitrev(k2, ilog2(R2))];
+            const int row = sub + R1 * k2;
+            const int kx = row > N / 2 ? row - N : row;
+            const int sh = tile_isqrt(kx * kx + m2yz);                  // shell = sh - 1; 0 is DC
+            if (sh >= 1 && sh <= NB) atomicAdd(&shell[sh], (double)x.x * (double)x.x * w + (double)x.y * (double)x.y * w);
+        }
+    }
+    if (POWER) {
+        __syncthreads();
+        const double s2 = (double)scale * (double)scale;
+        for (int i = threadIdx.x; i < NB; i += NT) partial[(size_t)blockIdx.x * NB + i] = shell[i + 1] * s2;
+    }
+}
+
+// psum[bin] += pnorm * sum over workgroups of partial[wg][bin], fixed summation order
+__global__ void __launch_bounds__(256)
+shell_partials_reduce_kernel(const double* __restrict__ partial, size_t nwg, int nb, double pnorm,
+                             double* __restrict__ psum) {
+    __shared__ double part[4];
+    const int bin = blockIdx.x;
+    double acc = 0.0;
+    for (size_t g = threadIdx.x; g < nwg; g += 256) acc += partial[g * nb + bin];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) psum[bin] += pnorm * ((part[0] + part[1]) + (part[2] + part[3]));
 }
 
 // ------------------------------------------------------- contiguous-row R2C pass
@@ -215,23 +267,32 @@ struct TwiddleCache {
     }
 } g_tw;
 
-template <int R1, int R2, int C>
+template <int R1, int R2, int C, bool POWER>
 int launch_c2c(float2* data, const float2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride,
-               float scale, hipStream_t s) {
+               float scale, double* partial, hipStream_t s) {
     constexpr int N = R1 * R2, NT = C * (R1 > R2 ? R1 : R2);
-    const size_t lds = (size_t)(N * C + N) * sizeof(float2);
+    const size_t lds = (size_t)(N * C + N) * sizeof(float2) + (POWER ? (N / 2) * sizeof(double) : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&strided_c2c_kernel<R1, R2, C>),
+        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&strided_c2c_kernel<R1, R2, C, POWER>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const size_t tiles = (ncols + C - 1) / C;
     AST_CHECK_ARG(tiles * batch < 0x7fffffffull);
-    strided_c2c_kernel<R1, R2, C><<<(unsigned)(tiles * batch), NT, lds, s>>>(data, tw, elem_stride, ncols, batch_stride,
-                                                                            (unsigned)tiles, scale);
+    strided_c2c_kernel<R1, R2, C, POWER><<<(unsigned)(tiles * batch), NT, lds, s>>>(data, tw, elem_stride, ncols,
+                                                                                   batch_stride, (unsigned)tiles, scale,
+                                                                                   partial);
     AST_CHECK_LAUNCH();
     return AST_OK;
+}
+
+template <bool POWER>
+int dispatch_c2c(size_t n, float2* d, const float2* tw, size_t elem_stride, size_t ncols, size_t batch,
+                 size_t batch_stride, float scale, double* partial, hipStream_t s) {
+    if (n == 1024) return launch_c2c<32, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s);
+    if (n == 512) return launch_c2c<16, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s);
+    return launch_c2c<16, 16, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s);
 }
 
 template <int R1, int R2, int C>
@@ -267,10 +328,7 @@ extern "C" int ast_fft_tile_c2c(void* data, int dtype, size_t n, size_t elem_str
     if (!tw) { ast::set_error("ast_fft_tile_c2c: twiddle table allocation failed"); return AST_ERR_HIP; }
     hipStream_t s = ast::as_stream(stream);
     AST_PROF("fft_tile.c2c", s);
-    float2* d = (float2*)data;
-    if (n == 1024) return launch_c2c<32, 32, 16>(d, tw, elem_stride, ncols, batch, batch_stride, (float)scale, s);
-    if (n == 512) return launch_c2c<16, 32, 16>(d, tw, elem_stride, ncols, batch, batch_stride, (float)scale, s);
-    return launch_c2c<16, 16, 16>(d, tw, elem_stride, ncols, batch, batch_stride, (float)scale, s);
+    return dispatch_c2c<false>(n, (float2*)data, tw, elem_stride, ncols, batch, batch_stride, (float)scale, nullptr, s);
 }
 
 extern "C" int ast_fft_tile_rows_r2c(const void* in, void* out, int dtype, size_t n, size_t nrows, size_t in_pitch,
@@ -300,4 +358,43 @@ extern "C" int ast_fft_tile_r2c_3d(const void* in, void* out, int dtype, size_t 
     rc = ast_fft_tile_c2c(out, dtype, n, nz, nz, n, n * nz, 1.0, stream);                          // y, per x-plane
     if (rc != AST_OK) return rc;
     return ast_fft_tile_c2c(out, dtype, n, n * nz, n * nz, 1, 0, scale, stream);                    // x
+}
+
+// Row pitch (in complex elements) of the scratch spectrum used by ast_fft_tile_power_3d:
+// n/2+1 rounded up to a multiple of 16 so every 128-byte tile row is line-aligned.
+extern "C" size_t ast_fft_tile_power_scratch_bytes(size_t n) {
+    const size_t nzp = ((n / 2 + 1) + 15) / 16 * 16;
+    const size_t tiles = (n / 2 + 1 + 15) / 16;
+    return n * n * nzp * sizeof(float2) + n * tiles * (n / 2 - 1) * sizeof(double);
+}
+
+// FFTPower's shell sums of an (n, n, n) real grid without ever writing the spectrum:
+// z pass (R2C) and y pass into `scratch`, x pass fused with the shell binning.
+// psum_d[shell] += L^3 * sum_modes w |delta_k|^2, delta_k = rfftn(grid)/n^3  (auto power only).
+extern "C" int ast_fft_tile_power_3d(const void* grid, void* scratch, size_t scratch_bytes, int dtype, size_t n,
+                                     double boxsize, double* psum, void* stream) {
+    AST_CHECK_ARG(grid != nullptr && scratch != nullptr && psum != nullptr && boxsize > 0.0);
+    AST_CHECK_ARG(ast_fft_tile_supported(dtype, n));
+    AST_CHECK_ARG(scratch_bytes >= ast_fft_tile_power_scratch_bytes(n));
+    const size_t nz = n / 2 + 1, nzp = (nz + 15) / 16 * 16, tiles = (nz + 15) / 16;
+    float2* spec = (float2*)scratch;
+    double* partial = (double*)((char*)scratch + n * n * nzp * sizeof(float2));
+    const float2* tw = g_tw.get((int)n);
+    if (!tw) { ast::set_error("ast_fft_tile_power_3d: twiddle table allocation failed"); return AST_ERR_HIP; }
+    hipStream_t s = ast::as_stream(stream);
+    int rc = ast_fft_tile_rows_r2c(grid, spec, dtype, n, n * n, n, nzp, 1.0, stream);                  // z
+    if (rc != AST_OK) return rc;
+    rc = ast_fft_tile_c2c(spec, dtype, n, nzp, nz, n, n * nzp, 1.0, stream);                          // y, per x-plane
+    if (rc != AST_OK) return rc;
+    const double inv_ng = 1.0 / ((double)n * (double)n * (double)n);
+    {
+        AST_PROF("fft_tile.c2c_power", s);
+        rc = dispatch_c2c<true>(n, spec, tw, n * nzp, nz, n, nzp, (float)inv_ng, partial, s);          // x + binning
+        if (rc != AST_OK) return rc;
+    }
+    AST_PROF("fft_tile.shell_reduce", s);
+    const int nb = (int)(n / 2 - 1);
+    shell_partials_reduce_kernel<<<nb, 256, 0, s>>>(partial, n * tiles, nb, boxsize * boxsize * boxsize, psum);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
 }

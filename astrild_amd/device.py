@@ -269,11 +269,41 @@ def finish_power(ksum, psum, nmodes):
         return {"k": ks / nm, "power": ps / nm, "modes": nm, "shotnoise": 0.0}
 
 
-def fftpower_1d(field1, boxsize, field2=None):
+_power_scratch = {}
+
+
+def power_sums_fused(field, boxsize, psum=None):
+    """(ksum, psum, nmodes) of the auto power of an fp32 cube of side 256/512/1024 through
+    the fused tile-FFT + shell-binning path (the spectrum is never written to HBM)."""
+    n = field.shape[0]
+    L = _lib.lib()
+    key = (torch.cuda.current_device(), n)
+    scratch = _power_scratch.get(key)
+    if scratch is None:
+        _power_scratch.clear()
+        scratch = _power_scratch[key] = torch.empty(int(L.ast_fft_tile_power_scratch_bytes(n)), dtype=torch.uint8,
+                                                    device=field.device)
+    if psum is None:
+        psum = torch.zeros(n // 2 - 1, dtype=torch.float64, device=field.device)
+    ksum, nmodes = shell_geometry(n, boxsize)
+    check(L.ast_fft_tile_power_3d(ptr(field), ptr(scratch), scratch.numel(), real_code(field), n, float(boxsize),
+                                  ptr(psum), stream()), "ast_fft_tile_power_3d")
+    return ksum, psum, nmodes
+
+
+def fused_power_supported(field):
+    n = field.shape[0]
+    return field.dim() == 3 and tuple(field.shape) == (n, n, n) and field.dtype == torch.float32 \
+        and bool(_lib.lib().ast_fft_tile_supported(F32, n))
+
+
+def fftpower_1d(field1, boxsize, field2=None, fused=True):
     """``FFTPower(first, mode="1d", kmin=2*pi/L[, second])`` for in-memory grids
     (nbodykit call sites: power_spectrum_3d.py:189-224, stats_subfind.py:142-150)."""
     n = field1.shape[0]
     assert tuple(field1.shape) == (n, n, n) and n % 2 == 0
+    if fused and field2 is None and fused_power_supported(field1):
+        return finish_power(*power_sums_fused(field1, boxsize))
     s1 = r2c(field1)
     s2 = None if field2 is None else r2c(field2)
     return finish_power(*power_bin_1d(s1, s2, n, boxsize))

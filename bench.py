@@ -98,11 +98,15 @@ def main():
         psum = torch.zeros(n // 2 - 1, dtype=torch.float64, device="cuda")
         dev.shell_geometry(n, L)          # data independent, cached like the FFT plan
 
+        fused = dev.fused_power_supported(grid)
+
         def step():
             dev.paint(pos, None, n, L, args.window, out=grid, method=args.method, check_dropped=False,
                       accumulate=False)       # zero-fill + paint
-            dev.r2c(grid, out=spec)
             psum.zero_()
+            if fused:                         # tile FFT with the shell binning fused into the last pass
+                return dev.power_sums_fused(grid, L, psum=psum)
+            dev.r2c(grid, out=spec)
             return dev.power_bin_1d(spec, None, n, L, psum=psum)
     else:
         from astrild_amd import slab
@@ -145,13 +149,16 @@ def main():
     stage_sites = {
         "paint": [k for k in prof if k.startswith("paint")],
         "fft": [k for k in prof if k.startswith("rocfft") or k.startswith("fft_tile") or k.startswith("slab.")],
-        "power_bin": [k for k in prof if k == "power_bin"],
+        "power_bin": [k for k in prof if k == "power_bin"],        # absent when fused into the last FFT pass
     }
     stage_bytes = {
         "paint": npart_rank * 3 * esz + ng_rank * esz,       # read positions once, write the grid once
         "fft": 3 * 2 * ng_rank * esz,                         # 3 axis passes x (read + write)
         "power_bin": ng_rank * esz,                           # half spectrum read once (~esz B per real cell)
     }
+    if world == 1 and not stage_sites["power_bin"]:
+        stage_bytes["fft"] += stage_bytes.pop("power_bin")    # fused: one stage carries both terms
+        stage_sites.pop("power_bin")
     stages = {}
     for name, sites in stage_sites.items():
         ms = sum(prof[s][1] for s in sites) / args.steps

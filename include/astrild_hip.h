@@ -172,6 +172,13 @@ int ast_fft_tile_c2c(void* data_d, int dtype, size_t n, size_t elem_stride, size
 int ast_fft_tile_rows_r2c(const void* in_d, void* out_d, int dtype, size_t n, size_t nrows, size_t in_pitch,
                           size_t out_pitch, double scale, void* stream);
 int ast_fft_tile_r2c_3d(const void* in_d, void* out_d, int dtype, size_t n, double scale, void* stream);
+/* a-4 + a-5 fused: FFTPower's shell sums of an (n, n, n) real grid.  z and y passes
+ * go through scratch_d (line-aligned row pitch); the x pass adds w |delta_k|^2 of its
+ * modes to per-workgroup shell tables instead of storing delta_k, and a fixed-order
+ * reduction adds them into psum_d (same meaning as in ast_power_bin_1d; auto power). */
+size_t ast_fft_tile_power_scratch_bytes(size_t n);
+int ast_fft_tile_power_3d(const void* grid_d, void* scratch_d, size_t scratch_bytes, int dtype, size_t n,
+                          double boxsize, double* psum_d, void* stream);
 
 /* ---------------------------------------------- a-5: k-shell power binning */
 

@@ -72,3 +72,24 @@ def test_tile_engine_rejects_unsupported(dev):
         dev.r2c(torch.zeros((256, 256, 256), dtype=torch.float64, device="cuda"), engine="tile")
     out = dev.r2c(torch.ones((64, 64, 64), dtype=torch.float32, device="cuda"))          # auto -> rocFFT
     assert abs(complex(out[0, 0, 0]) - 1.0) < 1e-6
+
+
+@pytest.mark.parametrize("n", [256, 512])
+def test_fused_fft_power_matches_unfused_and_oracle(dev, n):
+    from oracle import fftpower as offt
+    rng = np.random.default_rng(n + 1)
+    f = (1.0 + 0.5 * rng.standard_normal((n, n, n))).astype(np.float32)
+    t = dev.as_device(f)
+    L = 750.0
+    fused = dev.fftpower_1d(t, L)                     # fused tile path
+    plain = dev.fftpower_1d(t, L, fused=False)        # spectrum to HBM + separate binning
+    assert np.array_equal(fused["modes"], plain["modes"])
+    np.testing.assert_allclose(fused["k"], plain["k"], rtol=0, atol=0)
+    np.testing.assert_allclose(fused["power"], plain["power"], rtol=4e-6)      # two fp32 pipelines, each ~1e-6
+    if n == 256:
+        ref = offt.fftpower_1d(f, L)
+        assert np.array_equal(fused["modes"], ref["modes"])
+        # fp32 grid + fp32 FFT against the float64 oracle: 1e-6 on all but the few-mode lowest
+        # shells, where single-precision round-off of the O(1) mean shows (3e-6 bound)
+        np.testing.assert_allclose(fused["power"][4:], ref["power"].real[4:], rtol=1e-6)
+        np.testing.assert_allclose(fused["power"], ref["power"].real, rtol=3e-6)
