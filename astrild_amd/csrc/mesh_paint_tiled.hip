@@ -20,6 +20,13 @@
 // Spatially coherent input (lattice / Morton / slab ordered snapshots) gives
 // long runs: few atomics in A1/A2 and coalesced gathers in D.  Fully shuffled
 // input degrades to one run per particle — still correct.
+//
+// Default is the SINGLE-PASS variant: A1 and B are skipped, every tile gets a
+// fixed-capacity segment of the index list (twice the mean occupancy) and A2
+// reserves slots with the same one-atomic-per-(interval, tile) scheme; particles
+// that do not fit go to an overflow list and are deposited with global atomics
+// by a small extra kernel.  Exact for any input; the two-pass variant
+// (AST_PAINT_TWO_PASS) is kept for strongly clustered data.
 #include "ast_common.h"
 #include "paint_window.h"
 #include <cstdlib>
@@ -90,12 +97,18 @@ constexpr uint32_t CODE_DONE = 0xffffffffu;
 // another tile fall back to a global atomic of their own.  In the FILL pass the
 // final position of a particle is only known after the flush, so each thread
 // parks (slot, offset-in-interval) codes of its 32 particles in LDS meanwhile.
-template <typename T, int W, bool FILL>
+// MODE 0: count (two-pass A1)   1: fill at exact offsets (two-pass A2)
+// MODE 2: single pass — tile t owns index[t*cap, (t+1)*cap); overflow goes to ovf[]
+template <typename T, int W, int MODE>
 __global__ void __launch_bounds__(256)
 tile_index_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t* __restrict__ tile_count,
                   const uint32_t* __restrict__ tile_off, uint32_t* __restrict__ tile_fill,
-                  uint32_t* __restrict__ index, unsigned long long* dropped, int ablate) {
-    __shared__ uint32_t skey[AGG_SLOTS], scnt[AGG_SLOTS], sbase[AGG_SLOTS];
+                  uint32_t* __restrict__ index, uint32_t cap, uint32_t* __restrict__ ovf,
+                  unsigned long long* __restrict__ ovf_count, unsigned long long* dropped, int ablate) {
+    constexpr bool FILL = MODE != 0;
+    // skey/scnt are re-armed by each thread as soon as it leaves the scatter loop, so the
+    // scatter reads the interval's results from sbase/stile, which only the next flush rewrites
+    __shared__ uint32_t skey[AGG_SLOTS], scnt[AGG_SLOTS], sbase[AGG_SLOTS], stile[AGG_SLOTS];
     __shared__ uint32_t codes[FILL ? AGG_TRIPS * IDX_UNROLL : 1][256];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -131,8 +144,9 @@ tile_index_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t* __
                     const uint32_t old = atomicCAS(&skey[slot], SLOT_EMPTY, key);
                     hit = old == SLOT_EMPTY || old == key;
                     if (hit) val = (slot << 16) | atomicAdd(&scnt[slot], (uint32_t)r.len);
-                    else if (!FILL) atomicAdd(&tile_count[key], (uint32_t)r.len);
-                    else val = tile_off[key] + atomicAdd(&tile_fill[key], (uint32_t)r.len);
+                    else if (MODE == 0) atomicAdd(&tile_count[key], (uint32_t)r.len);
+                    else if (MODE == 1) val = tile_off[key] + atomicAdd(&tile_fill[key], (uint32_t)r.len);
+                    else val = atomicAdd(&tile_fill[key], (uint32_t)r.len);      // slot inside the tile's segment
                 }
                 if (FILL) {
                     const int hitb = __shfl((int)hit, r.head_lane, 64);
@@ -140,7 +154,9 @@ tile_index_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t* __
                     uint32_t code = CODE_DONE;
                     if (live) {
                         if (hitb) code = valb;
-                        else index[valb] = (uint32_t)p;
+                        else if (MODE == 1) index[valb] = (uint32_t)p;
+                        else if (valb < cap) index[(size_t)key * cap + valb] = (uint32_t)p;
+                        else ovf[atomicAdd(ovf_count, 1ull)] = (uint32_t)p;
                     }
                     codes[trip * IDX_UNROLL + u][tid] = code;
                 }
@@ -148,22 +164,66 @@ tile_index_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t* __
         }
         __syncthreads();
         if (skey[tid] != SLOT_EMPTY) {
-            if (!FILL) atomicAdd(&tile_count[skey[tid]], scnt[tid]);
-            else sbase[tid] = tile_off[skey[tid]] + atomicAdd(&tile_fill[skey[tid]], scnt[tid]);
+            if (MODE == 0) atomicAdd(&tile_count[skey[tid]], scnt[tid]);
+            else if (MODE == 1) sbase[tid] = tile_off[skey[tid]] + atomicAdd(&tile_fill[skey[tid]], scnt[tid]);
+            else { sbase[tid] = atomicAdd(&tile_fill[skey[tid]], scnt[tid]); stile[tid] = skey[tid]; }
         }
         __syncthreads();
         if (FILL) {
 #pragma unroll 4
             for (int j = 0; j < AGG_TRIPS * IDX_UNROLL; ++j) {
                 const uint32_t c = codes[j][tid];
-                if (c != CODE_DONE) index[sbase[c >> 16] + (c & 0xffffu)] = (uint32_t)(p0 + (size_t)j * 256 + tid);
+                if (c == CODE_DONE) continue;
+                const uint32_t p = (uint32_t)(p0 + (size_t)j * 256 + tid);
+                const uint32_t at = sbase[c >> 16] + (c & 0xffffu);
+                if (MODE == 1) index[at] = p;
+                else if (at < cap) index[(size_t)stile[c >> 16] * cap + at] = p;
+                else ovf[atomicAdd(ovf_count, 1ull)] = p;
             }
         }
         skey[tid] = SLOT_EMPTY;
         scnt[tid] = 0;
         __syncthreads();
     }
-    if (!FILL && dropped && ndrop) atomicAdd(dropped, ndrop);
+    if (MODE != 1 && dropped && ndrop) atomicAdd(dropped, ndrop);
+}
+
+// Particles that did not fit their tile's segment in the single-pass variant: plain
+// global-atomic deposit (the direct kernel's inner loop over an index list).
+template <typename T, int W>
+__global__ void __launch_bounds__(256)
+overflow_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, const uint32_t* __restrict__ ovf,
+                        const unsigned long long* __restrict__ ovf_count, TileGeom g, double scale,
+                        T* __restrict__ grid, unsigned long long* dropped) {
+    constexpr int LO = Window<W>::LO;
+    const unsigned long long n = *ovf_count;
+    unsigned long long ndrop = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const size_t p = ovf[i];
+        double fx, fy, fz;
+        const int bx = ast::locate<W>((double)pos[3 * p + 0] * g.inv_dx, g.n, fx);
+        const int by = ast::locate<W>((double)pos[3 * p + 1] * g.inv_dx, g.n, fy);
+        const int bz = ast::locate<W>((double)pos[3 * p + 2] * g.inv_dx, g.n, fz);
+        T wx[W], wy[W], wz[W];
+        Window<W>::weights(fx, wx);
+        Window<W>::weights(fy, wy);
+        Window<W>::weights(fz, wz);
+        const T m = (T)((mass ? (double)mass[p] : 1.0) * scale);
+#pragma unroll
+        for (int a = 0; a < W; ++a) {
+            int px = ast::wrap1(bx - LO + a, g.n) - g.x_start;
+            if (px < 0) px += g.n;
+            if (px >= g.nx_alloc) { ++ndrop; continue; }
+#pragma unroll
+            for (int b = 0; b < W; ++b) {
+                T* row = grid + ((size_t)px * g.n + ast::wrap1(by - LO + b, g.n)) * g.n;
+#pragma unroll
+                for (int c = 0; c < W; ++c) atomicAdd(row + ast::wrap1(bz - LO + c, g.n), m * wx[a] * wy[b] * wz[c]);
+            }
+        }
+    }
+    if (dropped && ndrop) atomicAdd(dropped, ndrop);
 }
 
 // ---- exclusive scan of tile_count (3 kernels, 1024 items per block) ----
@@ -224,7 +284,7 @@ template <typename T, int W>
 __global__ void __launch_bounds__(256)
 tile_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileGeom g, double scale,
                     const uint32_t* __restrict__ index, const uint32_t* __restrict__ tile_off,
-                    const uint32_t* __restrict__ tile_count, T* __restrict__ grid,
+                    const uint32_t* __restrict__ tile_count, uint32_t cap, T* __restrict__ grid,
                     unsigned long long* dropped, int ablate) {
     constexpr int LX = TX + W - 1, LY = TY + W - 1, LZ = TZ + W - 1;
     constexpr int LO = Window<W>::LO;
@@ -233,9 +293,10 @@ tile_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileG
     // both grid dtypes and is rounded to T once, at the flush.
     __shared__ double tile[LX * LY * LZ];
     const uint32_t t = blockIdx.x;
-    const uint32_t cnt = tile_count[t];
+    // cap != 0: single-pass layout (fixed segments, tile_count holds the slots REQUESTED)
+    const uint32_t cnt = cap ? min(tile_count[t], cap) : tile_count[t];
     if (cnt == 0) return;                       // uniform for the workgroup
-    const uint32_t off = tile_off[t];
+    const size_t off = cap ? (size_t)t * cap : (size_t)tile_off[t];
     for (int i = threadIdx.x; i < LX * LY * LZ; i += 256) tile[i] = 0.0;
     __syncthreads();
 
@@ -307,25 +368,39 @@ tile_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileG
 }
 
 struct Workspace {
-    uint32_t* tile_count;
-    uint32_t* tile_fill;
-    uint32_t* tile_off;
+    unsigned long long* ovf_count;   // single pass: particles in the overflow list
+    uint32_t* tile_count;            // two pass: exact counts; single pass: unused
+    uint32_t* tile_fill;             // slots requested per tile
+    uint32_t* tile_off;              // two pass: exclusive scan of tile_count
     uint32_t* block_sums;
-    uint32_t* index;
+    uint32_t* index;                 // particle indices, tile-major
+    uint32_t* ovf;                   // single pass: indices that did not fit their tile's segment
+    uint32_t cap;                    // single pass: index slots per tile
     size_t bytes;
 };
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-Workspace carve(void* base, size_t np, uint32_t ntiles) {
+// Single pass: every tile gets room for twice the mean occupancy (at least mean + 512).
+inline uint32_t tile_capacity(size_t np, uint32_t ntiles) {
+    const size_t mean = (np + ntiles - 1) / ntiles;
+    size_t cap = 2 * mean > mean + 512 ? 2 * mean : mean + 512;
+    cap = (cap + 63) / 64 * 64;
+    return (uint32_t)(cap > 0x7fffffffull ? 0x7fffffffull : cap);
+}
+
+Workspace carve(void* base, size_t np, uint32_t ntiles, bool two_pass) {
     Workspace w;
     size_t off = 0;
     auto take = [&](size_t bytes) { void* p = (char*)base + off; off += align256(bytes); return p; };
+    w.ovf_count = (unsigned long long*)take(8);
     w.tile_count = (uint32_t*)take((size_t)ntiles * 4);
     w.tile_fill = (uint32_t*)take((size_t)ntiles * 4);
     w.tile_off = (uint32_t*)take((size_t)ntiles * 4);
     w.block_sums = (uint32_t*)take((size_t)((ntiles + 1023) / 1024 + 1) * 4);
-    w.index = (uint32_t*)take(np * 4);
+    w.cap = two_pass ? 0 : tile_capacity(np, ntiles);
+    w.index = (uint32_t*)take(two_pass ? np * 4 : (size_t)ntiles * w.cap * 4);
+    w.ovf = (uint32_t*)take(two_pass ? 0 : np * 4);
     w.bytes = off;
     return w;
 }
@@ -345,48 +420,67 @@ bool tiled_geometry(int nmesh, int nx_alloc, TileGeom& g, uint32_t& ntiles) {
 
 template <typename T, int W>
 int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntiles, double scale, T* grid,
-              void* workspace, unsigned long long* dropped, hipStream_t s) {
-    Workspace w = carve(workspace, np, ntiles);
+              void* workspace, unsigned long long* dropped, int flags, hipStream_t s) {
+    const bool two_pass = (flags & AST_PAINT_TWO_PASS) != 0;
+    Workspace w = carve(workspace, np, ntiles, two_pass);
     const int abl = getenv("AST_PAINT_ABLATE") ? atoi(getenv("AST_PAINT_ABLATE")) : 0;
-    // tile_count and tile_fill are contiguous at the front of the workspace
-    AST_CHECK_HIP(hipMemsetAsync(w.tile_count, 0, (size_t)((char*)w.tile_off - (char*)w.tile_count), s));
+    // ovf_count, tile_count and tile_fill are contiguous at the front of the workspace
+    AST_CHECK_HIP(hipMemsetAsync(w.ovf_count, 0, (size_t)((char*)w.tile_off - (char*)w.ovf_count), s));
     const size_t per_interval = (size_t)256 * IDX_UNROLL * AGG_TRIPS;
     const size_t nintervals = (np + per_interval - 1) / per_interval;
     const unsigned ga = (unsigned)(nintervals > 8192 ? 8192 : nintervals);
-    {
-        AST_PROF("paint_tiled.count", s);
-        tile_index_kernel<T, W, false><<<ga, 256, 0, s>>>(pos, np, g, w.tile_count, nullptr, nullptr, nullptr, dropped, abl);
+    if (two_pass) {
+        {
+            AST_PROF("paint_tiled.count", s);
+            tile_index_kernel<T, W, 0><<<ga, 256, 0, s>>>(pos, np, g, w.tile_count, nullptr, nullptr, nullptr, 0, nullptr,
+                                                           nullptr, dropped, abl);
+        }
+        const uint32_t nblk = (ntiles + 1023) / 1024;
+        {
+            AST_PROF("paint_tiled.scan", s);
+            scan_blocks_kernel<<<nblk, 256, 0, s>>>(w.tile_count, w.tile_off, w.block_sums, ntiles);
+            scan_sums_kernel<<<1, 256, 0, s>>>(w.block_sums, nblk);
+            scan_add_kernel<<<nblk, 256, 0, s>>>(w.tile_off, w.block_sums, ntiles);
+        }
+        {
+            AST_PROF("paint_tiled.fill", s);
+            tile_index_kernel<T, W, 1><<<ga, 256, 0, s>>>(pos, np, g, nullptr, w.tile_off, w.tile_fill, w.index, 0, nullptr,
+                                                           nullptr, nullptr, abl);
+        }
+        AST_PROF("paint_tiled.deposit", s);
+        tile_deposit_kernel<T, W><<<ntiles, 256, 0, s>>>(pos, mass, g, scale, w.index, w.tile_off, w.tile_count, 0, grid,
+                                                         dropped, abl);
+    } else {
+        {
+            AST_PROF("paint_tiled.fill", s);
+            tile_index_kernel<T, W, 2><<<ga, 256, 0, s>>>(pos, np, g, nullptr, nullptr, w.tile_fill, w.index, w.cap, w.ovf,
+                                                           w.ovf_count, dropped, abl);
+        }
+        {
+            AST_PROF("paint_tiled.deposit", s);
+            tile_deposit_kernel<T, W><<<ntiles, 256, 0, s>>>(pos, mass, g, scale, w.index, nullptr, w.tile_fill, w.cap, grid,
+                                                             dropped, abl);
+        }
+        AST_PROF("paint_tiled.overflow", s);
+        overflow_deposit_kernel<T, W><<<1024, 256, 0, s>>>(pos, mass, w.ovf, w.ovf_count, g, scale, grid, dropped);
     }
-    const uint32_t nblk = (ntiles + 1023) / 1024;
-    {
-        AST_PROF("paint_tiled.scan", s);
-        scan_blocks_kernel<<<nblk, 256, 0, s>>>(w.tile_count, w.tile_off, w.block_sums, ntiles);
-        scan_sums_kernel<<<1, 256, 0, s>>>(w.block_sums, nblk);
-        scan_add_kernel<<<nblk, 256, 0, s>>>(w.tile_off, w.block_sums, ntiles);
-    }
-    {
-        AST_PROF("paint_tiled.fill", s);
-        tile_index_kernel<T, W, true><<<ga, 256, 0, s>>>(pos, np, g, nullptr, w.tile_off, w.tile_fill, w.index, nullptr, abl);
-    }
-    AST_PROF("paint_tiled.deposit", s);
-    tile_deposit_kernel<T, W><<<ntiles, 256, 0, s>>>(pos, mass, g, scale, w.index, w.tile_off, w.tile_count, grid, dropped, abl);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
 
 }  // namespace
 
-extern "C" size_t ast_paint_tiled_workspace_bytes(size_t np, int nmesh, int nx_alloc) {
+extern "C" size_t ast_paint_tiled_workspace_bytes(size_t np, int nmesh, int nx_alloc, int flags) {
     TileGeom g;
     uint32_t ntiles = 0;
     if (nmesh <= 0 || nx_alloc <= 0 || !tiled_geometry(nmesh, nx_alloc, g, ntiles)) return 0;
-    return carve(nullptr, np, ntiles).bytes;
+    return carve(nullptr, np, ntiles, (flags & AST_PAINT_TWO_PASS) != 0).bytes;
 }
 
 extern "C" int ast_paint_tiled(int window, int dtype, const void* pos, const void* mass, size_t np, int nmesh,
                                double boxsize, double scale, int x_start, int nx_alloc, void* grid,
                                void* workspace, size_t workspace_bytes, unsigned long long* dropped,
-                               void* stream) {
+                               int flags, void* stream) {
     AST_CHECK_ARG(window == AST_WIN_CIC || window == AST_WIN_TSC);
     AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
     AST_CHECK_ARG(nmesh > 0 && boxsize > 0.0);
@@ -403,18 +497,18 @@ extern "C" int ast_paint_tiled(int window, int dtype, const void* pos, const voi
     }
     g.x_start = x_start;
     g.inv_dx = (double)nmesh / boxsize;
-    if (workspace_bytes < carve(nullptr, np, ntiles).bytes) {
-        ast::set_error("ast_paint_tiled: workspace too small (%zu < %zu bytes)", workspace_bytes,
-                       carve(nullptr, np, ntiles).bytes);
+    const size_t need = carve(nullptr, np, ntiles, (flags & AST_PAINT_TWO_PASS) != 0).bytes;
+    if (workspace_bytes < need) {
+        ast::set_error("ast_paint_tiled: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
         return AST_ERR_WORKSPACE;
     }
     hipStream_t s = ast::as_stream(stream);
     if (dtype == AST_F32) {
         if (window == AST_WIN_CIC)
-            return run_tiled<float, 2>((const float*)pos, (const float*)mass, np, g, ntiles, scale, (float*)grid, workspace, dropped, s);
-        return run_tiled<float, 3>((const float*)pos, (const float*)mass, np, g, ntiles, scale, (float*)grid, workspace, dropped, s);
+            return run_tiled<float, 2>((const float*)pos, (const float*)mass, np, g, ntiles, scale, (float*)grid, workspace, dropped, flags, s);
+        return run_tiled<float, 3>((const float*)pos, (const float*)mass, np, g, ntiles, scale, (float*)grid, workspace, dropped, flags, s);
     }
     if (window == AST_WIN_CIC)
-        return run_tiled<double, 2>((const double*)pos, (const double*)mass, np, g, ntiles, scale, (double*)grid, workspace, dropped, s);
-    return run_tiled<double, 3>((const double*)pos, (const double*)mass, np, g, ntiles, scale, (double*)grid, workspace, dropped, s);
+        return run_tiled<double, 2>((const double*)pos, (const double*)mass, np, g, ntiles, scale, (double*)grid, workspace, dropped, flags, s);
+    return run_tiled<double, 3>((const double*)pos, (const double*)mass, np, g, ntiles, scale, (double*)grid, workspace, dropped, flags, s);
 }

@@ -138,7 +138,8 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
 
     pos: (Np, 3) CUDA tensor (float32/float64); mass: (Np,) or None.
     Returns the grid ``(nx_alloc, nmesh, nmesh)`` in pos.dtype.
-    method: "direct" (global float atomics), "tiled" (LDS tiles) or "auto".
+    method: "direct" (global float atomics), "tiled" (LDS tiles, single pass over the
+    particles), "tiled2" (LDS tiles, exact two-pass counting) or "auto" (= tiled when possible).
     accumulate: add into ``out`` (default when ``out`` is given) or zero it first.
     """
     L = _lib.lib()
@@ -154,11 +155,12 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     npart = pos.shape[0]
     dropped = torch.zeros(1, dtype=torch.int64, device=pos.device)
     ws_bytes = 0
-    if method in ("auto", "tiled") and win != 0 and npart < 2**32 - 1:
-        ws_bytes = int(L.ast_paint_tiled_workspace_bytes(npart, n, nx))
-    if method == "tiled" and ws_bytes == 0:
+    tflags = 1 if method == "tiled2" else 0
+    if method in ("auto", "tiled", "tiled2") and win != 0 and npart < 2**32 - 1:
+        ws_bytes = int(L.ast_paint_tiled_workspace_bytes(npart, n, nx, tflags))
+    if method in ("tiled", "tiled2") and ws_bytes == 0:
         raise _lib.AstrildHipError("tiled paint needs a CIC/TSC window and nmesh a multiple of 32")
-    use_tiled = ws_bytes > 0 and (method == "tiled" or npart >= 65536)
+    use_tiled = ws_bytes > 0 and (method in ("tiled", "tiled2") or npart >= 65536)
     if out is None:
         out = torch.zeros((nx, n, n), dtype=pos.dtype, device=pos.device)
     else:
@@ -168,7 +170,7 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     if use_tiled:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pos.device)
         check(L.ast_paint_tiled(win, code, ptr(pos), ptr(mass), npart, n, float(boxsize), float(scale),
-                                int(x_start), nx, ptr(out), ptr(ws), ws_bytes, ptr(dropped), stream()),
+                                int(x_start), nx, ptr(out), ptr(ws), ws_bytes, ptr(dropped), tflags, stream()),
               "ast_paint_tiled")
     else:
         check(L.ast_paint(win, code, ptr(pos), ptr(mass), npart, n, float(boxsize), float(scale),

@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--window", default="cic", choices=["cic", "tsc"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--order", default="natural", choices=["natural", "shuffled"])
-    ap.add_argument("--method", default="auto", choices=["auto", "tiled", "direct"])
+    ap.add_argument("--method", default="auto", choices=["auto", "tiled", "tiled2", "direct"])
     ap.add_argument("--cpu-sample", type=int, default=512, help="lattice side of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--kappa", type=int, default=1, help="also time the kappa-map pipeline (1/0)")
     return ap.parse_args()

@@ -8,16 +8,17 @@ window = sys.argv[2] if len(sys.argv) > 2 else "cic"
 orders = sys.argv[3].split(",") if len(sys.argv) > 3 else ["natural", "shuffled"]
 L = 1000.0
 ACC = os.environ.get("ACC", "0") == "1"
+METHOD = os.environ.get("METHOD", "tiled")
 for order in orders:
     pos = dev.synth_lattice_particles(n, n, L, shuffle=(order == "shuffled"), dtype=torch.float32)
     grid = torch.zeros((n, n, n), dtype=torch.float32, device="cuda")
     for _ in range(2):
-        dev.paint(pos, None, n, L, window, out=grid, method="tiled", check_dropped=False, accumulate=ACC)
+        dev.paint(pos, None, n, L, window, out=grid, method=METHOD, check_dropped=False, accumulate=ACC)
     torch.cuda.synchronize()
     dev.profile_enable(True)
     reps = 5
     for _ in range(reps):
-        dev.paint(pos, None, n, L, window, out=grid, method="tiled", check_dropped=False, accumulate=ACC)
+        dev.paint(pos, None, n, L, window, out=grid, method=METHOD, check_dropped=False, accumulate=ACC)
     torch.cuda.synchronize()
     rep = dev.profile_report()
     dev.profile_enable(False)

@@ -23,11 +23,11 @@ def _tt(dtype):
     return torch.float32 if dtype == np.float32 else torch.float64
 
 
-@pytest.mark.parametrize("method", ["direct", "tiled"])
+@pytest.mark.parametrize("method", ["direct", "tiled", "tiled2"])
 @pytest.mark.parametrize("window", ["ngp", "cic", "tsc"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_paint_random_particles_with_mass(dev, method, window, dtype):
-    if method == "tiled" and window == "ngp":
+    if method in ("tiled", "tiled2") and window == "ngp":
         pytest.skip("tiled path is CIC/TSC only")
     rng = np.random.default_rng(11)
     n, L, npart = 64, 250.0, 70000
@@ -40,7 +40,7 @@ def test_paint_random_particles_with_mass(dev, method, window, dtype):
     assert got.sum(dtype=np.float64) == pytest.approx(mass.sum(dtype=np.float64), rel=1e-6)
 
 
-@pytest.mark.parametrize("method", ["direct", "tiled"])
+@pytest.mark.parametrize("method", ["direct", "tiled", "tiled2"])
 @pytest.mark.parametrize("window", ["cic", "tsc"])
 def test_paint_lattice_particles_natural_and_shuffled(dev, method, window):
     n, L = 64, 1000.0
@@ -61,7 +61,7 @@ def test_paint_scale_folds_cell_volume(dev):
     np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12 * ref.max())
 
 
-@pytest.mark.parametrize("method", ["direct", "tiled"])
+@pytest.mark.parametrize("method", ["direct", "tiled", "tiled2"])
 @pytest.mark.parametrize("window", ["cic", "tsc"])
 def test_paint_slab_buffer_with_ghost_planes(dev, method, window):
     # rank owning planes [16, 32) of a 64-grid, one ghost plane each side
@@ -82,7 +82,7 @@ def test_paint_slab_buffer_with_ghost_planes(dev, method, window):
         dev.paint(dev.as_device(pos), None, n, L, window, method=method, x_start=x_start, nx_alloc=nx_alloc)
 
 
-@pytest.mark.parametrize("method", ["direct", "tiled"])
+@pytest.mark.parametrize("method", ["direct", "tiled", "tiled2"])
 def test_paint_accumulate_and_overwrite_modes(dev, method):
     rng = np.random.default_rng(17)
     n, L = 64, 100.0
@@ -171,7 +171,7 @@ def test_plane_wave_known_answer(dev):
     np.testing.assert_allclose(res["power"], exp, atol=1e-9 * L**3)
 
 
-@pytest.mark.parametrize("method", ["direct", "tiled"])
+@pytest.mark.parametrize("method", ["direct", "tiled", "tiled2"])
 def test_pipeline_cic_pk_lattice_fp32_vs_oracle(dev, method):
     # configs[0]-shaped: 64^3 here to keep the oracle in seconds; same code path as 128^3
     n, L = 64, 1000.0
@@ -210,3 +210,19 @@ def test_synthetic_generator_statistics(dev):
     # same multiset of particles, different order
     np.testing.assert_allclose(np.sort(sh[:, 0]), np.sort(pos[:, 0]), rtol=0, atol=0)
     assert not np.array_equal(sh, pos)
+
+
+def test_single_pass_overflow_path_on_clustered_input(dev):
+    # 90 % of the particles in one corner blob: most of them overflow their tile's fixed
+    # segment and take the global-atomic path; the result must not change
+    rng = np.random.default_rng(23)
+    n, L, npart = 64, 100.0, 200000
+    blob = rng.normal(10.0, 1.5, size=(int(0.9 * npart), 3))
+    rest = rng.uniform(0, L, size=(npart - len(blob), 3))
+    pos = np.concatenate([blob, rest])
+    rng.shuffle(pos)
+    mass = rng.uniform(0.5, 1.5, npart)
+    ref = omesh.paint(pos, mass, n, L, "cic")
+    for method in ("tiled", "tiled2"):
+        got = dev.paint(dev.as_device(pos), dev.as_device(mass), n, L, "cic", method=method).cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-11 * ref.max())
