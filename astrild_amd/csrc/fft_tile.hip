@@ -181,7 +181,7 @@ shell_partials_reduce_kernel(const double* __restrict__ partial, size_t nwg, int
 template <int R1, int R2, int C>
 __global__ void __launch_bounds__(C * R2)
 rows_r2c_kernel(const float* __restrict__ in, float2* __restrict__ out, const float2* __restrict__ tw_g,
-                size_t nrows, size_t in_pitch, size_t out_pitch, float scale) {
+                size_t nrows, size_t in_pitch, size_t out_pitch, float scale, float mean) {
     constexpr int M = R1 * R2, N = 2 * M;
     constexpr int NT = C * R2;
     constexpr int R2P = R2 + 1;
@@ -198,7 +198,11 @@ rows_r2c_kernel(const float* __restrict__ in, float2* __restrict__ out, const fl
         const float2* zin = reinterpret_cast<const float2*>(in + (row0 + r) * in_pitch);   // z[j] = x[2j] + i x[2j+1]
         float2 v[R1];
 #pragma unroll
-        for (int n1 = 0; n1 < R1; ++n1) v[n1] = row_ok ? zin[n1 * R2 + n2] : make_float2(0.f, 0.f);
+        for (int n1 = 0; n1 < R1; ++n1) {
+            v[n1] = row_ok ? zin[n1 * R2 + n2] : make_float2(mean, mean);
+            v[n1].x -= mean;                 // only the (discarded) DC mode sees the offset; fp32 round-off
+            v[n1].y -= mean;                 // of every other mode no longer scales with it
+        }
         fft_reg<R1>(v);
         __syncthreads();
 #pragma unroll
@@ -297,7 +301,7 @@ int dispatch_c2c(size_t n, float2* d, const float2* tw, size_t elem_stride, size
 
 template <int R1, int R2, int C>
 int launch_r2c(const float* in, float2* out, const float2* tw, size_t nrows, size_t in_pitch, size_t out_pitch,
-               float scale, hipStream_t s) {
+               float scale, float mean, hipStream_t s) {
     constexpr int M = R1 * R2, N = 2 * M, NT = C * R2;
     constexpr int BUF = C * (R1 * (R2 + 1) > M + 1 ? R1 * (R2 + 1) : M + 1);
     const size_t lds = (size_t)(BUF + N) * sizeof(float2);
@@ -309,7 +313,7 @@ int launch_r2c(const float* in, float2* out, const float2* tw, size_t nrows, siz
     }
     const size_t blocks = (nrows + C - 1) / C;
     AST_CHECK_ARG(blocks < 0x7fffffffull);
-    rows_r2c_kernel<R1, R2, C><<<(unsigned)blocks, NT, lds, s>>>(in, out, tw, nrows, in_pitch, out_pitch, scale);
+    rows_r2c_kernel<R1, R2, C><<<(unsigned)blocks, NT, lds, s>>>(in, out, tw, nrows, in_pitch, out_pitch, scale, mean);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
@@ -331,8 +335,8 @@ extern "C" int ast_fft_tile_c2c(void* data, int dtype, size_t n, size_t elem_str
     return dispatch_c2c<false>(n, (float2*)data, tw, elem_stride, ncols, batch, batch_stride, (float)scale, nullptr, s);
 }
 
-extern "C" int ast_fft_tile_rows_r2c(const void* in, void* out, int dtype, size_t n, size_t nrows, size_t in_pitch,
-                                     size_t out_pitch, double scale, void* stream) {
+static int rows_r2c_impl(const void* in, void* out, int dtype, size_t n, size_t nrows, size_t in_pitch,
+                         size_t out_pitch, double scale, double mean, void* stream) {
     AST_CHECK_ARG(in != nullptr && out != nullptr && in != out && nrows >= 1);
     AST_CHECK_ARG(ast_fft_tile_supported(dtype, n));
     AST_CHECK_ARG(in_pitch >= n && in_pitch % 2 == 0 && out_pitch >= n / 2 + 1);
@@ -342,9 +346,14 @@ extern "C" int ast_fft_tile_rows_r2c(const void* in, void* out, int dtype, size_
     AST_PROF("fft_tile.rows_r2c", s);
     const float* i = (const float*)in;
     float2* o = (float2*)out;
-    if (n == 1024) return launch_r2c<16, 32, 16>(i, o, tw, nrows, in_pitch, out_pitch, (float)scale, s);
-    if (n == 512) return launch_r2c<16, 16, 16>(i, o, tw, nrows, in_pitch, out_pitch, (float)scale, s);
-    return launch_r2c<8, 16, 16>(i, o, tw, nrows, in_pitch, out_pitch, (float)scale, s);
+    if (n == 1024) return launch_r2c<16, 32, 16>(i, o, tw, nrows, in_pitch, out_pitch, (float)scale, (float)mean, s);
+    if (n == 512) return launch_r2c<16, 16, 16>(i, o, tw, nrows, in_pitch, out_pitch, (float)scale, (float)mean, s);
+    return launch_r2c<8, 16, 16>(i, o, tw, nrows, in_pitch, out_pitch, (float)scale, (float)mean, s);
+}
+
+extern "C" int ast_fft_tile_rows_r2c(const void* in, void* out, int dtype, size_t n, size_t nrows, size_t in_pitch,
+                                     size_t out_pitch, double scale, void* stream) {
+    return rows_r2c_impl(in, out, dtype, n, nrows, in_pitch, out_pitch, scale, 0.0, stream);
 }
 
 // The three passes of an (n, n, n) real -> (n, n, n/2+1) half-spectrum transform,
@@ -372,7 +381,7 @@ extern "C" size_t ast_fft_tile_power_scratch_bytes(size_t n) {
 // z pass (R2C) and y pass into `scratch`, x pass fused with the shell binning.
 // psum_d[shell] += L^3 * sum_modes w |delta_k|^2, delta_k = rfftn(grid)/n^3  (auto power only).
 extern "C" int ast_fft_tile_power_3d(const void* grid, void* scratch, size_t scratch_bytes, int dtype, size_t n,
-                                     double boxsize, double* psum, void* stream) {
+                                     double boxsize, double mean, double* psum, void* stream) {
     AST_CHECK_ARG(grid != nullptr && scratch != nullptr && psum != nullptr && boxsize > 0.0);
     AST_CHECK_ARG(ast_fft_tile_supported(dtype, n));
     AST_CHECK_ARG(scratch_bytes >= ast_fft_tile_power_scratch_bytes(n));
@@ -382,7 +391,7 @@ extern "C" int ast_fft_tile_power_3d(const void* grid, void* scratch, size_t scr
     const float2* tw = g_tw.get((int)n);
     if (!tw) { ast::set_error("ast_fft_tile_power_3d: twiddle table allocation failed"); return AST_ERR_HIP; }
     hipStream_t s = ast::as_stream(stream);
-    int rc = ast_fft_tile_rows_r2c(grid, spec, dtype, n, n * n, n, nzp, 1.0, stream);                  // z
+    int rc = rows_r2c_impl(grid, spec, dtype, n, n * n, n, nzp, 1.0, mean, stream);                   // z
     if (rc != AST_OK) return rc;
     rc = ast_fft_tile_c2c(spec, dtype, n, nzp, nz, n, n * nzp, 1.0, stream);                          // y, per x-plane
     if (rc != AST_OK) return rc;

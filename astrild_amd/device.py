@@ -274,9 +274,11 @@ def finish_power(ksum, psum, nmodes):
 _power_scratch = {}
 
 
-def power_sums_fused(field, boxsize, psum=None):
+def power_sums_fused(field, boxsize, psum=None, mean=0.0):
     """(ksum, psum, nmodes) of the auto power of an fp32 cube of side 256/512/1024 through
-    the fused tile-FFT + shell-binning path (the spectrum is never written to HBM)."""
+    the fused tile-FFT + shell-binning path (the spectrum is never written to HBM).
+    ``mean`` is subtracted from the cells on load: it only touches the discarded DC mode
+    and keeps fp32 round-off from scaling with the mean density (pass total_mass/Ng)."""
     n = field.shape[0]
     L = _lib.lib()
     key = (torch.cuda.current_device(), n)
@@ -289,7 +291,7 @@ def power_sums_fused(field, boxsize, psum=None):
         psum = torch.zeros(n // 2 - 1, dtype=torch.float64, device=field.device)
     ksum, nmodes = shell_geometry(n, boxsize)
     check(L.ast_fft_tile_power_3d(ptr(field), ptr(scratch), scratch.numel(), real_code(field), n, float(boxsize),
-                                  ptr(psum), stream()), "ast_fft_tile_power_3d")
+                                  float(mean), ptr(psum), stream()), "ast_fft_tile_power_3d")
     return ksum, psum, nmodes
 
 

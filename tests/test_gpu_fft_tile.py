@@ -93,3 +93,19 @@ def test_fused_fft_power_matches_unfused_and_oracle(dev, n):
         # shells, where single-precision round-off of the O(1) mean shows (3e-6 bound)
         np.testing.assert_allclose(fused["power"][4:], ref["power"].real[4:], rtol=1e-6)
         np.testing.assert_allclose(fused["power"], ref["power"].real, rtol=3e-6)
+
+
+def test_mean_subtraction_recovers_cold_low_k_shells_in_fp32(dev):
+    # lattice + small jitter: low-k power is ~1e-5 of the peak; the fp32 FFT round-off of the
+    # O(1) mean density swamps it unless the mean is removed on load
+    n, L = 256, 1000.0
+    pos = dev.synth_lattice_particles(n, n, L, seed=3, dtype=torch.float32)
+    g32 = dev.paint(pos, None, n, L, "cic")
+    ref = dev.fftpower_1d(dev.paint(pos.double(), None, n, L, "cic"), L)          # fp64 pipeline
+    plain = dev.finish_power(*dev.power_sums_fused(g32, L))
+    centred = dev.finish_power(*dev.power_sums_fused(g32, L, mean=1.0))
+    err_plain = np.abs(plain["power"] / ref["power"] - 1)
+    err_centred = np.abs(centred["power"] / ref["power"] - 1)
+    assert err_centred.max() < 2e-5                     # fp32 grid cells still carry 6e-8 of the mean
+    assert err_centred[:8].max() < 0.2 * err_plain[:8].max() + 1e-7
+    np.testing.assert_allclose(centred["power"][n // 8:], ref["power"][n // 8:], rtol=1e-6)
