@@ -84,12 +84,15 @@ __device__ inline WaveRuns wave_runs(uint32_t key, bool live, int lane) {
 }
 
 constexpr int IDX_UNROLL = 4;      // particles per thread per trip: keeps 12 loads in flight
-constexpr int AGG_TRIPS = 8;       // trips of 1024 particles between flushes of the LDS table
+#ifndef AGG_TRIPS_N
+#define AGG_TRIPS_N 4
+#endif
+constexpr int AGG_TRIPS = AGG_TRIPS_N;       // trips of 1024 particles between flushes of the LDS table
 constexpr int AGG_SLOTS = 256;     // direct-mapped by (tile id & 255)
 constexpr uint32_t SLOT_EMPTY = 0xffffffffu;
 constexpr uint32_t CODE_DONE = 0xffffffffu;
 
-// Both passes walk the particle array in contiguous intervals of 8192 particles
+// Both passes walk the particle array in contiguous intervals of 4096 particles
 // per workgroup.  Global atomics are the bottleneck of a naive version (one per
 // run: ~2/3 of the kernel time), so run heads first combine into a small
 // direct-mapped LDS table keyed by tile id; the table is flushed once per
