@@ -7,10 +7,12 @@ per GPU, ``torch.distributed`` over RCCL/xGMI (backend "nccl").  Per step:
   1. paint the rank's particles into its slab buffer (owned planes + ghost planes);
   2. ghost fold: ghost planes go to the two ring neighbours and are added into
      their owned planes (grouped send/recv, N^2 elements per plane);
-  3. batched 2D R2C over (y, z) of the owned planes;
-  4. pack + ONE all-to-all: rank r keeps ky in [r*N/P, (r+1)*N/P) for ALL x.  With
-     point-to-point xGMI every GPU talks to its 7 peers at once, so all 7 links
-     carry 1/P^2 of the spectrum each (67 MB per pair at 1024^3 fp32, P = 8);
+  3. batched 2D R2C over (y, z) of the owned planes, in `chunks` groups of planes;
+  4. pack + all-to-all per chunk (grouped send/recv to every peer, issued asynchronously
+     so chunk c travels while chunk c+1 is transformed): rank r keeps ky in
+     [r*N/P, (r+1)*N/P) for ALL x.  With point-to-point xGMI every GPU talks to its 7
+     peers at once, so all 7 links carry 1/P^2 of the spectrum each (67 MB per pair at
+     1024^3 fp32, P = 8);
   5. strided 1D C2C along x (1/Ng folded into this pass);
   6. shell binning of the local (N, N/P, N/2+1) block, then one all-reduce of the
      N/2-1 shell sums (4 KB).
@@ -125,11 +127,29 @@ def ghost_fold(buf, nloc, gl, gh, ops, group=None):
     return owned
 
 
+def exchange_chunk(packed_c, block, chunk, pc, nloc, group=None):
+    """Step 4 for one chunk of `pc` local planes.  packed_c: (P, pc, nly, nz) — piece s goes
+    to rank s; it lands in block[s_src*nloc + chunk*pc : ... + pc] of the receiver.  Returns
+    the outstanding work handles (the local piece is copied right away)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    ops_list = []
+    for s in range(world):
+        dst = block[s * nloc + chunk * pc: s * nloc + (chunk + 1) * pc]
+        if s == rank:
+            dst.copy_(packed_c[s])
+            continue
+        # complex payload moved as (re, im) pairs of the real dtype: every c10d backend takes that
+        ops_list.append(dist.P2POp(dist.isend, torch.view_as_real(packed_c[s]), s, group))
+        ops_list.append(dist.P2POp(dist.irecv, torch.view_as_real(dst), s, group))
+    return dist.batch_isend_irecv(ops_list) if ops_list else []
+
+
 class SlabPowerPipeline:
     """CIC/TSC + slab FFT + P(k) for the synthetic lattice workload of bench.py."""
 
     def __init__(self, n, boxsize, npside, window="cic", dtype=torch.float32, seed=20240601, shuffle=False,
-                 ghost=4, ops=None, group=None, pos=None):
+                 ghost=4, ops=None, group=None, pos=None, chunks=None):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -143,7 +163,9 @@ class SlabPowerPipeline:
         # particles jitter across slab boundaries: ghost planes take base cells up to
         # `ghost` planes outside, plus the window's own reach of one plane
         self.gl = self.gh = ghost + 1
-        if self.nloc + self.gl + self.gh > n:
+        if P == 1:
+            self.gl = self.gh = 0          # one rank owns the whole periodic grid: no ghosts, no fold
+        elif self.nloc + self.gl + self.gh > n:
             raise ValueError("slab too thin for the ghost zone")
         self.x_start = (self.rank * self.nloc - self.gl) % n
         self.nx_alloc = self.nloc + self.gl + self.gh
@@ -152,7 +174,13 @@ class SlabPowerPipeline:
         o = self.ops
         self.buf = o.empty((self.nx_alloc, n, n))
         self.spec2d = o.empty((self.nloc, n, self.nz), o.cdtype)
-        self.packed = o.empty((P, self.nloc, self.nloc, self.nz), o.cdtype)
+        if chunks is None:
+            chunks = 4 if self.nloc % 4 == 0 and self.nloc >= 16 else 1
+        if self.nloc % chunks:
+            raise ValueError(f"{self.nloc} local planes do not split into {chunks} chunks")
+        self.chunks = chunks
+        self.pc = self.nloc // chunks
+        self.packed = o.empty((chunks, P, self.pc, self.nloc, self.nz), o.cdtype)
         self.block = o.empty((n, self.nloc, self.nz), o.cdtype)
         self.psum = o.zeros((n // 2 - 1,), torch.float64)
         self.i0 = (0, n)
@@ -165,14 +193,21 @@ class SlabPowerPipeline:
     def paint(self, check=False):
         """check=True synchronises and raises if a deposit fell outside the ghost zone."""
         self.ops.paint(self.pos, None, self.n, self.L, self.window, self.buf, self.x_start, self.nx_alloc, check)
+        if self.world == 1:
+            return self.buf
         return ghost_fold(self.buf, self.nloc, self.gl, self.gh, self.ops, self.group)
 
     def forward_fft(self, owned):
         o = self.ops
-        o.fft2d_planes(owned, self.spec2d)
-        o.pack(self.spec2d, self.packed, self.world)
-        # complex payload moved as (re, im) pairs of the real dtype: every c10d backend takes that
-        dist.all_to_all_single(torch.view_as_real(self.block), torch.view_as_real(self.packed), group=self.group)
+        pending = []
+        for c in range(self.chunks):
+            planes = owned[c * self.pc:(c + 1) * self.pc]
+            spec = self.spec2d[c * self.pc:(c + 1) * self.pc]
+            o.fft2d_planes(planes, spec)
+            o.pack(spec, self.packed[c], self.world)
+            pending += exchange_chunk(self.packed[c], self.block, c, self.pc, self.nloc, self.group)
+        for work in pending:
+            work.wait()
         return o.fft1d_axis0(self.block, 1.0 / float(self.n) ** 3)
 
     def step(self, check=False):

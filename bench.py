@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=512, help="lattice side of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--kappa", type=int, default=1, help="also time the kappa-map pipeline (1/0)")
     ap.add_argument("--bispec", type=int, default=1, help="also time the 512^3 bispectrum (1/0)")
+    ap.add_argument("--slab", type=int, default=0, help="run the slab-decomposed pipeline even on one GPU (rehearsal)")
     return ap.parse_args()
 
 
@@ -99,6 +100,11 @@ def kappa_leg(dev, steps, warmup):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE JSON line: everything else a library may print there
+    # (RCCL's version banner at communicator creation, for one) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -108,7 +114,13 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
-    if world > 1:
+    use_slab = world > 1 or bool(args.slab)
+    if use_slab:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from astrild_amd import device as dev
@@ -119,7 +131,7 @@ def main():
     esz = 4 if args.dtype == "f32" else 8
     npart_total = npside ** 3
 
-    if world == 1:
+    if not use_slab:
         pos = dev.synth_lattice_particles(npside, n, L, seed=20240601, shuffle=(args.order == "shuffled"), dtype=tdt)
         grid = torch.empty((n, n, n), dtype=tdt, device="cuda")
         spec = torch.empty((n, n, n // 2 + 1), dtype=torch.complex64 if args.dtype == "f32" else torch.complex128,
@@ -145,7 +157,7 @@ def main():
         step = pipe.step
 
     def barrier():
-        if world > 1:
+        if use_slab:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -160,7 +172,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = dev.profile_report()
     dev.profile_enable(False)
-    if world > 1:
+    if use_slab:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -185,7 +197,7 @@ def main():
         "fft": 3 * 2 * ng_rank * esz,                         # 3 axis passes x (read + write)
         "power_bin": ng_rank * esz,                           # half spectrum read once (~esz B per real cell)
     }
-    if world == 1 and not stage_sites["power_bin"]:
+    if not use_slab and not stage_sites["power_bin"]:
         stage_bytes["fft"] += stage_bytes.pop("power_bin")    # fused: one stage carries both terms
         stage_sites.pop("power_bin")
     stages = {}
@@ -201,7 +213,7 @@ def main():
     # WRITE_SIZE in separate runs, gfx950 x2 read correction; profiles/r01_pmc_traffic.json says how)
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if dom == "paint" and world == 1 and n == 1024 and npside == 1024 and args.window == "cic" \
+    if dom == "paint" and not use_slab and n == 1024 and npside == 1024 and args.window == "cic" \
             and args.dtype == "f32" and args.order == "natural" and os.path.isfile(pmc_file):
         traffic = json.load(open(pmc_file)).get("paint_stage_corrected_GB_per_step")
         traffic = None if traffic is None else traffic * 1e9
@@ -224,10 +236,10 @@ def main():
         "config": {"workload": f"{npside}^3 lattice+Gaussian(0.5 cell) particles ({args.order} order) -> "
                                f"{args.window.upper()} paint on {n}^3 grid -> 3D R2C -> FFTPower 1d shells",
                    "ngrid": n, "nparticles": npart_total, "boxsize": L,
-                   "parallelism": "single GPU" if world == 1 else f"axis-0 slabs x{world}, RCCL all-to-all transpose"},
+                   "parallelism": "single GPU" if not use_slab else f"axis-0 slabs x{world}, RCCL all-to-all transpose"},
         "roofline": roofline,
     }
-    if rank == 0 and world == 1:
+    if rank == 0 and not use_slab:
         if args.cpu_sample:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.window, L)
         del pos, grid, spec
@@ -239,8 +251,9 @@ def main():
         if args.kappa:
             out["kappa"] = kappa_leg(dev, args.steps, args.warmup)
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if use_slab:
         dist.destroy_process_group()
 
 

@@ -81,3 +81,30 @@ def test_slab_pack_unpack_round_trip(hip):
     _lib.check(hip.ast_slab_unpack(dev.ptr(packed), dev.ptr(back), 0, n0, n1, n2, parts, dev.stream()))
     assert torch.equal(back, x)
     assert hip.ast_slab_pack(dev.ptr(x), dev.ptr(packed), 0, n0, n1, n2, 5, dev.stream()) < 0     # 12 % 5 != 0
+
+
+def test_slab_pipeline_object_on_one_gpu_over_nccl(hip):
+    """The real SlabPowerPipeline (HipSlabOps, chunked exchange, all-reduces) with
+    torch.distributed's nccl (= RCCL) backend at world_size 1, against the single-GPU path."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from astrild_amd import device as dev, slab
+    torch.cuda.set_device(0)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n, L = 256, 1000.0
+        pipe = slab.SlabPowerPipeline(n, L, n, window="cic", dtype=torch.float32, seed=5, chunks=4)
+        ks, ps, nm = pipe.step(check=True)
+        res = dev.finish_power(ks, ps, nm)
+        pos = dev.synth_lattice_particles(n, n, L, seed=5, dtype=torch.float32)
+        ref = dev.fftpower_1d(dev.paint(pos, None, n, L, "cic"), L)
+        assert np.array_equal(res["modes"], ref["modes"])
+        np.testing.assert_allclose(res["k"], ref["k"], rtol=1e-12)
+        np.testing.assert_allclose(res["power"], ref["power"], rtol=5e-6)
+    finally:
+        dist.destroy_process_group()

@@ -26,7 +26,7 @@ def _particles():
     return omesh.lattice_particles(NPS, N, L, seed=7, sigma_cells=0.5)
 
 
-def _worker(rank, world, port, window, out_dir):
+def _worker(rank, world, port, window, out_dir, chunks=2):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -36,7 +36,7 @@ def _worker(rank, world, port, window, out_dir):
         ppr = len(pos) // world
         mine = torch.from_numpy(np.ascontiguousarray(pos[rank * ppr:(rank + 1) * ppr]))
         pipe = slab.SlabPowerPipeline(N, L, NPS, window=window, dtype=torch.float64, ghost=2,
-                                      ops=NumpySlabOps(), pos=mine)
+                                      ops=NumpySlabOps(), pos=mine, chunks=chunks)
         owned = pipe.paint(check=True).clone()
         ks, ps, nm = pipe.step(check=True)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), owned=owned.numpy(), ks=ks.numpy(), ps=ps.numpy(),
@@ -45,11 +45,11 @@ def _worker(rank, world, port, window, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("window", ["cic", "tsc"])
-def test_slab_pipeline_two_ranks_matches_single_process_oracle(tmp_path, window):
+@pytest.mark.parametrize("window,chunks", [("cic", 1), ("cic", 4), ("tsc", 2)])
+def test_slab_pipeline_two_ranks_matches_single_process_oracle(tmp_path, window, chunks):
     world = 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, window, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, window, str(tmp_path), chunks), nprocs=world, join=True)
     pos = _particles()
     full = omesh.paint(pos, None, N, L, window)
     ref = offt.fftpower_1d(full, L)
@@ -76,6 +76,14 @@ def test_slab_rejects_bad_geometry():
     try:
         from tests.slab_doubles import NumpySlabOps
         with pytest.raises(ValueError):
-            slab.SlabPowerPipeline(16, 1.0, 16, ops=NumpySlabOps(), pos=torch.zeros((0, 3), dtype=torch.float64))
+            slab.SlabPowerPipeline(16, 1.0, 16, ops=NumpySlabOps(), pos=torch.zeros((0, 3), dtype=torch.float64),
+                                   chunks=3)
+        # a single rank owns the whole periodic grid and needs no ghost zone
+        pos = torch.from_numpy(_particles())
+        pipe = slab.SlabPowerPipeline(N, L, NPS, dtype=torch.float64, ops=NumpySlabOps(), pos=pos, chunks=2)
+        ks, ps, nm = pipe.step(check=True)
+        ref = offt.fftpower_1d(omesh.paint(_particles(), None, N, L, "cic"), L)
+        assert np.array_equal(nm.numpy(), ref["modes"])
+        np.testing.assert_allclose(ps.numpy() / nm.numpy(), ref["power"].real, rtol=1e-10)
     finally:
         dist.destroy_process_group()
