@@ -67,6 +67,8 @@ SIGNATURES = {
     "ast_minmax": (_i, [_vp, _i, _sz, _vp, _vp]),
     "ast_histogram": (_i, [_vp, _i, _sz, _d, _d, _i, _vp, _vp]),
     "ast_add": (_i, [_vp, _vp, _vp, _i, _sz, _vp]),
+    "ast_nfw_paint": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _d, _i, _i, _d, _i, _vp, _i, _vp]),
+    "ast_add_patch": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
 }
 
 _lib = None

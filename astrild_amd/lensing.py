@@ -177,6 +177,44 @@ def add(a, b, out=None):
     return out
 
 
+# --------------------------------------------------- f-2 NFW halo stamps
+def nfw_paint(halo_cat, extent, direction, suppress, suppression_R, npix, signal, out=None):
+    """Add the NFW deflection-angle ("alpha") or moving-lens temperature ("dT") stamp of
+    every halo of ``halo_cat`` (dict of equal-length sequences with astrild's keys) onto an
+    npix x npix map — SkyUtils.analytic_Halo_signal_to_SkyArray (sky_utils.py:79-137)."""
+    nh = len(halo_cat["m200"])
+    f64 = lambda key: as_device(np.ascontiguousarray(np.asarray(halo_cat[key], dtype=np.float64)))
+    i32 = lambda arr: as_device(np.ascontiguousarray(np.asarray(arr, dtype=np.int32)))
+    if out is None:
+        out = torch.zeros((npix, npix), dtype=torch.float64, device=device())
+    if nh == 0:
+        return out
+    sig = {"alpha": 0, "dT": 1}[signal]
+    mask = sum(1 << int(d) for d in set(int(d) for d in direction))
+    if sig == 0 and int(np.sum(list(direction))) > 1:
+        raise AssertionError("Only 0 and 1 are valid direction indications.")
+    r200_pix = np.asarray(halo_cat["r200_pix"])
+    stamp = np.array([int(2 * r * extent) + 1 for r in r200_pix])       # sky_utils.py:112,130
+    dist = as_device(np.ascontiguousarray(np.asarray(halo_cat["Dc"], dtype=np.float64) * 0.6774))
+    vx = f64("theta1_tv") if sig == 1 else None
+    vy = f64("theta2_tv") if sig == 1 else None
+    keep = [f64("r200_deg"), f64("m200"), f64("c_NFW"), dist, vx, vy, i32(stamp), i32(halo_cat["theta1_pix"]),
+            i32(halo_cat["theta2_pix"])]
+    for start in range(0, nh, 65535):                                  # grid.y limit
+        n = min(65535, nh - start)
+        sl = [None if t is None else t[start:start + n] for t in keep]
+        check(_lib.lib().ast_nfw_paint(*[ptr(t) for t in sl], n, float(extent), mask, int(bool(suppress)),
+                                       float(suppression_R), sig, ptr(out), int(npix), stream()), "ast_nfw_paint")
+    return out
+
+
+def add_patch(limg, simg, cen_pix):
+    """limg[y, x] += simg, clipped at the boundary (SkyUtils.add_patch_to_map, sky_utils.py:140-173)."""
+    check(_lib.lib().ast_add_patch(ptr(limg), limg.shape[0], ptr(simg), simg.shape[0], int(cen_pix[0]),
+                                   int(cen_pix[1]), stream()), "ast_add_patch")
+    return limg
+
+
 # ------------------------------------------------- synthetic planes + bench leg
 def synth_kappa_planes(nplanes, npix, seed0=4242, rms=0.01, dtype=torch.float64):
     """Gaussian random fields with P(l) ~ (l + l0)^-2, one per plane.

@@ -3,9 +3,8 @@ unit conversion + reshape, PDF, filters, galaxy shape noise, kappa -> deflection
 crop / division / merge.  ``self.data`` holds numpy arrays like the reference;
 the arithmetic runs on the GPU through libastrild_hip.so.
 
-Not carried over (out of scope or "next"): NFW halo painting
-constructors, wl_peak_counts (lenstools), create_cmb (broken in the reference,
-sky_array.py:735-739), resize (skimage)."""
+Not carried over (out of scope): wl_peak_counts (lenstools), create_cmb
+(broken in the reference, sky_array.py:735-739), resize (skimage)."""
 import copy
 from typing import Dict, List, Optional, Tuple, Union
 
@@ -59,6 +58,41 @@ class SkyArray:
                    map_file: Optional[str] = None) -> "SkyArray":
         assert map_array.shape[0] == map_array.shape[1]
         return cls(map_array, opening_angle, quantity, {"sim": dir_in}, map_file)
+
+    @classmethod
+    def from_halo_series(cls, halo, npix: int = 100, extent: float = 1, direction: List[int] = [0, 1],
+                         suppress: bool = False, suppression_R: float = 1, to: str = "dT") -> "SkyArray":
+        """Analytic NFW map of one halo (sky_array.py:189-259)."""
+        quantity = {"dT": "rs", "alpha": "alpha"}[to]
+        if not (1 in direction and 0 in direction):
+            quantity += "_x" if 0 in direction else "_y"
+        if to == "dT":
+            map_array = SkyUtils.NFW_temperature_perturbation_map(
+                halo.r200_deg, halo.m200, halo.c_NFW, [halo.theta1_tv, halo.theta2_tv], halo.Dc, npix=npix,
+                extent=extent, direction=direction, suppress=suppress, suppression_R=suppression_R)
+        else:
+            map_array = SkyUtils.NFW_deflection_angle_map(
+                halo.r200_deg, halo.m200, halo.c_NFW, halo.Dc, npix=npix, extent=extent, direction=direction,
+                suppress=suppress, suppression_R=suppression_R)
+        return cls(map_array, 2 * halo.r200_deg * extent, quantity, dirs=None, map_file=None)
+
+    @classmethod
+    def from_halo_dataframe(cls, halo_cat, npix: int = 8192, extent: float = 1, direction: List[int] = [0, 1],
+                            suppress: bool = False, suppression_R: float = 1, opening_angle: float = 20.0,
+                            ncpus: int = 1, to: str = "dT") -> "SkyArray":
+        """Sum of the NFW maps of a halo catalogue (sky_array.py:262-337).  ``ncpus`` is accepted
+        for compatibility: every halo is painted by one GPU launch."""
+        keys = ["r200_deg", "r200_pix", "m200", "c_NFW", "Dc", "theta1_pix", "theta2_pix"]
+        if to == "dT":
+            keys += ["theta1_tv", "theta2_tv"]
+        halo_dict = {k: np.asarray(halo_cat[k]) for k in keys}
+        quantity = {"dT": "rs", "alpha": "alpha"}[to]
+        if not (1 in direction and 0 in direction):
+            quantity += "_x" if 0 in direction else "_y"
+        map_array = SkyUtils.analytic_Halo_signal_to_SkyArray(
+            np.arange(len(halo_dict["m200"])), halo_dict, extent, direction, suppress, suppression_R, npix, to)
+        map_array = np.nan_to_num(map_array, copy=False, nan=0.0, posinf=0.0, neginf=0.0)
+        return cls(map_array, opening_angle, quantity, dirs=None, map_file=None)
 
     @property
     def npix(self) -> int:

@@ -38,6 +38,49 @@ def _call_cal_phi(kappa: np.ndarray, npix: int, opening_angle: float) -> np.ndar
 
 class SkyUtils:
     @staticmethod
+    def analytic_Halo_signal_to_SkyArray(halo_idx, halo_cat, extent, direction, suppress, suppression_R,
+                                         npix: int, signal: str = "dT") -> np.ndarray:
+        """Sum of the analytic NFW stamps of the selected halos (sky_utils.py:79-137): one GPU
+        launch over all halos instead of a Python loop (and joblib batches) of numpy stamps."""
+        sel = {key: np.asarray(val)[np.asarray(halo_idx)] for key, val in halo_cat.items()}
+        return lensing.nfw_paint(sel, extent, direction, suppress, suppression_R, npix, signal).cpu().numpy()
+
+    @staticmethod
+    def add_patch_to_map(limg: np.ndarray, simg: np.ndarray, cen_pix: tuple) -> np.ndarray:
+        """sky_utils.py:140-173."""
+        big = as_device(np.ascontiguousarray(limg, dtype=np.float64))
+        small = as_device(np.ascontiguousarray(simg, dtype=np.float64))
+        return lensing.add_patch(big, small, cen_pix).cpu().numpy()
+
+    @staticmethod
+    def _single_stamp(theta_200c, M_200c, c_200c, angu_diam_dist, npix, extent, direction, suppress,
+                      suppression_R, signal, vel=(0.0, 0.0)):
+        # a stamp of npix pixels centred on itself: the map IS the stamp
+        cat = {"r200_deg": [theta_200c], "m200": [M_200c], "c_NFW": [c_200c], "Dc": [angu_diam_dist / 0.6774],
+               "theta1_pix": [npix // 2], "theta2_pix": [npix // 2], "theta1_tv": [vel[0]], "theta2_tv": [vel[1]],
+               "r200_pix": [(npix - 1) / (2.0 * extent)]}
+        out = lensing.nfw_paint(cat, extent, direction, suppress, suppression_R, npix, signal)
+        return out.cpu().numpy()
+
+    @staticmethod
+    def NFW_deflection_angle_map(theta_200c, M_200c, c_200c, angu_diam_dist, npix: int = 100, extent: float = 1,
+                                 direction=(0,), suppress: bool = False, suppression_R: float = 1) -> np.ndarray:
+        """sky_utils.py:214-282 (odd npix: the reference's stamps always are)."""
+        assert np.sum(direction) <= 1, "Only 0 and 1 are valid direction indications."
+        assert npix % 2 == 1, "stamp maps have an odd number of pixels"
+        return SkyUtils._single_stamp(theta_200c, M_200c, c_200c, angu_diam_dist, npix, extent, direction,
+                                      suppress, suppression_R, "alpha")
+
+    @staticmethod
+    def NFW_temperature_perturbation_map(theta_200c, M_200c, c_200c, vel, angu_diam_dist, npix: int = 100,
+                                         extent: float = 1, direction=(0, 1), suppress: bool = False,
+                                         suppression_R: float = 1) -> np.ndarray:
+        """sky_utils.py:176-211."""
+        assert npix % 2 == 1, "stamp maps have an odd number of pixels"
+        return SkyUtils._single_stamp(theta_200c, M_200c, c_200c, angu_diam_dist, npix, extent, direction,
+                                      suppress, suppression_R, "dT", vel)
+
+    @staticmethod
     def convert_code_to_phy_units(quantity: str, map_df):
         """RayRamses code units -> physical units, in place on the DataFrame column
         (sky_utils.py:318-339): / c^2 for shear/deflt/kappa_2, / c^3 for isw_rs."""

@@ -298,6 +298,26 @@ int ast_histogram(const void* buf_d, int dtype, size_t count, double lo, double 
 /* out[i] = a[i] + b[i]  (add_galaxy_shape_noise, sky_array.py:693-706). */
 int ast_add(const void* a_d, const void* b_d, void* out_d, int dtype, size_t count, void* stream);
 
+/* ------------------------------------- f-2: analytic NFW halo signals (next row) */
+
+/* Paint the deflection-angle (signal 0) or moving-lens temperature (signal 1) stamp
+ * of every halo onto an npix x npix fp64 map, clipped at the map edge.  Replaces
+ * SkyUtils.analytic_Halo_signal_to_SkyArray and the NFW_*_map / add_patch_to_map
+ * helpers it loops over (rays/skys/sky_utils.py:79-282).  Per-halo device arrays:
+ * r200 [deg], m200 [M_sun], concentration, angular diameter distance [Mpc] (the
+ * reference passes Dc * 0.6774), transverse velocities [km/s] (signal 1 only), stamp
+ * edge length int(2 * r200_pix * extent) + 1, stamp centre (theta1_pix = column,
+ * theta2_pix = row).  dir_mask: bit 0 = direction 0 (x), bit 1 = direction 1 (y).
+ * map_d is ACCUMULATED into. */
+int ast_nfw_paint(const double* r200_deg_d, const double* m200_d, const double* c_nfw_d, const double* dist_d,
+                  const double* vel_x_d, const double* vel_y_d, const int* stamp_npix_d, const int* cen_x_d,
+                  const int* cen_y_d, size_t nhalo, double extent, int dir_mask, int suppress,
+                  double suppression_r, int signal, double* map_d, int npix, void* stream);
+
+/* limg[y, x] += simg[i, j] for the in-bounds part of a stamp centred at (cen_x, cen_y)
+ * (SkyUtils.add_patch_to_map, sky_utils.py:140-173). */
+int ast_add_patch(double* limg_d, int nl, const double* simg_d, int ns, int cen_x, int cen_y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
