@@ -10,20 +10,6 @@
 
 namespace ast {
 
-// Rare paths kept out of line so the hot loops stay small: particles more than
-// one box length outside [0, L), or beyond the int32 range in grid units.
-__device__ __noinline__ inline int wrap_slow_i(int i, int n) {
-    int r = i % n;
-    return r < 0 ? r + n : r;
-}
-__device__ __noinline__ inline int wrap_slow_d(double fl, int n) {
-    double r = fl - floor(fl / (double)n) * (double)n;    // in [0, n] up to rounding
-    int i = (int)r;
-    if (i >= n) i -= n;
-    if (i < 0) i += n;
-    return i;
-}
-
 // periodic wrap of an index that is at most one period out of range
 __device__ inline int wrap1(int i, int n) {
     if (i < 0) i += n;
@@ -59,18 +45,20 @@ template <> struct Window<3> {
     }
 };
 
-// s = x * n/L  ->  base cell wrapped into [0, n) and the offset s - floor(..)
+// s = x * n/L  ->  base cell wrapped into [0, n) and the offset s - floor(..).
+// Branch-free and call-free on purpose: an earlier version kept the rare far-out-of-box case
+// in a noinline helper, and the call sites alone cost the deposit kernels ~20 SGPRs, SGPR
+// spills and a wave of occupancy.  The period is removed in double (exact for |s| < 2^52),
+// with one correction step either way for non-power-of-two n.
 template <int W>
 __device__ inline int locate(double s, int n, double& frac) {
     const double fl = floor(W == 2 ? s : s + 0.5);
     frac = s - fl;
-    if (fabs(fl) < 1073741824.0) {
-        const int i = (int)fl;
-        if ((unsigned)i < (unsigned)n) return i;
-        if (i >= -n && i < 2 * n) return wrap1(i, n);
-        return wrap_slow_i(i, n);
-    }
-    return wrap_slow_d(fl, n);
+    const double dn = (double)n, inv_dn = 1.0 / dn;      // loop invariant: hoisted by the compiler
+    double r = fl - floor(fl * inv_dn) * dn;
+    r = r >= dn ? r - dn : r;
+    r = r < 0.0 ? r + dn : r;
+    return (int)r;
 }
 
 }  // namespace ast

@@ -140,7 +140,8 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     Returns the grid ``(nx_alloc, nmesh, nmesh)`` in pos.dtype.
     method: "direct" (global float atomics), "tiled" (LDS tiles, single pass over the
     particles), "tiled2" (LDS tiles, exact two-pass counting) or "auto" (= tiled when possible).
-    accumulate: add into ``out`` (default when ``out`` is given) or zero it first.
+    accumulate: add into ``out`` (default when ``out`` is given) or overwrite it (default
+    for a fresh grid; the tiled path then needs no zero-fill and flushes without atomics).
     """
     L = _lib.lib()
     n = int(nmesh)
@@ -155,23 +156,29 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     npart = pos.shape[0]
     dropped = torch.zeros(1, dtype=torch.int64, device=pos.device)
     ws_bytes = 0
-    tflags = 1 if method == "tiled2" else 0
+    tflags = (1 if method == "tiled2" else 0) | (0 if accumulate else 2)      # TWO_PASS | OVERWRITE
     if method in ("auto", "tiled", "tiled2") and win != 0 and npart < 2**32 - 1:
-        ws_bytes = int(L.ast_paint_tiled_workspace_bytes(npart, n, nx, tflags))
+        ws_bytes = int(L.ast_paint_tiled_workspace_bytes(win, code, npart, n, nx, tflags))
     if method in ("tiled", "tiled2") and ws_bytes == 0:
         raise _lib.AstrildHipError("tiled paint needs a CIC/TSC window and nmesh a multiple of 32")
     use_tiled = ws_bytes > 0 and (method in ("tiled", "tiled2") or npart >= 65536)
     if out is None:
-        out = torch.zeros((nx, n, n), dtype=pos.dtype, device=pos.device)
+        alloc = torch.empty if (use_tiled and not accumulate) else torch.zeros
+        out = alloc((nx, n, n), dtype=pos.dtype, device=pos.device)
     else:
         assert out.is_cuda and out.dtype == pos.dtype and out.numel() == nx * n * n and out.is_contiguous()
-        if not accumulate:
+        if not accumulate and not use_tiled:
             out.zero_()
     if use_tiled:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pos.device)
+        mass_bound = 1.0
+        if mass is not None and not accumulate and npart:
+            lo_hi = torch.empty(2, dtype=torch.float64, device=pos.device)      # bound for the fixed-point tiles
+            check(L.ast_minmax(ptr(mass), code, npart, ptr(lo_hi), stream()), "ast_minmax")
+            mass_bound = float(lo_hi.abs().max()) or 1.0
         check(L.ast_paint_tiled(win, code, ptr(pos), ptr(mass), npart, n, float(boxsize), float(scale),
-                                int(x_start), nx, ptr(out), ptr(ws), ws_bytes, ptr(dropped), tflags, stream()),
-              "ast_paint_tiled")
+                                int(x_start), nx, ptr(out), ptr(ws), ws_bytes, ptr(dropped), tflags,
+                                mass_bound, stream()), "ast_paint_tiled")
     else:
         check(L.ast_paint(win, code, ptr(pos), ptr(mass), npart, n, float(boxsize), float(scale),
                           int(x_start), nx, ptr(out), ptr(dropped), stream()), "ast_paint")

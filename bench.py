@@ -143,7 +143,7 @@ def main():
 
         def step():
             dev.paint(pos, None, n, L, args.window, out=grid, method=args.method, check_dropped=False,
-                      accumulate=False)       # zero-fill + paint
+                      accumulate=False)       # overwrite mode: no zero-fill pass
             psum.zero_()
             if fused:                         # tile FFT with the shell binning fused into the last pass
                 return dev.power_sums_fused(grid, L, psum=psum, mean=npart_total / float(n) ** 3)

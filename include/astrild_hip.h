@@ -119,16 +119,23 @@ int ast_paint(int window, int dtype, const void* pos_d, const void* mass_d, size
  * grid tiles: particles are run-length grouped by the tile of their base
  * cell (no particle data is moved), each workgroup accumulates one tile in
  * LDS and flushes it once.  workspace_d must hold
- * ast_paint_tiled_workspace_bytes(np, nmesh, nx_alloc, flags) bytes. */
+ * ast_paint_tiled_workspace_bytes(window, dtype, np, nmesh, nx_alloc, flags) bytes. */
 /* flags: 0 = single pass over the particles (fixed-capacity tile segments, overflow
  * deposited with global atomics); AST_PAINT_TWO_PASS = exact count + scan first
  * (one more read of the positions, no overflow path: for strongly clustered input). */
 #define AST_PAINT_TWO_PASS 1
-size_t ast_paint_tiled_workspace_bytes(size_t np, int nmesh, int nx_alloc, int flags);
+/* AST_PAINT_OVERWRITE: grid_d is OVERWRITTEN with this paint instead of accumulated into
+ * (no zero-fill needed).  Each workgroup then walks a whole z-column of tiles with the z
+ * halo carried in LDS; owned cells leave as plain stores, the x/y halo ring goes through
+ * per-column records folded in by a second kernel — no global float atomics in the flush.
+ * The LDS tiles then accumulate in 64-bit fixed point (order-independent, so the paint is
+ * bit-reproducible); `mass_bound` must be >= max |mass| when mass_d is given (ast_minmax). */
+#define AST_PAINT_OVERWRITE 2
+size_t ast_paint_tiled_workspace_bytes(int window, int dtype, size_t np, int nmesh, int nx_alloc, int flags);
 int ast_paint_tiled(int window, int dtype, const void* pos_d, const void* mass_d, size_t np,
                     int nmesh, double boxsize, double scale, int x_start, int nx_alloc,
                     void* grid_d, void* workspace_d, size_t workspace_bytes,
-                    unsigned long long* dropped_d, int flags, void* stream);
+                    unsigned long long* dropped_d, int flags, double mass_bound, void* stream);
 
 /* dst[i] += src[i] — ghost-plane fold after a slab paint. */
 int ast_accumulate(void* dst_d, const void* src_d, int dtype, size_t count, void* stream);
