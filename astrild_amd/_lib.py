@@ -69,6 +69,11 @@ SIGNATURES = {
     "ast_add": (_i, [_vp, _vp, _vp, _i, _sz, _vp]),
     "ast_nfw_paint": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _d, _i, _i, _d, _i, _vp, _i, _vp]),
     "ast_add_patch": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
+    "ast_dgd_filter": (_i, [_vp, _vp, _vp, _i, _d, _d, _i, _i, _vp]),
+    "ast_hann_apodize": (_i, [_vp, _vp, _i, _vp]),
+    "ast_gaussian_filter_order": (_i, [_vp, _vp, _vp, _sz, _i, _d, _i, _i, _i, _vp]),
+    "ast_convolve2d": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ast_aperture_photometry": (_i, [_vp, _vp, _vp, _i, _d, _vp]),
 }
 
 _lib = None

@@ -39,6 +39,117 @@ class Filters:
         return img - Filters.gaussian(img, theta, theta_i, fwhm_i)
 
     @staticmethod
+    def _dgd(img, theta, theta_i, direction, order):
+        from ... import _lib
+        from ...device import ptr, stream
+        import torch
+        _npix = len(img)
+        theta_deg = angle_value(theta, "deg", "deg")
+        theta_i_pix = int(np.ceil(_npix * angle_value(theta_i, "deg", "deg") / theta_deg))
+        t = as_device(np.ascontiguousarray(img, dtype=np.float64))
+        out = torch.empty_like(t)
+        work = torch.empty(2 * t.numel(), dtype=torch.float64, device=t.device)
+        # theta_fov_deg / len(dist) with theta_fov_deg = theta * len(dist) / npix  (filters.py:349-354)
+        h = (theta_deg * _npix / _npix) / _npix
+        _lib.check(_lib.lib().ast_dgd_filter(ptr(t), ptr(out), ptr(work), _npix, float(theta_i_pix), h,
+                                            int(direction), order, stream()), "ast_dgd_filter")
+        return out.cpu().numpy()
+
+    @staticmethod
+    def gaussian_third_derivative(img: np.ndarray, theta, theta_i, direction: int) -> np.ndarray:
+        """DGD3 dipole window times the image (filters.py:305-355).  theta, theta_i: Quantities or degrees."""
+        return Filters._dgd(img, theta, theta_i, direction, 3)
+
+    @staticmethod
+    def gaussian_first_derivative(img: np.ndarray, theta, theta_i, direction: int) -> np.ndarray:
+        """First-derivative Gaussian window times the image (filters.py:358-400)."""
+        return Filters._dgd(img, theta, theta_i, direction, 1)
+
+    @staticmethod
+    def gaussian_field(theta: np.ndarray, sigma) -> np.ndarray:
+        """filters.py:403-413 (plain formula; the windows above evaluate it on the GPU)."""
+        return np.exp(-theta ** 2 / (2 * sigma ** 2)) / (2 * np.pi * sigma ** 2)
+
+    @staticmethod
+    def apodization(img: np.ndarray, theta=None, theta_i=None, r200=None, suppress_radius=None) -> np.ndarray:
+        """img * outer(hann, hann)  (filters.py:150-178; the extra arguments are unused there too)."""
+        from ... import _lib
+        from ...device import ptr, stream
+        import torch
+        t = as_device(np.ascontiguousarray(img, dtype=np.float64))
+        out = torch.empty_like(t)
+        _lib.check(_lib.lib().ast_hann_apodize(ptr(t), ptr(out), len(img), stream()), "ast_hann_apodize")
+        return out.cpu().numpy()
+
+    @staticmethod
+    def gaussian_third_derivative_convolution(img: np.ndarray, theta, theta_i, direction=1) -> np.ndarray:
+        """Third-derivative Gaussians at s/2, s, 2s combined as g1 - g2 + g3, each with scipy's
+        ``gaussian_filter(order=3*direction, mode="nearest")`` semantics (filters.py:260-304).
+        direction: int or per-axis sequence."""
+        from ... import _lib
+        from ...device import ptr, stream
+        import torch
+        _npix = img.shape[0]
+        s_pix = int(np.ceil(_npix * angle_value(theta_i, "deg", "deg") / angle_value(theta, "deg", "deg")))
+        order = 3 * np.asarray(direction)
+        o0, o1 = (int(order), int(order)) if order.ndim == 0 else (int(order[0]), int(order[1]))
+        t = as_device(np.ascontiguousarray(img, dtype=np.float64))
+        acc = None
+        for fac, sign in ((0.5, 1.0), (1.0, -1.0), (2.0, 1.0)):
+            sigma = s_pix * fac
+            radius = int(4.0 * sigma + 0.5)
+            nwork = t.numel() + 2 * (2 * radius + 1)
+            work = torch.empty(nwork, dtype=torch.float64, device=t.device)
+            out = torch.empty_like(t)
+            _lib.check(_lib.lib().ast_gaussian_filter_order(ptr(t), ptr(out), ptr(work), nwork, _npix, float(sigma),
+                                                           o0, o1, 1, stream()), "ast_gaussian_filter_order")
+            # gauss_1 - gauss_2 + gauss_3 in that order
+            acc = out if acc is None else (acc - out if sign < 0 else acc + out)
+        return acc.cpu().numpy()
+
+    @staticmethod
+    def gaussian_compensated(img: np.ndarray, theta, theta_i, theta_o) -> np.ndarray:
+        """Compensated Gaussian of arxiv:1907.06657 Eq. 16 convolved with the image (filters.py:415-459)."""
+        from ... import _lib
+        from ...device import ptr, stream
+        import torch
+        pw = angle_value(theta, "deg", "deg") / img.shape[0]
+        t_i = angle_value(theta_i, "deg", "deg") / pw
+        t_o = angle_value(theta_o, "deg", "deg") / pw
+        t_o_int = int(np.ceil(t_o))
+        y, x = np.ogrid[-t_o_int:t_o_int, -t_o_int:t_o_int]
+        dist = np.sqrt(x ** 2 + y ** 2)
+        xx, x_o = dist / t_i, t_o / t_i
+        window = (np.exp(-xx ** 2.0) / (np.pi * t_i ** 2.0)) - ((1.0 - np.exp(-x_o ** 2.0)) / (np.pi * t_o ** 2.0))
+        window[t_o < dist] = 0
+        t = as_device(np.ascontiguousarray(img, dtype=np.float64))
+        w = as_device(np.ascontiguousarray(window, dtype=np.float64))
+        out = torch.empty_like(t)
+        _lib.check(_lib.lib().ast_convolve2d(ptr(t), ptr(w), ptr(out), img.shape[0], w.shape[0], w.shape[1],
+                                             stream()), "ast_convolve2d")
+        return out.cpu().numpy()
+
+    @staticmethod
+    def aperture_photometry(img: np.ndarray, theta, alpha) -> np.ndarray:
+        """img minus its mean over the ring alpha < r < sqrt(2) alpha (filters.py:40-73).  Like the
+        reference this also updates ``img`` in place when it is a float64 array."""
+        from ... import _lib
+        from ...device import ptr, stream
+        import torch
+        _npix = len(img)
+        pix_per_deg = _npix / angle_value(theta, "deg", "deg")
+        alpha_pix = int(np.ceil(angle_value(alpha, "deg", "deg") * pix_per_deg))
+        t = as_device(np.ascontiguousarray(img, dtype=np.float64))
+        work = torch.empty(2048, dtype=torch.float64, device=t.device)
+        _lib.check(_lib.lib().ast_aperture_photometry(ptr(t), ptr(t), ptr(work), _npix, float(alpha_pix), stream()),
+                   "ast_aperture_photometry")
+        res = t.cpu().numpy()
+        if isinstance(img, np.ndarray) and img.dtype == np.float64:
+            img[...] = res
+            return img
+        return res
+
+    @staticmethod
     def sigma_to_fwhm(sigma: float) -> float:
         return sigma * (2 * np.sqrt(2 * np.log(2)))
 

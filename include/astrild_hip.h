@@ -325,6 +325,34 @@ int ast_nfw_paint(const double* r200_deg_d, const double* m200_d, const double* 
  * (SkyUtils.add_patch_to_map, sky_utils.py:140-173). */
 int ast_add_patch(double* limg_d, int nl, const double* simg_d, int ns, int cen_x, int cen_y, void* stream);
 
+/* --------------------------- f-3: flat-sky window filters (next row, first part) */
+
+/* Filters.gaussian_third_derivative (order 3, "DGD3") and gaussian_first_derivative (order 1)
+ * of rays/utils/filters.py:305-400: out = img * d^order/d(axis)^order W, W a sum of Gaussians of
+ * the pixel distance to the map centre (sigma_pix = ceil(npix * theta_i / theta)), derivatives by
+ * repeated np.gradient(.., h, edge_order=2) with h = theta_fov / npix.  work_d: 2 npix^2 doubles. */
+int ast_dgd_filter(const double* img_d, double* out_d, double* work_d, int npix, double sigma_pix, double h,
+                   int axis, int order, void* stream);
+
+/* Filters.apodization (filters.py:150-178): img * outer(hann(npix), hann(npix)). */
+int ast_hann_apodize(const double* img_d, double* out_d, int npix, void* stream);
+
+/* scipy.ndimage.gaussian_filter(img, sigma, order=(order0, order1), mode) as called by
+ * Filters.gaussian_third_derivative_convolution (filters.py:260-304): mode 0 "reflect", 1 "nearest".
+ * work_d: npix^2 + 2 (2 r + 1) doubles, r = int(4 sigma + 0.5). */
+int ast_gaussian_filter_order(const double* img_d, double* out_d, double* work_d, size_t work_doubles, int npix,
+                              double sigma, int order0, int order1, int mode, void* stream);
+
+/* scipy.ndimage.convolve(img, window) with its defaults (reflect, origin 0), the last line of
+ * Filters.gaussian_compensated (filters.py:415-459).  img_d != out_d. */
+int ast_convolve2d(const double* img_d, const double* window_d, double* out_d, int npix, int kh, int kw,
+                   void* stream);
+
+/* Filters.aperture_photometry (filters.py:40-73): out = img - mean(img[alpha_pix < d < sqrt(2) alpha_pix]).
+ * work_d: 2048 doubles. */
+int ast_aperture_photometry(const double* img_d, double* out_d, double* work_d, int npix, double alpha_pix,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

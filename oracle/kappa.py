@@ -217,3 +217,70 @@ def analytic_halo_signal_map(halo_cat, extent, direction, suppress, suppression_
                 direction, suppress, suppression_r)
         out = add_patch_to_map(out, stamp, (halo_cat["theta1_pix"][i], halo_cat["theta2_pix"][i]))
     return out
+
+
+# ------------------------------------------------ f-3 dipole windows, apodization
+def gaussian_field(theta, sigma):
+    """rays/utils/filters.py:403-413."""
+    return np.exp(-theta ** 2 / (2 * sigma ** 2)) / (2 * np.pi * sigma ** 2)
+
+
+def dgd_filter(img, theta_deg, theta_i_deg, direction, order=3):
+    """Filters.gaussian_third_derivative (order 3, filters.py:305-355) /
+    gaussian_first_derivative (order 1, :358-400): window from repeated np.gradient, times img."""
+    img = np.asarray(img, dtype=np.float64)
+    npix = len(img)
+    x1 = np.linspace(1, npix, npix) - npix / 2 - 0.5
+    x, y = np.meshgrid(x1, x1)
+    dist = np.sqrt(x ** 2 + y ** 2)
+    theta_fov = theta_deg * len(dist) / npix
+    s = np.ceil(npix * theta_i_deg / theta_deg).astype("int")
+    if order == 3:
+        w = gaussian_field(dist, s * 0.5) - gaussian_field(dist, s) + gaussian_field(dist, s * 2.0)
+    else:
+        w = gaussian_field(dist, s * 0.5)
+    for _ in range(order):
+        w = np.gradient(w, theta_fov / len(dist), axis=direction, edge_order=2)
+    return np.multiply(w, img)
+
+
+def apodization(img):
+    """rays/utils/filters.py:150-178 with scipy.signal.hann(n) = 0.5 - 0.5 cos(2 pi k / (n-1))."""
+    n = len(img)
+    h = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n) / (n - 1))
+    return np.asarray(img, dtype=np.float64) * np.outer(h, h)
+
+
+def dgd3_convolution(img, theta_deg, theta_i_deg, direction=1):
+    """Filters.gaussian_third_derivative_convolution, rays/utils/filters.py:260-304."""
+    img = np.asarray(img, dtype=np.float64)
+    s = np.ceil(img.shape[0] * theta_i_deg / theta_deg).astype("int")
+    g = [ndimage.gaussian_filter(img, sigma=s * f, order=3 * direction, output=np.float64, mode="nearest")
+         for f in (0.5, 1.0, 2.0)]
+    return g[0] - g[1] + g[2]
+
+
+def gaussian_compensated(img, theta_deg, theta_i_deg, theta_o_deg):
+    """Filters.gaussian_compensated, rays/utils/filters.py:415-459."""
+    img = np.asarray(img, dtype=np.float64)
+    pw = theta_deg / img.shape[0]
+    t_i, t_o = theta_i_deg / pw, theta_o_deg / pw
+    t_o_int = np.ceil(t_o).astype("int")
+    y, x = np.ogrid[-t_o_int:t_o_int, -t_o_int:t_o_int]
+    dist = np.sqrt(x ** 2 + y ** 2)
+    xx, x_o = dist / t_i, t_o / t_i
+    gt = (np.exp(-xx ** 2.0) / (np.pi * t_i ** 2.0)) - ((1.0 - np.exp(-x_o ** 2.0)) / (np.pi * t_o ** 2.0))
+    gt[t_o < dist] = 0
+    return ndimage.convolve(img, gt)
+
+
+def aperture_photometry(img, theta_deg, alpha_deg):
+    """Filters.aperture_photometry, rays/utils/filters.py:40-73."""
+    img = np.array(img, dtype=np.float64)
+    npix = len(img)
+    x1 = np.linspace(1, npix, npix) - npix / 2 - 0.5
+    x, y = np.meshgrid(x1, x1)
+    d = np.sqrt(x ** 2 + y ** 2)
+    a = np.ceil(alpha_deg * npix / theta_deg).astype("int")
+    ring = np.logical_and(a < d, d < a * np.sqrt(2))
+    return img - np.mean(img[ring])

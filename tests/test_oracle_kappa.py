@@ -120,3 +120,12 @@ def test_gsn_and_pdf_and_reshape():
     assert len(vals) == 50 and np.isclose((vals * np.diff(edges)).sum(), 1.0)
     v = np.arange(16.0)
     assert np.array_equal(ok.rays_to_map(v), v.reshape(4, 4))
+
+
+def test_dgd3_window_matches_reference_test(dt_map):
+    g = GOLD["dgd3"]
+    for case in g["cases"]:
+        f = ok.dgd_filter(dt_map, g["theta_deg"], g["theta_i_deg"], case["direction"], order=3)
+        x_slice, y_slice = f[:, len(f) // 2], f[len(f) // 2, :]
+        assert x_slice.max() == case["x_slice_max"]
+        npt.assert_almost_equal(y_slice.max() * 1e7, case["y_slice_max_times_1e7"], decimal=case["decimal"])
