@@ -8,7 +8,8 @@ import ctypes as ct
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libastrild_hip.so")
+# ASTRILD_HIP_LIB: load another build of the same ABI (perf experiments: scripts/build_variants.sh)
+LIB_PATH = os.environ.get("ASTRILD_HIP_LIB") or os.path.join(_HERE, "libastrild_hip.so")
 
 F32, F64 = 0, 1
 WIN = {"ngp": 0, "nnb": 0, "nearest": 0, "cic": 1, "tsc": 2}

@@ -41,6 +41,10 @@ using ast::Window;
 #define TILE_TZ 32
 #endif
 constexpr int TX = TILE_TX, TY = TILE_TY, TZ = TILE_TZ;   // owned cells per tile
+#ifndef PAINT_ABLATE
+#define PAINT_ABLATE 0        // perf experiments only: 1 no flush stores, 2 no LDS atomics, 32 no gather
+#endif
+constexpr int ablate = PAINT_ABLATE;
 
 struct TileGeom {
     int n, x_start, nx_alloc;
@@ -53,11 +57,18 @@ struct TileGeom {
 template <typename T, int W>
 __device__ inline uint32_t tile_of(T x, T y, T z, const TileGeom& g) {
     double f;
-    int bx = ast::locate<W>((double)x * g.inv_dx, g.n, f) - g.x_start;
+    // fast path: positions less than a box length outside the box (paint_window.h locate_rel)
+    int cx = ast::locate_rel<W>((double)x * g.inv_dx, g.n, 0, f);
+    int by = ast::locate_rel<W>((double)y * g.inv_dx, g.n, 0, f);
+    int bz = ast::locate_rel<W>((double)z * g.inv_dx, g.n, 0, f);
+    if ((unsigned)cx >= (unsigned)g.n || (unsigned)by >= (unsigned)g.n || (unsigned)bz >= (unsigned)g.n) {
+        cx = ast::locate<W>((double)x * g.inv_dx, g.n, f);
+        by = ast::locate<W>((double)y * g.inv_dx, g.n, f);
+        bz = ast::locate<W>((double)z * g.inv_dx, g.n, f);
+    }
+    int bx = cx - g.x_start;
     if (bx < 0) bx += g.n;
     if (bx >= g.nx_alloc) return 0xffffffffu;
-    const int by = ast::locate<W>((double)y * g.inv_dx, g.n, f);
-    const int bz = ast::locate<W>((double)z * g.inv_dx, g.n, f);
     return (uint32_t)(((bx / TX) * g.nty + by / TY) * g.ntz + bz / TZ);
 }
 
@@ -107,7 +118,7 @@ __global__ void __launch_bounds__(256)
 tile_index_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t* __restrict__ tile_count,
                   const uint32_t* __restrict__ tile_off, uint32_t* __restrict__ tile_fill,
                   uint32_t* __restrict__ index, uint32_t cap, uint32_t* __restrict__ ovf,
-                  unsigned long long* __restrict__ ovf_count, unsigned long long* dropped, int ablate) {
+                  unsigned long long* __restrict__ ovf_count, unsigned long long* dropped) {
     constexpr bool FILL = MODE != 0;
     // skey/scnt are re-armed by each thread as soon as it leaves the scatter loop, so the
     // scatter reads the interval's results from sbase/stile, which only the next flush rewrites
@@ -128,9 +139,12 @@ tile_index_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t* __
             T x[IDX_UNROLL], y[IDX_UNROLL], z[IDX_UNROLL];
 #pragma unroll
             for (int u = 0; u < IDX_UNROLL; ++u) {
-                const size_t p = p0 + (size_t)trip * per_trip + (size_t)u * 256 + tid;
-                if (p < np) { x[u] = pos[3 * p + 0]; y[u] = pos[3 * p + 1]; z[u] = pos[3 * p + 2]; }
-                else { x[u] = y[u] = z[u] = (T)0; }
+                // unconditional (lanes past the end re-load the last particle): a predicated load
+                // costs a branch and a full s_waitcnt each, i.e. IDX_UNROLL serial round trips
+                const size_t p = min(p0 + (size_t)trip * per_trip + (size_t)u * 256 + tid, np - 1);
+                x[u] = pos[3 * p + 0];
+                y[u] = pos[3 * p + 1];
+                z[u] = pos[3 * p + 2];
             }
 #pragma unroll
             for (int u = 0; u < IDX_UNROLL; ++u) {
@@ -288,7 +302,7 @@ __global__ void __launch_bounds__(256)
 tile_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileGeom g, double scale,
                     const uint32_t* __restrict__ index, const uint32_t* __restrict__ tile_off,
                     const uint32_t* __restrict__ tile_count, uint32_t cap, T* __restrict__ grid,
-                    unsigned long long* dropped, int ablate) {
+                    unsigned long long* dropped) {
     constexpr int LX = TX + W - 1, LY = TY + W - 1, LZ = TZ + W - 1;
     constexpr int LO = Window<W>::LO;
     // ds_add_f32 retires ~0.33 lanes/clk/CU on gfx950 against ~7 for ds_add_f64
@@ -394,29 +408,41 @@ template <int W> struct RingMap {            // halo ring of one (LX x LY) plane
     }
 };
 
-template <typename T, int W>
+template <typename T, int W, bool HAS_MASS>
 __global__ void __launch_bounds__(256)
 column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileGeom g, double scale,
                       const uint32_t* __restrict__ index, const uint32_t* __restrict__ tile_off,
                       const uint32_t* __restrict__ tile_count, uint32_t cap, double mass_bound,
-                      T* __restrict__ grid, T* __restrict__ rec, unsigned long long* dropped, int ablate) {
+                      T* __restrict__ grid, T* __restrict__ rec, unsigned long long* dropped) {
     constexpr int LX = TX + W - 1, LY = TY + W - 1, LZ = TZ + W - 1;
     constexpr int LO = Window<W>::LO, H = W - 1;
     using RM = RingMap<W>;
     // The LDS tile accumulates in 64-bit FIXED POINT: ds_add_u64 retires ~1.9x the lanes per
     // clock of ds_add_f64 on scattered addresses (scripts/micro/lds_atomics.hip), integer sums
-    // do not depend on arrival order (the whole paint becomes bit-reproducible), and with the
-    // quantum chosen per column below nothing is lost against an fp64 accumulator.
-    __shared__ unsigned long long tile[LX * LY * LZ];        // ((a * LY + b) * LZ + c), c fastest
+    // do not depend on arrival order (the whole paint is bit-reproducible), and the quantum
+    // chosen per column below sits far under the rounding of the output type.
+    //
+    // double -> integer is one add with M = 1.5 * 2^52: bits(x + M) = 0x4338 << 48 + round(x).
+    //  * T = double: the 0x4338 is stripped per term and sums may use 62 bits.
+    //  * T = float: the raw bits are added.  K terms leave K * (0x4338 << 48) + sum in the cell,
+    //    so the low 48 bits are the sum mod 2^48; cells start at BIAS = 2^47, which keeps those
+    //    48 bits non-negative, and the flush turns them into a double by or-ing them under the
+    //    exponent of 2^52 (one v_and_or_b32) and subtracting 2^52 + 2^47.
+    constexpr bool RAW = sizeof(T) == 4;
+    constexpr int SUM_BITS = RAW ? 47 : 62;
+    constexpr unsigned long long BIAS = RAW ? (1ull << 47) : 0ull;
+    // The z planes of the tile form a RING of LZ slots: local plane c of tile tz lives in slot
+    // (c + tz * TZ) mod LZ, so the W-1 halo planes carried from one tile to the next stay where
+    // they are and the flush only has to re-arm the TZ slots it stored.
+    __shared__ unsigned long long tile[LX * LY * LZ];        // ((a * LY + b) * LZ + slot), slot fastest
     const int col = blockIdx.x;
     const int ty = col % g.nty, tx = col / g.nty;
     const int ox = tx * TX, oy = ty * TY;
     const bool x_periodic = g.nx_alloc == g.n;
     unsigned long long ndrop = 0;
-    for (int i = threadIdx.x; i < LX * LY * LZ; i += 256) tile[i] = 0ull;
+    for (int i = threadIdx.x; i < LX * LY * LZ; i += 256) tile[i] = BIAS;
     // quantum: a cell collects at most the particles of two consecutive tiles, each contribution
-    // is <= mass_bound * |scale|; keep every sum below 2^62 and every term below 2^50 (so the
-    // double -> integer conversion is one add with the 1.5 * 2^52 constant)
+    // is <= mass_bound * |scale|; keep every sum below 2^SUM_BITS and every term below 2^50
     uint32_t cmax = 1;
     for (int tz = 0; tz < g.ntz; ++tz) {
         const uint32_t t = (uint32_t)((tx * g.nty + ty) * g.ntz + tz);
@@ -424,138 +450,202 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     }
     const int bits = 33 - __clz((int)min(cmax, 0x3fffffffu));            // 2 * cmax < 2^bits
     const double vmax = mass_bound * fabs(scale) > 0.0 ? mass_bound * fabs(scale) : 1.0;
-    const double invq = exp2((double)min(50, 62 - bits)) / vmax;
+    const double invq = exp2((double)min(50, SUM_BITS - bits)) / vmax;
     const double q = 1.0 / invq;
+    // tile-relative cell lookup (paint_window.h locate_rel); x also carries the slab offset
+    int orx = g.x_start + ox;
+    if (orx >= g.n) orx -= g.n;
+    const unsigned ex = (unsigned)min(TX, g.n), ey = (unsigned)min(TY, g.n), ez = (unsigned)min(TZ, g.n);
     __syncthreads();
 
-    // The walk is software-pipelined over batches of 256*U particles: while a batch is being
-    // deposited, the indices of the next batch (possibly of the next tile) are already in flight,
-    // so each batch pays one memory round trip (positions), not two.
-    constexpr int U = 4;
+    // The walk is software-pipelined over batches of 256*U particles, across tile boundaries:
+    // while batch k is deposited, the positions of batch k+1 and the indices of batch k+2 are in
+    // flight, so the gather latency (and the flush between two tiles) is covered by work of the
+    // same wave.  All loads are unconditional (lanes past the end of a batch re-load its last
+    // particle): a predicated load costs a branch and a full s_waitcnt each.
+#ifndef DEP_U
+#define DEP_U 2
+#endif
+    constexpr int U = DEP_U;
+    struct Batch { int tz; uint32_t i0, cnt; size_t off; };       // tz == g.ntz: past the end
     auto tile_span = [&](int tz, uint32_t& cnt, size_t& off) {
         const uint32_t t = (uint32_t)((tx * g.nty + ty) * g.ntz + tz);
         cnt = cap ? min(tile_count[t], cap) : tile_count[t];
         off = cap ? (size_t)t * cap : (size_t)tile_off[t];
     };
-    uint32_t nidx[U];                       // prefetched indices of the batch (ntz_, ni0)
-    int ntz_ = -1;
-    uint32_t ni0 = 0;
-    auto prefetch = [&](int tz, uint32_t i0, uint32_t cnt, size_t off) {
+    auto next_batch = [&](Batch bt) -> Batch {
+        if (bt.tz >= 0 && bt.tz < g.ntz && bt.i0 + 256 * U < bt.cnt) { bt.i0 += 256 * U; return bt; }
+        for (int nt = bt.tz + 1; nt < g.ntz; ++nt) {
+            uint32_t cnt;
+            size_t off;
+            tile_span(nt, cnt, off);
+            if (cnt) return Batch{nt, 0u, cnt, off};
+        }
+        return Batch{g.ntz, 0u, bt.cnt, bt.off};                  // keeps a loadable span
+    };
+    auto load_idx = [&](const Batch& bt, uint32_t (&idx)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t i = i0 + u * 256 + threadIdx.x;
-            nidx[u] = i < cnt ? index[off + i] : 0u;
+            const uint32_t i = min(bt.i0 + u * 256 + threadIdx.x, bt.cnt - 1);
+            idx[u] = index[bt.off + i];
         }
-        ntz_ = tz;
-        ni0 = i0;
+    };
+    auto load_pos = [&](const uint32_t (&idx)[U], T (&p)[3 * U], T (&m)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t q3 = (ablate & 32) ? (size_t)((idx[u] % 1000000u) * 3) : (size_t)idx[u] * 3;
+            p[3 * u + 0] = pos[q3 + 0];
+            p[3 * u + 1] = pos[q3 + 1];
+            p[3 * u + 2] = pos[q3 + 2];
+            m[u] = HAS_MASS ? mass[idx[u]] : (T)1;      // compile time: a run-time choice would merge the
+        }                                               // loaded value with a constant and wait for it
     };
 
-    for (int tz = 0; tz < g.ntz; ++tz) {
-        uint32_t cnt;
-        size_t off;
-        tile_span(tz, cnt, off);
-        const int oz = tz * TZ;
-        for (uint32_t i0 = 0; i0 < cnt; i0 += 256 * U) {
-            if (!(ntz_ == tz && ni0 == i0)) prefetch(tz, i0, cnt, off);       // not in flight yet (uniform)
-            T px[U], py[U], pz[U], pm[U];
-            bool on[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t i = i0 + u * 256 + threadIdx.x;
-                on[u] = i < cnt;
-                const size_t p = (ablate & 32) ? (size_t)(off + i0 + u * 256 + threadIdx.x) % 1000000u : (size_t)nidx[u];
-                px[u] = on[u] ? pos[3 * p + 0] : (T)0;
-                py[u] = on[u] ? pos[3 * p + 1] : (T)0;
-                pz[u] = on[u] ? pos[3 * p + 2] : (T)0;
-                pm[u] = (on[u] && mass) ? mass[p] : (T)1;
-            }
-            // next batch: same tile, or the first batch of the next non-empty tile
-            if (i0 + 256 * U < cnt) {
-                prefetch(tz, i0 + 256 * U, cnt, off);
-            } else {
-                ntz_ = -1;
-                for (int nt = tz + 1; nt < g.ntz; ++nt) {
-                    uint32_t ncnt;
-                    size_t noff;
-                    tile_span(nt, ncnt, noff);
-                    if (ncnt) { prefetch(nt, 0, ncnt, noff); break; }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (!on[u]) continue;
-                double fx, fy, fz;
-                int bx = ast::locate<W>((double)px[u] * g.inv_dx, g.n, fx) - g.x_start;
+    Batch cur = next_batch(Batch{-1, 0u, 0u, 0});
+    Batch nxt = next_batch(cur);
+    int sh = 0;                             // (tz * TZ) mod LZ
+    int oz = 0;
+    // deposit one batch: positions pc / masses mc of batch `cur`
+    auto deposit = [&](const T (&pc)[3 * U], const T (&mc)[U]) {
+        #pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (cur.i0 + u * 256 + threadIdx.x >= cur.cnt) continue;
+            double fx, fy, fz;
+            int lx = ast::locate_rel<W>((double)pc[3 * u + 0] * g.inv_dx, g.n, orx, fx);
+            int ly = ast::locate_rel<W>((double)pc[3 * u + 1] * g.inv_dx, g.n, oy, fy);
+            int lz = ast::locate_rel<W>((double)pc[3 * u + 2] * g.inv_dx, g.n, oz, fz);
+            if ((unsigned)lx >= ex || (unsigned)ly >= ey || (unsigned)lz >= ez) {
+                // more than a box length outside the box (rare): the general reduction
+                int bx = ast::locate<W>((double)pc[3 * u + 0] * g.inv_dx, g.n, fx) - g.x_start;
                 if (bx < 0) bx += g.n;
-                const int lx = bx - ox;
-                const int ly = ast::locate<W>((double)py[u] * g.inv_dx, g.n, fy) - oy;
-                const int lz = ast::locate<W>((double)pz[u] * g.inv_dx, g.n, fz) - oz;
-                T wx[W], wy[W], wz[W];
-                Window<W>::weights(fx, wx);
-                Window<W>::weights(fy, wy);
-                Window<W>::weights(fz, wz);
-                const T m = (T)((double)pm[u] * scale);
+                lx = bx - ox;
+                ly = ast::locate<W>((double)pc[3 * u + 1] * g.inv_dx, g.n, fy) - oy;
+                lz = ast::locate<W>((double)pc[3 * u + 2] * g.inv_dx, g.n, fz) - oz;
+                if ((unsigned)lx >= ex || (unsigned)ly >= ey || (unsigned)lz >= ez) continue;   // not in this tile: cannot happen
+            }
+            // weights and products in double, pre-scaled by 1/quantum: one multiply and the
+            // magic-number add per deposit
+            double wx[W], wy[W], wz[W];
+            Window<W>::weights(fx, wx);
+            Window<W>::weights(fy, wy);
+            Window<W>::weights(fz, wz);
+            const double m = (double)(T)((double)mc[u] * scale) * invq;
+            unsigned long long* slot[W];          // (lx, ly) row at the ring slots of planes lz + c
+            int sl = lz + sh;
+            sl = sl >= LZ ? sl - LZ : sl;
+            unsigned long long* const row0 = &tile[(lx * LY + ly) * LZ];
 #pragma unroll
-                for (int a = 0; a < W; ++a) {
-                    const T ma = m * wx[a];
+            for (int c = 0; c < W; ++c) {
+                slot[c] = row0 + sl;
+                sl = sl + 1 == LZ ? 0 : sl + 1;
+            }
 #pragma unroll
-                    for (int b = 0; b < W; ++b) {
-                        const T mab = ma * wy[b];
-                        unsigned long long* row = &tile[((lx + a) * LY + (ly + b)) * LZ + lz];
+            for (int a = 0; a < W; ++a) {
+                const double mwa = m * wx[a];
 #pragma unroll
-                        for (int c = 0; c < W; ++c) {
-                            const double x = (double)(mab * wz[c]) * invq;             // |x| < 2^50
-                            const long long fx = __double_as_longlong(x + 6755399441055744.0) - 0x4338000000000000ll;
-                            if (ablate & 2) asm volatile("" ::"v"(fx), "v"(row)); else atomicAdd(row + c, (unsigned long long)fx);
-                        }
+                for (int b = 0; b < W; ++b) {
+                    const double mab = mwa * wy[b];
+#pragma unroll
+                    for (int c = 0; c < W; ++c) {
+                        const double x = mab * wz[c];                              // |x| < 2^50
+                        long long v = __double_as_longlong(x + 6755399441055744.0);
+                        if (!RAW) v -= 0x4338000000000000ll;
+                        unsigned long long* cell = slot[c] + (a * LY + b) * LZ;
+                        if (ablate & 2) asm volatile("" ::"v"(v), "v"(cell)); else atomicAdd(cell, (unsigned long long)v);
                     }
                 }
             }
         }
-        __syncthreads();
+    };
+    // Two register sets, used alternately (a copy at the end of a step would have to wait for
+    // the loads it copies): pos/mass A|B of batch k|k+1, indices X|Y of batch k+1|k+2.
+    T pA[3 * U], mA[U], pB[3 * U], mB[U];
+    uint32_t iX[U], iY[U];
+    if (cur.tz < g.ntz) {                   // uniform: the column holds particles
+        load_idx(cur, iY);
+        load_idx(nxt, iX);
+        load_pos(iY, pA, mA);
+    }
+    // One loop, two phases with the register sets swapped, so no set is ever copied; tiles are
+    // flushed (all the empty ones too: every grid cell gets written) before the first batch of a
+    // later tile is deposited.
+    int ftz = 0;                            // next tile to flush; the ring is positioned for it
+    auto flush_until = [&](int tz_end) {
+        for (; ftz < tz_end; ++ftz) {
+            __syncthreads();
 
-        // planes c = 0..TZ-1 are final: z = oz - LO + c
-        for (int i = threadIdx.x; i < LX * LY * TZ; i += 256) {
-            const int c = i % TZ, ab = i / TZ, b = ab % LY, a = ab / LY;
-            const T v = (T)((double)(long long)tile[ab * LZ + c] * q);
-            const int z = ast::wrap1(oz - LO + c, g.n);
-            if (ablate & 1) continue;
-            if (RM::owned(a, TX) && RM::owned(b, TY)) {
-                const int px = ox + a - LO;
-                if (px < g.nx_alloc) grid[((size_t)px * g.n + oy + b - LO) * g.n + z] = v;
-            } else {
-                rec[((size_t)col * RM::COUNT + RM::cell(a, b)) * g.n + z] = v;
-                if (!x_periodic && v != (T)0) {            // a halo that points outside a slab buffer
+            // planes c = 0..TZ-1 are final (z = ftz * TZ - LO + c): store them and re-arm their slots
+            for (int i = threadIdx.x; i < LX * LY * TZ; i += 256) {
+                const int c = i % TZ, ab = i / TZ, b = ab % LY, a = ab / LY;
+                int sl = c + sh;
+                sl = sl >= LZ ? sl - LZ : sl;
+                const unsigned long long raw = tile[ab * LZ + sl];
+                tile[ab * LZ + sl] = BIAS;
+                T v;
+                if (RAW) {
+                    const unsigned long long dbits = (raw & 0x0000ffffffffffffull) | 0x4330000000000000ull;
+                    v = (T)((__longlong_as_double((long long)dbits) - 4644337115725824.0) * q);      // 2^52 + 2^47
+                } else {
+                    v = (T)((double)(long long)raw * q);
+                }
+                const int z = ast::wrap1(ftz * TZ - LO + c, g.n);
+                if (ablate & 1) continue;
+                if (RM::owned(a, TX) && RM::owned(b, TY)) {
                     const int px = ox + a - LO;
-                    if (px < 0 || px >= g.nx_alloc) ++ndrop;
+                    if (px < g.nx_alloc) grid[((size_t)px * g.n + oy + b - LO) * g.n + z] = v;
+                } else {
+                    rec[((size_t)col * RM::COUNT + RM::cell(a, b)) * g.n + z] = v;
+                    if (!x_periodic && v != (T)0) {            // a halo that points outside a slab buffer
+                        const int px = ox + a - LO;
+                        if (px < 0 || px >= g.nx_alloc) ++ndrop;
+                    }
                 }
             }
+            sh += TZ;
+            sh = sh >= LZ ? sh - LZ : sh;
+            __syncthreads();
         }
-        // carry the z halo down: planes TZ..TZ+H-1 -> 0..H-1, everything else back to zero
-        // (a leaner sweep with per-thread precomputed targets cost 20 more VGPRs and one wave
-        // per SIMD of occupancy: slower)
-        unsigned long long keep[(LX * LY * LZ + 255) / 256];
-#pragma unroll
-        for (int k = 0; k < (LX * LY * LZ + 255) / 256; ++k) {
-            const int i = threadIdx.x + k * 256;
-            const int c = i % LZ;
-            keep[k] = (i < LX * LY * LZ && c < H) ? tile[i + TZ] : 0ull;
+    };
+    for (;;) {
+        flush_until(cur.tz);
+        if (cur.tz >= g.ntz) break;
+        oz = cur.tz * TZ;
+        {
+            const Batch nn = next_batch(nxt);
+            load_pos(iX, pB, mB);                         // batch k+1 (a harmless re-load at the end)
+            load_idx(nn, iY);                             // batch k+2
+            deposit(pA, mA);
+            cur = nxt;
+            nxt = nn;
         }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < (LX * LY * LZ + 255) / 256; ++k) {
-            const int i = threadIdx.x + k * 256;
-            if (i < LX * LY * LZ) tile[i] = keep[k];
+        flush_until(cur.tz);
+        if (cur.tz >= g.ntz) break;
+        oz = cur.tz * TZ;
+        {
+            const Batch nn = next_batch(nxt);
+            load_pos(iY, pA, mA);
+            load_idx(nn, iX);
+            deposit(pB, mB);
+            cur = nxt;
+            nxt = nn;
         }
-        __syncthreads();
     }
 
-    // the carried planes now hold z = n - LO + k (k < H), i.e. the periodic wrap onto planes this
-    // workgroup stored at its first tile: add them where they were stored
+    // the H planes still in the ring hold z = n - LO + k (k < H), i.e. the periodic wrap onto planes
+    // this workgroup stored at its first tile: add them where they were stored
     __threadfence();
     for (int i = threadIdx.x; i < LX * LY * H; i += 256) {
         const int k = i % H, ab = i / H, b = ab % LY, a = ab / LY;
-        const T v = (T)((double)(long long)tile[ab * LZ + k] * q);
+        int sl = k + sh;
+        sl = sl >= LZ ? sl - LZ : sl;
+        const unsigned long long raw = tile[ab * LZ + sl];
+        T v;
+        if (RAW) {
+            const unsigned long long dbits = (raw & 0x0000ffffffffffffull) | 0x4330000000000000ull;
+            v = (T)((__longlong_as_double((long long)dbits) - 4644337115725824.0) * q);
+        } else {
+            v = (T)((double)(long long)raw * q);
+        }
         if (v == (T)0) continue;
         const int z = ast::wrap1(k - LO, g.n);
         if (RM::owned(a, TX) && RM::owned(b, TY)) {
@@ -670,7 +760,6 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
     Workspace w = carve(workspace, np, ntiles, two_pass,
                         record_bytes(W == 3 ? AST_WIN_TSC : AST_WIN_CIC, g, sizeof(T), flags));
     const unsigned ncols = (unsigned)(g.ntx * g.nty);
-    const int abl = getenv("AST_PAINT_ABLATE") ? atoi(getenv("AST_PAINT_ABLATE")) : 0;
     // ovf_count, tile_count and tile_fill are contiguous at the front of the workspace
     AST_CHECK_HIP(hipMemsetAsync(w.ovf_count, 0, (size_t)((char*)w.tile_off - (char*)w.ovf_count), s));
     const size_t per_interval = (size_t)256 * IDX_UNROLL * AGG_TRIPS;
@@ -680,7 +769,7 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
         {
             AST_PROF("paint_tiled.count", s);
             tile_index_kernel<T, W, 0><<<ga, 256, 0, s>>>(pos, np, g, w.tile_count, nullptr, nullptr, nullptr, 0, nullptr,
-                                                           nullptr, dropped, abl);
+                                                           nullptr, dropped);
         }
         const uint32_t nblk = (ntiles + 1023) / 1024;
         {
@@ -692,39 +781,47 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
         {
             AST_PROF("paint_tiled.fill", s);
             tile_index_kernel<T, W, 1><<<ga, 256, 0, s>>>(pos, np, g, nullptr, w.tile_off, w.tile_fill, w.index, 0, nullptr,
-                                                           nullptr, nullptr, abl);
+                                                           nullptr, nullptr);
         }
         if (overwrite) {
             {
                 AST_PROF("paint_tiled.deposit", s);
-                column_deposit_kernel<T, W><<<ncols, 256, 0, s>>>(pos, mass, g, scale, w.index, w.tile_off, w.tile_count, 0,
-                                                                  mass ? mass_bound : 1.0, grid, (T*)w.rec, dropped, abl);
+                if (mass)
+                    column_deposit_kernel<T, W, true><<<ncols, 256, 0, s>>>(pos, mass, g, scale, w.index, w.tile_off, w.tile_count,
+                                                                            0, mass_bound, grid, (T*)w.rec, dropped);
+                else
+                    column_deposit_kernel<T, W, false><<<ncols, 256, 0, s>>>(pos, mass, g, scale, w.index, w.tile_off, w.tile_count,
+                                                                             0, 1.0, grid, (T*)w.rec, dropped);
             }
             AST_PROF("paint_tiled.fold", s);
             column_fold_kernel<T, W><<<ncols, 256, 0, s>>>((const T*)w.rec, g, grid);
         } else {
             AST_PROF("paint_tiled.deposit", s);
             tile_deposit_kernel<T, W><<<ntiles, 256, 0, s>>>(pos, mass, g, scale, w.index, w.tile_off, w.tile_count, 0,
-                                                             grid, dropped, abl);
+                                                             grid, dropped);
         }
     } else {
         {
             AST_PROF("paint_tiled.fill", s);
             tile_index_kernel<T, W, 2><<<ga, 256, 0, s>>>(pos, np, g, nullptr, nullptr, w.tile_fill, w.index, w.cap, w.ovf,
-                                                           w.ovf_count, dropped, abl);
+                                                           w.ovf_count, dropped);
         }
         if (overwrite) {
             {
                 AST_PROF("paint_tiled.deposit", s);
-                column_deposit_kernel<T, W><<<ncols, 256, 0, s>>>(pos, mass, g, scale, w.index, nullptr, w.tile_fill, w.cap,
-                                                                  mass ? mass_bound : 1.0, grid, (T*)w.rec, dropped, abl);
+                if (mass)
+                    column_deposit_kernel<T, W, true><<<ncols, 256, 0, s>>>(pos, mass, g, scale, w.index, nullptr, w.tile_fill, w.cap,
+                                                                            mass_bound, grid, (T*)w.rec, dropped);
+                else
+                    column_deposit_kernel<T, W, false><<<ncols, 256, 0, s>>>(pos, mass, g, scale, w.index, nullptr, w.tile_fill, w.cap,
+                                                                             1.0, grid, (T*)w.rec, dropped);
             }
             AST_PROF("paint_tiled.fold", s);
             column_fold_kernel<T, W><<<ncols, 256, 0, s>>>((const T*)w.rec, g, grid);
         } else {
             AST_PROF("paint_tiled.deposit", s);
             tile_deposit_kernel<T, W><<<ntiles, 256, 0, s>>>(pos, mass, g, scale, w.index, nullptr, w.tile_fill, w.cap, grid,
-                                                             dropped, abl);
+                                                             dropped);
         }
         AST_PROF("paint_tiled.overflow", s);
         overflow_deposit_kernel<T, W><<<1024, 256, 0, s>>>(pos, mass, w.ovf, w.ovf_count, g, scale, grid, dropped);

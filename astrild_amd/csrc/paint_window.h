@@ -61,4 +61,18 @@ __device__ inline int locate(double s, int n, double& frac) {
     return (int)r;
 }
 
+// Fast variant for callers that can test the result: base cell minus `origin` (origin in
+// [0, n)), reduced by at most one period either way.  Exactly (cell - origin) mod n for positions
+// less than one box length outside the box; anything further out comes back >= n as unsigned
+// and the caller falls back to locate().  The double -> int conversion saturates.
+template <int W>
+__device__ inline int locate_rel(double s, int n, int origin, double& frac) {
+    const double fl = floor(W == 2 ? s : s + 0.5);
+    frac = s - fl;
+    int l = (int)fl - origin;
+    l = (int)min((unsigned)l, (unsigned)(l + n));
+    l = (int)min((unsigned)l, (unsigned)(l - n));
+    return l;
+}
+
 }  // namespace ast
