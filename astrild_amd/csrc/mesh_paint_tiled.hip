@@ -30,6 +30,7 @@
 #include "ast_common.h"
 #include "paint_window.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -42,9 +43,31 @@ using ast::Window;
 #endif
 constexpr int TX = TILE_TX, TY = TILE_TY, TZ = TILE_TZ;   // owned cells per tile
 #ifndef PAINT_ABLATE
-#define PAINT_ABLATE 0        // perf experiments only: 1 no flush stores, 2 no LDS atomics, 32 no gather
+#define PAINT_ABLATE 0        // perf experiments only: 1 no flush stores, 2 no LDS atomics, 32 no gather,
+                              // 64 no flush barriers, 128 no flush, 256 no deposit arithmetic
 #endif
 constexpr int ablate = PAINT_ABLATE;
+
+// -DPAINT_STAMPS: s_memtime stamps of wave 0 of 64 sample workgroups of the column deposit kernel
+// (scripts/perf_timeline.py reads them through ast_debug_stamps)
+#ifdef PAINT_STAMPS
+__device__ unsigned long long g_stamps[64 * 4096];
+__device__ unsigned g_nstamp[64];
+#define STAMP_DECL unsigned nst_ = 0
+#define STAMP(id)                                                                                     \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x % 257 == 3 && blockIdx.x / 257 < 64 && nst_ < 4096)         \
+            g_stamps[(blockIdx.x / 257) * 4096 + nst_++] = (__builtin_amdgcn_s_memtime() << 8) | (id); \
+    } while (0)
+#define STAMP_END                                                                                     \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x % 257 == 3 && blockIdx.x / 257 < 64) g_nstamp[blockIdx.x / 257] = nst_; \
+    } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(id) do {} while (0)
+#define STAMP_END do {} while (0)
+#endif
 
 struct TileGeom {
     int n, x_start, nx_alloc;
@@ -52,24 +75,35 @@ struct TileGeom {
     double inv_dx;
 };
 
-// base cell (window centre for TSC, lower corner for CIC) -> tile id, or
-// 0xffffffff when the base plane is outside the buffer.
-template <typename T, int W>
-__device__ inline uint32_t tile_of(T x, T y, T z, const TileGeom& g) {
-    double f;
-    // fast path: positions less than a box length outside the box (paint_window.h locate_rel)
-    int cx = ast::locate_rel<W>((double)x * g.inv_dx, g.n, 0, f);
-    int by = ast::locate_rel<W>((double)y * g.inv_dx, g.n, 0, f);
-    int bz = ast::locate_rel<W>((double)z * g.inv_dx, g.n, 0, f);
-    if ((unsigned)cx >= (unsigned)g.n || (unsigned)by >= (unsigned)g.n || (unsigned)bz >= (unsigned)g.n) {
-        cx = ast::locate<W>((double)x * g.inv_dx, g.n, f);
-        by = ast::locate<W>((double)y * g.inv_dx, g.n, f);
-        bz = ast::locate<W>((double)z * g.inv_dx, g.n, f);
+// base cell (window centre for TSC, lower corner for CIC) -> tile id, or 0xffffffff when the
+// base plane is outside the buffer.  The common case is a position inside the box: cell =
+// (int)floor(s) needs no reduction at all, and only then does the deposit kernel's unreduced
+// lookup agree, so everything else (one box length out: locate_rel would do, but the flag is
+// what matters) takes the general path and marks the tile's column in col_flags.
+// PLAINX: the buffer is the whole periodic grid (x_start = 0, nx_alloc = n).
+template <typename T, int W, bool PLAINX>
+__device__ inline uint32_t tile_of(T x, T y, T z, const TileGeom& g, uint32_t* __restrict__ col_flags) {
+    const double sx = (double)x * g.inv_dx, sy = (double)y * g.inv_dx, sz = (double)z * g.inv_dx;
+    int cx = (int)floor(W == 2 ? sx : sx + 0.5);
+    int cy = (int)floor(W == 2 ? sy : sy + 0.5);
+    int cz = (int)floor(W == 2 ? sz : sz + 0.5);
+    const bool far = max(max((unsigned)cx, (unsigned)cy), (unsigned)cz) >= (unsigned)g.n;
+    if (far) {
+        double f;
+        cx = ast::locate<W>(sx, g.n, f);
+        cy = ast::locate<W>(sy, g.n, f);
+        cz = ast::locate<W>(sz, g.n, f);
     }
-    int bx = cx - g.x_start;
-    if (bx < 0) bx += g.n;
-    if (bx >= g.nx_alloc) return 0xffffffffu;
-    return (uint32_t)(((bx / TX) * g.nty + by / TY) * g.ntz + bz / TZ);
+    unsigned bx = (unsigned)cx;
+    if (!PLAINX) {
+        int b = cx - g.x_start;
+        if (b < 0) b += g.n;
+        if (b >= g.nx_alloc) return 0xffffffffu;
+        bx = (unsigned)b;
+    }
+    const uint32_t col = (bx / TX) * (unsigned)g.nty + (unsigned)cy / TY;
+    if (far && col_flags) atomicOr(&col_flags[col], 1u);
+    return col * (unsigned)g.ntz + (unsigned)cz / TZ;
 }
 
 // Run structure of one wave's 64 consecutive particles.
@@ -81,7 +115,8 @@ struct WaveRuns {
 
 __device__ inline WaveRuns wave_runs(uint32_t key, bool live, int lane) {
     WaveRuns r;
-    const uint32_t prev = __shfl_up(key, 1, 64);
+    // key of lane - 1 in ONE instruction (v_mov_b32_dpp wave_shr:1; lane 0 keeps the fill value)
+    const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)key, 0x138, 0xf, 0xf, false);
     r.head = live && (lane == 0 || prev != key);
     const unsigned long long hmask = __ballot(r.head);
     const unsigned long long dmask = __ballot(!live);
@@ -110,19 +145,24 @@ constexpr uint32_t CODE_DONE = 0xffffffffu;
 // interval with ONE global atomic per distinct tile.  Runs whose slot is taken by
 // another tile fall back to a global atomic of their own.  In the FILL pass the
 // final position of a particle is only known after the flush, so each thread
-// parks (slot, offset-in-interval) codes of its 32 particles in LDS meanwhile.
+// parks (slot, offset-in-interval) codes of its 16 particles in LDS meanwhile.
+// The kernel is instruction-issue bound (rocprofv3 SQ counters: the sum of all issued
+// instructions x 4 cycles is the kernel time), so the per-particle path is kept short.
 // MODE 0: count (two-pass A1)   1: fill at exact offsets (two-pass A2)
 // MODE 2: single pass — tile t owns index[t*cap, (t+1)*cap); overflow goes to ovf[]
-template <typename T, int W, int MODE>
+template <typename T, int W, int MODE, bool PLAINX>
 __global__ void __launch_bounds__(256)
 tile_index_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t* __restrict__ tile_count,
                   const uint32_t* __restrict__ tile_off, uint32_t* __restrict__ tile_fill,
                   uint32_t* __restrict__ index, uint32_t cap, uint32_t* __restrict__ ovf,
-                  unsigned long long* __restrict__ ovf_count, unsigned long long* dropped) {
+                  unsigned long long* __restrict__ ovf_count, uint32_t* __restrict__ col_flags,
+                  unsigned long long* dropped) {
     constexpr bool FILL = MODE != 0;
     // skey/scnt are re-armed by each thread as soon as it leaves the scatter loop, so the
-    // scatter reads the interval's results from sbase/stile, which only the next flush rewrites
-    __shared__ uint32_t skey[AGG_SLOTS], scnt[AGG_SLOTS], sbase[AGG_SLOTS], stile[AGG_SLOTS];
+    // scatter reads the interval's results from sdst/sroom, which only the next flush rewrites:
+    // sdst = first index element of the slot's tile segment part, sroom = elements left in it
+    __shared__ uint32_t skey[AGG_SLOTS], scnt[AGG_SLOTS], sroom[AGG_SLOTS];
+    __shared__ unsigned long long sdst[AGG_SLOTS];
     __shared__ uint32_t codes[FILL ? AGG_TRIPS * IDX_UNROLL : 1][256];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -135,6 +175,7 @@ tile_index_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t* __
     unsigned long long ndrop = 0;
     for (size_t interval = blockIdx.x; interval < nintervals; interval += gridDim.x) {
         const size_t p0 = interval * per_interval;
+        const bool full = p0 + per_interval <= np;            // uniform: no lane of the interval is past the end
         for (int trip = 0; trip < AGG_TRIPS; ++trip) {
             T x[IDX_UNROLL], y[IDX_UNROLL], z[IDX_UNROLL];
 #pragma unroll
@@ -149,12 +190,13 @@ tile_index_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t* __
 #pragma unroll
             for (int u = 0; u < IDX_UNROLL; ++u) {
                 const size_t p = p0 + (size_t)trip * per_trip + (size_t)u * 256 + tid;
-                const bool valid = p < np;
-                const uint32_t key = valid ? tile_of<T, W>(x[u], y[u], z[u], g) : 0xffffffffu;
+                const bool valid = full || p < np;
+                uint32_t key = tile_of<T, W, PLAINX>(x[u], y[u], z[u], g, MODE != 1 ? col_flags : nullptr);
+                if (!valid) key = 0xffffffffu;
                 const bool live = key != 0xffffffffu;
-                if (valid && !live) ++ndrop;
+                if (!PLAINX && valid && !live) ++ndrop;
                 const WaveRuns r = wave_runs(key, live, lane);
-                bool hit = false;
+                bool hit = true;
                 uint32_t val = 0;               // hit: slot << 16 | offset in the interval; miss: global slot
                 if (r.head) {
                     const uint32_t slot = key & (AGG_SLOTS - 1);
@@ -166,14 +208,16 @@ tile_index_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t* __
                     else val = atomicAdd(&tile_fill[key], (uint32_t)r.len);      // slot inside the tile's segment
                 }
                 if (FILL) {
-                    const int hitb = __shfl((int)hit, r.head_lane, 64);
                     const uint32_t valb = __shfl(val, r.head_lane, 64) + (uint32_t)(lane - r.head_lane);
-                    uint32_t code = CODE_DONE;
-                    if (live) {
-                        if (hitb) code = valb;
-                        else if (MODE == 1) index[valb] = (uint32_t)p;
-                        else if (valb < cap) index[(size_t)key * cap + valb] = (uint32_t)p;
-                        else ovf[atomicAdd(ovf_count, 1ull)] = (uint32_t)p;
+                    uint32_t code = live ? valb : CODE_DONE;
+                    if (__any(!hit)) {                    // uniform and rare: some run lost its slot to another tile
+                        const int hitb = __shfl((int)hit, r.head_lane, 64);
+                        if (live && !hitb) {
+                            code = CODE_DONE;
+                            if (MODE == 1) index[valb] = (uint32_t)p;
+                            else if (valb < cap) index[(size_t)key * cap + valb] = (uint32_t)p;
+                            else ovf[atomicAdd(ovf_count, 1ull)] = (uint32_t)p;
+                        }
                     }
                     codes[trip * IDX_UNROLL + u][tid] = code;
                 }
@@ -181,9 +225,14 @@ tile_index_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t* __
         }
         __syncthreads();
         if (skey[tid] != SLOT_EMPTY) {
-            if (MODE == 0) atomicAdd(&tile_count[skey[tid]], scnt[tid]);
-            else if (MODE == 1) sbase[tid] = tile_off[skey[tid]] + atomicAdd(&tile_fill[skey[tid]], scnt[tid]);
-            else { sbase[tid] = atomicAdd(&tile_fill[skey[tid]], scnt[tid]); stile[tid] = skey[tid]; }
+            const uint32_t t = skey[tid], c = scnt[tid];
+            if (MODE == 0) atomicAdd(&tile_count[t], c);
+            else if (MODE == 1) { sdst[tid] = (unsigned long long)tile_off[t] + atomicAdd(&tile_fill[t], c); sroom[tid] = 0xffffffffu; }
+            else {
+                const uint32_t base = min(atomicAdd(&tile_fill[t], c), cap);
+                sdst[tid] = (unsigned long long)t * cap + base;
+                sroom[tid] = cap - base;
+            }
         }
         __syncthreads();
         if (FILL) {
@@ -192,9 +241,8 @@ tile_index_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t* __
                 const uint32_t c = codes[j][tid];
                 if (c == CODE_DONE) continue;
                 const uint32_t p = (uint32_t)(p0 + (size_t)j * 256 + tid);
-                const uint32_t at = sbase[c >> 16] + (c & 0xffffu);
-                if (MODE == 1) index[at] = p;
-                else if (at < cap) index[(size_t)stile[c >> 16] * cap + at] = p;
+                const uint32_t slot = c >> 16, at = c & 0xffffu;
+                if (at < sroom[slot]) index[sdst[slot] + at] = p;
                 else ovf[atomicAdd(ovf_count, 1ull)] = p;
             }
         }
@@ -413,7 +461,8 @@ __global__ void __launch_bounds__(256)
 column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileGeom g, double scale,
                       const uint32_t* __restrict__ index, const uint32_t* __restrict__ tile_off,
                       const uint32_t* __restrict__ tile_count, uint32_t cap, double mass_bound,
-                      T* __restrict__ grid, T* __restrict__ rec, unsigned long long* dropped) {
+                      const uint32_t* __restrict__ col_flags, T* __restrict__ grid, T* __restrict__ rec,
+                      unsigned long long* dropped) {
     constexpr int LX = TX + W - 1, LY = TY + W - 1, LZ = TZ + W - 1;
     constexpr int LO = Window<W>::LO, H = W - 1;
     using RM = RingMap<W>;
@@ -436,11 +485,28 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     // they are and the flush only has to re-arm the TZ slots it stored.
     __shared__ unsigned long long tile[LX * LY * LZ];        // ((a * LY + b) * LZ + slot), slot fastest
     const int col = blockIdx.x;
+    STAMP_DECL;
     const int ty = col % g.nty, tx = col / g.nty;
     const int ox = tx * TX, oy = ty * TY;
     const bool x_periodic = g.nx_alloc == g.n;
     unsigned long long ndrop = 0;
     for (int i = threadIdx.x; i < LX * LY * LZ; i += 256) tile[i] = BIAS;
+    // where the z line of LDS column (a, b) goes: the owned cells' grid line or the halo ring's
+    // record line (bit 0: a halo that points outside a slab buffer, counted as dropped when
+    // non-zero); 0 = an owned plane the buffer does not hold
+    __shared__ unsigned long long dest[LX * LY];
+    for (int ab = threadIdx.x; ab < LX * LY; ab += 256) {
+        const int b = ab % LY, a = ab / LY;
+        const int px = ox + a - LO;
+        unsigned long long d;
+        if (RM::owned(a, TX) && RM::owned(b, TY)) {
+            d = px < g.nx_alloc ? (unsigned long long)(grid + ((size_t)px * g.n + oy + b - LO) * g.n) : 0ull;
+        } else {
+            d = (unsigned long long)(rec + ((size_t)col * RM::COUNT + RM::cell(a, b)) * g.n);
+            if (!x_periodic && (px < 0 || px >= g.nx_alloc)) d |= 1ull;
+        }
+        dest[ab] = d;
+    }
     // quantum: a cell collects at most the particles of two consecutive tiles, each contribution
     // is <= mass_bound * |scale|; keep every sum below 2^SUM_BITS and every term below 2^50
     uint32_t cmax = 1;
@@ -468,8 +534,13 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
 #endif
     constexpr int U = DEP_U;
     struct Batch { int tz; uint32_t i0, cnt; size_t off; };       // tz == g.ntz: past the end
-    auto tile_span = [&](int tz, uint32_t& cnt, size_t& off) {
-        const uint32_t t = (uint32_t)((tx * g.nty + ty) * g.ntz + tz);
+    // The walk starts at a column-dependent tile and wraps around the periodic z edge (the ring
+    // does not care), so concurrently running columns are at different z: in lockstep all of
+    // them would store to / gather from addresses a large power of two apart.
+    const int tz0 = ablate & 512 ? 0 : (int)(((unsigned)col * 2654435761u >> 16) % (unsigned)g.ntz);
+    auto phys = [&](int step) { const int t = tz0 + step; return t >= g.ntz ? t - g.ntz : t; };   // step -> tile
+    auto tile_span = [&](int step, uint32_t& cnt, size_t& off) {
+        const uint32_t t = (uint32_t)((tx * g.nty + ty) * g.ntz + phys(step));
         cnt = cap ? min(tile_count[t], cap) : tile_count[t];
         off = cap ? (size_t)t * cap : (size_t)tile_off[t];
     };
@@ -494,6 +565,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const size_t q3 = (ablate & 32) ? (size_t)((idx[u] % 1000000u) * 3) : (size_t)idx[u] * 3;
+            if (ablate & 1024) { p[3 * u + 0] = p[3 * u + 1] = p[3 * u + 2] = (T)idx[u]; continue; }
             p[3 * u + 0] = pos[q3 + 0];
             p[3 * u + 1] = pos[q3 + 1];
             p[3 * u + 2] = pos[q3 + 2];
@@ -505,26 +577,45 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     Batch nxt = next_batch(cur);
     int sh = 0;                             // (tz * TZ) mod LZ
     int oz = 0;
-    // deposit one batch: positions pc / masses mc of batch `cur`
-    auto deposit = [&](const T (&pc)[3 * U], const T (&mc)[U]) {
-        #pragma unroll
+    // deposit one batch: positions pc / masses mc of batch `cur`.  CAREFUL = false: every particle
+    // of the column lies inside the box and the tile does not straddle the periodic x edge, so
+    // the unreduced cell (int)floor(s) minus the tile origin is the LDS coordinate (the same
+    // expression decided the particle's tile in tile_of(); it raised col_flags otherwise).
+    auto deposit = [&](const T (&pc)[3 * U], const T (&mc)[U], auto careful_tag) {
+        constexpr bool CAREFUL = decltype(careful_tag)::value;
+#pragma unroll
         for (int u = 0; u < U; ++u) {
             if (cur.i0 + u * 256 + threadIdx.x >= cur.cnt) continue;
+            if (ablate & 256) { asm volatile("" ::"v"(pc[3 * u]), "v"(pc[3 * u + 1]), "v"(pc[3 * u + 2])); continue; }
             double fx, fy, fz;
-            int lx = ast::locate_rel<W>((double)pc[3 * u + 0] * g.inv_dx, g.n, orx, fx);
-            int ly = ast::locate_rel<W>((double)pc[3 * u + 1] * g.inv_dx, g.n, oy, fy);
-            int lz = ast::locate_rel<W>((double)pc[3 * u + 2] * g.inv_dx, g.n, oz, fz);
-            if ((unsigned)lx >= ex || (unsigned)ly >= ey || (unsigned)lz >= ez) {
-                // more than a box length outside the box (rare): the general reduction
-                int bx = ast::locate<W>((double)pc[3 * u + 0] * g.inv_dx, g.n, fx) - g.x_start;
-                if (bx < 0) bx += g.n;
-                lx = bx - ox;
-                ly = ast::locate<W>((double)pc[3 * u + 1] * g.inv_dx, g.n, fy) - oy;
-                lz = ast::locate<W>((double)pc[3 * u + 2] * g.inv_dx, g.n, fz) - oz;
-                if ((unsigned)lx >= ex || (unsigned)ly >= ey || (unsigned)lz >= ez) continue;   // not in this tile: cannot happen
+            int lx, ly, lz;
+            if (!CAREFUL) {
+                const double sx = (double)pc[3 * u + 0] * g.inv_dx, sy = (double)pc[3 * u + 1] * g.inv_dx,
+                             sz = (double)pc[3 * u + 2] * g.inv_dx;
+                const double flx = floor(W == 2 ? sx : sx + 0.5), fly = floor(W == 2 ? sy : sy + 0.5),
+                             flz = floor(W == 2 ? sz : sz + 0.5);
+                fx = sx - flx;
+                fy = sy - fly;
+                fz = sz - flz;
+                lx = (int)flx - orx;
+                ly = (int)fly - oy;
+                lz = (int)flz - oz;
+            } else {
+                lx = ast::locate_rel<W>((double)pc[3 * u + 0] * g.inv_dx, g.n, orx, fx);
+                ly = ast::locate_rel<W>((double)pc[3 * u + 1] * g.inv_dx, g.n, oy, fy);
+                lz = ast::locate_rel<W>((double)pc[3 * u + 2] * g.inv_dx, g.n, oz, fz);
+                if ((unsigned)lx >= ex || (unsigned)ly >= ey || (unsigned)lz >= ez) {
+                    // more than a box length outside the box: the general reduction
+                    int bx = ast::locate<W>((double)pc[3 * u + 0] * g.inv_dx, g.n, fx) - g.x_start;
+                    if (bx < 0) bx += g.n;
+                    lx = bx - ox;
+                    ly = ast::locate<W>((double)pc[3 * u + 1] * g.inv_dx, g.n, fy) - oy;
+                    lz = ast::locate<W>((double)pc[3 * u + 2] * g.inv_dx, g.n, fz) - oz;
+                    if ((unsigned)lx >= ex || (unsigned)ly >= ey || (unsigned)lz >= ez) continue;   // not in this tile: cannot happen
+                }
             }
-            // weights and products in double, pre-scaled by 1/quantum: one multiply and the
-            // magic-number add per deposit
+            // weights and products in double, pre-scaled by 1/quantum; the last product and the
+            // magic-number add are one fma (a single rounding of the exact product to the quantum)
             double wx[W], wy[W], wz[W];
             Window<W>::weights(fx, wx);
             Window<W>::weights(fy, wy);
@@ -547,8 +638,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
                     const double mab = mwa * wy[b];
 #pragma unroll
                     for (int c = 0; c < W; ++c) {
-                        const double x = mab * wz[c];                              // |x| < 2^50
-                        long long v = __double_as_longlong(x + 6755399441055744.0);
+                        long long v = __double_as_longlong(__fma_rn(mab, wz[c], 6755399441055744.0));   // |mab wz| < 2^50
                         if (!RAW) v -= 0x4338000000000000ll;
                         unsigned long long* cell = slot[c] + (a * LY + b) * LZ;
                         if (ablate & 2) asm volatile("" ::"v"(v), "v"(cell)); else atomicAdd(cell, (unsigned long long)v);
@@ -557,6 +647,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
             }
         }
     };
+    const bool careful = col_flags[col] != 0 || orx + TX > g.n;       // uniform
     // Two register sets, used alternately (a copy at the end of a step would have to wait for
     // the loads it copies): pos/mass A|B of batch k|k+1, indices X|Y of batch k+1|k+2.
     T pA[3 * U], mA[U], pB[3 * U], mB[U];
@@ -572,15 +663,25 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     int ftz = 0;                            // next tile to flush; the ring is positioned for it
     auto flush_until = [&](int tz_end) {
         for (; ftz < tz_end; ++ftz) {
-            __syncthreads();
+            STAMP(5);
+            if (!(ablate & 64)) __syncthreads();
+            STAMP(6);
 
-            // planes c = 0..TZ-1 are final (z = ftz * TZ - LO + c): store them and re-arm their slots
-            for (int i = threadIdx.x; i < LX * LY * TZ; i += 256) {
-                const int c = i % TZ, ab = i / TZ, b = ab % LY, a = ab / LY;
-                int sl = c + sh;
-                sl = sl >= LZ ? sl - LZ : sl;
+            // planes c = 0..TZ-1 are final (z = ftz * TZ - LO + c): store them and re-arm their slots.
+            // A thread keeps its plane c and walks the (a, b) columns; everything but the value
+            // comes from the per-column table.
+            static_assert(256 % TZ == 0, "flush mapping");
+            const int c = threadIdx.x % TZ;
+            int sl = c + sh;
+            sl = sl >= LZ ? sl - LZ : sl;
+            const int z = ast::wrap1(phys(ftz) * TZ - LO + c, g.n);
+#pragma unroll
+            for (int k = 0; k < (LX * LY * TZ + 255) / 256; ++k) {
+                const int ab = threadIdx.x / TZ + k * (256 / TZ);
+                if (ab >= LX * LY || (ablate & 128)) break;
                 const unsigned long long raw = tile[ab * LZ + sl];
                 tile[ab * LZ + sl] = BIAS;
+                const unsigned long long d = dest[ab];
                 T v;
                 if (RAW) {
                     const unsigned long long dbits = (raw & 0x0000ffffffffffffull) | 0x4330000000000000ull;
@@ -588,52 +689,60 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
                 } else {
                     v = (T)((double)(long long)raw * q);
                 }
-                const int z = ast::wrap1(ftz * TZ - LO + c, g.n);
-                if (ablate & 1) continue;
-                if (RM::owned(a, TX) && RM::owned(b, TY)) {
-                    const int px = ox + a - LO;
-                    if (px < g.nx_alloc) grid[((size_t)px * g.n + oy + b - LO) * g.n + z] = v;
-                } else {
-                    rec[((size_t)col * RM::COUNT + RM::cell(a, b)) * g.n + z] = v;
-                    if (!x_periodic && v != (T)0) {            // a halo that points outside a slab buffer
-                        const int px = ox + a - LO;
-                        if (px < 0 || px >= g.nx_alloc) ++ndrop;
-                    }
-                }
+                if ((ablate & 1) || d == 0ull) continue;
+                ((T*)(d & ~1ull))[z] = v;
+                if (!x_periodic && (d & 1ull) && v != (T)0) ++ndrop;
             }
             sh += TZ;
             sh = sh >= LZ ? sh - LZ : sh;
-            __syncthreads();
+            STAMP(7);
+            if (!(ablate & 64)) __syncthreads();
+            STAMP(8);
         }
     };
+    STAMP(0);
     for (;;) {
         flush_until(cur.tz);
         if (cur.tz >= g.ntz) break;
-        oz = cur.tz * TZ;
+        oz = phys(cur.tz) * TZ;
         {
+            STAMP(1);
             const Batch nn = next_batch(nxt);
+            STAMP(2);
             load_pos(iX, pB, mB);                         // batch k+1 (a harmless re-load at the end)
             load_idx(nn, iY);                             // batch k+2
-            deposit(pA, mA);
+            STAMP(3);
+            if (careful) deposit(pA, mA, std::true_type{}); else deposit(pA, mA, std::false_type{});
+            STAMP(4);
             cur = nxt;
             nxt = nn;
         }
         flush_until(cur.tz);
         if (cur.tz >= g.ntz) break;
-        oz = cur.tz * TZ;
+        oz = phys(cur.tz) * TZ;
         {
+            STAMP(1);
             const Batch nn = next_batch(nxt);
+            STAMP(2);
             load_pos(iY, pA, mA);
             load_idx(nn, iX);
-            deposit(pB, mB);
+            STAMP(3);
+            if (careful) deposit(pB, mB, std::true_type{}); else deposit(pB, mB, std::false_type{});
+            STAMP(4);
             cur = nxt;
             nxt = nn;
         }
     }
+    STAMP(9);
+    STAMP_END;
 
     // the H planes still in the ring hold z = n - LO + k (k < H), i.e. the periodic wrap onto planes
     // this workgroup stored at its first tile: add them where they were stored
-    __threadfence();
+    // The stores being added to were issued by this workgroup and are in its XCD's L2, where the
+    // atomics execute: draining the workgroup's stores is all the ordering needed.  (A
+    // __threadfence() here is a buffer_wbl2 + buffer_inv of the whole L2 per wave.)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
     for (int i = threadIdx.x; i < LX * LY * H; i += 256) {
         const int k = i % H, ab = i / H, b = ab % LY, a = ab / LY;
         int sl = k + sh;
@@ -647,7 +756,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
             v = (T)((double)(long long)raw * q);
         }
         if (v == (T)0) continue;
-        const int z = ast::wrap1(k - LO, g.n);
+        const int z = ast::wrap1(tz0 * TZ + k - LO, g.n);
         if (RM::owned(a, TX) && RM::owned(b, TY)) {
             const int px = ox + a - LO;
             if (px < g.nx_alloc) atomicAdd(&grid[((size_t)px * g.n + oy + b - LO) * g.n + z], v);
@@ -657,6 +766,33 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     }
     if (dropped && ndrop) atomicAdd(dropped, ndrop);
 }
+
+#ifdef PAINT_WALK_TEST
+// perf experiment: the plainest possible walk over a column's index lists and positions
+template <typename T>
+__global__ void __launch_bounds__(256)
+walk_test_kernel(const T* __restrict__ pos, TileGeom g, const uint32_t* __restrict__ index,
+                 const uint32_t* __restrict__ tile_count, uint32_t cap, T* out) {
+    __shared__ T pad[5400];
+    T acc = 0;
+    for (int tz = 0; tz < g.ntz; ++tz) {
+        const uint32_t t = blockIdx.x * g.ntz + tz;
+        const uint32_t cnt = min(tile_count[t], cap);
+        const size_t off = (size_t)t * cap;
+        for (uint32_t i0 = 0; i0 < cnt; i0 += 1024) {
+            uint32_t idx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) idx[u] = index[off + min(i0 + u * 256 + threadIdx.x, cnt - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t q = (size_t)idx[u] * 3;
+                acc += pos[q] + pos[q + 1] + pos[q + 2];
+            }
+        }
+    }
+    if (acc == (T)1234.5) { out[0] = acc; pad[threadIdx.x] = acc; out[1] = pad[(threadIdx.x * 7) % 5400]; }
+}
+#endif
 
 // Every column adds its neighbours' halo records into its own border rows.
 template <typename T, int W>
@@ -695,6 +831,7 @@ column_fold_kernel(const T* __restrict__ rec, TileGeom g, T* __restrict__ grid) 
 
 struct Workspace {
     unsigned long long* ovf_count;   // single pass: particles in the overflow list
+    uint32_t* col_flags;             // per tile column: 1 = holds a particle outside the box (general cell lookup)
     uint32_t* tile_count;            // two pass: exact counts; single pass: unused
     uint32_t* tile_fill;             // slots requested per tile
     uint32_t* tile_off;              // two pass: exclusive scan of tile_count
@@ -716,11 +853,12 @@ inline uint32_t tile_capacity(size_t np, uint32_t ntiles) {
     return (uint32_t)(cap > 0x7fffffffull ? 0x7fffffffull : cap);
 }
 
-Workspace carve(void* base, size_t np, uint32_t ntiles, bool two_pass, size_t rec_bytes) {
+Workspace carve(void* base, size_t np, uint32_t ntiles, uint32_t ncols, bool two_pass, size_t rec_bytes) {
     Workspace w;
     size_t off = 0;
     auto take = [&](size_t bytes) { void* p = (char*)base + off; off += align256(bytes); return p; };
     w.ovf_count = (unsigned long long*)take(8);
+    w.col_flags = (uint32_t*)take((size_t)ncols * 4);
     w.tile_count = (uint32_t*)take((size_t)ntiles * 4);
     w.tile_fill = (uint32_t*)take((size_t)ntiles * 4);
     w.tile_off = (uint32_t*)take((size_t)ntiles * 4);
@@ -757,19 +895,47 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
               void* workspace, unsigned long long* dropped, int flags, double mass_bound, hipStream_t s) {
     const bool two_pass = (flags & AST_PAINT_TWO_PASS) != 0;
     const bool overwrite = (flags & AST_PAINT_OVERWRITE) != 0;
-    Workspace w = carve(workspace, np, ntiles, two_pass,
-                        record_bytes(W == 3 ? AST_WIN_TSC : AST_WIN_CIC, g, sizeof(T), flags));
     const unsigned ncols = (unsigned)(g.ntx * g.nty);
-    // ovf_count, tile_count and tile_fill are contiguous at the front of the workspace
+    Workspace w = carve(workspace, np, ntiles, ncols, two_pass,
+                        record_bytes(W == 3 ? AST_WIN_TSC : AST_WIN_CIC, g, sizeof(T), flags));
+    // ovf_count, col_flags, tile_count and tile_fill are contiguous at the front of the workspace
     AST_CHECK_HIP(hipMemsetAsync(w.ovf_count, 0, (size_t)((char*)w.tile_off - (char*)w.ovf_count), s));
     const size_t per_interval = (size_t)256 * IDX_UNROLL * AGG_TRIPS;
     const size_t nintervals = (np + per_interval - 1) / per_interval;
     const unsigned ga = (unsigned)(nintervals > 8192 ? 8192 : nintervals);
+    const bool plainx = g.x_start == 0 && g.nx_alloc == g.n;
+    auto index_pass = [&](auto mode, uint32_t* tile_count, const uint32_t* tile_off, uint32_t* tile_fill, uint32_t* index,
+                          uint32_t cap, uint32_t* ovf, unsigned long long* ovf_count, unsigned long long* drop) {
+        constexpr int MODE = decltype(mode)::value;
+        if (plainx)
+            tile_index_kernel<T, W, MODE, true><<<ga, 256, 0, s>>>(pos, np, g, tile_count, tile_off, tile_fill, index, cap, ovf,
+                                                                   ovf_count, w.col_flags, drop);
+        else
+            tile_index_kernel<T, W, MODE, false><<<ga, 256, 0, s>>>(pos, np, g, tile_count, tile_off, tile_fill, index, cap, ovf,
+                                                                    ovf_count, w.col_flags, drop);
+    };
+    auto deposit_pass = [&](const uint32_t* tile_off, const uint32_t* tile_count, uint32_t cap) {
+        if (overwrite) {
+            {
+                AST_PROF("paint_tiled.deposit", s);
+                if (mass)
+                    column_deposit_kernel<T, W, true><<<ncols, 256, 0, s>>>(pos, mass, g, scale, w.index, tile_off, tile_count, cap,
+                                                                            mass_bound, w.col_flags, grid, (T*)w.rec, dropped);
+                else
+                    column_deposit_kernel<T, W, false><<<ncols, 256, 0, s>>>(pos, mass, g, scale, w.index, tile_off, tile_count, cap,
+                                                                             1.0, w.col_flags, grid, (T*)w.rec, dropped);
+            }
+            AST_PROF("paint_tiled.fold", s);
+            column_fold_kernel<T, W><<<ncols, 256, 0, s>>>((const T*)w.rec, g, grid);
+        } else {
+            AST_PROF("paint_tiled.deposit", s);
+            tile_deposit_kernel<T, W><<<ntiles, 256, 0, s>>>(pos, mass, g, scale, w.index, tile_off, tile_count, cap, grid, dropped);
+        }
+    };
     if (two_pass) {
         {
             AST_PROF("paint_tiled.count", s);
-            tile_index_kernel<T, W, 0><<<ga, 256, 0, s>>>(pos, np, g, w.tile_count, nullptr, nullptr, nullptr, 0, nullptr,
-                                                           nullptr, dropped);
+            index_pass(std::integral_constant<int, 0>{}, w.tile_count, nullptr, nullptr, nullptr, 0, nullptr, nullptr, dropped);
         }
         const uint32_t nblk = (ntiles + 1023) / 1024;
         {
@@ -780,49 +946,21 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
         }
         {
             AST_PROF("paint_tiled.fill", s);
-            tile_index_kernel<T, W, 1><<<ga, 256, 0, s>>>(pos, np, g, nullptr, w.tile_off, w.tile_fill, w.index, 0, nullptr,
-                                                           nullptr, nullptr);
+            index_pass(std::integral_constant<int, 1>{}, nullptr, w.tile_off, w.tile_fill, w.index, 0, nullptr, nullptr, nullptr);
         }
-        if (overwrite) {
-            {
-                AST_PROF("paint_tiled.deposit", s);
-                if (mass)
-                    column_deposit_kernel<T, W, true><<<ncols, 256, 0, s>>>(pos, mass, g, scale, w.index, w.tile_off, w.tile_count,
-                                                                            0, mass_bound, grid, (T*)w.rec, dropped);
-                else
-                    column_deposit_kernel<T, W, false><<<ncols, 256, 0, s>>>(pos, mass, g, scale, w.index, w.tile_off, w.tile_count,
-                                                                             0, 1.0, grid, (T*)w.rec, dropped);
-            }
-            AST_PROF("paint_tiled.fold", s);
-            column_fold_kernel<T, W><<<ncols, 256, 0, s>>>((const T*)w.rec, g, grid);
-        } else {
-            AST_PROF("paint_tiled.deposit", s);
-            tile_deposit_kernel<T, W><<<ntiles, 256, 0, s>>>(pos, mass, g, scale, w.index, w.tile_off, w.tile_count, 0,
-                                                             grid, dropped);
-        }
+        deposit_pass(w.tile_off, w.tile_count, 0);
     } else {
         {
             AST_PROF("paint_tiled.fill", s);
-            tile_index_kernel<T, W, 2><<<ga, 256, 0, s>>>(pos, np, g, nullptr, nullptr, w.tile_fill, w.index, w.cap, w.ovf,
-                                                           w.ovf_count, dropped);
+            index_pass(std::integral_constant<int, 2>{}, nullptr, nullptr, w.tile_fill, w.index, w.cap, w.ovf, w.ovf_count, dropped);
         }
-        if (overwrite) {
-            {
-                AST_PROF("paint_tiled.deposit", s);
-                if (mass)
-                    column_deposit_kernel<T, W, true><<<ncols, 256, 0, s>>>(pos, mass, g, scale, w.index, nullptr, w.tile_fill, w.cap,
-                                                                            mass_bound, grid, (T*)w.rec, dropped);
-                else
-                    column_deposit_kernel<T, W, false><<<ncols, 256, 0, s>>>(pos, mass, g, scale, w.index, nullptr, w.tile_fill, w.cap,
-                                                                             1.0, grid, (T*)w.rec, dropped);
-            }
-            AST_PROF("paint_tiled.fold", s);
-            column_fold_kernel<T, W><<<ncols, 256, 0, s>>>((const T*)w.rec, g, grid);
-        } else {
-            AST_PROF("paint_tiled.deposit", s);
-            tile_deposit_kernel<T, W><<<ntiles, 256, 0, s>>>(pos, mass, g, scale, w.index, nullptr, w.tile_fill, w.cap, grid,
-                                                             dropped);
+        deposit_pass(nullptr, w.tile_fill, w.cap);
+#ifdef PAINT_WALK_TEST
+        {
+            AST_PROF("paint_tiled.walktest", s);
+            walk_test_kernel<T><<<ncols, 256, 0, s>>>(pos, g, w.index, w.tile_fill, w.cap, (T*)w.rec);
         }
+#endif
         AST_PROF("paint_tiled.overflow", s);
         overflow_deposit_kernel<T, W><<<1024, 256, 0, s>>>(pos, mass, w.ovf, w.ovf_count, g, scale, grid, dropped);
     }
@@ -832,11 +970,22 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
 
 }  // namespace
 
+#ifdef PAINT_STAMPS
+extern "C" int ast_debug_stamps(unsigned long long* stamps_host, unsigned* counts_host) {
+    AST_CHECK_HIP(hipDeviceSynchronize());
+    AST_CHECK_HIP(hipMemcpyFromSymbol(stamps_host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64 * 4096));
+    AST_CHECK_HIP(hipMemcpyFromSymbol(counts_host, HIP_SYMBOL(g_nstamp), sizeof(unsigned) * 64));
+    unsigned zero[64] = {0};
+    AST_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_nstamp), zero, sizeof(zero)));
+    return AST_OK;
+}
+#endif
+
 extern "C" size_t ast_paint_tiled_workspace_bytes(int window, int dtype, size_t np, int nmesh, int nx_alloc, int flags) {
     TileGeom g;
     uint32_t ntiles = 0;
     if (nmesh <= 0 || nx_alloc <= 0 || !tiled_geometry(nmesh, nx_alloc, g, ntiles)) return 0;
-    return carve(nullptr, np, ntiles, (flags & AST_PAINT_TWO_PASS) != 0,
+    return carve(nullptr, np, ntiles, (uint32_t)(g.ntx * g.nty), (flags & AST_PAINT_TWO_PASS) != 0,
                  record_bytes(window, g, dtype == AST_F32 ? 4 : 8, flags)).bytes;
 }
 
@@ -866,7 +1015,7 @@ extern "C" int ast_paint_tiled(int window, int dtype, const void* pos, const voi
     }
     g.x_start = x_start;
     g.inv_dx = (double)nmesh / boxsize;
-    const size_t need = carve(nullptr, np, ntiles, (flags & AST_PAINT_TWO_PASS) != 0,
+    const size_t need = carve(nullptr, np, ntiles, (uint32_t)(g.ntx * g.nty), (flags & AST_PAINT_TWO_PASS) != 0,
                               record_bytes(window, g, dtype == AST_F32 ? 4 : 8, flags)).bytes;
     if (workspace_bytes < need) {
         ast::set_error("ast_paint_tiled: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
