@@ -68,6 +68,21 @@ __device__ unsigned g_nstamp[64];
 #define STAMP(id) do {} while (0)
 #define STAMP_END do {} while (0)
 #endif
+#if defined(PAINT_STAMPS) && PAINT_STAMPS == 2      // stamps in the index kernel instead of the deposit kernel
+#define FSTAMP_DECL STAMP_DECL
+#define FSTAMP(id) STAMP(id)
+#define FSTAMP_END STAMP_END
+#define DSTAMP_DECL
+#define DSTAMP(id) do {} while (0)
+#define DSTAMP_END do {} while (0)
+#else
+#define FSTAMP_DECL
+#define FSTAMP(id) do {} while (0)
+#define FSTAMP_END do {} while (0)
+#define DSTAMP_DECL STAMP_DECL
+#define DSTAMP(id) STAMP(id)
+#define DSTAMP_END STAMP_END
+#endif
 
 struct TileGeom {
     int n, x_start, nx_alloc;
@@ -138,6 +153,22 @@ constexpr int AGG_SLOTS = 256;     // direct-mapped by (tile id & 255)
 constexpr uint32_t SLOT_EMPTY = 0xffffffffu;
 constexpr uint32_t CODE_DONE = 0xffffffffu;
 
+// A run of consecutive particle ids placed by one thread: slots from the tile's counter, then the
+// ids.  Deliberately NOT inlined: its returning atomics and stores would otherwise share registers
+// with the caller's common path, and the compiler then guards that path with s_waitcnt vmcnt(0),
+// i.e. waits for the prefetched positions at every particle.
+template <int MODE>
+__device__ __noinline__ void place_run_slow(uint32_t key, uint32_t p1, uint32_t len, const uint32_t* __restrict__ tile_off,
+                                            uint32_t* __restrict__ tile_fill, uint32_t* __restrict__ index, uint32_t cap,
+                                            uint32_t* __restrict__ ovf, unsigned long long* __restrict__ ovf_count) {
+    const uint32_t b = atomicAdd(&tile_fill[key], len);
+    for (uint32_t i = 0; i < len; ++i) {
+        if (MODE == 1) index[(size_t)tile_off[key] + b + i] = p1 + i;
+        else if (b + i < cap) index[(size_t)key * cap + b + i] = p1 + i;
+        else ovf[atomicAdd(ovf_count, 1ull)] = p1 + i;
+    }
+}
+
 // Both passes walk the particle array in contiguous intervals of 4096 particles
 // per workgroup.  Global atomics are the bottleneck of a naive version (one per
 // run: ~2/3 of the kernel time), so run heads first combine into a small
@@ -164,29 +195,42 @@ tile_index_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t* __
     __shared__ uint32_t skey[AGG_SLOTS], scnt[AGG_SLOTS], sroom[AGG_SLOTS];
     __shared__ unsigned long long sdst[AGG_SLOTS];
     __shared__ uint32_t codes[FILL ? AGG_TRIPS * IDX_UNROLL : 1][256];
+    constexpr uint32_t MISS_CAP = FILL ? 512 : 1;
+    __shared__ uint32_t smiss_key[MISS_CAP], smiss_p[MISS_CAP], smiss_len[MISS_CAP], smiss_n;
+    FSTAMP_DECL;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     skey[tid] = SLOT_EMPTY;
     scnt[tid] = 0;
+    if (tid == 0) smiss_n = 0;
     __syncthreads();
     const size_t per_trip = 256 * IDX_UNROLL;
     const size_t per_interval = per_trip * AGG_TRIPS;
     const size_t nintervals = (np + per_interval - 1) / per_interval;
     unsigned long long ndrop = 0;
+    // positions are fetched one trip ahead (two register sets, used alternately; the last trip of an
+    // interval fetches the first trip of the workgroup's next interval, across its flush)
+    auto fetch = [&](size_t pbase, T (&x)[IDX_UNROLL], T (&y)[IDX_UNROLL], T (&z)[IDX_UNROLL]) {
+#pragma unroll
+        for (int u = 0; u < IDX_UNROLL; ++u) {
+            // unconditional (lanes past the end re-load the last particle): a predicated load
+            // costs a branch and a full s_waitcnt each, i.e. IDX_UNROLL serial round trips
+            const size_t p = min(pbase + (size_t)u * 256 + tid, np - 1);
+            x[u] = pos[3 * p + 0];
+            y[u] = pos[3 * p + 1];
+            z[u] = pos[3 * p + 2];
+        }
+    };
+    auto place_run = [&](uint32_t key, uint32_t p1, uint32_t len) {
+        place_run_slow<MODE>(key, p1, len, tile_off, tile_fill, index, cap, ovf, ovf_count);
+    };
+    static_assert(AGG_TRIPS % 2 == 0, "two register sets");
+    T xa[IDX_UNROLL], ya[IDX_UNROLL], za[IDX_UNROLL], xb[IDX_UNROLL], yb[IDX_UNROLL], zb[IDX_UNROLL];
+    if ((size_t)blockIdx.x < nintervals) fetch((size_t)blockIdx.x * per_interval, xa, ya, za);
     for (size_t interval = blockIdx.x; interval < nintervals; interval += gridDim.x) {
         const size_t p0 = interval * per_interval;
         const bool full = p0 + per_interval <= np;            // uniform: no lane of the interval is past the end
-        for (int trip = 0; trip < AGG_TRIPS; ++trip) {
-            T x[IDX_UNROLL], y[IDX_UNROLL], z[IDX_UNROLL];
-#pragma unroll
-            for (int u = 0; u < IDX_UNROLL; ++u) {
-                // unconditional (lanes past the end re-load the last particle): a predicated load
-                // costs a branch and a full s_waitcnt each, i.e. IDX_UNROLL serial round trips
-                const size_t p = min(p0 + (size_t)trip * per_trip + (size_t)u * 256 + tid, np - 1);
-                x[u] = pos[3 * p + 0];
-                y[u] = pos[3 * p + 1];
-                z[u] = pos[3 * p + 2];
-            }
+        auto process = [&](int trip, const T (&x)[IDX_UNROLL], const T (&y)[IDX_UNROLL], const T (&z)[IDX_UNROLL]) {
 #pragma unroll
             for (int u = 0; u < IDX_UNROLL; ++u) {
                 const size_t p = p0 + (size_t)trip * per_trip + (size_t)u * 256 + tid;
@@ -196,34 +240,55 @@ tile_index_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t* __
                 const bool live = key != 0xffffffffu;
                 if (!PLAINX && valid && !live) ++ndrop;
                 const WaveRuns r = wave_runs(key, live, lane);
-                bool hit = true;
-                uint32_t val = 0;               // hit: slot << 16 | offset in the interval; miss: global slot
+                bool parked = false;            // run handled outside the table (miss list, or placed by its head lane)
+                uint32_t val = 0;               // slot << 16 | offset in the interval
                 if (r.head) {
-                    const uint32_t slot = key & (AGG_SLOTS - 1);
+                    const uint32_t slot = (key * 2654435761u) >> 24;      // 256 slots; a plain mask maps the x / y neighbour columns (tile id +- 4096, +- 32) onto the column's own slots
                     const uint32_t old = atomicCAS(&skey[slot], SLOT_EMPTY, key);
-                    hit = old == SLOT_EMPTY || old == key;
-                    if (hit) val = (slot << 16) | atomicAdd(&scnt[slot], (uint32_t)r.len);
-                    else if (MODE == 0) atomicAdd(&tile_count[key], (uint32_t)r.len);
-                    else if (MODE == 1) val = tile_off[key] + atomicAdd(&tile_fill[key], (uint32_t)r.len);
-                    else val = atomicAdd(&tile_fill[key], (uint32_t)r.len);      // slot inside the tile's segment
+                    if (old == SLOT_EMPTY || old == key) {
+                        val = (slot << 16) | atomicAdd(&scnt[slot], (uint32_t)r.len);
+                    } else if (MODE == 0) {
+                        atomicAdd(&tile_count[key], (uint32_t)r.len);
+                    } else {
+                        // the slot belongs to another tile.  A returning global atomic here would park the
+                        // whole wave for a memory round trip (with half-cell jitter ~85 % of the waves
+                        // hold a stray of a neighbour column), so the run - consecutive particle ids -
+                        // goes to a list that is placed once per interval, all atomics in flight together.
+                        // Nothing the common path reads may depend on a vector-memory result: the
+                        // compiler would wait for the prefetched positions with it.
+                        parked = true;
+                        const uint32_t mi = atomicAdd(&smiss_n, 1u);
+                        if (mi < MISS_CAP) {
+                            smiss_key[mi] = key;
+                            smiss_p[mi] = (uint32_t)p;
+                            smiss_len[mi] = (uint32_t)r.len;
+                        } else {
+                            place_run(key, (uint32_t)p, (uint32_t)r.len);      // list full (scattered input)
+                        }
+                    }
                 }
                 if (FILL) {
                     const uint32_t valb = __shfl(val, r.head_lane, 64) + (uint32_t)(lane - r.head_lane);
                     uint32_t code = live ? valb : CODE_DONE;
-                    if (__any(!hit)) {                    // uniform and rare: some run lost its slot to another tile
-                        const int hitb = __shfl((int)hit, r.head_lane, 64);
-                        if (live && !hitb) {
-                            code = CODE_DONE;
-                            if (MODE == 1) index[valb] = (uint32_t)p;
-                            else if (valb < cap) index[(size_t)key * cap + valb] = (uint32_t)p;
-                            else ovf[atomicAdd(ovf_count, 1ull)] = (uint32_t)p;
-                        }
+                    if (__any(parked)) {                  // uniform
+                        if (__shfl((int)parked, r.head_lane, 64)) code = CODE_DONE;
                     }
                     codes[trip * IDX_UNROLL + u][tid] = code;
                 }
             }
+        };
+#pragma unroll
+        for (int trip = 0; trip < AGG_TRIPS; trip += 2) {
+            FSTAMP(1);
+            fetch(p0 + (size_t)(trip + 1) * per_trip, xb, yb, zb);
+            process(trip, xa, ya, za);
+            FSTAMP(2);
+            fetch(trip + 2 < AGG_TRIPS ? p0 + (size_t)(trip + 2) * per_trip : (interval + gridDim.x) * per_interval, xa, ya, za);
+            process(trip + 1, xb, yb, zb);
+            FSTAMP(2);
         }
         __syncthreads();
+        FSTAMP(3);
         if (skey[tid] != SLOT_EMPTY) {
             const uint32_t t = skey[tid], c = scnt[tid];
             if (MODE == 0) atomicAdd(&tile_count[t], c);
@@ -234,8 +299,17 @@ tile_index_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t* __
                 sroom[tid] = cap - base;
             }
         }
-        __syncthreads();
         if (FILL) {
+            const uint32_t nm = min(smiss_n, MISS_CAP);
+            for (uint32_t e = tid; e < nm; e += 256) {
+                place_run(smiss_key[e], smiss_p[e], smiss_len[e]);
+            }
+        }
+        FSTAMP(4);
+        __syncthreads();
+        FSTAMP(5);
+        if (FILL) {
+            if (tid == 0) smiss_n = 0;
 #pragma unroll 4
             for (int j = 0; j < AGG_TRIPS * IDX_UNROLL; ++j) {
                 const uint32_t c = codes[j][tid];
@@ -248,8 +322,11 @@ tile_index_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t* __
         }
         skey[tid] = SLOT_EMPTY;
         scnt[tid] = 0;
+        FSTAMP(6);
         __syncthreads();
+        FSTAMP(7);
     }
+    FSTAMP_END;
     if (MODE != 1 && dropped && ndrop) atomicAdd(dropped, ndrop);
 }
 
@@ -485,7 +562,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     // they are and the flush only has to re-arm the TZ slots it stored.
     __shared__ unsigned long long tile[LX * LY * LZ];        // ((a * LY + b) * LZ + slot), slot fastest
     const int col = blockIdx.x;
-    STAMP_DECL;
+    DSTAMP_DECL;
     const int ty = col % g.nty, tx = col / g.nty;
     const int ox = tx * TX, oy = ty * TY;
     const bool x_periodic = g.nx_alloc == g.n;
@@ -663,57 +740,80 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     int ftz = 0;                            // next tile to flush; the ring is positioned for it
     auto flush_until = [&](int tz_end) {
         for (; ftz < tz_end; ++ftz) {
-            STAMP(5);
+            DSTAMP(5);
             if (!(ablate & 64)) __syncthreads();
-            STAMP(6);
+            DSTAMP(6);
 
             // planes c = 0..TZ-1 are final (z = ftz * TZ - LO + c): store them and re-arm their slots.
-            // A thread keeps its plane c and walks the (a, b) columns; everything but the value
-            // comes from the per-column table.
-            static_assert(256 % TZ == 0, "flush mapping");
-            const int c = threadIdx.x % TZ;
-            int sl = c + sh;
-            sl = sl >= LZ ? sl - LZ : sl;
-            const int z = ast::wrap1(phys(ftz) * TZ - LO + c, g.n);
+            // A thread keeps its VW consecutive planes (one 16-byte store: the flush is bound by the
+            // rate at which a CU issues stores, and dword stores move a quarter of the bytes per
+            // instruction) and walks the (a, b) columns; everything but the values comes from the
+            // per-column table.
+            constexpr int VW = 16 / (int)sizeof(T), LPC = TZ / VW, CPI = 256 / LPC;    // values per lane, lanes per column, columns per sweep
+            static_assert(TZ % VW == 0 && 256 % LPC == 0, "flush mapping");
+            typedef T vec_t __attribute__((ext_vector_type(VW), aligned(4)));
+            const int c0 = (threadIdx.x % LPC) * VW;
+            int sl[VW];
+            sl[0] = c0 + sh;
+            sl[0] = sl[0] >= LZ ? sl[0] - LZ : sl[0];
 #pragma unroll
-            for (int k = 0; k < (LX * LY * TZ + 255) / 256; ++k) {
-                const int ab = threadIdx.x / TZ + k * (256 / TZ);
+            for (int i = 1; i < VW; ++i) sl[i] = sl[i - 1] + 1 == LZ ? 0 : sl[i - 1] + 1;
+            const int z0 = phys(ftz) * TZ - LO + c0;
+            const bool straight = z0 >= 0 && z0 + VW <= g.n;          // no periodic wrap inside the vector
+#pragma unroll
+            for (int k = 0; k < (LX * LY + CPI - 1) / CPI; ++k) {
+                const int ab = threadIdx.x / LPC + k * CPI;
                 if (ab >= LX * LY || (ablate & 128)) break;
-                const unsigned long long raw = tile[ab * LZ + sl];
-                tile[ab * LZ + sl] = BIAS;
-                const unsigned long long d = dest[ab];
-                T v;
-                if (RAW) {
-                    const unsigned long long dbits = (raw & 0x0000ffffffffffffull) | 0x4330000000000000ull;
-                    v = (T)((__longlong_as_double((long long)dbits) - 4644337115725824.0) * q);      // 2^52 + 2^47
-                } else {
-                    v = (T)((double)(long long)raw * q);
+                vec_t v;
+#pragma unroll
+                for (int i = 0; i < VW; ++i) {
+                    const unsigned long long raw = tile[ab * LZ + sl[i]];
+                    tile[ab * LZ + sl[i]] = BIAS;
+                    if (RAW) {
+                        const unsigned long long dbits = (raw & 0x0000ffffffffffffull) | 0x4330000000000000ull;
+                        v[i] = (T)((__longlong_as_double((long long)dbits) - 4644337115725824.0) * q);      // 2^52 + 2^47
+                    } else {
+                        v[i] = (T)((double)(long long)raw * q);
+                    }
                 }
+                const unsigned long long d = dest[ab];
                 if ((ablate & 1) || d == 0ull) continue;
-                ((T*)(d & ~1ull))[z] = v;
-                if (!x_periodic && (d & 1ull) && v != (T)0) ++ndrop;
+                // (global address space spelled out: a pointer rebuilt from an integer is "flat")
+                typedef __attribute__((address_space(1))) T gT;
+                typedef __attribute__((address_space(1))) vec_t gvec_t;
+                gT* const line = (gT*)(d & ~1ull);
+                if (straight) {
+                    *(gvec_t*)(line + z0) = v;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < VW; ++i) line[ast::wrap1(z0 + i, g.n)] = v[i];
+                }
+                if (!x_periodic && (d & 1ull)) {
+#pragma unroll
+                    for (int i = 0; i < VW; ++i) ndrop += v[i] != (T)0;
+                }
             }
             sh += TZ;
             sh = sh >= LZ ? sh - LZ : sh;
-            STAMP(7);
+            DSTAMP(7);
             if (!(ablate & 64)) __syncthreads();
-            STAMP(8);
+            DSTAMP(8);
         }
     };
-    STAMP(0);
+    DSTAMP(0);
     for (;;) {
         flush_until(cur.tz);
         if (cur.tz >= g.ntz) break;
         oz = phys(cur.tz) * TZ;
         {
-            STAMP(1);
+            DSTAMP(1);
             const Batch nn = next_batch(nxt);
-            STAMP(2);
+            DSTAMP(2);
             load_pos(iX, pB, mB);                         // batch k+1 (a harmless re-load at the end)
             load_idx(nn, iY);                             // batch k+2
-            STAMP(3);
+            DSTAMP(3);
             if (careful) deposit(pA, mA, std::true_type{}); else deposit(pA, mA, std::false_type{});
-            STAMP(4);
+            DSTAMP(4);
             cur = nxt;
             nxt = nn;
         }
@@ -721,20 +821,20 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
         if (cur.tz >= g.ntz) break;
         oz = phys(cur.tz) * TZ;
         {
-            STAMP(1);
+            DSTAMP(1);
             const Batch nn = next_batch(nxt);
-            STAMP(2);
+            DSTAMP(2);
             load_pos(iY, pA, mA);
             load_idx(nn, iX);
-            STAMP(3);
+            DSTAMP(3);
             if (careful) deposit(pB, mB, std::true_type{}); else deposit(pB, mB, std::false_type{});
-            STAMP(4);
+            DSTAMP(4);
             cur = nxt;
             nxt = nn;
         }
     }
-    STAMP(9);
-    STAMP_END;
+    DSTAMP(9);
+    DSTAMP_END;
 
     // the H planes still in the ring hold z = n - LO + k (k < H), i.e. the periodic wrap onto planes
     // this workgroup stored at its first tile: add them where they were stored
@@ -794,38 +894,66 @@ walk_test_kernel(const T* __restrict__ pos, TileGeom g, const uint32_t* __restri
 }
 #endif
 
-// Every column adds its neighbours' halo records into its own border rows.
+// Every column adds its neighbours' halo records into its own border rows.  Only the border cells
+// have anything to add (15 of 64 for CIC, 28 for TSC), each from at most 3 neighbours: a small
+// table of (grid line, up to 3 record lines) is built in LDS and then walked with 16-byte
+// loads/stores along z, sources added in a fixed order.
 template <typename T, int W>
 __global__ void __launch_bounds__(256)
 column_fold_kernel(const T* __restrict__ rec, TileGeom g, T* __restrict__ grid) {
     constexpr int LO = Window<W>::LO;
     using RM = RingMap<W>;
+    constexpr int VW = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VW)));          // lines are 16-byte aligned (n % 32 == 0)
+    __shared__ unsigned long long line_dst[TX * TY], line_src[TX * TY][3];
+    __shared__ int nlines;
     const int col = blockIdx.x;
     const int ty = col % g.nty, tx = col / g.nty;
     const int ox = tx * TX, oy = ty * TY;
     const bool x_periodic = g.nx_alloc == g.n;
-    for (int idx = threadIdx.x; idx < TX * TY * g.n; idx += 256) {
-        const int z = idx % g.n, cellid = idx / g.n;
-        const int ao = cellid / TY, bo = cellid % TY;                 // owned cell of this column
-        if (ox + ao >= g.nx_alloc) continue;
-        T sum = (T)0;
-        bool any = false;
+    if (threadIdx.x == 0) nlines = 0;
+    __syncthreads();
+    if (threadIdx.x < TX * TY) {
+        const int ao = threadIdx.x / TY, bo = threadIdx.x % TY;       // owned cell of this column
+        unsigned long long src[3] = {0ull, 0ull, 0ull};
+        int ns = 0;
+        if (ox + ao < g.nx_alloc) {
 #pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
+            for (int dx = -1; dx <= 1; ++dx) {
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy) {
-                if (dx == 0 && dy == 0) continue;
-                const int a = ao + LO - dx * TX, b = bo + LO - dy * TY;   // this cell in the neighbour's LDS frame
-                if (a < 0 || a >= RM::LX || b < 0 || b >= RM::LY) continue;
-                int ntx = tx + dx;
-                if (x_periodic) ntx = ast::wrap1(ntx, g.ntx);
-                else if (ntx < 0 || ntx >= g.ntx) continue;
-                const int nty_ = ast::wrap1(ty + dy, g.nty);
-                sum += rec[((size_t)(ntx * g.nty + nty_) * RM::COUNT + RM::cell(a, b)) * g.n + z];
-                any = true;
+                for (int dy = -1; dy <= 1; ++dy) {
+                    if (dx == 0 && dy == 0) continue;
+                    const int a = ao + LO - dx * TX, b = bo + LO - dy * TY;   // this cell in the neighbour's LDS frame
+                    if (a < 0 || a >= RM::LX || b < 0 || b >= RM::LY) continue;
+                    int ntx = tx + dx;
+                    if (x_periodic) ntx = ast::wrap1(ntx, g.ntx);
+                    else if (ntx < 0 || ntx >= g.ntx) continue;
+                    const int nty_ = ast::wrap1(ty + dy, g.nty);
+                    if (ns < 3) src[ns++] = (unsigned long long)(rec + ((size_t)(ntx * g.nty + nty_) * RM::COUNT + RM::cell(a, b)) * g.n);
+                }
             }
         }
-        if (any) grid[((size_t)(ox + ao) * g.n + oy + bo) * g.n + z] += sum;
+        if (ns) {
+            const int k = atomicAdd(&nlines, 1);
+            line_dst[k] = (unsigned long long)(grid + ((size_t)(ox + ao) * g.n + oy + bo) * g.n);
+            line_src[k][0] = src[0];
+            line_src[k][1] = src[1];
+            line_src[k][2] = src[2];
+        }
+    }
+    __syncthreads();
+    const int per_line = g.n / VW;
+    const int items = nlines * per_line;
+    for (int it = threadIdx.x; it < items; it += 256) {
+        const int k = it / per_line, zc = (it % per_line) * VW;
+        typedef __attribute__((address_space(1))) vec_t gvec_t;
+        gvec_t* const dst = (gvec_t*)((__attribute__((address_space(1))) T*)line_dst[k] + zc);
+        // sum of the neighbours first, then onto the cell (the slot order of the table is not
+        // deterministic, the order within a cell is)
+        vec_t sum = *(const gvec_t*)((__attribute__((address_space(1))) T*)line_src[k][0] + zc);
+        if (line_src[k][1]) sum += *(const gvec_t*)((__attribute__((address_space(1))) T*)line_src[k][1] + zc);
+        if (line_src[k][2]) sum += *(const gvec_t*)((__attribute__((address_space(1))) T*)line_src[k][2] + zc);
+        *dst = *dst + sum;
     }
 }
 

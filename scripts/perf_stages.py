@@ -16,7 +16,7 @@ for order in orders:
         dev.paint(pos, None, n, L, window, out=grid, method=METHOD, check_dropped=False, accumulate=ACC)
     torch.cuda.synchronize()
     dev.profile_enable(True)
-    reps = 5
+    reps = int(os.environ.get("REPS", "20"))
     for _ in range(reps):
         dev.paint(pos, None, n, L, window, out=grid, method=METHOD, check_dropped=False, accumulate=ACC)
     torch.cuda.synchronize()

@@ -16,6 +16,8 @@ for rep in range(2):
     dev.paint(pos, None, n, L, window, out=grid, method="tiled", check_dropped=False, accumulate=False)
     torch.cuda.synchronize()
     f(st.ctypes.data, cn.ctypes.data)          # read + reset; keep the second (warm) run
+if os.environ.get("FILL"):
+    names0 = {1: "(gap)", 2: "trip", 3: "barrier 1", 4: "table flush+misses", 5: "barrier 2", 6: "scatter", 7: "barrier 3"}
 names = {0: "start", 1: "iter", 2: "next_batch", 3: "issue loads", 4: "deposit", 5: "pre-flush", 6: "barrier A", 7: "flush", 8: "barrier B", 9: "end"}
 tot = collections.Counter(); cnt = collections.Counter(); span = []
 for w in range(64):
@@ -28,5 +30,7 @@ for w in range(64):
         tot[ids[i]] += t[i] - t[i - 1]; cnt[ids[i]] += 1
 print(f"{len(span)} sampled workgroups, mean lifetime {np.mean(span):.0f} ticks (s_memtime: 100 MHz constant clock if ticks look small)")
 allt = sum(tot.values())
+if os.environ.get("FILL"):
+    names = names0
 for i in sorted(tot):
     print(f"  ends at {names.get(i, i):12s}: {100 * tot[i] / allt:5.1f} % of lifetime, {cnt[i] / len(span):6.1f} per workgroup, mean {tot[i] / cnt[i]:8.0f} ticks")
