@@ -77,7 +77,10 @@ __device__ inline void fft_reg(float2 (&v)[R]) {
 // is written out as one row of `partial` ([workgroup][shell], summed by
 // shell_partials_reduce_kernel in a fixed order).  The spectrum never goes back to HBM.
 __device__ inline int tile_isqrt(int v) {
-    int r = (int)__fsqrt_rn((float)v);
+    // raw v_sqrt_f32 (1 ulp) is enough: v < 2^24 is exact in float and the two integer checks
+    // repair an estimate that is off by one either way (a correctly rounded sqrtf costs ~10 more
+    // instructions per mode, and this epilogue is half of the pass's vector work)
+    int r = (int)__builtin_amdgcn_sqrtf((float)v);
     if (r * r > v) --r;
     if ((r + 1) * (r + 1) <= v) ++r;
     return r;
@@ -108,9 +111,12 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
     {                                                 // stage 1: task (c, n2 = sub)
         const bool task1 = sub < R2;
         float2 v[R1];
+        // unconditional loads (columns past the end re-read the last valid one, idle sub-tasks the
+        // last row block): predicated loads compile to a branch each
+        const float2* lbase = data + (size_t)b * batch_stride + min(c0 + c, ncols - 1);
+        const int lsub = task1 ? sub : R2 - 1;
 #pragma unroll
-        for (int n1 = 0; n1 < R1; ++n1)
-            v[n1] = (col_ok && task1) ? base[(size_t)(n1 * R2 + sub) * elem_stride] : make_float2(0.f, 0.f);
+        for (int n1 = 0; n1 < R1; ++n1) v[n1] = lbase[(size_t)(n1 * R2 + lsub) * elem_stride];
         fft_reg<R1>(v);
         __syncthreads();                              // twiddle table is in LDS
         if (task1) {
@@ -151,7 +157,9 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
             const int row = sub + R1 * k2;
             const int kx = row > N / 2 ? row - N : row;
             const int sh = tile_isqrt(kx * kx + m2yz);                  // shell = sh - 1; 0 is DC
-            if (sh >= 1 && sh <= NB) atomicAdd(&shell[sh], (double)x.x * (double)x.x * w + (double)x.y * (double)x.y * w);
+            // |delta_k|^2 in fp32 (one rounding of 6e-8 per mode, random over the >= 18 modes of a
+            // shell), accumulated in double
+            if (sh >= 1 && sh <= NB) atomicAdd(&shell[sh], (double)(fmaf(x.x, x.x, x.y * x.y) * w));
         }
     }
     if (POWER) {
@@ -193,13 +201,13 @@ rows_r2c_kernel(const float* __restrict__ in, float2* __restrict__ out, const fl
 
     const size_t row0 = (size_t)blockIdx.x * C;
     const int n2 = threadIdx.x % R2, r = threadIdx.x / R2;        // stage-1 task (r, n2)
-    const bool row_ok = row0 + r < nrows;
     {
-        const float2* zin = reinterpret_cast<const float2*>(in + (row0 + r) * in_pitch);   // z[j] = x[2j] + i x[2j+1]
+        // z[j] = x[2j] + i x[2j+1]; rows past the end re-read the last one (unconditional loads)
+        const float2* zin = reinterpret_cast<const float2*>(in + min(row0 + r, nrows - 1) * in_pitch);
         float2 v[R1];
 #pragma unroll
         for (int n1 = 0; n1 < R1; ++n1) {
-            v[n1] = row_ok ? zin[n1 * R2 + n2] : make_float2(mean, mean);
+            v[n1] = zin[n1 * R2 + n2];
             v[n1].x -= mean;                 // only the (discarded) DC mode sees the offset; fp32 round-off
             v[n1].y -= mean;                 // of every other mode no longer scales with it
         }
