@@ -10,7 +10,8 @@ L = 1000.0
 ACC = os.environ.get("ACC", "0") == "1"
 METHOD = os.environ.get("METHOD", "tiled")
 for order in orders:
-    pos = dev.synth_lattice_particles(n, n, L, shuffle=(order == "shuffled"), dtype=torch.float32)
+    pos = dev.synth_lattice_particles(n, n, L, shuffle=(order == "shuffled"), dtype=torch.float32,
+                                      sigma_cells=float(os.environ.get("SIGMA", "0.5")))
     grid = torch.zeros((n, n, n), dtype=torch.float32, device="cuda")
     for _ in range(2):
         dev.paint(pos, None, n, L, window, out=grid, method=METHOD, check_dropped=False, accumulate=ACC)
