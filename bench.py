@@ -112,6 +112,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    # rehearsal of the N > 1 code path on a one-GPU box (timings are meaningless there):
+    # ASTRILD_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo instead of RCCL
+    rehearsal = os.environ.get("ASTRILD_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
     use_slab = world > 1 or bool(args.slab)
@@ -121,7 +126,10 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from astrild_amd import device as dev
     n = args.ngrid

@@ -108,3 +108,30 @@ def test_slab_pipeline_object_on_one_gpu_over_nccl(hip):
         np.testing.assert_allclose(res["power"], ref["power"], rtol=5e-6)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,dt,rtol", [(2, 64, "f64", 1e-9), (4, 256, "f32", 3e-5)])
+def test_ranks_share_one_gpu_over_gloo(hip, tmp_path, world, n, dt, rtol):
+    """The real multi-rank data flow (ghost fold, chunked exchange, all-reduces) with HipSlabOps:
+    `world` processes, all on cuda:0, gloo instead of RCCL (one GPU here), against the single-GPU path."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from astrild_amd import device as dev
+    torch.cuda.set_device(0)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "rank0.npz")
+    worker = os.path.join(os.path.dirname(__file__), "slab_gpu_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(n), out, dt]) for r in range(world)]
+    codes = [p.wait(timeout=300) for p in procs]
+    assert codes == [0] * world
+    got = np.load(out)
+    dtype = torch.float64 if dt == "f64" else torch.float32
+    pos = dev.synth_lattice_particles(n, n, 1000.0, seed=5, dtype=dtype)
+    ref = dev.fftpower_1d(dev.paint(pos, None, n, 1000.0, "cic"), 1000.0)
+    assert np.array_equal(got["modes"], ref["modes"])
+    np.testing.assert_allclose(got["k"], ref["k"], rtol=1e-12)
+    np.testing.assert_allclose(got["power"], ref["power"], rtol=rtol)
