@@ -244,3 +244,23 @@ def test_overwrite_paint_is_bit_reproducible_and_order_independent(dev, window):
     d = dev.paint(nat, mass, n, L, window, method="tiled")
     e = dev.paint(nat, mass, n, L, window, method="tiled")
     assert torch.equal(d, e)
+
+
+@pytest.mark.parametrize("window", ["cic", "tsc"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_tiled_paint_far_outside_the_box_and_on_its_edges(dev, window, dtype):
+    """Positions several box lengths away, exactly on 0 / L / -L and just below 0: the general cell
+    reduction of both tiled kernels (column flags, careful deposit variant) against the oracle."""
+    rng = np.random.default_rng(5)
+    n, L = 64, 100.0
+    far = rng.uniform(-7.5 * L, 9.25 * L, size=(40000, 3))
+    inside = rng.uniform(0, L, size=(40000, 3))
+    edges = np.array([[0.0, 0.0, 0.0], [L, L, L], [-L, 2 * L, 0.0], [-1e-6, L - 1e-6, 0.5 * L], [3 * L, -4 * L, L],
+                      [L * (1 - 2.0 ** -24), 0.0, L * (1 - 2.0 ** -24)]])
+    pos = np.concatenate([inside, far, edges]).astype(dtype)
+    for method in ("tiled", "tiled2"):
+        got = dev.paint(dev.as_device(pos), None, n, L, window, method=method).cpu().numpy()
+        ref = omesh.paint(pos, None, n, L, window)
+        tol = 1e-11 if dtype == np.float64 else 2e-6
+        np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * ref.max())
+        assert got.sum(dtype=np.float64) == pytest.approx(len(pos), rel=1e-6)
