@@ -1030,7 +1030,12 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
     AST_CHECK_HIP(hipMemsetAsync(w.ovf_count, 0, (size_t)((char*)w.tile_off - (char*)w.ovf_count), s));
     const size_t per_interval = (size_t)256 * IDX_UNROLL * AGG_TRIPS;
     const size_t nintervals = (np + per_interval - 1) / per_interval;
-    const unsigned ga = (unsigned)(nintervals > 8192 ? 8192 : nintervals);
+    // grid of the index pass: ONE interval per workgroup.  Measured at 1024^3: 8192 workgroups of 32
+    // intervals 4.72 ms, 65536 x 4: 4.40, 262144 x 1: 4.28; persistent grids of a few per CU are the
+    // slowest (4.95-5.0): short workgroups keep the CUs' phases mixed and leave no ragged last round.
+    // (The kernel still loops, for inputs beyond 2^31 intervals and for AST_PAINT_INDEX_GRID experiments.)
+    const size_t want = getenv("AST_PAINT_INDEX_GRID") ? (size_t)atol(getenv("AST_PAINT_INDEX_GRID")) : (size_t)0x7fffffff;
+    const unsigned ga = (unsigned)(nintervals > want ? want : nintervals);
     const bool plainx = g.x_start == 0 && g.nx_alloc == g.n;
     auto index_pass = [&](auto mode, uint32_t* tile_count, const uint32_t* tile_off, uint32_t* tile_fill, uint32_t* index,
                           uint32_t cap, uint32_t* ovf, unsigned long long* ovf_count, unsigned long long* drop) {
