@@ -74,8 +74,8 @@ __device__ inline void fft_reg(float2 (&v)[R]) {
 // POWER = true is the last (x) pass of the 3D transform fused with FFTPower's shell
 // binning: batch index = ky, column = kz, row = kx; instead of storing delta_k each
 // thread adds w |delta_k|^2 of its modes into the workgroup's LDS shell table, which
-// is written out as one row of `partial` ([workgroup][shell], summed by
-// shell_partials_reduce_kernel in a fixed order).  The spectrum never goes back to HBM.
+// is written out as one row of `partial` ([workgroup][shell], summed by the
+// shell_partials_stage1/2 kernels in a fixed order).  The spectrum never goes back to HBM.
 __device__ inline int tile_isqrt(int v) {
     // raw v_sqrt_f32 (1 ulp) is enough: v < 2^24 is exact in float and the two integer checks
     // repair an estimate that is off by one either way (a correctly rounded sqrtf costs ~10 more
@@ -169,18 +169,40 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
     }
 }
 
-// psum[bin] += pnorm * sum over workgroups of partial[wg][bin], fixed summation order
+// psum[bin] += pnorm * sum over workgroups of partial[wg][bin], fixed summation order, in two
+// stages that both read whole rows (lanes = consecutive bins): REDUCE_ROWS blocks each add up a
+// contiguous range of workgroup rows, then one block adds those.  (One block per bin striding down
+// the matrix read 8 of every 4096 bytes it touched: 0.15 ms for 138 MB at 1024^3.)
+constexpr int REDUCE_ROWS = 1024;
 __global__ void __launch_bounds__(256)
-shell_partials_reduce_kernel(const double* __restrict__ partial, size_t nwg, int nb, double pnorm,
-                             double* __restrict__ psum) {
-    __shared__ double part[4];
-    const int bin = blockIdx.x;
+shell_partials_stage1_kernel(const double* __restrict__ partial, size_t nwg, int nb, double* __restrict__ partial2) {
+    const size_t per = (nwg + REDUCE_ROWS - 1) / REDUCE_ROWS;
+    const size_t g0 = (size_t)blockIdx.x * per, g1 = g0 + per < nwg ? g0 + per : nwg;
+    for (int bin = threadIdx.x; bin < nb; bin += 256) {
+        double acc = 0.0;
+#pragma unroll 8
+        for (size_t g = g0; g < g1; ++g) acc += partial[g * nb + bin];
+        partial2[(size_t)blockIdx.x * nb + bin] = acc;
+    }
+}
+// 8 bins per block: 32 row groups x 8 bins, each thread adds REDUCE_ROWS / 32 rows, then the groups in order
+__global__ void __launch_bounds__(256)
+shell_partials_stage2_kernel(const double* __restrict__ partial2, int nb, double pnorm, double* __restrict__ psum) {
+    __shared__ double part[32][8];
+    const int b8 = threadIdx.x & 7, grp = threadIdx.x >> 3;
+    const int bin = blockIdx.x * 8 + b8;
     double acc = 0.0;
-    for (size_t g = threadIdx.x; g < nwg; g += 256) acc += partial[g * nb + bin];
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    if (bin < nb) {
+#pragma unroll 8
+        for (int r = grp; r < REDUCE_ROWS; r += 32) acc += partial2[(size_t)r * nb + bin];
+    }
+    part[grp][b8] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) psum[bin] += pnorm * ((part[0] + part[1]) + (part[2] + part[3]));
+    if (grp == 0 && bin < nb) {
+        double t = 0.0;
+        for (int k = 0; k < 32; ++k) t += part[k][b8];
+        psum[bin] += pnorm * t;
+    }
 }
 
 // ------------------------------------------------------- contiguous-row R2C pass
@@ -411,7 +433,9 @@ extern "C" int ast_fft_tile_power_3d(const void* grid, void* scratch, size_t scr
     }
     AST_PROF("fft_tile.shell_reduce", s);
     const int nb = (int)(n / 2 - 1);
-    shell_partials_reduce_kernel<<<nb, 256, 0, s>>>(partial, n * tiles, nb, boxsize * boxsize * boxsize, psum);
+    double* partial2 = (double*)scratch;                   // the spectrum scratch is dead after the x pass
+    shell_partials_stage1_kernel<<<REDUCE_ROWS, 256, 0, s>>>(partial, n * tiles, nb, partial2);
+    shell_partials_stage2_kernel<<<(nb + 7) / 8, 256, 0, s>>>(partial2, nb, boxsize * boxsize * boxsize, psum);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
