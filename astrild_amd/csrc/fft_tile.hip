@@ -16,6 +16,7 @@
 // are C * 8 B = 128 B contiguous per row of the tile; every thread keeps R1 (R2)
 // independent 8-byte loads in flight.
 #include "ast_common.h"
+#include "paint_tile_geom.h"
 #include <cmath>
 #include <mutex>
 #include <vector>
@@ -208,10 +209,15 @@ shell_partials_stage2_kernel(const double* __restrict__ partial2, int nb, double
 // ------------------------------------------------------- contiguous-row R2C pass
 // in: nrows rows of N = 2*M reals (pitch in_pitch reals); out: rows of M+1 complex.
 // M = R1*R2.  One workgroup transforms C rows.
-template <int R1, int R2, int C>
+// FOLDW = 2 / 3 (CIC / TSC): `in` is the grid a deferred-fold paint left (AST_PAINT_DEFER_FOLD) and `rec`
+// its halo records; the up to three record lines that end in a border row are added as the row is
+// loaded — sum of the records first, then onto the row, the order of column_fold_kernel, so the
+// result is bit-identical to folding first.  Rows are (x, y) lines of the periodic n^3 grid.
+template <int R1, int R2, int C, int FOLDW>
 __global__ void __launch_bounds__(C * R2)
 rows_r2c_kernel(const float* __restrict__ in, float2* __restrict__ out, const float2* __restrict__ tw_g,
-                size_t nrows, size_t in_pitch, size_t out_pitch, float scale, float mean) {
+                size_t nrows, size_t in_pitch, size_t out_pitch, float scale, float mean,
+                const float* __restrict__ rec) {
     constexpr int M = R1 * R2, N = 2 * M;
     constexpr int NT = C * R2;
     constexpr int R2P = R2 + 1;
@@ -228,8 +234,42 @@ rows_r2c_kernel(const float* __restrict__ in, float2* __restrict__ out, const fl
         const float2* zin = reinterpret_cast<const float2*>(in + min(row0 + r, nrows - 1) * in_pitch);
         float2 v[R1];
 #pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) v[n1] = zin[n1 * R2 + n2];
+        if (FOLDW != 0) {
+            constexpr int W = FOLDW != 0 ? FOLDW : 2;
+            const int ng = (int)(2 * M);
+            const size_t row = min(row0 + r, nrows - 1);
+            const float* src[3];
+            const int ns = ast::halo_sources<float, W>(rec, (int)(row / ng), (int)(row % ng), ng, ng / ast::TX, ng / ast::TY, src);
+            if (ns > 0) {                    // 15 of 64 rows (CIC); the loads and adds stay inside the branch
+                float2 h[R1];
+#pragma unroll
+                for (int n1 = 0; n1 < R1; ++n1) h[n1] = reinterpret_cast<const float2*>(src[0])[n1 * R2 + n2];
+                if (ns > 1) {
+#pragma unroll
+                    for (int n1 = 0; n1 < R1; ++n1) {
+                        const float2 t = reinterpret_cast<const float2*>(src[1])[n1 * R2 + n2];
+                        h[n1].x += t.x;
+                        h[n1].y += t.y;
+                    }
+                }
+                if (ns > 2) {
+#pragma unroll
+                    for (int n1 = 0; n1 < R1; ++n1) {
+                        const float2 t = reinterpret_cast<const float2*>(src[2])[n1 * R2 + n2];
+                        h[n1].x += t.x;
+                        h[n1].y += t.y;
+                    }
+                }
+#pragma unroll
+                for (int n1 = 0; n1 < R1; ++n1) {
+                    v[n1].x += h[n1].x;
+                    v[n1].y += h[n1].y;
+                }
+            }
+        }
+#pragma unroll
         for (int n1 = 0; n1 < R1; ++n1) {
-            v[n1] = zin[n1 * R2 + n2];
             v[n1].x -= mean;                 // only the (discarded) DC mode sees the offset; fp32 round-off
             v[n1].y -= mean;                 // of every other mode no longer scales with it
         }
@@ -329,21 +369,21 @@ int dispatch_c2c(size_t n, float2* d, const float2* tw, size_t elem_stride, size
     return launch_c2c<16, 16, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s);
 }
 
-template <int R1, int R2, int C>
+template <int R1, int R2, int C, int FOLDW = 0>
 int launch_r2c(const float* in, float2* out, const float2* tw, size_t nrows, size_t in_pitch, size_t out_pitch,
-               float scale, float mean, hipStream_t s) {
+               float scale, float mean, hipStream_t s, const float* rec = nullptr) {
     constexpr int M = R1 * R2, N = 2 * M, NT = C * R2;
     constexpr int BUF = C * (R1 * (R2 + 1) > M + 1 ? R1 * (R2 + 1) : M + 1);
     const size_t lds = (size_t)(BUF + N) * sizeof(float2);
     static bool attr_set = false;
     if (!attr_set) {
-        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rows_r2c_kernel<R1, R2, C>),
+        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rows_r2c_kernel<R1, R2, C, FOLDW>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const size_t blocks = (nrows + C - 1) / C;
     AST_CHECK_ARG(blocks < 0x7fffffffull);
-    rows_r2c_kernel<R1, R2, C><<<(unsigned)blocks, NT, lds, s>>>(in, out, tw, nrows, in_pitch, out_pitch, scale, mean);
+    rows_r2c_kernel<R1, R2, C, FOLDW><<<(unsigned)blocks, NT, lds, s>>>(in, out, tw, nrows, in_pitch, out_pitch, scale, mean, rec);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
@@ -366,7 +406,8 @@ extern "C" int ast_fft_tile_c2c(void* data, int dtype, size_t n, size_t elem_str
 }
 
 static int rows_r2c_impl(const void* in, void* out, int dtype, size_t n, size_t nrows, size_t in_pitch,
-                         size_t out_pitch, double scale, double mean, void* stream) {
+                         size_t out_pitch, double scale, double mean, void* stream, const void* rec = nullptr,
+                         int window = 0) {
     AST_CHECK_ARG(in != nullptr && out != nullptr && in != out && nrows >= 1);
     AST_CHECK_ARG(ast_fft_tile_supported(dtype, n));
     AST_CHECK_ARG(in_pitch >= n && in_pitch % 2 == 0 && out_pitch >= n / 2 + 1);
@@ -376,6 +417,19 @@ static int rows_r2c_impl(const void* in, void* out, int dtype, size_t n, size_t 
     AST_PROF("fft_tile.rows_r2c", s);
     const float* i = (const float*)in;
     float2* o = (float2*)out;
+    if (rec != nullptr) {                    // fold the paint's halo records while loading (whole periodic grid)
+        AST_CHECK_ARG(nrows == n * n && in_pitch == n && (window == AST_WIN_CIC || window == AST_WIN_TSC));
+        const float* h = (const float*)rec;
+        const float sc = (float)scale, mn = (float)mean;
+        if (window == AST_WIN_CIC) {
+            if (n == 1024) return launch_r2c<16, 32, 16, 2>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h);
+            if (n == 512) return launch_r2c<16, 16, 16, 2>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h);
+            return launch_r2c<8, 16, 16, 2>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h);
+        }
+        if (n == 1024) return launch_r2c<16, 32, 16, 3>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h);
+        if (n == 512) return launch_r2c<16, 16, 16, 3>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h);
+        return launch_r2c<8, 16, 16, 3>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h);
+    }
     if (n == 1024) return launch_r2c<16, 32, 16>(i, o, tw, nrows, in_pitch, out_pitch, (float)scale, (float)mean, s);
     if (n == 512) return launch_r2c<16, 16, 16>(i, o, tw, nrows, in_pitch, out_pitch, (float)scale, (float)mean, s);
     return launch_r2c<8, 16, 16>(i, o, tw, nrows, in_pitch, out_pitch, (float)scale, (float)mean, s);
@@ -410,8 +464,25 @@ extern "C" size_t ast_fft_tile_power_scratch_bytes(size_t n) {
 // FFTPower's shell sums of an (n, n, n) real grid without ever writing the spectrum:
 // z pass (R2C) and y pass into `scratch`, x pass fused with the shell binning.
 // psum_d[shell] += L^3 * sum_modes w |delta_k|^2, delta_k = rfftn(grid)/n^3  (auto power only).
+static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, int dtype, size_t n, double boxsize,
+                         double mean, double* psum, const void* rec, int window, void* stream);
+
 extern "C" int ast_fft_tile_power_3d(const void* grid, void* scratch, size_t scratch_bytes, int dtype, size_t n,
                                      double boxsize, double mean, double* psum, void* stream) {
+    return power_3d_impl(grid, scratch, scratch_bytes, dtype, n, boxsize, mean, psum, nullptr, 0, stream);
+}
+
+// The same for a grid painted with AST_PAINT_OVERWRITE | AST_PAINT_DEFER_FOLD: `halo_rec` (from
+// ast_paint_tiled_halo) is folded into the border rows as the z pass loads them.
+extern "C" int ast_fft_tile_power_3d_halo(const void* grid, const void* halo_rec, int window, void* scratch,
+                                          size_t scratch_bytes, int dtype, size_t n, double boxsize, double mean,
+                                          double* psum, void* stream) {
+    AST_CHECK_ARG(halo_rec != nullptr && (window == AST_WIN_CIC || window == AST_WIN_TSC));
+    return power_3d_impl(grid, scratch, scratch_bytes, dtype, n, boxsize, mean, psum, halo_rec, window, stream);
+}
+
+static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, int dtype, size_t n, double boxsize,
+                         double mean, double* psum, const void* rec, int window, void* stream) {
     AST_CHECK_ARG(grid != nullptr && scratch != nullptr && psum != nullptr && boxsize > 0.0);
     AST_CHECK_ARG(ast_fft_tile_supported(dtype, n));
     AST_CHECK_ARG(scratch_bytes >= ast_fft_tile_power_scratch_bytes(n));
@@ -421,7 +492,7 @@ extern "C" int ast_fft_tile_power_3d(const void* grid, void* scratch, size_t scr
     const float2* tw = g_tw.get((int)n);
     if (!tw) { ast::set_error("ast_fft_tile_power_3d: twiddle table allocation failed"); return AST_ERR_HIP; }
     hipStream_t s = ast::as_stream(stream);
-    int rc = rows_r2c_impl(grid, spec, dtype, n, n * n, n, nzp, 1.0, mean, stream);                   // z
+    int rc = rows_r2c_impl(grid, spec, dtype, n, n * n, n, nzp, 1.0, mean, stream, rec, window);      // z
     if (rc != AST_OK) return rc;
     rc = ast_fft_tile_c2c(spec, dtype, n, nzp, nz, n, n * nzp, 1.0, stream);                          // y, per x-plane
     if (rc != AST_OK) return rc;

@@ -28,7 +28,7 @@
 // by a small extra kernel.  Exact for any input; the two-pass variant
 // (AST_PAINT_TWO_PASS) is kept for strongly clustered data.
 #include "ast_common.h"
-#include "paint_window.h"
+#include "paint_tile_geom.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -36,12 +36,10 @@ namespace {
 
 using ast::Window;
 
-#ifndef TILE_TX
-#define TILE_TX 8
-#define TILE_TY 8
-#define TILE_TZ 32
-#endif
-constexpr int TX = TILE_TX, TY = TILE_TY, TZ = TILE_TZ;   // owned cells per tile
+using ast::TX;
+using ast::TY;
+using ast::TZ;
+using ast::RingMap;
 #ifndef PAINT_ABLATE
 #define PAINT_ABLATE 0        // perf experiments only: 1 no flush stores, 2 no LDS atomics, 32 no gather,
                               // 64 no flush barriers, 128 no flush, 256 no deposit arithmetic
@@ -521,18 +519,6 @@ tile_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileG
 // write, contiguous in z).  Every grid cell is written, so no zero-fill is needed, and the
 // 1.3 TB/s global float-atomic flush (4 ms of the 13 ms tile kernel at 1024^3) is gone.
 // The few planes that wrap around the periodic z edge are added atomically at the end.
-template <int W> struct RingMap {            // halo ring of one (LX x LY) plane of the LDS tile
-    static constexpr int HL = Window<W>::LO, HH = W - 1 - Window<W>::LO, H = HL + HH;
-    static constexpr int LX = TX + W - 1, LY = TY + W - 1;
-    static constexpr int COUNT = H * LY + TX * H;
-    __device__ static inline bool owned(int v, int t) { return v >= HL && v < HL + t; }
-    __device__ static inline int to_h(int v, int t) { return v < HL ? v : v - t; }
-    __device__ static inline int cell(int a, int b) {        // (a, b) outside the owned block
-        if (!owned(a, TX)) return to_h(a, TX) * LY + b;
-        return H * LY + (a - HL) * H + to_h(b, TY);
-    }
-};
-
 template <typename T, int W, bool HAS_MASS>
 __global__ void __launch_bounds__(256)
 column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileGeom g, double scale,
@@ -1058,8 +1044,10 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
                     column_deposit_kernel<T, W, false><<<ncols, 256, 0, s>>>(pos, mass, g, scale, w.index, tile_off, tile_count, cap,
                                                                              1.0, w.col_flags, grid, (T*)w.rec, dropped);
             }
-            AST_PROF("paint_tiled.fold", s);
-            column_fold_kernel<T, W><<<ncols, 256, 0, s>>>((const T*)w.rec, g, grid);
+            if (!(flags & AST_PAINT_DEFER_FOLD)) {
+                AST_PROF("paint_tiled.fold", s);
+                column_fold_kernel<T, W><<<ncols, 256, 0, s>>>((const T*)w.rec, g, grid);
+            }
         } else {
             AST_PROF("paint_tiled.deposit", s);
             tile_deposit_kernel<T, W><<<ntiles, 256, 0, s>>>(pos, mass, g, scale, w.index, tile_off, tile_count, cap, grid, dropped);
@@ -1122,6 +1110,21 @@ extern "C" size_t ast_paint_tiled_workspace_bytes(int window, int dtype, size_t 
                  record_bytes(window, g, dtype == AST_F32 ? 4 : 8, flags)).bytes;
 }
 
+// Where ast_paint_tiled(... AST_PAINT_OVERWRITE | AST_PAINT_DEFER_FOLD) left the halo records of a paint with
+// these parameters (inside `workspace`), for ast_fft_tile_power_3d_halo.
+extern "C" int ast_paint_tiled_halo(void* workspace, int window, int dtype, size_t np, int nmesh, int nx_alloc, int flags,
+                                    void** rec_out) {
+    AST_CHECK_ARG(workspace && rec_out && (flags & AST_PAINT_OVERWRITE));
+    AST_CHECK_ARG(window == AST_WIN_CIC || window == AST_WIN_TSC);
+    TileGeom g;
+    uint32_t ntiles = 0;
+    AST_CHECK_ARG(nmesh > 0 && nx_alloc > 0 && tiled_geometry(nmesh, nx_alloc, g, ntiles));
+    const size_t esz = dtype == AST_F32 ? 4 : 8;
+    *rec_out = carve(workspace, np, ntiles, (uint32_t)(g.ntx * g.nty), (flags & AST_PAINT_TWO_PASS) != 0,
+                     record_bytes(window, g, esz, flags)).rec;
+    return AST_OK;
+}
+
 extern "C" int ast_paint_tiled(int window, int dtype, const void* pos, const void* mass, size_t np, int nmesh,
                                double boxsize, double scale, int x_start, int nx_alloc, void* grid,
                                void* workspace, size_t workspace_bytes, unsigned long long* dropped,
@@ -1140,6 +1143,7 @@ extern "C" int ast_paint_tiled(int window, int dtype, const void* pos, const voi
     }
     AST_CHECK_ARG(pos != nullptr && workspace != nullptr);
     AST_CHECK_ARG(!(flags & AST_PAINT_OVERWRITE) || mass == nullptr || mass_bound > 0.0);
+    AST_CHECK_ARG(!(flags & AST_PAINT_DEFER_FOLD) || ((flags & AST_PAINT_OVERWRITE) && x_start == 0 && nx_alloc == nmesh));
     TileGeom g;
     uint32_t ntiles = 0;
     if (!tiled_geometry(nmesh, nx_alloc, g, ntiles)) {

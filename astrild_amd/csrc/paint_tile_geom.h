@@ -1,0 +1,52 @@
+// Tile geometry of the LDS-tiled paint, shared with the FFT z pass that can fold the halo
+// records of the column walk while it loads the grid rows (fft_tile.hip).
+#pragma once
+#include "paint_window.h"
+
+namespace ast {
+
+#ifndef TILE_TX
+#define TILE_TX 8
+#define TILE_TY 8
+#define TILE_TZ 32
+#endif
+constexpr int TX = TILE_TX, TY = TILE_TY, TZ = TILE_TZ;   // owned cells per tile
+
+// halo ring of one (LX x LY) plane of the LDS tile: the cells a column deposits for its x / y
+// neighbours, kept as z lines of the column's halo record [column][ring cell][z]
+template <int W> struct RingMap {
+    static constexpr int HL = Window<W>::LO, HH = W - 1 - Window<W>::LO, H = HL + HH;
+    static constexpr int LX = TX + W - 1, LY = TY + W - 1;
+    static constexpr int COUNT = H * LY + TX * H;
+    __device__ static inline bool owned(int v, int t) { return v >= HL && v < HL + t; }
+    __device__ static inline int to_h(int v, int t) { return v < HL ? v : v - t; }
+    __device__ static inline int cell(int a, int b) {        // (a, b) outside the owned block
+        if (!owned(a, TX)) return to_h(a, TX) * LY + b;
+        return H * LY + (a - HL) * H + to_h(b, TY);
+    }
+};
+
+// The record lines that end in the owned grid line (x, y) of a periodic (nx_alloc = n) grid: up to 3,
+// in the fixed order the fold adds them (dx outer, dy inner).  Returns their count.
+template <typename T, int W>
+__device__ inline int halo_sources(const T* rec, int x, int y, int n, int ntx, int nty, const T* (&src)[3]) {
+    constexpr int LO = Window<W>::LO;
+    using RM = RingMap<W>;
+    const int tx = x / TX, ao = x % TX, ty = y / TY, bo = y % TY;
+    int ns = 0;
+    src[0] = src[1] = src[2] = nullptr;
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            if (dx == 0 && dy == 0) continue;
+            const int a = ao + LO - dx * TX, b = bo + LO - dy * TY;   // this cell in the neighbour's LDS frame
+            if (a < 0 || a >= RM::LX || b < 0 || b >= RM::LY) continue;
+            const int ntx_ = wrap1(tx + dx, ntx), nty_ = wrap1(ty + dy, nty);
+            if (ns < 3) src[ns++] = rec + ((size_t)(ntx_ * nty + nty_) * RM::COUNT + RM::cell(a, b)) * (size_t)n;
+        }
+    }
+    return ns;
+}
+
+}  // namespace ast

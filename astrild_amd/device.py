@@ -132,8 +132,17 @@ def ngp_assign(x, y, z, values, npar, dtype=torch.float64):
     return grid
 
 
+class PaintHalo:
+    """Halo records of a ``paint(..., defer_fold=True)``: the grid is complete only once they are
+    folded in, which ``power_sums_fused(grid, ..., halo=)`` does while its z pass loads the rows.
+    Keeps the paint's workspace alive."""
+
+    def __init__(self, workspace, rec_ptr, window_code):
+        self.workspace, self.rec_ptr, self.window_code = workspace, rec_ptr, window_code
+
+
 def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="auto",
-          x_start=0, nx_alloc=None, check_dropped=True, accumulate=None):
+          x_start=0, nx_alloc=None, check_dropped=True, accumulate=None, defer_fold=False):
     """pmesh ``ParticleMesh.paint(pos, mass=, resampler=)`` on the GPU.
 
     pos: (Np, 3) CUDA tensor (float32/float64); mass: (Np,) or None.
@@ -142,6 +151,8 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     particles), "tiled2" (LDS tiles, exact two-pass counting) or "auto" (= tiled when possible).
     accumulate: add into ``out`` (default when ``out`` is given) or overwrite it (default
     for a fresh grid; the tiled path then needs no zero-fill and flushes without atomics).
+    defer_fold: (tiled overwrite of the whole grid only) skip the paint's last kernel and return
+    ``(grid, PaintHalo)`` for ``power_sums_fused(..., halo=)``; the grid alone is incomplete.
     """
     L = _lib.lib()
     n = int(nmesh)
@@ -156,12 +167,14 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     npart = pos.shape[0]
     dropped = torch.zeros(1, dtype=torch.int64, device=pos.device)
     ws_bytes = 0
-    tflags = (1 if method == "tiled2" else 0) | (0 if accumulate else 2)      # TWO_PASS | OVERWRITE
+    tflags = (1 if method == "tiled2" else 0) | (0 if accumulate else 2) | (4 if defer_fold else 0)   # TWO_PASS | OVERWRITE | DEFER_FOLD
     if method in ("auto", "tiled", "tiled2") and win != 0 and npart < 2**32 - 1:
         ws_bytes = int(L.ast_paint_tiled_workspace_bytes(win, code, npart, n, nx, tflags))
     if method in ("tiled", "tiled2") and ws_bytes == 0:
         raise _lib.AstrildHipError("tiled paint needs a CIC/TSC window and nmesh a multiple of 32")
     use_tiled = ws_bytes > 0 and (method in ("tiled", "tiled2") or npart >= 65536)
+    if defer_fold and not (use_tiled and not accumulate and x_start == 0 and nx == n):
+        raise _lib.AstrildHipError("defer_fold needs the tiled overwrite paint of the whole periodic grid")
     if out is None:
         alloc = torch.empty if (use_tiled and not accumulate) else torch.zeros
         out = alloc((nx, n, n), dtype=pos.dtype, device=pos.device)
@@ -187,6 +200,10 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
         if nd:
             raise _lib.AstrildHipError(f"{nd} deposits fell outside the grid buffer "
                                        f"(x_start={x_start}, nx_alloc={nx})")
+    if defer_fold:
+        rec = ct.c_void_p()
+        check(L.ast_paint_tiled_halo(ptr(ws), win, code, npart, n, nx, tflags, ct.byref(rec)), "ast_paint_tiled_halo")
+        return out, PaintHalo(ws, rec, win)
     return out
 
 
@@ -281,7 +298,7 @@ def finish_power(ksum, psum, nmodes):
 _power_scratch = {}
 
 
-def power_sums_fused(field, boxsize, psum=None, mean=0.0):
+def power_sums_fused(field, boxsize, psum=None, mean=0.0, halo=None):
     """(ksum, psum, nmodes) of the auto power of an fp32 cube of side 256/512/1024 through
     the fused tile-FFT + shell-binning path (the spectrum is never written to HBM).
     ``mean`` is subtracted from the cells on load: it only touches the discarded DC mode
@@ -297,6 +314,11 @@ def power_sums_fused(field, boxsize, psum=None, mean=0.0):
     if psum is None:
         psum = torch.zeros(n // 2 - 1, dtype=torch.float64, device=field.device)
     ksum, nmodes = shell_geometry(n, boxsize)
+    if halo is not None:                      # grid from paint(..., defer_fold=True)
+        check(L.ast_fft_tile_power_3d_halo(ptr(field), halo.rec_ptr, halo.window_code, ptr(scratch), scratch.numel(),
+                                           real_code(field), n, float(boxsize), float(mean), ptr(psum), stream()),
+              "ast_fft_tile_power_3d_halo")
+        return ksum, psum, nmodes
     check(L.ast_fft_tile_power_3d(ptr(field), ptr(scratch), scratch.numel(), real_code(field), n, float(boxsize),
                                   float(mean), ptr(psum), stream()), "ast_fft_tile_power_3d")
     return ksum, psum, nmodes
@@ -306,6 +328,18 @@ def fused_power_supported(field):
     n = field.shape[0]
     return field.dim() == 3 and tuple(field.shape) == (n, n, n) and field.dtype == torch.float32 \
         and bool(_lib.lib().ast_fft_tile_supported(F32, n))
+
+
+def paint_power_1d(pos, mass, nmesh, boxsize, window="cic", scale=1.0):
+    """``pm.paint(...)`` followed by ``FFTPower(ArrayMesh(grid), mode="1d")`` (stats_subfind.py:130-150)
+    as one pipeline: where the fused fp32 path applies, the paint's halo fold rides on the FFT's z pass."""
+    n = int(nmesh)
+    fast = pos.dtype == torch.float32 and n % 32 == 0 and pos.shape[0] >= 65536 \
+        and bool(_lib.lib().ast_fft_tile_supported(F32, n))
+    if fast:
+        grid, halo = paint(pos, mass, n, boxsize, window, scale=scale, method="tiled", defer_fold=True)
+        return finish_power(*power_sums_fused(grid, boxsize, halo=halo))
+    return fftpower_1d(paint(pos, mass, n, boxsize, window, scale=scale), boxsize)
 
 
 def fftpower_1d(field1, boxsize, field2=None, fused=True):

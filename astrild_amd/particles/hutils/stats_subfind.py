@@ -26,8 +26,8 @@ class SubFind:
         pos = dev.as_device(np.ascontiguousarray(pos_field), SubFind.dtype)
         mass = dev.as_device(np.ascontiguousarray(mass_field), SubFind.dtype)
         # pm.paint(pos, mass=mass, resampler="tsc") / dx**3   (stats_subfind.py:130-132)
-        value_map = dev.paint(pos, mass, nbins, boxsize, "tsc", scale=1.0 / dx ** 3)
-        r = dev.fftpower_1d(value_map, boxsize)
+        # ... then FFTPower(ArrayMesh(value_map), mode="1d")                 (stats_subfind.py:134-150)
+        r = dev.paint_power_1d(pos, mass, nbins, boxsize, "tsc", scale=1.0 / dx ** 3)
         k = np.array(r["k"])
         Pk = np.array(r["power"] - r["shotnoise"])
         return k, Pk
