@@ -78,13 +78,17 @@ __device__ inline void fft_reg(float2 (&v)[R]) {
 // is written out as one row of `partial` ([workgroup][shell], summed by the
 // shell_partials_stage1/2 kernels in a fixed order).  The spectrum never goes back to HBM.
 __device__ inline int tile_isqrt(int v) {
-    // raw v_sqrt_f32 (1 ulp) is enough: v < 2^24 is exact in float and the two integer checks
-    // repair an estimate that is off by one either way (a correctly rounded sqrtf costs ~10 more
-    // instructions per mode, and this epilogue is half of the pass's vector work)
-    int r = (int)__builtin_amdgcn_sqrtf((float)v);
-    if (r * r > v) --r;
-    if ((r + 1) * (r + 1) <= v) ++r;
-    return r;
+    // floor(sqrt(v)) for 0 <= v <= 3 * 512^2 from ONE raw v_sqrt_f32 (1 ulp) of v + 1/2: v and v + 1/2 are
+    // exact in float; for a perfect square r^2 the argument's root is r + 1/(4r), for the largest v below
+    // the next square it is (r+1) - 1/(4(r+1)) - both more than 4 ulp away from the integer at r = 887, more
+    // below - so truncation gives r without the two integer repairs (8 instructions per mode in an
+    // epilogue that is half of this pass's vector work).  Checked exhaustively by test_gpu_fft_tile.
+    return (int)__builtin_amdgcn_sqrtf((float)v + 0.5f);
+}
+
+// test hook: out[v] = tile_isqrt(v)
+__global__ void tile_isqrt_table_kernel(int* out, int count) {
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < count; v += gridDim.x * blockDim.x) out[v] = tile_isqrt(v);
 }
 
 template <int R1, int R2, int C, bool POWER>
@@ -433,6 +437,14 @@ static int rows_r2c_impl(const void* in, void* out, int dtype, size_t n, size_t 
     if (n == 1024) return launch_r2c<16, 32, 16>(i, o, tw, nrows, in_pitch, out_pitch, (float)scale, (float)mean, s);
     if (n == 512) return launch_r2c<16, 16, 16>(i, o, tw, nrows, in_pitch, out_pitch, (float)scale, (float)mean, s);
     return launch_r2c<8, 16, 16>(i, o, tw, nrows, in_pitch, out_pitch, (float)scale, (float)mean, s);
+}
+
+// out_d[v] = the shell lookup's floor(sqrt(v)), v < count: lets the tests check it against integers
+extern "C" int ast_fft_tile_isqrt_table(int* out, int count, void* stream) {
+    AST_CHECK_ARG(out != nullptr && count > 0);
+    tile_isqrt_table_kernel<<<1024, 256, 0, ast::as_stream(stream)>>>(out, count);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
 }
 
 extern "C" int ast_fft_tile_rows_r2c(const void* in, void* out, int dtype, size_t n, size_t nrows, size_t in_pitch,

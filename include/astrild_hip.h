@@ -197,6 +197,8 @@ int ast_fft_tile_r2c_3d(const void* in_d, void* out_d, int dtype, size_t n, doub
  * modes to per-workgroup shell tables instead of storing delta_k, and a fixed-order
  * reduction adds them into psum_d (same meaning as in ast_power_bin_1d; auto power). */
 size_t ast_fft_tile_power_scratch_bytes(size_t n);
+/* test hook: out_d[v] = the fused binning's floor(sqrt(v)) (one hardware sqrt, no repair), v < count */
+int ast_fft_tile_isqrt_table(int* out_d, int count, void* stream);
 /* `mean`: a constant subtracted from every cell as it is loaded (0 = none).  It only
  * changes the DC mode, which FFTPower discards, but with it the fp32 round-off of all
  * other modes no longer scales with the O(1) mean density (cold low-k shells gain). */

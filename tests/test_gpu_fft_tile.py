@@ -143,3 +143,21 @@ def test_paint_power_pipeline_with_mass_matches_separate_calls(hip):
     ref = dev.fftpower_1d(dev.paint(pos, mass, n, L, "tsc", scale=1.0 / dx ** 3), L)
     assert np.array_equal(got["modes"], ref["modes"])
     np.testing.assert_array_equal(got["power"], ref["power"])
+
+
+def test_shell_lookup_isqrt_is_exact_for_every_mode_norm(hip):
+    """The fused binning takes floor(sqrt(|m|^2)) from one hardware sqrt of |m|^2 + 1/2: exact for all
+    |m|^2 up to 3 * 512^2 (side 1024), checked against integer arithmetic."""
+    import math
+    from astrild_amd import _lib
+    from astrild_amd.device import ptr, stream
+    torch.cuda.set_device(0)
+    count = 3 * 512 * 512 + 1
+    out = torch.empty(count, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().ast_fft_tile_isqrt_table(ptr(out), count, stream()), "ast_fft_tile_isqrt_table")
+    v = np.arange(count, dtype=np.int64)
+    ref = np.floor(np.sqrt(v.astype(np.float64))).astype(np.int64)
+    ref -= ref * ref > v
+    ref += (ref + 1) * (ref + 1) <= v
+    assert np.array_equal(out.cpu().numpy().astype(np.int64), ref)
+    assert math.isqrt(count - 1) == int(ref[-1])
