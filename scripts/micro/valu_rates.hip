@@ -5,7 +5,7 @@
 #include <cstdio>
 
 #define OPS(X) X(mul_f64) X(add_f64) X(fma_f64) X(floor_f64) X(cvt_i32_f64) X(cvt_f64_i32) X(cvt_f64_f32) X(cvt_f32_f64) \
-    X(mul_f32) X(fma_f32) X(floor_f32) X(cvt_i32_f32) X(min_u32) X(add_u32) X(mad_u64_u32) X(lshl_add_u64)
+    X(pk_add_f32) X(pk_mul_f32) X(pk_fma_f32) X(mul_f32) X(fma_f32) X(floor_f32) X(cvt_i32_f32) X(min_u32) X(add_u32) X(mad_u64_u32) X(lshl_add_u64)
 
 enum Op {
 #define X(n) OP_##n,
@@ -33,6 +33,9 @@ __global__ void __launch_bounds__(256) k(double* out, int iters, double seed) {
             if (OP == OP_cvt_f64_i32) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(d[u]) : "v"(i32[u]));
             if (OP == OP_cvt_f64_f32) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d[u]) : "v"(f[u]));
             if (OP == OP_cvt_f32_f64) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(f[u]) : "v"(d[u]));
+            if (OP == OP_pk_add_f32) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(d[u]) : "v"(seed));
+            if (OP == OP_pk_mul_f32) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(d[u]) : "v"(seed));
+            if (OP == OP_pk_fma_f32) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(d[u]) : "v"(seed));
             if (OP == OP_mul_f32) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f[u]) : "v"((float)seed));
             if (OP == OP_fma_f32) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[u]) : "v"((float)seed));
             if (OP == OP_floor_f32) asm volatile("v_floor_f32 %0, %0" : "+v"(f[u]));
