@@ -105,16 +105,24 @@ __global__ void tile_isqrt_table_kernel(int* out, int count) {
 
 template <int R1, int R2, int C, bool POWER>
 __global__ void __launch_bounds__(C * (R1 > R2 ? R1 : R2))
+// N = 1024 with binning: 128 VGPRs, so that two 8-wave workgroups fit a CU (see SPLIT below)
+__attribute__((amdgpu_waves_per_eu(POWER && R1 * R2 >= 1024 ? 4 : 1, POWER && R1 * R2 >= 1024 ? 4 : 8)))
 strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, size_t elem_stride,
                    size_t ncols, size_t batch_stride, unsigned tiles_per_batch, float scale,
                    double* __restrict__ partial) {
     constexpr int N = R1 * R2;
     constexpr int NT = C * (R1 > R2 ? R1 : R2);
     constexpr int NB = N / 2 - 1;    // shells when POWER
+    // SPLIT (N = 1024, binning pass): the stage-1 -> stage-2 exchange goes through LDS in two rounds, so the
+    // buffer is 64 KB instead of 128 KB and TWO workgroups fit a CU: with one, the loads, the two register
+    // FFTs and the binning of a tile run strictly one after the other (x pass 1.83 -> 1.54 ms).  The y pass
+    // is bound by its 128-byte strided reads AND writes and loses a little with it (1.96 -> 2.03): not split.
+    constexpr bool SPLIT = POWER && R1 == R2 && N * C * sizeof(float2) > 64 * 1024;
+    constexpr int YN = SPLIT ? N / 2 : N;
     extern __shared__ float2 lds[];
-    float2* Y = lds;                 // [n2][k1][c]
-    float2* tw = lds + N * C;        // exp(-2 pi i m / N)
-    double* shell = reinterpret_cast<double*>(lds + N * C + N);     // [NB + 1] when POWER
+    float2* Y = lds;                 // [n2][k1][c]  (SPLIT: [n2 mod R2/2][k1][c])
+    float2* tw = lds + YN * C;       // exp(-2 pi i m / N)
+    double* shell = reinterpret_cast<double*>(lds + YN * C + N);    // [NB + 1] when POWER
     for (int i = threadIdx.x; i < N; i += NT) tw[i] = tw_g[i];
     if (POWER)
         for (int i = threadIdx.x; i <= NB; i += NT) shell[i] = 0.0;
@@ -125,6 +133,7 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
     const bool col_ok = c0 + c < ncols;
     float2* base = data + (size_t)b * batch_stride + c0 + c;
 
+    float2 u[R2];
     {                                                 // stage 1: task (c, n2 = sub)
         const bool task1 = sub < R2;
         float2 v[R1];
@@ -136,20 +145,43 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
         for (int n1 = 0; n1 < R1; ++n1) v[n1] = lbase[(size_t)(n1 * R2 + lsub) * elem_stride];
         fft_reg<R1>(v);
         __syncthreads();                              // twiddle table is in LDS
-        if (task1) {
+        if (!SPLIT) {
+            if (task1) {
 #pragma unroll
-            for (int k1 = 0; k1 < R1; ++k1) {
-                float2 y = v[bitrev(k1, ilog2(R1))];
-                if (k1 != 0) y = cmul(y, tw[sub * k1]);
-                Y[(sub * R1 + k1) * C + c] = y;
+                for (int k1 = 0; k1 < R1; ++k1) {
+                    float2 y = v[bitrev(k1, ilog2(R1))];
+                    if (k1 != 0) y = cmul(y, tw[sub * k1]);
+                    Y[(sub * R1 + k1) * C + c] = y;
+                }
+            }
+            __syncthreads();
+            if (sub < R1) {                           // stage 2: task (c, k1 = sub)
+#pragma unroll
+                for (int n2 = 0; n2 < R2; ++n2) u[n2] = Y[(n2 * R1 + sub) * C + c];
+            }
+        } else {
+            // R1 == R2: every thread has a task in both stages.  Round r carries the n2 of half r:
+            // its producers write all their k1 (and are done with v), every thread collects 16 of
+            // its 32 inputs.  Peak registers: v plus half of u.
+            constexpr int H = R2 / 2;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if (sub / H == half) {                // wave-uniform: C = 16, H = 16 -> 4 waves per half
+#pragma unroll
+                    for (int k1 = 0; k1 < R1; ++k1) {
+                        float2 y = v[bitrev(k1, ilog2(R1))];
+                        if (k1 != 0) y = cmul(y, tw[sub * k1]);
+                        Y[((sub - half * H) * R1 + k1) * C + c] = y;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int nh = 0; nh < H; ++nh) u[half * H + nh] = Y[(nh * R1 + sub) * C + c];
+                if (half == 0) __syncthreads();       // round 0 has been read: round 1 may overwrite it
             }
         }
     }
-    __syncthreads();
-    float2 u[R2];
-    if (sub < R1) {                                   // stage 2: task (c, k1 = sub)
-#pragma unroll
-        for (int n2 = 0; n2 < R2; ++n2) u[n2] = Y[(n2 * R1 + sub) * C + c];
+    if (sub < R1) {
         fft_reg<R2>(u);
         if (col_ok && !POWER) {
 #pragma unroll
@@ -361,7 +393,8 @@ template <int R1, int R2, int C, bool POWER>
 int launch_c2c(float2* data, const float2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride,
                float scale, double* partial, hipStream_t s) {
     constexpr int N = R1 * R2, NT = C * (R1 > R2 ? R1 : R2);
-    const size_t lds = (size_t)(N * C + N) * sizeof(float2) + (POWER ? (N / 2) * sizeof(double) : 0);
+    constexpr bool SPLIT = POWER && R1 == R2 && N * C * sizeof(float2) > 64 * 1024;       // as in the kernel
+    const size_t lds = (size_t)((SPLIT ? N / 2 : N) * C + N) * sizeof(float2) + (POWER ? (N / 2) * sizeof(double) : 0);
     static bool attr_set = false;
     if (!attr_set) {
         AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&strided_c2c_kernel<R1, R2, C, POWER>),
