@@ -15,6 +15,7 @@ F32, F64 = 0, 1
 WIN = {"ngp": 0, "nnb": 0, "nearest": 0, "cic": 1, "tsc": 2}
 FFT_R2C, FFT_C2R, FFT_C2C_FWD, FFT_C2C_INV = 0, 1, 2, 3
 ERR_WORKSPACE = -4
+SUM_PARTS = 1024          # AST_SUM_PARTS
 
 
 class AstrildHipError(RuntimeError):
@@ -35,7 +36,7 @@ SIGNATURES = {
     "ast_ngp_assign": (_i, [_vp, _vp, _vp, _vp, _i, _sz, _i, _vp, _vp, _vp, _vp]),
     "ast_paint": (_i, [_i, _i, _vp, _vp, _sz, _i, _d, _d, _i, _i, _vp, _vp, _vp]),
     "ast_paint_tiled_workspace_bytes": (_sz, [_i, _i, _sz, _i, _i, _i]),
-    "ast_paint_tiled": (_i, [_i, _i, _vp, _vp, _sz, _i, _d, _d, _i, _i, _vp, _vp, _sz, _vp, _i, _d, _vp]),
+    "ast_paint_tiled": (_i, [_i, _i, _vp, _vp, _sz, _i, _d, _d, _i, _i, _vp, _vp, _sz, _vp, _i, _d, _d, _vp]),
     "ast_accumulate": (_i, [_vp, _vp, _i, _sz, _vp]),
     "ast_fft_plan_create": (_i, [ct.POINTER(_vp), _i, _i, _i, ct.POINTER(_sz), _sz, _d, _i]),
     "ast_fft_plan_create_strided_1d": (_i, [ct.POINTER(_vp), _i, _i, _sz, _sz, _sz, _sz, _d]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     "ast_smooth_plan_destroy": (_i, [_vp]),
     "ast_gaussian_smooth": (_i, [_vp, _vp, _d, _i, _vp]),
     "ast_minmax": (_i, [_vp, _i, _sz, _vp, _vp]),
+    "ast_sum": (_i, [_vp, _i, _sz, _vp, _vp]),
     "ast_histogram": (_i, [_vp, _i, _sz, _d, _d, _i, _vp, _vp]),
     "ast_add": (_i, [_vp, _vp, _vp, _i, _sz, _vp]),
     "ast_nfw_paint": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _d, _i, _i, _d, _i, _vp, _i, _vp]),

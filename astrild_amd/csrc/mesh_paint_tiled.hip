@@ -525,7 +525,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
                       const uint32_t* __restrict__ index, const uint32_t* __restrict__ tile_off,
                       const uint32_t* __restrict__ tile_count, uint32_t cap, double mass_bound,
                       const uint32_t* __restrict__ col_flags, T* __restrict__ grid, T* __restrict__ rec,
-                      unsigned long long* dropped) {
+                      double offset, unsigned long long* dropped) {
     constexpr int LX = TX + W - 1, LY = TY + W - 1, LZ = TZ + W - 1;
     constexpr int LO = Window<W>::LO, H = W - 1;
     using RM = RingMap<W>;
@@ -554,16 +554,18 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     const bool x_periodic = g.nx_alloc == g.n;
     unsigned long long ndrop = 0;
     for (int i = threadIdx.x; i < LX * LY * LZ; i += 256) tile[i] = BIAS;
-    // where the z line of LDS column (a, b) goes: the owned cells' grid line or the halo ring's
-    // record line (bit 0: a halo that points outside a slab buffer, counted as dropped when
-    // non-zero); 0 = an owned plane the buffer does not hold
+    // where the z line of LDS column (a, b) goes: the owned cells' grid line (bit 1 set: `offset`
+    // is subtracted there, in double, before the one rounding to T) or the halo ring's record line
+    // (bit 0: a halo that points outside a slab buffer, counted as dropped when non-zero);
+    // 0 = an owned plane the buffer does not hold (last x tile of a slab buffer with
+    // nx_alloc % TX != 0): deposits there are counted as dropped
     __shared__ unsigned long long dest[LX * LY];
     for (int ab = threadIdx.x; ab < LX * LY; ab += 256) {
         const int b = ab % LY, a = ab / LY;
         const int px = ox + a - LO;
         unsigned long long d;
         if (RM::owned(a, TX) && RM::owned(b, TY)) {
-            d = px < g.nx_alloc ? (unsigned long long)(grid + ((size_t)px * g.n + oy + b - LO) * g.n) : 0ull;
+            d = px < g.nx_alloc ? ((unsigned long long)(grid + ((size_t)px * g.n + oy + b - LO) * g.n) | 2ull) : 0ull;
         } else {
             d = (unsigned long long)(rec + ((size_t)col * RM::COUNT + RM::cell(a, b)) * g.n);
             if (!x_periodic && (px < 0 || px >= g.nx_alloc)) d |= 1ull;
@@ -750,24 +752,28 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
             for (int k = 0; k < (LX * LY + CPI - 1) / CPI; ++k) {
                 const int ab = threadIdx.x / LPC + k * CPI;
                 if (ab >= LX * LY || (ablate & 128)) break;
+                const unsigned long long d = dest[ab];
+                const double sub = (d & 2ull) ? offset : 0.0;
                 vec_t v;
+                bool any = false;
 #pragma unroll
                 for (int i = 0; i < VW; ++i) {
                     const unsigned long long raw = tile[ab * LZ + sl[i]];
                     tile[ab * LZ + sl[i]] = BIAS;
+                    any |= raw != BIAS;
                     if (RAW) {
                         const unsigned long long dbits = (raw & 0x0000ffffffffffffull) | 0x4330000000000000ull;
-                        v[i] = (T)((__longlong_as_double((long long)dbits) - 4644337115725824.0) * q);      // 2^52 + 2^47
+                        v[i] = (T)((__longlong_as_double((long long)dbits) - 4644337115725824.0) * q - sub);      // 2^52 + 2^47
                     } else {
-                        v[i] = (T)((double)(long long)raw * q);
+                        v[i] = (T)((double)(long long)raw * q - sub);
                     }
                 }
-                const unsigned long long d = dest[ab];
-                if ((ablate & 1) || d == 0ull) continue;
+                if (d == 0ull) { ndrop += any; continue; }
+                if (ablate & 1) continue;
                 // (global address space spelled out: a pointer rebuilt from an integer is "flat")
                 typedef __attribute__((address_space(1))) T gT;
                 typedef __attribute__((address_space(1))) vec_t gvec_t;
-                gT* const line = (gT*)(d & ~1ull);
+                gT* const line = (gT*)(d & ~3ull);
                 if (straight) {
                     *(gvec_t*)(line + z0) = v;
                 } else {
@@ -846,6 +852,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
         if (RM::owned(a, TX) && RM::owned(b, TY)) {
             const int px = ox + a - LO;
             if (px < g.nx_alloc) atomicAdd(&grid[((size_t)px * g.n + oy + b - LO) * g.n + z], v);
+            else ++ndrop;                   // owned plane the buffer does not hold
         } else {
             atomicAdd(&rec[((size_t)col * RM::COUNT + RM::cell(a, b)) * g.n + z], v);
         }
@@ -1006,7 +1013,7 @@ inline size_t record_bytes(int window, const TileGeom& g, size_t esz, int flags)
 
 template <typename T, int W>
 int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntiles, double scale, T* grid,
-              void* workspace, unsigned long long* dropped, int flags, double mass_bound, hipStream_t s) {
+              void* workspace, unsigned long long* dropped, int flags, double mass_bound, double offset, hipStream_t s) {
     const bool two_pass = (flags & AST_PAINT_TWO_PASS) != 0;
     const bool overwrite = (flags & AST_PAINT_OVERWRITE) != 0;
     const unsigned ncols = (unsigned)(g.ntx * g.nty);
@@ -1039,10 +1046,10 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
                 AST_PROF("paint_tiled.deposit", s);
                 if (mass)
                     column_deposit_kernel<T, W, true><<<ncols, 256, 0, s>>>(pos, mass, g, scale, w.index, tile_off, tile_count, cap,
-                                                                            mass_bound, w.col_flags, grid, (T*)w.rec, dropped);
+                                                                            mass_bound, w.col_flags, grid, (T*)w.rec, offset, dropped);
                 else
                     column_deposit_kernel<T, W, false><<<ncols, 256, 0, s>>>(pos, mass, g, scale, w.index, tile_off, tile_count, cap,
-                                                                             1.0, w.col_flags, grid, (T*)w.rec, dropped);
+                                                                             1.0, w.col_flags, grid, (T*)w.rec, offset, dropped);
             }
             if (!(flags & AST_PAINT_DEFER_FOLD)) {
                 AST_PROF("paint_tiled.fold", s);
@@ -1128,7 +1135,7 @@ extern "C" int ast_paint_tiled_halo(void* workspace, int window, int dtype, size
 extern "C" int ast_paint_tiled(int window, int dtype, const void* pos, const void* mass, size_t np, int nmesh,
                                double boxsize, double scale, int x_start, int nx_alloc, void* grid,
                                void* workspace, size_t workspace_bytes, unsigned long long* dropped,
-                               int flags, double mass_bound, void* stream) {
+                               int flags, double mass_bound, double offset, void* stream) {
     AST_CHECK_ARG(window == AST_WIN_CIC || window == AST_WIN_TSC);
     AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
     AST_CHECK_ARG(nmesh > 0 && boxsize > 0.0);
@@ -1144,6 +1151,7 @@ extern "C" int ast_paint_tiled(int window, int dtype, const void* pos, const voi
     AST_CHECK_ARG(pos != nullptr && workspace != nullptr);
     AST_CHECK_ARG(!(flags & AST_PAINT_OVERWRITE) || mass == nullptr || mass_bound > 0.0);
     AST_CHECK_ARG(!(flags & AST_PAINT_DEFER_FOLD) || ((flags & AST_PAINT_OVERWRITE) && x_start == 0 && nx_alloc == nmesh));
+    AST_CHECK_ARG(offset == 0.0 || (flags & AST_PAINT_OVERWRITE));
     TileGeom g;
     uint32_t ntiles = 0;
     if (!tiled_geometry(nmesh, nx_alloc, g, ntiles)) {
@@ -1161,10 +1169,10 @@ extern "C" int ast_paint_tiled(int window, int dtype, const void* pos, const voi
     hipStream_t s = ast::as_stream(stream);
     if (dtype == AST_F32) {
         if (window == AST_WIN_CIC)
-            return run_tiled<float, 2>((const float*)pos, (const float*)mass, np, g, ntiles, scale, (float*)grid, workspace, dropped, flags, mass_bound, s);
-        return run_tiled<float, 3>((const float*)pos, (const float*)mass, np, g, ntiles, scale, (float*)grid, workspace, dropped, flags, mass_bound, s);
+            return run_tiled<float, 2>((const float*)pos, (const float*)mass, np, g, ntiles, scale, (float*)grid, workspace, dropped, flags, mass_bound, offset, s);
+        return run_tiled<float, 3>((const float*)pos, (const float*)mass, np, g, ntiles, scale, (float*)grid, workspace, dropped, flags, mass_bound, offset, s);
     }
     if (window == AST_WIN_CIC)
-        return run_tiled<double, 2>((const double*)pos, (const double*)mass, np, g, ntiles, scale, (double*)grid, workspace, dropped, flags, mass_bound, s);
-    return run_tiled<double, 3>((const double*)pos, (const double*)mass, np, g, ntiles, scale, (double*)grid, workspace, dropped, flags, mass_bound, s);
+        return run_tiled<double, 2>((const double*)pos, (const double*)mass, np, g, ntiles, scale, (double*)grid, workspace, dropped, flags, mass_bound, offset, s);
+    return run_tiled<double, 3>((const double*)pos, (const double*)mass, np, g, ntiles, scale, (double*)grid, workspace, dropped, flags, mass_bound, offset, s);
 }

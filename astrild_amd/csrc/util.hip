@@ -141,6 +141,29 @@ __global__ void minmax_finish(unsigned long long* keys) {
     reinterpret_cast<double*>(keys)[1] = hi;
 }
 
+// Fixed-order sum in double: AST_SUM_PARTS block partials (each block a fixed contiguous range,
+// lanes a fixed stride, tree in a fixed order), then one block adds the partials in index order.
+template <typename T>
+__global__ void __launch_bounds__(256) sum_stage1_kernel(const T* __restrict__ buf, size_t n, double* __restrict__ part) {
+    const size_t per = (n + gridDim.x - 1) / gridDim.x;
+    const size_t i0 = (size_t)blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+    double acc = 0.0;
+    for (size_t i = i0 + threadIdx.x; i < i1; i += 256) acc += (double)buf[i];
+    __shared__ double sh[256];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+__global__ void sum_stage2_kernel(const double* __restrict__ part, int nparts, double* out) {
+    double t = 0.0;
+    for (int i = 0; i < nparts; ++i) t += part[i];
+    *out = t;
+}
+
 // np.histogram with uniform bins (numpy/lib/_histograms_impl.py fast path):
 //   f = (v - lo) * (nbins / (hi - lo));  idx = (int) f;  idx == nbins -> nbins-1;
 //   then numpy corrects against the float64 edges: v < edge[idx] -> idx-1,
@@ -269,6 +292,19 @@ extern "C" int ast_minmax(const void* buf, int dtype, size_t count, double* out,
     else
         minmax_kernel<double><<<g, 256, 0, s>>>((const double*)buf, count, keys);
     minmax_finish<<<1, 1, 0, s>>>(keys);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+extern "C" int ast_sum(const void* buf, int dtype, size_t count, double* out, void* stream) {
+    AST_CHECK_ARG(buf && out && count > 0);
+    AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
+    hipStream_t s = ast::as_stream(stream);
+    if (dtype == AST_F32)
+        sum_stage1_kernel<float><<<AST_SUM_PARTS, 256, 0, s>>>((const float*)buf, count, out + 1);
+    else
+        sum_stage1_kernel<double><<<AST_SUM_PARTS, 256, 0, s>>>((const double*)buf, count, out + 1);
+    sum_stage2_kernel<<<1, 1, 0, s>>>(out + 1, AST_SUM_PARTS, out);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }

@@ -132,6 +132,15 @@ def ngp_assign(x, y, z, values, npar, dtype=torch.float64):
     return grid
 
 
+def total_mass(mass, npart):
+    """Sum of the particle masses in double, fixed order (``npart`` for unit masses)."""
+    if mass is None:
+        return float(npart)
+    out = torch.empty(1 + _lib.SUM_PARTS, dtype=torch.float64, device=mass.device)
+    check(_lib.lib().ast_sum(ptr(mass), real_code(mass), mass.numel(), ptr(out), stream()), "ast_sum")
+    return float(out[0].item())
+
+
 class PaintHalo:
     """Halo records of a ``paint(..., defer_fold=True)``: the grid is complete only once they are
     folded in, which ``power_sums_fused(grid, ..., halo=)`` does while its z pass loads the rows.
@@ -142,7 +151,8 @@ class PaintHalo:
 
 
 def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="auto",
-          x_start=0, nx_alloc=None, check_dropped=True, accumulate=None, defer_fold=False):
+          x_start=0, nx_alloc=None, check_dropped=True, accumulate=None, defer_fold=False, offset=0.0,
+          hint=None):
     """pmesh ``ParticleMesh.paint(pos, mass=, resampler=)`` on the GPU.
 
     pos: (Np, 3) CUDA tensor (float32/float64); mass: (Np,) or None.
@@ -153,6 +163,9 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     for a fresh grid; the tiled path then needs no zero-fill and flushes without atomics).
     defer_fold: (tiled overwrite of the whole grid only) skip the paint's last kernel and return
     ``(grid, PaintHalo)`` for ``power_sums_fused(..., halo=)``; the grid alone is incomplete.
+    offset: (tiled overwrite only) owned cells are stored as ``sum - offset``, subtracted in double
+    before the one rounding to the grid dtype; ``offset="mean"`` uses total mass * scale / nmesh^3,
+    i.e. the grid holds rho - mean (only the DC mode changes, which FFTPower discards).
     """
     L = _lib.lib()
     n = int(nmesh)
@@ -182,6 +195,12 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
         assert out.is_cuda and out.dtype == pos.dtype and out.numel() == nx * n * n and out.is_contiguous()
         if not accumulate and not use_tiled:
             out.zero_()
+    if offset != 0.0 and not (use_tiled and not accumulate):
+        raise _lib.AstrildHipError("offset needs the tiled overwrite paint")
+    if isinstance(offset, str):
+        if offset != "mean":
+            raise ValueError(offset)
+        offset = total_mass(mass, npart) * float(scale) / float(n) ** 3
     if use_tiled:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pos.device)
         mass_bound = 1.0
@@ -191,7 +210,7 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
             mass_bound = float(lo_hi.abs().max()) or 1.0
         check(L.ast_paint_tiled(win, code, ptr(pos), ptr(mass), npart, n, float(boxsize), float(scale),
                                 int(x_start), nx, ptr(out), ptr(ws), ws_bytes, ptr(dropped), tflags,
-                                mass_bound, stream()), "ast_paint_tiled")
+                                mass_bound, float(offset), stream()), "ast_paint_tiled")
     else:
         check(L.ast_paint(win, code, ptr(pos), ptr(mass), npart, n, float(boxsize), float(scale),
                           int(x_start), nx, ptr(out), ptr(dropped), stream()), "ast_paint")
@@ -337,7 +356,9 @@ def paint_power_1d(pos, mass, nmesh, boxsize, window="cic", scale=1.0):
     fast = pos.dtype == torch.float32 and n % 32 == 0 and pos.shape[0] >= 65536 \
         and bool(_lib.lib().ast_fft_tile_supported(F32, n))
     if fast:
-        grid, halo = paint(pos, mass, n, boxsize, window, scale=scale, method="tiled", defer_fold=True)
+        # the grid holds rho - mean (subtracted before the fp32 rounding): only the discarded DC mode differs
+        grid, halo = paint(pos, mass, n, boxsize, window, scale=scale, method="tiled", defer_fold=True,
+                           offset="mean")
         return finish_power(*power_sums_fused(grid, boxsize, halo=halo))
     return fftpower_1d(paint(pos, mass, n, boxsize, window, scale=scale), boxsize)
 
@@ -405,23 +426,34 @@ def bispectrum(field, boxsize, edges, triangles):
     used = sorted({s for t in triangles for s in t})
     spec = r2c(field)
     scratch = torch.empty_like(spec)
-    dfields, ifields = {}, {}
-    key = (torch.cuda.current_device(), n, tuple(edges), tuple(triangles), field.dtype)
+    key = (torch.cuda.current_device(), n, tuple(edges), tuple(triangles))
     ntri = _tri_cache.get(key)
+    if ntri is None:
+        # Triangle counts depend on the geometry only; they are computed ONCE per (N, edges, triangles), always in
+        # float64: I_s(0) equals the shell's mode count (1e6 at 512^3), and the fp32 round-off of that one cell
+        # alone would move sum I_i I_j I_l / Ng by thousands.  In double the sum is within ~1e-3 of the integer.
+        iscratch = torch.empty(spec.shape, dtype=torch.complex128, device=spec.device)
+        ifields = {}
+        for s in used:
+            shell_filter(None, n, edges[s], edges[s + 1], out=iscratch)
+            ifields[s] = c2r(iscratch, (n, n, n))
+        dens = torch.cat([triple_product_sum(ifields[i], ifields[j], ifields[l]) for (i, j, l) in triangles]).cpu().numpy()
+        del ifields, iscratch
+        exact = dens / float(n) ** 3
+        ntri = np.rint(exact).astype(np.int64)
+        worst = float(np.abs(exact - ntri).max()) if len(exact) else 0.0
+        if worst > 0.05:
+            raise _lib.AstrildHipError(f"triangle counts are not integers to 0.05 (worst {worst:.3g})")
+        _tri_cache[key] = ntri
+        _tri_cache[key + ("residual",)] = worst
+    dfields = {}
     for s in used:
         shell_filter(spec, n, edges[s], edges[s + 1], out=scratch)
         dfields[s] = c2r(scratch, (n, n, n))
-        if ntri is None:
-            shell_filter(None, n, edges[s], edges[s + 1], out=scratch)
-            ifields[s] = c2r(scratch, (n, n, n))
     nums = [triple_product_sum(dfields[i], dfields[j], dfields[l]) for (i, j, l) in triangles]
-    if ntri is None:
-        dens = [triple_product_sum(ifields[i], ifields[j], ifields[l]) for (i, j, l) in triangles]
-        ntri = np.rint(torch.cat(dens).cpu().numpy() / float(n) ** 3).astype(np.int64)
-        _tri_cache[key] = ntri
     num = torch.cat(nums).cpu().numpy()
     kf = 2.0 * np.pi / boxsize
     kmid = np.array([[kf * 0.5 * (edges[s] + edges[s + 1]) for s in t] for t in triangles])
     with np.errstate(invalid="ignore", divide="ignore"):
         b = float(boxsize) ** 6 * num / (ntri * float(n) ** 3)
-    return {"B": b, "ntri": ntri, "k": kmid}
+    return {"B": b, "ntri": ntri, "k": kmid, "ntri_residual": _tri_cache[key + ("residual",)]}

@@ -41,26 +41,53 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=512, help="lattice side of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--kappa", type=int, default=1, help="also time the kappa-map pipeline (1/0)")
     ap.add_argument("--bispec", type=int, default=1, help="also time the 512^3 bispectrum (1/0)")
+    ap.add_argument("--legs", type=int, default=1, help="also time the shuffled-order and TSC legs (1/0)")
     ap.add_argument("--slab", type=int, default=0, help="run the slab-decomposed pipeline even on one GPU (rehearsal)")
     return ap.parse_args()
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(sample, window, boxsize):
     """The oracle (numpy port of the reference's CPU path: pmesh-convention paint,
     rfftn, FFTPower binning; float64 like the reference) on a bounded sample of the
-    workload: sample^3 particles on a sample^3 grid, single thread."""
+    workload: sample^3 particles on a sample^3 grid.  `value` is the single-thread figure
+    (how astrild runs: one MPI rank, FFTW without threads, numpy); `threaded` repeats the
+    FFT + binning with scipy.fft on every host core - the paint of the port
+    is numpy bincount and has no threaded form."""
     from oracle import mesh as omesh, fftpower as offt
+    import scipy.fft
+    ncpu = os.cpu_count() or 1
     pos = omesh.lattice_particles(sample, sample, boxsize, seed=20240601)
     t0 = time.perf_counter()
     grid = omesh.paint(pos, None, sample, boxsize, window)
     t1 = time.perf_counter()
     offt.fftpower_1d(grid, boxsize)
     t2 = time.perf_counter()
+    spec = scipy.fft.rfftn(grid, workers=ncpu) / grid.size
+    t3 = time.perf_counter()
+    p3d = (spec * np.conj(spec)).real * boxsize ** 3
+    p3d[0, 0, 0] = 0.0
+    offt.project_1d(p3d, sample, boxsize)
+    t4 = time.perf_counter()
     n = pos.shape[0]
     return {
         "value": n / (t2 - t0), "unit": "particles/s", "cores": 1, "kind": "port",
         "sample": f"{sample}^3 particles on a {sample}^3 grid, float64, numpy bincount paint {t1 - t0:.2f}s + "
-                  f"numpy rfftn/shell binning {t2 - t1:.2f}s; host has {os.cpu_count()} logical cores",
+                  f"numpy rfftn/shell binning {t2 - t1:.2f}s (1024^3 is not run: the numpy port's temporaries "
+                  f"need > 100 GB of host RAM)",
+        "threaded": {"value": n / ((t1 - t0) + (t4 - t2)), "cores": ncpu,
+                     "fft_s": round(t3 - t2, 3), "binning_s": round(t4 - t3, 3), "paint_s_single_thread": round(t1 - t0, 3),
+                     "note": f"scipy.fft.rfftn(workers={ncpu}) + numpy shell binning; paint as in the single-thread leg"},
+        "cpu_model": _cpu_model(), "logical_cores": ncpu,
     }
 
 
@@ -135,111 +162,20 @@ def main():
     n = args.ngrid
     npside = args.npside or n
     L = 1000.0
-    tdt = torch.float32 if args.dtype == "f32" else torch.float64
-    esz = 4 if args.dtype == "f32" else 8
-    npart_total = npside ** 3
-
-    if not use_slab:
-        pos = dev.synth_lattice_particles(npside, n, L, seed=20240601, shuffle=(args.order == "shuffled"), dtype=tdt)
-        grid = torch.empty((n, n, n), dtype=tdt, device="cuda")
-        spec = torch.empty((n, n, n // 2 + 1), dtype=torch.complex64 if args.dtype == "f32" else torch.complex128,
-                           device="cuda")
-        psum = torch.zeros(n // 2 - 1, dtype=torch.float64, device="cuda")
-        dev.shell_geometry(n, L)          # data independent, cached like the FFT plan
-
-        fused = dev.fused_power_supported(grid)
-
-        def step():
-            if fused and args.method in ("auto", "tiled"):
-                # the paint's halo fold rides on the z pass of the FFT (one kernel and ~2 GB less)
-                _, halo = dev.paint(pos, None, n, L, args.window, out=grid, method="tiled", check_dropped=False,
-                                    accumulate=False, defer_fold=True)
-                psum.zero_()
-                return dev.power_sums_fused(grid, L, psum=psum, mean=npart_total / float(n) ** 3, halo=halo)
-            dev.paint(pos, None, n, L, args.window, out=grid, method=args.method, check_dropped=False,
-                      accumulate=False)       # overwrite mode: no zero-fill pass
-            psum.zero_()
-            if fused:                         # tile FFT with the shell binning fused into the last pass
-                return dev.power_sums_fused(grid, L, psum=psum, mean=npart_total / float(n) ** 3)
-            dev.r2c(grid, out=spec)
-            return dev.power_bin_1d(spec, None, n, L, psum=psum)
-    else:
-        from astrild_amd import slab
-        pipe = slab.SlabPowerPipeline(n, L, npside, window=args.window, dtype=tdt, seed=20240601,
-                                      shuffle=(args.order == "shuffled"))
-        pipe.step(check=True)             # once, untimed: no deposit may fall outside the ghost zone
-        step = pipe.step
 
     def barrier():
         if use_slab:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    dev.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sums = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = dev.profile_report()
-    dev.profile_enable(False)
-    if use_slab:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    ms_per_step = elapsed / args.steps * 1e3
-    value = npart_total / (elapsed / args.steps)
-
-    # sanity: the spectrum that was timed is a real one (finite, positive at Nyquist-ish k)
-    res = dev.finish_power(*sums)
-    assert np.isfinite(res["power"]).all() and res["power"][-1] > 0
-
-    # ---- roofline per logical stage: SURVEY.md §8(d) algorithmic bytes / HIP-event time ----
-    npart_rank = npart_total / world
-    ng_rank = n ** 3 / world
-    stage_sites = {
-        "paint": [k for k in prof if k.startswith("paint")],
-        "fft": [k for k in prof if k.startswith("rocfft") or k.startswith("fft_tile") or k.startswith("slab.")],
-        "power_bin": [k for k in prof if k == "power_bin"],        # absent when fused into the last FFT pass
-    }
-    stage_bytes = {
-        "paint": npart_rank * 3 * esz + ng_rank * esz,       # read positions once, write the grid once
-        "fft": 3 * 2 * ng_rank * esz,                         # 3 axis passes x (read + write)
-        "power_bin": ng_rank * esz,                           # half spectrum read once (~esz B per real cell)
-    }
-    if not use_slab and not stage_sites["power_bin"]:
-        stage_bytes["fft"] += stage_bytes.pop("power_bin")    # fused: one stage carries both terms
-        stage_sites.pop("power_bin")
-    stages = {}
-    for name, sites in stage_sites.items():
-        ms = sum(prof[s][1] for s in sites) / args.steps
-        if ms > 0:
-            gbs = stage_bytes[name] / ms / 1e6
-            stages[name] = {"ms": round(ms, 4), "alg_GB": round(stage_bytes[name] / 1e9, 3),
-                            "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
-                            "kernels": {s: round(prof[s][1] / args.steps, 4) for s in sites}}
-    dom = max(stages, key=lambda k: stages[k]["ms"])
-    # HBM traffic of the dominant stage from the PMC passes of the same command (rocprofv3 --pmc FETCH_SIZE /
-    # WRITE_SIZE in separate runs, gfx950 x2 read correction; profiles/r01_pmc_traffic.json says how)
-    traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if dom == "paint" and not use_slab and n == 1024 and npside == 1024 and args.window == "cic" \
-            and args.dtype == "f32" and args.order == "natural" and os.path.isfile(pmc_file):
-        traffic = json.load(open(pmc_file)).get("paint_stage_corrected_GB_per_step")
-        traffic = None if traffic is None else traffic * 1e9
-    roofline = {
-        "bound": "hbm", "kernel": f"{dom} stage ({'+'.join(stage_sites[dom])})",
-        "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": stages[dom]["frac"], "traffic": traffic,
-        "end_to_end": {"alg_GB": round(sum(stage_bytes.values()) / 1e9, 3),
-                       "GBps": round(sum(stage_bytes.values()) * world / (ms_per_step * 1e6), 1),
-                       "frac": round(sum(stage_bytes.values()) * world / (ms_per_step * 1e6) / (HBM_PEAK_GBS * world), 4)},
-        "stages": stages,
-    }
+    if not use_slab:
+        leg = power_leg(dev, n, npside, L, args.window, args.order, args.dtype, args.method, args.steps, args.warmup)
+    else:
+        leg = slab_leg(dev, dist, n, npside, L, args, world, barrier)
+    ms_per_step = leg["ms_per_step"]
+    npart_total = npside ** 3
+    value = npart_total / (ms_per_step * 1e-3)
+    roofline = leg["roofline"]
 
     out = {
         "metric": "particles/sec CIC+3D-FFT P(k) on 1024^3 grid" if n == 1024 and args.window == "cic"
@@ -250,13 +186,28 @@ def main():
         "config": {"workload": f"{npside}^3 lattice+Gaussian(0.5 cell) particles ({args.order} order) -> "
                                f"{args.window.upper()} paint on {n}^3 grid -> 3D R2C -> FFTPower 1d shells",
                    "ngrid": n, "nparticles": npart_total, "boxsize": L,
+                   "order_note": "natural = lattice order, the spatially coherent best case for the scatter; the "
+                                 "shuffled (worst case) and TSC figures are in `legs`",
+                   "outside_timed_step": "FFT twiddles, per-shell geometry sums (sum w|k|, mode counts: data independent, "
+                                         "cached per (N, L) like an FFT plan), workspace allocation",
                    "parallelism": "single GPU" if not use_slab else f"axis-0 slabs x{world}, RCCL all-to-all transpose"},
         "roofline": roofline,
     }
     if rank == 0 and not use_slab:
+        if args.legs:
+            # the other orderings / windows of the same workload, a few steps each (same kernels, same accounting)
+            legs = {}
+            for name, (win, order) in {"shuffled_cic": ("cic", "shuffled"), "natural_tsc": ("tsc", "natural"),
+                                       "natural_cic": ("cic", "natural")}.items():
+                if (win, order) == (args.window, args.order):
+                    continue
+                lg = power_leg(dev, n, npside, L, win, order, args.dtype, args.method, steps=3, warmup=1)
+                legs[name] = {"ms_per_step": round(lg["ms_per_step"], 3), "particles_per_s": npart_total / (lg["ms_per_step"] * 1e-3),
+                              "end_to_end_frac": lg["roofline"]["end_to_end"]["frac"],
+                              "stages": {k: {"ms": v["ms"], "frac": v["frac"]} for k, v in lg["roofline"]["stages"].items()}}
+            out["legs"] = legs
         if args.cpu_sample:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.window, L)
-        del pos, grid, spec
         torch.cuda.empty_cache()
         if args.bispec:
             out["bispectrum"] = bispectrum_leg(dev)
@@ -269,6 +220,157 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_slab:
         dist.destroy_process_group()
+
+
+def _stage_table(prof, steps, npart_rank, ng_rank, esz, fused_bin):
+    """Roofline per logical stage: SURVEY.md §8(d) algorithmic bytes / HIP-event time."""
+    stage_sites = {
+        "paint": [k for k in prof if k.startswith("paint")],
+        "fft": [k for k in prof if k.startswith("rocfft") or k.startswith("fft_tile") or k.startswith("slab.")],
+        "power_bin": [k for k in prof if k == "power_bin"],        # absent when fused into the last FFT pass
+    }
+    stage_bytes = {
+        "paint": npart_rank * 3 * esz + ng_rank * esz,       # read positions once, write the grid once
+        "fft": 3 * 2 * ng_rank * esz,                         # 3 axis passes x (read + write)
+        "power_bin": ng_rank * esz,                           # half spectrum read once (~esz B per real cell)
+    }
+    if fused_bin and not stage_sites["power_bin"]:
+        stage_bytes["fft"] += stage_bytes.pop("power_bin")    # fused: one stage carries both terms
+        stage_sites.pop("power_bin")
+    stages = {}
+    for name, sites in stage_sites.items():
+        ms = sum(prof[s][1] for s in sites) / steps
+        if ms > 0:
+            gbs = stage_bytes[name] / ms / 1e6
+            stages[name] = {"ms": round(ms, 4), "alg_GB": round(stage_bytes[name] / 1e9, 3),
+                            "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                            "kernels": {s: round(prof[s][1] / steps, 4) for s in sites}}
+    return stages, stage_sites, stage_bytes
+
+
+def _traffic_from_profiles():
+    """HBM traffic of the paint stage from the PMC passes kept under profiles/ (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs, gfx950 x2 read correction).  It is NOT measured by this run: the newest
+    profiles/r*_pmc_traffic.json is quoted together with where it came from, and only if the paint kernels'
+    source is byte-identical to the one profiled (else null)."""
+    import glob
+    import hashlib
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    doc = json.load(open(files[-1]))
+    src = os.path.join(ROOT, "astrild_amd", "csrc", "mesh_paint_tiled.hip")
+    sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16] if os.path.isfile(src) else None
+    source = {"file": os.path.relpath(files[-1], ROOT), "paint_src_sha256_16": doc.get("paint_src_sha256_16"),
+              "current_paint_src_sha256_16": sha, "measured_in_this_run": False}
+    gb = doc.get("paint_stage_corrected_GB_per_step")
+    if gb is None or doc.get("paint_src_sha256_16") != sha:
+        return None, source
+    return gb * 1e9, source
+
+
+def power_leg(dev, n, npside, L, window, order, dtype, method, steps, warmup):
+    """One configuration of the 3D path on ONE GPU: paint -> 3D R2C -> shell binning, `steps` timed steps."""
+    tdt = torch.float32 if dtype == "f32" else torch.float64
+    esz = 4 if dtype == "f32" else 8
+    npart_total = npside ** 3
+    pos = dev.synth_lattice_particles(npside, n, L, seed=20240601, shuffle=(order == "shuffled"), dtype=tdt)
+    grid = torch.empty((n, n, n), dtype=tdt, device="cuda")
+    psum = torch.zeros(n // 2 - 1, dtype=torch.float64, device="cuda")
+    dev.shell_geometry(n, L)          # data independent, cached like the FFT plan
+    fused = dev.fused_power_supported(grid)
+    spec = None
+    if not fused:
+        spec = torch.empty((n, n, n // 2 + 1), dtype=torch.complex64 if dtype == "f32" else torch.complex128, device="cuda")
+    mean = npart_total / float(n) ** 3
+    hint = "scattered" if order == "shuffled" else None
+
+    def step():
+        if fused and method in ("auto", "tiled"):
+            # the paint stores rho - mean (subtracted in double before the fp32 rounding) and its halo fold rides
+            # on the z pass of the FFT (one kernel and ~2 GB less)
+            _, halo = dev.paint(pos, None, n, L, window, out=grid, method="tiled", check_dropped=False,
+                                accumulate=False, defer_fold=True, offset=mean, hint=hint)
+            psum.zero_()
+            return dev.power_sums_fused(grid, L, psum=psum, halo=halo)
+        dev.paint(pos, None, n, L, window, out=grid, method=method, check_dropped=False,
+                  accumulate=False, hint=hint)       # overwrite mode: no zero-fill pass
+        psum.zero_()
+        if fused:                         # tile FFT with the shell binning fused into the last pass
+            return dev.power_sums_fused(grid, L, psum=psum, mean=mean)
+        dev.r2c(grid, out=spec)
+        return dev.power_bin_1d(spec, None, n, L, psum=psum)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    dev.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sums = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = dev.profile_report()
+    dev.profile_enable(False)
+    ms_per_step = elapsed / steps * 1e3
+    # sanity: the spectrum that was timed is a real one (finite, positive at Nyquist-ish k)
+    res = dev.finish_power(*sums)
+    assert np.isfinite(res["power"]).all() and res["power"][-1] > 0
+    stages, stage_sites, stage_bytes = _stage_table(prof, steps, npart_total, n ** 3, esz, fused_bin=True)
+    dom = max(stages, key=lambda k: stages[k]["ms"])
+    traffic, source = (None, None)
+    if dom == "paint" and n == 1024 and npside == 1024 and window == "cic" and dtype == "f32" and order == "natural":
+        traffic, source = _traffic_from_profiles()
+    total = sum(stage_bytes.values())
+    roofline = {
+        "bound": "hbm", "kernel": f"{dom} stage ({'+'.join(stage_sites[dom])})",
+        "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": stages[dom]["frac"], "traffic": traffic, "traffic_source": source,
+        "end_to_end": {"alg_GB": round(total / 1e9, 3), "GBps": round(total / (ms_per_step * 1e6), 1),
+                       "frac": round(total / (ms_per_step * 1e6) / HBM_PEAK_GBS, 4)},
+        "stages": stages,
+    }
+    del pos, grid, spec
+    torch.cuda.empty_cache()
+    return {"ms_per_step": ms_per_step, "roofline": roofline}
+
+
+def slab_leg(dev, dist, n, npside, L, args, world, barrier):
+    from astrild_amd import slab
+    tdt = torch.float32 if args.dtype == "f32" else torch.float64
+    esz = 4 if args.dtype == "f32" else 8
+    pipe = slab.SlabPowerPipeline(n, L, npside, window=args.window, dtype=tdt, seed=20240601,
+                                  shuffle=(args.order == "shuffled"))
+    pipe.step(check=True)             # once, untimed: no deposit may fall outside the ghost zone
+    for _ in range(args.warmup):
+        pipe.step()
+    barrier()
+    dev.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sums = pipe.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = dev.profile_report()
+    dev.profile_enable(False)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    res = dev.finish_power(*sums)
+    assert np.isfinite(res["power"]).all() and res["power"][-1] > 0
+    stages, stage_sites, stage_bytes = _stage_table(prof, args.steps, npside ** 3 / world, n ** 3 / world, esz, fused_bin=False)
+    dom = max(stages, key=lambda k: stages[k]["ms"])
+    total = sum(stage_bytes.values())
+    roofline = {
+        "bound": "hbm", "kernel": f"{dom} stage ({'+'.join(stage_sites[dom])}), rank 0 of {world}",
+        "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": stages[dom]["frac"], "traffic": None,
+        "end_to_end": {"alg_GB": round(total * world / 1e9, 3), "GBps": round(total * world / (ms_per_step * 1e6), 1),
+                       "frac": round(total / (ms_per_step * 1e6) / HBM_PEAK_GBS, 4)},
+        "stages": stages, "ranks": world, "backend": dist.get_backend(),
+    }
+    return {"ms_per_step": ms_per_step, "roofline": roofline}
 
 
 if __name__ == "__main__":

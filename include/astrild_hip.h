@@ -136,11 +136,17 @@ int ast_paint(int window, int dtype, const void* pos_d, const void* mass_d, size
  * the grid is complete only after ast_fft_tile_power_3d_halo has read it, which folds the records
  * while its z pass loads the rows (one kernel and ~2 GB of traffic less at 1024^3). */
 #define AST_PAINT_DEFER_FOLD 4
+/* offset (AST_PAINT_OVERWRITE only, else 0): every OWNED cell is stored as (sum - offset), the
+ * subtraction done in double on the exact fixed-point sum before the single rounding to `dtype`
+ * (halo records stay additive).  With offset = total mass * scale / nmesh^3 the grid holds the
+ * density CONTRAST rho - mean: only the DC mode of its spectrum changes (FFTPower discards it),
+ * and fp32 cells stop carrying the rounding error of the O(1) mean. */
 size_t ast_paint_tiled_workspace_bytes(int window, int dtype, size_t np, int nmesh, int nx_alloc, int flags);
 int ast_paint_tiled(int window, int dtype, const void* pos_d, const void* mass_d, size_t np,
                     int nmesh, double boxsize, double scale, int x_start, int nx_alloc,
                     void* grid_d, void* workspace_d, size_t workspace_bytes,
-                    unsigned long long* dropped_d, int flags, double mass_bound, void* stream);
+                    unsigned long long* dropped_d, int flags, double mass_bound, double offset,
+                    void* stream);
 /* Where a paint with AST_PAINT_OVERWRITE | AST_PAINT_DEFER_FOLD and these parameters left its halo
  * records inside workspace_d (for ast_fft_tile_power_3d_halo). */
 int ast_paint_tiled_halo(void* workspace_d, int window, int dtype, size_t np, int nmesh, int nx_alloc, int flags,
@@ -309,6 +315,11 @@ int ast_smooth_plan_create(ast_smooth_plan** plan, int npix);
 int ast_smooth_plan_destroy(ast_smooth_plan* plan);
 int ast_gaussian_smooth(ast_smooth_plan* plan, double* img_d, double sigma_px, int mode,
                         void* stream);
+
+/* Sum of a buffer in double, fixed summation order (bit-reproducible): out_d[0]; out_d must hold
+ * 1 + AST_SUM_PARTS doubles (the rest is scratch). */
+#define AST_SUM_PARTS 1024
+int ast_sum(const void* buf_d, int dtype, size_t count, double* out_d, void* stream);
 
 /* min and max of a buffer -> out_d[0], out_d[1] (double, device). */
 int ast_minmax(const void* buf_d, int dtype, size_t count, double* out_d, void* stream);

@@ -112,3 +112,54 @@ def test_kappa_stack_and_pipeline_properties_at_4096(hip, dev):
     assert float((b1 - 2 * a1).abs().max()) < 1e-12 * scale
     z1, z2 = plan.alphas(torch.zeros_like(sm))
     assert float(z1.abs().max()) == 0.0 and float(z2.abs().max()) == 0.0
+
+
+def _triangles_brute_force(n, lo_hi_i, lo_hi_j, lo_hi_l):
+    """Exact integer count of closed triangles q1 + q2 + q3 = 0 with |q1| in shell i, |q2| in j, |q3| in l on the
+    FULL integer lattice (independent of any FFT): enumerate q1, q2 and test -(q1+q2), with the DFT's aliasing."""
+    def shell_vectors(lo, hi):
+        r = np.arange(-hi, hi + 1)
+        g = np.stack(np.meshgrid(r, r, r, indexing="ij"), axis=-1).reshape(-1, 3)
+        m2 = (g ** 2).sum(axis=1)
+        return g[(m2 >= lo * lo) & (m2 < hi * hi)]
+    a, b = shell_vectors(*lo_hi_i), shell_vectors(*lo_hi_j)
+    lo, hi = lo_hi_l
+    total = 0
+    for chunk in np.array_split(a, max(1, len(a) * len(b) // 4_000_000)):
+        q3 = -(chunk[:, None, :] + b[None, :, :])
+        q3 = (q3 + n // 2) % n - n // 2          # alias into [-n/2, n/2)
+        q3 = np.where(q3 == -n // 2, n // 2, q3)   # the DFT keeps index n/2 (|m| is what matters)
+        m2 = (q3.astype(np.int64) ** 2).sum(axis=2)
+        total += int(((m2 >= lo * lo) & (m2 < hi * hi)).sum())
+    return total
+
+
+def test_config_e_bispectrum_512(dev):
+    """BASELINE.json configs[4] at its stated size: FFT triangle counting on a 512^3 grid.
+    N_tri: within 1e-3 of an integer for every bin (fp64 I-fields), and the lowest bins equal an
+    independent integer enumeration exactly; B: fp32 pipeline against the fp64 pipeline."""
+    n, L, width = 512, 1000.0, 8
+    pos = dev.synth_lattice_particles(n, n, L, seed=20240601, dtype=torch.float32)
+    grid = dev.paint(pos, None, n, L, "cic")
+    edges = list(range(1, n // 2 + 1, width))
+    nsh = len(edges) - 1
+    tri = [(i, i, i) for i in range(nsh)] + [(0, i, i) for i in range(1, nsh)] + \
+          [(i, i, min(nsh - 1, 2 * i)) for i in range(1, nsh // 2)]
+    dev._tri_cache.clear()
+    r32 = dev.bispectrum(grid, L, edges, tri)
+    assert r32["ntri_residual"] < 1e-3
+    assert (r32["ntri"] >= 0).all() and r32["ntri"][:nsh].min() > 0
+    # exact integer check, no FFT involved: equilateral (0,0,0), squeezed (0,1,1), isosceles (1,1,2)
+    for t in [(0, 0, 0), (0, 1, 1), (1, 1, 2)]:
+        want = _triangles_brute_force(n, *[(edges[s], edges[s + 1]) for s in t])
+        assert int(r32["ntri"][tri.index(t)]) == want, t
+    g64 = dev.paint(pos.double(), None, n, L, "cic")
+    del pos
+    r64 = dev.bispectrum(g64, L, edges, tri)
+    assert np.array_equal(r64["ntri"], r32["ntri"])
+    ok = r64["ntri"] > 0
+    scale = np.abs(r64["B"][ok]).max()
+    # fp32 fields: relative 1e-5 of each bin, with a floor at 1e-6 of the largest |B| (bins near zero crossings)
+    np.testing.assert_allclose(r32["B"][ok], r64["B"][ok], rtol=1e-5, atol=1e-6 * scale)
+    dev._tri_cache.clear()
+    dev.clear_plan_cache()

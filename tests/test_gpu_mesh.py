@@ -264,3 +264,82 @@ def test_tiled_paint_far_outside_the_box_and_on_its_edges(dev, window, dtype):
         tol = 1e-11 if dtype == np.float64 else 2e-6
         np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * ref.max())
         assert got.sum(dtype=np.float64) == pytest.approx(len(pos), rel=1e-6)
+
+
+@pytest.mark.parametrize("window", ["cic", "tsc"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_paint_offset_stores_the_density_contrast(dev, window, dtype):
+    """offset="mean": owned cells hold rho - mean, subtracted in double before the one rounding to the
+    grid dtype, so an fp32 cell is accurate to 6e-8 of |delta| (not of the O(1) mean); with masses and
+    a cell-volume scale; both the folded grid and the deferred-fold pair (grid + halo records)."""
+    rng = np.random.default_rng(31)
+    n, L = 64, 320.0
+    pos = omesh.lattice_particles(n, n, L, seed=3, dtype=dtype)
+    mass = rng.uniform(0.5, 2.0, size=len(pos)).astype(dtype)
+    scale = (n / L) ** 3
+    ref = omesh.paint(pos, mass, n, L, window) * scale
+    mean = mass.astype(np.float64).sum() * scale / n ** 3
+    delta = ref - mean
+    got = dev.paint(dev.as_device(pos), dev.as_device(mass), n, L, window, scale=scale, method="tiled",
+                    offset="mean").cpu().numpy()
+    err = np.abs(got - delta)
+    if dtype == np.float64:
+        assert err.max() <= 1e-12 * np.abs(ref).max()
+    else:
+        # cells no halo record is folded into (interior of the 8 x 8 tile footprint): ONE rounding of the exact
+        # fixed-point sum minus the mean -> half an fp32 ulp of |delta|
+        ix = np.arange(n) % 8
+        inner = ((ix > 1) & (ix < 6))[:, None, None] & ((ix > 1) & (ix < 6))[None, :, None] & np.ones(n, bool)[None, None, :]
+        assert (err[inner] <= 6.0e-8 * np.abs(delta[inner]) + 1e-9 * np.abs(ref).max()).all()
+        # border cells add up to three fp32 records in fp32
+        assert err.max() <= 2.5e-7 * np.abs(ref).max()
+    assert abs(got.sum(dtype=np.float64)) < 1e-3 * np.abs(delta).sum()
+    assert dev.total_mass(dev.as_device(mass), len(mass)) == pytest.approx(mass.astype(np.float64).sum(), rel=1e-14)
+
+
+@pytest.mark.parametrize("window", ["cic", "tsc"])
+def test_slab_buffer_with_a_partial_last_tile_reports_lost_deposits(dev, window):
+    """nx_alloc % 8 != 0: a particle whose base plane is the buffer's last plane deposits its +1 (+2)
+    planes onto owned cells of a plane the buffer does not hold.  Every paint variant must count
+    them (they used to vanish silently in the overwrite column walk)."""
+    from astrild_amd._lib import AstrildHipError
+    n, L = 64, 64.0
+    rng = np.random.default_rng(8)
+    x_start, nx_alloc = 10, 18                           # planes 10..27; 18 % 8 = 2
+    inside = rng.uniform(0, L, size=(70000, 3))
+    inside[:, 0] = rng.uniform(x_start + 1.0, x_start + nx_alloc - 2.0, size=len(inside))
+    for method in ("direct", "tiled", "tiled2"):
+        for accumulate in (None, False):
+            ok = dev.paint(dev.as_device(inside), None, n, L, window, method=method, x_start=x_start, nx_alloc=nx_alloc,
+                           accumulate=accumulate).cpu().numpy()
+            ref = omesh.paint(inside, None, n, L, window)[x_start:x_start + nx_alloc]
+            np.testing.assert_allclose(ok, ref, rtol=1e-12, atol=1e-12)
+            bad = inside.copy()
+            bad[0] = [x_start + nx_alloc - 1 + 0.4, 20.3, 30.6]       # base plane = last buffer plane (CIC); +1 is outside
+            with pytest.raises(AstrildHipError, match="outside the grid buffer"):
+                dev.paint(dev.as_device(bad), None, n, L, window, method=method, x_start=x_start, nx_alloc=nx_alloc,
+                          accumulate=accumulate)
+
+
+def test_config_a_128_cic_power_vs_oracle(dev):
+    """BASELINE.json configs[0] at its stated size: 128^3 synthetic particles -> CIC -> P(k).
+    fp64 (the reference's dtype) against the oracle to 1e-9 on every shell, mode counts and k exact;
+    fp32 through the fused pipeline (paint stores rho - mean) against the same oracle."""
+    n, L = 128, 1000.0
+    pos = omesh.lattice_particles(n, n, L, seed=20240601)
+    ref = offt.fftpower_1d(omesh.paint(pos, None, n, L, "cic"), L)
+    res = dev.fftpower_1d(dev.paint(dev.as_device(pos), None, n, L, "cic", method="tiled"), L)
+    np.testing.assert_array_equal(res["modes"], ref["modes"])
+    np.testing.assert_allclose(res["k"], ref["k"], rtol=1e-12)
+    np.testing.assert_allclose(res["power"], ref["power"].real, rtol=1e-9)
+    pos32 = pos.astype(np.float32)
+    ref32 = offt.fftpower_1d(omesh.paint(pos32, None, n, L, "cic"), L)       # same fp32 positions, fp64 arithmetic
+    for window in ("cic",):
+        got = dev.paint_power_1d(dev.as_device(pos32), None, n, L, window)
+        np.testing.assert_array_equal(got["modes"], ref32["modes"])
+        rel = np.abs(got["power"] / ref32["power"].real - 1.0)
+        # fp32 grid + fp32 FFT: 1e-6 wherever a shell holds >= 1e-3 of the peak power; the cold lattice's
+        # lowest shells (1e-5 of the peak) are bounded by the white round-off floor instead (DESIGN.md §6)
+        strong = ref32["power"].real >= 1e-3 * ref32["power"].real.max()
+        assert rel[strong].max() < 1e-6
+        assert rel.max() < 1e-5

@@ -110,7 +110,9 @@ def test_slab_pipeline_object_on_one_gpu_over_nccl(hip):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,dt,rtol", [(2, 64, "f64", 1e-9), (4, 256, "f32", 3e-5)])
+@pytest.mark.parametrize("world,n,dt,rtol", [(2, 64, "f64", 1e-9), (4, 256, "f32", 3e-5),
+                                             # config C rehearsal at its stated size: the 1024^3 problem on 2 / 4 ranks
+                                             (2, 1024, "f32", 3e-5), (4, 1024, "f32", 3e-5)])
 def test_ranks_share_one_gpu_over_gloo(hip, tmp_path, world, n, dt, rtol):
     """The real multi-rank data flow (ghost fold, chunked exchange, all-reduces) with HipSlabOps:
     `world` processes, all on cuda:0, gloo instead of RCCL (one GPU here), against the single-GPU path."""
@@ -126,7 +128,7 @@ def test_ranks_share_one_gpu_over_gloo(hip, tmp_path, world, n, dt, rtol):
     out = str(tmp_path / "rank0.npz")
     worker = os.path.join(os.path.dirname(__file__), "slab_gpu_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(n), out, dt]) for r in range(world)]
-    codes = [p.wait(timeout=300) for p in procs]
+    codes = [p.wait(timeout=900) for p in procs]
     assert codes == [0] * world
     got = np.load(out)
     dtype = torch.float64 if dt == "f64" else torch.float32
