@@ -328,6 +328,212 @@ tile_index_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t* __
     if (MODE != 1 && dropped && ndrop) atomicAdd(dropped, ndrop);
 }
 
+// ------------------------------------------------------------------------------------
+// Single pass, COMPACT lists (the format of the overwrite column walk): per tile
+//   * group records {first, mask}: the particles first + b, for every set bit b of mask, of one
+//     32-particle window (first is a multiple of 32) - 8 bytes for up to 32 particles.  The walk
+//     reads a window's positions with one fully coalesced, line-aligned 384-byte access, so a
+//     spatially coherent input costs ~0.3 B per particle of list traffic instead of a 4-byte id,
+//     and neither the list nor the gather depends on where the runs are interrupted;
+//   * stray records {x, y, z, m}: a particle with fewer than MINPOP companions of its tile in its
+//     window is COPIED (the index pass has it in registers anyway... it re-reads it from L2 when
+//     the destination is known): 16 bytes written and read back contiguously, instead of a 4-byte
+//     id plus a 64/128-byte line per stray in the walk's gather.  Fully scattered input turns
+//     into a binned copy of the particles.
+// Slots are reserved like in tile_index_kernel: an LDS table keyed by tile (one returning 64-bit
+// global atomic per distinct tile and interval: run count in the high word, stray count in the low),
+// a miss list for hash collisions, overflow list for what does not fit a tile's segments.
+constexpr int MINPOP = 8;              // records with fewer particles would waste the walk's lanes
+constexpr int GROUP_ITERS = 3;         // tiles that can get a record per 32-particle window
+constexpr uint32_t LREC_CAP = 512;     // records parked in LDS per interval (128 windows x up to 3; rest: slow path)
+struct GroupRec { uint32_t first, mask; };
+
+template <typename T>
+__device__ inline void store_stray(T* __restrict__ strays, size_t slot, T x, T y, T z, T m) {
+    typedef T vec4_t __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<vec4_t*>(strays + 4 * slot) = vec4_t{x, y, z, m};
+}
+
+// One group or one stray placed by one thread (hash collision in the LDS table, or LDS lists full).
+// NOT inlined, for the reason given at place_run_slow.
+template <typename T>
+__device__ __noinline__ void place_group_slow(uint32_t key, uint32_t a, uint32_t mask, const T* __restrict__ pos,
+                                              const T* __restrict__ mass, unsigned long long* __restrict__ fill64,
+                                              GroupRec* __restrict__ recs, uint32_t rcap, T* __restrict__ strays,
+                                              uint32_t scap, uint32_t* __restrict__ ovf,
+                                              unsigned long long* __restrict__ ovf_count) {
+    if (mask) {
+        const uint32_t r = (uint32_t)(atomicAdd(&fill64[key], 1ull << 32) >> 32);
+        if (r < rcap) { recs[(size_t)key * rcap + r] = GroupRec{a, mask}; return; }
+        for (uint32_t m = mask; m; m &= m - 1) ovf[atomicAdd(ovf_count, 1ull)] = a + (uint32_t)__ffs((int)m) - 1u;
+    } else {
+        const uint32_t sidx = (uint32_t)atomicAdd(&fill64[key], 1ull);
+        if (sidx < scap) store_stray(strays, (size_t)key * scap + sidx, pos[3 * (size_t)a], pos[3 * (size_t)a + 1],
+                                     pos[3 * (size_t)a + 2], mass ? mass[a] : (T)1);
+        else ovf[atomicAdd(ovf_count, 1ull)] = a;
+    }
+}
+
+template <typename T, int W, bool PLAINX>
+__global__ void __launch_bounds__(256)
+tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t np, TileGeom g,
+                  unsigned long long* __restrict__ fill64, GroupRec* __restrict__ recs, uint32_t rcap,
+                  T* __restrict__ strays, uint32_t scap, uint32_t* __restrict__ ovf,
+                  unsigned long long* __restrict__ ovf_count, uint32_t* __restrict__ col_flags,
+                  unsigned long long* dropped) {
+    __shared__ uint32_t skey[AGG_SLOTS], srun[AGG_SLOTS], sstray[AGG_SLOTS], sroom_run[AGG_SLOTS], sroom_stray[AGG_SLOTS];
+    __shared__ unsigned long long sdst_run[AGG_SLOTS], sdst_stray[AGG_SLOTS];
+    __shared__ uint32_t codes[AGG_TRIPS * IDX_UNROLL][256];           // strays only: slot << 16 | offset, or CODE_DONE
+    __shared__ uint32_t lrec_first[LREC_CAP], lrec_mask[LREC_CAP], lrec_dst[LREC_CAP], lrec_n;
+    constexpr uint32_t MISS_CAP = 512;
+    __shared__ uint32_t smiss_key[MISS_CAP], smiss_a[MISS_CAP], smiss_b[MISS_CAP], smiss_n;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int half = lane >> 5;
+    skey[tid] = SLOT_EMPTY;
+    srun[tid] = 0;
+    sstray[tid] = 0;
+    if (tid == 0) { smiss_n = 0; lrec_n = 0; }
+    __syncthreads();
+    const size_t per_trip = 256 * IDX_UNROLL;
+    const size_t per_interval = per_trip * AGG_TRIPS;
+    const size_t nintervals = (np + per_interval - 1) / per_interval;
+    unsigned long long ndrop = 0;
+    auto fetch = [&](size_t pbase, T (&x)[IDX_UNROLL], T (&y)[IDX_UNROLL], T (&z)[IDX_UNROLL]) {
+#pragma unroll
+        for (int u = 0; u < IDX_UNROLL; ++u) {
+            const size_t p = min(pbase + (size_t)u * 256 + tid, np - 1);      // unconditional loads
+            x[u] = pos[3 * p + 0];
+            y[u] = pos[3 * p + 1];
+            z[u] = pos[3 * p + 2];
+        }
+    };
+    auto slow = [&](uint32_t key, uint32_t a, uint32_t mask) {
+        place_group_slow<T>(key, a, mask, pos, mass, fill64, recs, rcap, strays, scap, ovf, ovf_count);
+    };
+    // the table slot of a tile, or -1 when it belongs to another tile of this interval
+    auto slot_of = [&](uint32_t key) -> int {
+        const uint32_t slot = (key * 2654435761u) >> 24;
+        const uint32_t old = atomicCAS(&skey[slot], SLOT_EMPTY, key);
+        return (old == SLOT_EMPTY || old == key) ? (int)slot : -1;
+    };
+    auto miss = [&](uint32_t key, uint32_t a, uint32_t mask) {
+        const uint32_t mi = atomicAdd(&smiss_n, 1u);
+        if (mi < MISS_CAP) { smiss_key[mi] = key; smiss_a[mi] = a; smiss_b[mi] = mask; }
+        else slow(key, a, mask);                                   // list full (scattered input)
+    };
+    static_assert(AGG_TRIPS % 2 == 0, "two register sets");
+    T xa[IDX_UNROLL], ya[IDX_UNROLL], za[IDX_UNROLL], xb[IDX_UNROLL], yb[IDX_UNROLL], zb[IDX_UNROLL];
+    if ((size_t)blockIdx.x < nintervals) fetch((size_t)blockIdx.x * per_interval, xa, ya, za);
+    for (size_t interval = blockIdx.x; interval < nintervals; interval += gridDim.x) {
+        const size_t p0 = interval * per_interval;
+        const bool full = p0 + per_interval <= np;
+        auto process = [&](int trip, const T (&x)[IDX_UNROLL], const T (&y)[IDX_UNROLL], const T (&z)[IDX_UNROLL]) {
+#pragma unroll
+            for (int u = 0; u < IDX_UNROLL; ++u) {
+                const size_t p = p0 + (size_t)trip * per_trip + (size_t)u * 256 + tid;
+                const bool valid = full || p < np;
+                uint32_t key = tile_of<T, W, PLAINX>(x[u], y[u], z[u], g, col_flags);
+                if (!valid) key = 0xffffffffu;
+                const bool live = key != 0xffffffffu;
+                if (!PLAINX && valid && !live) ++ndrop;
+                // up to GROUP_ITERS tiles per 32-lane window get a group record: the tile of the first
+                // undecided lane is the candidate; fewer than MINPOP takers -> they are strays
+                bool pending = live, stray = false;
+#pragma unroll
+                for (int it = 0; it < GROUP_ITERS; ++it) {
+                    const unsigned long long pend = __ballot(pending);
+                    const uint32_t plo = (uint32_t)pend, phi = (uint32_t)(pend >> 32);
+                    if (__popc(plo) < MINPOP && __popc(phi) < MINPOP) break;            // uniform
+                    const uint32_t mine = half ? phi : plo;
+                    const int cl = mine ? half * 32 + __ffs((int)mine) - 1 : lane;      // candidate lane of my window
+                    const uint32_t ck = (uint32_t)__shfl((int)key, cl, 64);
+                    const bool match = pending && key == ck;
+                    const unsigned long long mb = __ballot(match);
+                    const uint32_t mm = half ? (uint32_t)(mb >> 32) : (uint32_t)mb;
+                    if (__popc(mm) >= MINPOP) {
+                        if (lane == cl && match) {
+                            const uint32_t first = (uint32_t)p - (uint32_t)(lane & 31);
+                            const int slot = slot_of(key);
+                            if (slot < 0) {
+                                miss(key, first, mm);
+                            } else {
+                                const uint32_t k = atomicAdd(&lrec_n, 1u);
+                                if (k < LREC_CAP) {
+                                    lrec_first[k] = first;
+                                    lrec_mask[k] = mm;
+                                    lrec_dst[k] = ((uint32_t)slot << 16) | atomicAdd(&srun[slot], 1u);
+                                } else {
+                                    slow(key, first, mm);
+                                }
+                            }
+                        }
+                    } else {
+                        stray = stray || match;
+                    }
+                    pending = pending && !match;
+                }
+                stray = stray || pending;
+                uint32_t code = CODE_DONE;
+                if (stray) {
+                    const int slot = slot_of(key);
+                    if (slot < 0) miss(key, (uint32_t)p, 0u);
+                    else code = ((uint32_t)slot << 16) | atomicAdd(&sstray[slot], 1u);
+                }
+                codes[trip * IDX_UNROLL + u][tid] = code;
+            }
+        };
+#pragma unroll
+        for (int trip = 0; trip < AGG_TRIPS; trip += 2) {
+            fetch(p0 + (size_t)(trip + 1) * per_trip, xb, yb, zb);
+            process(trip, xa, ya, za);
+            fetch(trip + 2 < AGG_TRIPS ? p0 + (size_t)(trip + 2) * per_trip : (interval + gridDim.x) * per_interval, xa, ya, za);
+            process(trip + 1, xb, yb, zb);
+        }
+        __syncthreads();
+        if (skey[tid] != SLOT_EMPTY) {
+            const uint32_t t = skey[tid], cr = srun[tid], cs = sstray[tid];
+            const unsigned long long old = atomicAdd(&fill64[t], ((unsigned long long)cr << 32) | cs);
+            const uint32_t br = min((uint32_t)(old >> 32), rcap), bs = min((uint32_t)old, scap);
+            sdst_run[tid] = (unsigned long long)t * rcap + br;
+            sroom_run[tid] = rcap - br;
+            sdst_stray[tid] = (unsigned long long)t * scap + bs;
+            sroom_stray[tid] = scap - bs;
+        }
+        {
+            const uint32_t nm = min(smiss_n, MISS_CAP);
+            for (uint32_t e = tid; e < nm; e += 256) slow(smiss_key[e], smiss_a[e], smiss_b[e]);
+        }
+        __syncthreads();
+        {
+            const uint32_t nr = min(lrec_n, LREC_CAP);
+            for (uint32_t k = tid; k < nr; k += 256) {
+                const uint32_t d = lrec_dst[k], slot = d >> 16, at = d & 0xffffu;
+                if (at < sroom_run[slot]) recs[sdst_run[slot] + at] = GroupRec{lrec_first[k], lrec_mask[k]};
+                else for (uint32_t m = lrec_mask[k]; m; m &= m - 1) ovf[atomicAdd(ovf_count, 1ull)] = lrec_first[k] + (uint32_t)__ffs((int)m) - 1u;
+            }
+        }
+#pragma unroll 4
+        for (int j = 0; j < AGG_TRIPS * IDX_UNROLL; ++j) {
+            const uint32_t c = codes[j][tid];
+            if (c == CODE_DONE) continue;
+            const size_t p = p0 + (size_t)j * 256 + tid;
+            const uint32_t slot = c >> 16, at = c & 0xffffu;
+            // the position comes back from L2 (this workgroup read it a moment ago)
+            if (at < sroom_stray[slot]) store_stray(strays, (size_t)(sdst_stray[slot] + at), pos[3 * p], pos[3 * p + 1], pos[3 * p + 2],
+                                                    mass ? mass[p] : (T)1);
+            else ovf[atomicAdd(ovf_count, 1ull)] = (uint32_t)p;
+        }
+        __syncthreads();                    // everyone is done with the table before it is re-armed
+        skey[tid] = SLOT_EMPTY;
+        srun[tid] = 0;
+        sstray[tid] = 0;
+        if (tid == 0) { smiss_n = 0; lrec_n = 0; }
+        __syncthreads();
+    }
+    if (dropped && ndrop) atomicAdd(dropped, ndrop);
+}
+
 // Particles that did not fit their tile's segment in the single-pass variant: plain
 // global-atomic deposit (the direct kernel's inner loop over an index list).
 template <typename T, int W>
@@ -519,11 +725,24 @@ tile_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileG
 // write, contiguous in z).  Every grid cell is written, so no zero-fill is needed, and the
 // 1.3 TB/s global float-atomic flush (4 ms of the 13 ms tile kernel at 1024^3) is gone.
 // The few planes that wrap around the periodic z edge are added atomically at the end.
-template <typename T, int W, bool HAS_MASS>
+// The particle lists a column walk reads.  FMT 0: 4-byte particle ids per tile (exact offsets of the two-pass
+// variant, tile_off / tile_count).  FMT 1: the compact lists of tile_group_kernel (group records + stray copies
+// in fixed-capacity segments, counts in fill64: records in the high word, strays in the low).
+struct WalkLists {
+    const uint32_t* index;
+    const uint32_t* tile_off;
+    const uint32_t* tile_count;
+    const unsigned long long* fill64;
+    const GroupRec* recs;
+    const void* strays;
+    uint32_t rcap, scap;
+    size_t np;
+};
+
+template <typename T, int W, bool HAS_MASS, int FMT>
 __global__ void __launch_bounds__(256)
 column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileGeom g, double scale,
-                      const uint32_t* __restrict__ index, const uint32_t* __restrict__ tile_off,
-                      const uint32_t* __restrict__ tile_count, uint32_t cap, double mass_bound,
+                      WalkLists wl, double mass_bound,
                       const uint32_t* __restrict__ col_flags, T* __restrict__ grid, T* __restrict__ rec,
                       double offset, unsigned long long* dropped) {
     constexpr int LX = TX + W - 1, LY = TY + W - 1, LZ = TZ + W - 1;
@@ -577,7 +796,12 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     uint32_t cmax = 1;
     for (int tz = 0; tz < g.ntz; ++tz) {
         const uint32_t t = (uint32_t)((tx * g.nty + ty) * g.ntz + tz);
-        cmax = max(cmax, cap ? min(tile_count[t], cap) : tile_count[t]);
+        if (FMT == 0) {
+            cmax = max(cmax, wl.tile_count[t]);
+        } else {                              // an upper bound: every record full
+            const unsigned long long f = wl.fill64[t];
+            cmax = max(cmax, min((uint32_t)(f >> 32), wl.rcap) * 32u + min((uint32_t)f, wl.scap));
+        }
     }
     const int bits = 33 - __clz((int)min(cmax, 0x3fffffffu));            // 2 * cmax < 2^bits
     const double vmax = mass_bound * fabs(scale) > 0.0 ? mass_bound * fabs(scale) : 1.0;
@@ -598,37 +822,74 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
 #define DEP_U 2
 #endif
     constexpr int U = DEP_U;
-    struct Batch { int tz; uint32_t i0, cnt; size_t off; };       // tz == g.ntz: past the end
+    // kind 0: ids (FMT 0) / group records (FMT 1); kind 1: stray copies (FMT 1).  tz == g.ntz: past the end
+    struct Batch { int tz; uint32_t i0, cnt; size_t off; int kind; };
     // The walk starts at a column-dependent tile and wraps around the periodic z edge (the ring
     // does not care), so concurrently running columns are at different z: in lockstep all of
     // them would store to / gather from addresses a large power of two apart.
     const int tz0 = ablate & 512 ? 0 : (int)(((unsigned)col * 2654435761u >> 16) % (unsigned)g.ntz);
     auto phys = [&](int step) { const int t = tz0 + step; return t >= g.ntz ? t - g.ntz : t; };   // step -> tile
-    auto tile_span = [&](int step, uint32_t& cnt, size_t& off) {
+    auto tile_span = [&](int step, int kind, uint32_t& cnt, size_t& off) {
         const uint32_t t = (uint32_t)((tx * g.nty + ty) * g.ntz + phys(step));
-        cnt = cap ? min(tile_count[t], cap) : tile_count[t];
-        off = cap ? (size_t)t * cap : (size_t)tile_off[t];
+        if (FMT == 0) {
+            cnt = wl.tile_count[t];
+            off = (size_t)wl.tile_off[t];
+        } else {
+            const unsigned long long f = wl.fill64[t];
+            cnt = kind == 0 ? min((uint32_t)(f >> 32), wl.rcap) : min((uint32_t)f, wl.scap);
+            off = (size_t)t * (kind == 0 ? wl.rcap : wl.scap);
+        }
     };
+    // entries of a list one batch covers: 256 * U particles = 8 * U group records
+    auto batch_len = [&](int kind) -> uint32_t { return FMT == 1 && kind == 0 ? 8u * U : 256u * U; };
     auto next_batch = [&](Batch bt) -> Batch {
-        if (bt.tz >= 0 && bt.tz < g.ntz && bt.i0 + 256 * U < bt.cnt) { bt.i0 += 256 * U; return bt; }
-        for (int nt = bt.tz + 1; nt < g.ntz; ++nt) {
+        if (bt.tz >= 0 && bt.tz < g.ntz && bt.i0 + batch_len(bt.kind) < bt.cnt) { bt.i0 += batch_len(bt.kind); return bt; }
+        int nt = bt.tz, kind = bt.kind;
+        for (;;) {
+            if (FMT == 1 && kind == 0) kind = 1; else { kind = 0; ++nt; }       // a tile's records, then its strays
+            if (nt >= g.ntz) break;
             uint32_t cnt;
             size_t off;
-            tile_span(nt, cnt, off);
-            if (cnt) return Batch{nt, 0u, cnt, off};
+            tile_span(nt, kind, cnt, off);
+            if (cnt) return Batch{nt, 0u, cnt, off, kind};
         }
-        return Batch{g.ntz, 0u, bt.cnt, bt.off};                  // keeps a loadable span
+        return Batch{g.ntz, 0u, bt.cnt, bt.off, bt.kind};                  // keeps a loadable span
     };
-    auto load_idx = [&](const Batch& bt, uint32_t (&idx)[U]) {
+    // stage 1 of a batch: the particle ids (kind 0) or list positions (kind 1) of this thread's U slots and
+    // which of them hold a particle (bit u of act)
+    auto load_idx = [&](const Batch& bt, uint32_t (&idx)[U], uint32_t& act) {
+        act = 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t i = min(bt.i0 + u * 256 + threadIdx.x, bt.cnt - 1);
-            idx[u] = index[bt.off + i];
+            if (FMT == 0) {
+                const uint32_t i = bt.i0 + u * 256 + threadIdx.x;
+                idx[u] = wl.index[bt.off + min(i, bt.cnt - 1)];
+                act |= (uint32_t)(i < bt.cnt) << u;
+            } else if (bt.kind == 0) {
+                const uint32_t r = bt.i0 + u * 8 + (threadIdx.x >> 5), b = threadIdx.x & 31;
+                const GroupRec gr = wl.recs[bt.off + min(r, bt.cnt - 1)];
+                idx[u] = (uint32_t)min((size_t)gr.first + b, wl.np - 1);
+                act |= (uint32_t)(r < bt.cnt && ((gr.mask >> b) & 1u)) << u;
+            } else {
+                const uint32_t i = bt.i0 + u * 256 + threadIdx.x;
+                idx[u] = min(i, bt.cnt - 1);
+                act |= (uint32_t)(i < bt.cnt) << u;
+            }
         }
     };
-    auto load_pos = [&](const uint32_t (&idx)[U], T (&p)[3 * U], T (&m)[U]) {
+    // stage 2: positions and masses (a gather through the ids, or the stray copies themselves)
+    auto load_pos = [&](const Batch& bt, const uint32_t (&idx)[U], T (&p)[3 * U], T (&m)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            if (FMT == 1 && bt.kind == 1) {
+                typedef T vec4_t __attribute__((ext_vector_type(4)));
+                const vec4_t v = reinterpret_cast<const vec4_t*>(wl.strays)[bt.off + idx[u]];
+                p[3 * u + 0] = v.x;
+                p[3 * u + 1] = v.y;
+                p[3 * u + 2] = v.z;
+                m[u] = HAS_MASS ? v.w : (T)1;
+                continue;
+            }
             const size_t q3 = (ablate & 32) ? (size_t)((idx[u] % 1000000u) * 3) : (size_t)idx[u] * 3;
             if (ablate & 1024) { p[3 * u + 0] = p[3 * u + 1] = p[3 * u + 2] = (T)idx[u]; continue; }
             p[3 * u + 0] = pos[q3 + 0];
@@ -638,7 +899,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
         }                                               // loaded value with a constant and wait for it
     };
 
-    Batch cur = next_batch(Batch{-1, 0u, 0u, 0});
+    Batch cur = next_batch(Batch{-1, 0u, 0u, 0, 1});
     Batch nxt = next_batch(cur);
     int sh = 0;                             // (tz * TZ) mod LZ
     int oz = 0;
@@ -646,11 +907,11 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     // of the column lies inside the box and the tile does not straddle the periodic x edge, so
     // the unreduced cell (int)floor(s) minus the tile origin is the LDS coordinate (the same
     // expression decided the particle's tile in tile_of(); it raised col_flags otherwise).
-    auto deposit = [&](const T (&pc)[3 * U], const T (&mc)[U], auto careful_tag) {
+    auto deposit = [&](const T (&pc)[3 * U], const T (&mc)[U], uint32_t act, auto careful_tag) {
         constexpr bool CAREFUL = decltype(careful_tag)::value;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (cur.i0 + u * 256 + threadIdx.x >= cur.cnt) continue;
+            if (!((act >> u) & 1u)) continue;
             if (ablate & 256) { asm volatile("" ::"v"(pc[3 * u]), "v"(pc[3 * u + 1]), "v"(pc[3 * u + 2])); continue; }
             double fx, fy, fz;
             int lx, ly, lz;
@@ -717,10 +978,11 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     // the loads it copies): pos/mass A|B of batch k|k+1, indices X|Y of batch k+1|k+2.
     T pA[3 * U], mA[U], pB[3 * U], mB[U];
     uint32_t iX[U], iY[U];
+    uint32_t aX = 0, aY = 0, aA = 0, aB = 0;          // occupied slots of the id sets / position sets
     if (cur.tz < g.ntz) {                   // uniform: the column holds particles
-        load_idx(cur, iY);
-        load_idx(nxt, iX);
-        load_pos(iY, pA, mA);
+        load_idx(cur, iY, aA);
+        load_idx(nxt, iX, aX);
+        load_pos(cur, iY, pA, mA);
     }
     // One loop, two phases with the register sets swapped, so no set is ever copied; tiles are
     // flushed (all the empty ones too: every grid cell gets written) before the first batch of a
@@ -801,10 +1063,11 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
             DSTAMP(1);
             const Batch nn = next_batch(nxt);
             DSTAMP(2);
-            load_pos(iX, pB, mB);                         // batch k+1 (a harmless re-load at the end)
-            load_idx(nn, iY);                             // batch k+2
+            load_pos(nxt, iX, pB, mB);                    // batch k+1 (a harmless re-load at the end)
+            aB = aX;
+            load_idx(nn, iY, aY);                         // batch k+2
             DSTAMP(3);
-            if (careful) deposit(pA, mA, std::true_type{}); else deposit(pA, mA, std::false_type{});
+            if (careful) deposit(pA, mA, aA, std::true_type{}); else deposit(pA, mA, aA, std::false_type{});
             DSTAMP(4);
             cur = nxt;
             nxt = nn;
@@ -816,10 +1079,11 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
             DSTAMP(1);
             const Batch nn = next_batch(nxt);
             DSTAMP(2);
-            load_pos(iY, pA, mA);
-            load_idx(nn, iX);
+            load_pos(nxt, iY, pA, mA);
+            aA = aY;
+            load_idx(nn, iX, aX);
             DSTAMP(3);
-            if (careful) deposit(pB, mB, std::true_type{}); else deposit(pB, mB, std::false_type{});
+            if (careful) deposit(pB, mB, aB, std::true_type{}); else deposit(pB, mB, aB, std::false_type{});
             DSTAMP(4);
             cur = nxt;
             nxt = nn;
@@ -961,6 +1225,11 @@ struct Workspace {
     uint32_t* ovf;                   // single pass: indices that did not fit their tile's segment
     void* rec;                       // OVERWRITE flush: per-column halo records [column][ring cell][z]
     uint32_t cap;                    // single pass: index slots per tile
+    // single pass + OVERWRITE: the compact lists of tile_group_kernel instead of `index`
+    unsigned long long* fill64;      // per tile: group records requested << 32 | strays requested
+    GroupRec* recs;                  // [tile][rcap]
+    void* strays;                    // [tile][scap] x {x, y, z, m}
+    uint32_t rcap, scap;
     size_t bytes;
 };
 
@@ -974,7 +1243,13 @@ inline uint32_t tile_capacity(size_t np, uint32_t ntiles) {
     return (uint32_t)(cap > 0x7fffffffull ? 0x7fffffffull : cap);
 }
 
-Workspace carve(void* base, size_t np, uint32_t ntiles, uint32_t ncols, bool two_pass, size_t rec_bytes) {
+// flags decide the list format: two pass -> exact id lists; single pass -> fixed-capacity id segments, or
+// (with AST_PAINT_OVERWRITE) the compact group / stray lists.  A tile's group segment holds cap / MINPOP records
+// (enough for `cap` particles however they are grouped), its stray segment cap / 4 copies - or `cap` with
+// AST_PAINT_SCATTERED, for input without spatial order where every particle is a stray.
+Workspace carve(void* base, size_t np, uint32_t ntiles, uint32_t ncols, int flags, size_t esz, size_t rec_bytes) {
+    const bool two_pass = (flags & AST_PAINT_TWO_PASS) != 0;
+    const bool compact = !two_pass && (flags & AST_PAINT_OVERWRITE);
     Workspace w;
     size_t off = 0;
     auto take = [&](size_t bytes) { void* p = (char*)base + off; off += align256(bytes); return p; };
@@ -982,10 +1257,15 @@ Workspace carve(void* base, size_t np, uint32_t ntiles, uint32_t ncols, bool two
     w.col_flags = (uint32_t*)take((size_t)ncols * 4);
     w.tile_count = (uint32_t*)take((size_t)ntiles * 4);
     w.tile_fill = (uint32_t*)take((size_t)ntiles * 4);
+    w.fill64 = (unsigned long long*)take(compact ? (size_t)ntiles * 8 : 0);
     w.tile_off = (uint32_t*)take((size_t)ntiles * 4);
     w.block_sums = (uint32_t*)take((size_t)((ntiles + 1023) / 1024 + 1) * 4);
     w.cap = two_pass ? 0 : tile_capacity(np, ntiles);
-    w.index = (uint32_t*)take(two_pass ? np * 4 : (size_t)ntiles * w.cap * 4);
+    w.rcap = compact ? (w.cap + MINPOP - 1) / MINPOP : 0;
+    w.scap = compact ? ((flags & AST_PAINT_SCATTERED) ? w.cap : (w.cap + 3) / 4) : 0;
+    w.index = (uint32_t*)take(two_pass ? np * 4 : compact ? 0 : (size_t)ntiles * w.cap * 4);
+    w.recs = (GroupRec*)take((size_t)ntiles * w.rcap * sizeof(GroupRec));
+    w.strays = take((size_t)ntiles * w.scap * 4 * esz);
     w.ovf = (uint32_t*)take(two_pass ? 0 : np * 4);
     w.rec = take(rec_bytes);
     w.bytes = off;
@@ -1017,9 +1297,9 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
     const bool two_pass = (flags & AST_PAINT_TWO_PASS) != 0;
     const bool overwrite = (flags & AST_PAINT_OVERWRITE) != 0;
     const unsigned ncols = (unsigned)(g.ntx * g.nty);
-    Workspace w = carve(workspace, np, ntiles, ncols, two_pass,
+    Workspace w = carve(workspace, np, ntiles, ncols, flags, sizeof(T),
                         record_bytes(W == 3 ? AST_WIN_TSC : AST_WIN_CIC, g, sizeof(T), flags));
-    // ovf_count, col_flags, tile_count and tile_fill are contiguous at the front of the workspace
+    // ovf_count, col_flags, tile_count, tile_fill and fill64 are contiguous at the front of the workspace
     AST_CHECK_HIP(hipMemsetAsync(w.ovf_count, 0, (size_t)((char*)w.tile_off - (char*)w.ovf_count), s));
     const size_t per_interval = (size_t)256 * IDX_UNROLL * AGG_TRIPS;
     const size_t nintervals = (np + per_interval - 1) / per_interval;
@@ -1044,12 +1324,15 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
         if (overwrite) {
             {
                 AST_PROF("paint_tiled.deposit", s);
-                if (mass)
-                    column_deposit_kernel<T, W, true><<<ncols, 256, 0, s>>>(pos, mass, g, scale, w.index, tile_off, tile_count, cap,
-                                                                            mass_bound, w.col_flags, grid, (T*)w.rec, offset, dropped);
-                else
-                    column_deposit_kernel<T, W, false><<<ncols, 256, 0, s>>>(pos, mass, g, scale, w.index, tile_off, tile_count, cap,
-                                                                             1.0, w.col_flags, grid, (T*)w.rec, offset, dropped);
+                WalkLists wl{w.index, tile_off, tile_count, w.fill64, w.recs, w.strays, w.rcap, w.scap, np};
+                auto launch = [&](auto has_mass, auto fmt) {
+                    column_deposit_kernel<T, W, decltype(has_mass)::value, decltype(fmt)::value><<<ncols, 256, 0, s>>>(
+                        pos, mass, g, scale, wl, mass ? mass_bound : 1.0, w.col_flags, grid, (T*)w.rec, offset, dropped);
+                };
+                using I0 = std::integral_constant<int, 0>;
+                using I1 = std::integral_constant<int, 1>;
+                if (two_pass) { if (mass) launch(std::true_type{}, I0{}); else launch(std::false_type{}, I0{}); }
+                else { if (mass) launch(std::true_type{}, I1{}); else launch(std::false_type{}, I1{}); }
             }
             if (!(flags & AST_PAINT_DEFER_FOLD)) {
                 AST_PROF("paint_tiled.fold", s);
@@ -1077,6 +1360,19 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
             index_pass(std::integral_constant<int, 1>{}, nullptr, w.tile_off, w.tile_fill, w.index, 0, nullptr, nullptr, nullptr);
         }
         deposit_pass(w.tile_off, w.tile_count, 0);
+    } else if (overwrite) {
+        {
+            AST_PROF("paint_tiled.fill", s);
+            if (plainx)
+                tile_group_kernel<T, W, true><<<ga, 256, 0, s>>>(pos, mass, np, g, w.fill64, w.recs, w.rcap, (T*)w.strays, w.scap,
+                                                                 w.ovf, w.ovf_count, w.col_flags, dropped);
+            else
+                tile_group_kernel<T, W, false><<<ga, 256, 0, s>>>(pos, mass, np, g, w.fill64, w.recs, w.rcap, (T*)w.strays, w.scap,
+                                                                  w.ovf, w.ovf_count, w.col_flags, dropped);
+        }
+        deposit_pass(nullptr, nullptr, 0);
+        AST_PROF("paint_tiled.overflow", s);
+        overflow_deposit_kernel<T, W><<<1024, 256, 0, s>>>(pos, mass, w.ovf, w.ovf_count, g, scale, grid, dropped);
     } else {
         {
             AST_PROF("paint_tiled.fill", s);
@@ -1113,7 +1409,7 @@ extern "C" size_t ast_paint_tiled_workspace_bytes(int window, int dtype, size_t 
     TileGeom g;
     uint32_t ntiles = 0;
     if (nmesh <= 0 || nx_alloc <= 0 || !tiled_geometry(nmesh, nx_alloc, g, ntiles)) return 0;
-    return carve(nullptr, np, ntiles, (uint32_t)(g.ntx * g.nty), (flags & AST_PAINT_TWO_PASS) != 0,
+    return carve(nullptr, np, ntiles, (uint32_t)(g.ntx * g.nty), flags, dtype == AST_F32 ? 4 : 8,
                  record_bytes(window, g, dtype == AST_F32 ? 4 : 8, flags)).bytes;
 }
 
@@ -1127,8 +1423,40 @@ extern "C" int ast_paint_tiled_halo(void* workspace, int window, int dtype, size
     uint32_t ntiles = 0;
     AST_CHECK_ARG(nmesh > 0 && nx_alloc > 0 && tiled_geometry(nmesh, nx_alloc, g, ntiles));
     const size_t esz = dtype == AST_F32 ? 4 : 8;
-    *rec_out = carve(workspace, np, ntiles, (uint32_t)(g.ntx * g.nty), (flags & AST_PAINT_TWO_PASS) != 0,
-                     record_bytes(window, g, esz, flags)).rec;
+    *rec_out = carve(workspace, np, ntiles, (uint32_t)(g.ntx * g.nty), flags, esz, record_bytes(window, g, esz, flags)).rec;
+    return AST_OK;
+}
+
+// out[0] = group records kept, out[1] = stray copies kept, out[2] = particles on the overflow list,
+// out[3] = largest number of strays any tile asked for
+__global__ void __launch_bounds__(256)
+list_stats_kernel(const unsigned long long* __restrict__ fill64, uint32_t ntiles, uint32_t rcap, uint32_t scap,
+                  const unsigned long long* __restrict__ ovf_count, unsigned long long* out) {
+    unsigned long long nr = 0, ns = 0, smax = 0;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += gridDim.x * blockDim.x) {
+        const unsigned long long f = fill64[t];
+        nr += min((uint32_t)(f >> 32), rcap);
+        ns += min((uint32_t)f, scap);
+        smax = max(smax, (unsigned long long)(uint32_t)f);
+    }
+    atomicAdd(&out[0], nr);
+    atomicAdd(&out[1], ns);
+    atomicMax(&out[3], smax);
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[2] = *ovf_count;
+}
+
+extern "C" int ast_paint_tiled_list_stats(void* workspace, int window, int dtype, size_t np, int nmesh, int nx_alloc,
+                                          int flags, unsigned long long* out, void* stream) {
+    AST_CHECK_ARG(workspace && out && (flags & AST_PAINT_OVERWRITE) && !(flags & AST_PAINT_TWO_PASS));
+    TileGeom g;
+    uint32_t ntiles = 0;
+    AST_CHECK_ARG(nmesh > 0 && nx_alloc > 0 && tiled_geometry(nmesh, nx_alloc, g, ntiles));
+    const size_t esz = dtype == AST_F32 ? 4 : 8;
+    const Workspace w = carve(workspace, np, ntiles, (uint32_t)(g.ntx * g.nty), flags, esz, record_bytes(window, g, esz, flags));
+    hipStream_t s = ast::as_stream(stream);
+    AST_CHECK_HIP(hipMemsetAsync(out, 0, 4 * sizeof(unsigned long long), s));
+    list_stats_kernel<<<256, 256, 0, s>>>(w.fill64, ntiles, w.rcap, w.scap, w.ovf_count, out);
+    AST_CHECK_LAUNCH();
     return AST_OK;
 }
 
@@ -1160,7 +1488,7 @@ extern "C" int ast_paint_tiled(int window, int dtype, const void* pos, const voi
     }
     g.x_start = x_start;
     g.inv_dx = (double)nmesh / boxsize;
-    const size_t need = carve(nullptr, np, ntiles, (uint32_t)(g.ntx * g.nty), (flags & AST_PAINT_TWO_PASS) != 0,
+    const size_t need = carve(nullptr, np, ntiles, (uint32_t)(g.ntx * g.nty), flags, dtype == AST_F32 ? 4 : 8,
                               record_bytes(window, g, dtype == AST_F32 ? 4 : 8, flags)).bytes;
     if (workspace_bytes < need) {
         ast::set_error("ast_paint_tiled: workspace too small (%zu < %zu bytes)", workspace_bytes, need);

@@ -152,7 +152,7 @@ class PaintHalo:
 
 def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="auto",
           x_start=0, nx_alloc=None, check_dropped=True, accumulate=None, defer_fold=False, offset=0.0,
-          hint=None):
+          hint=None, stats=None):
     """pmesh ``ParticleMesh.paint(pos, mass=, resampler=)`` on the GPU.
 
     pos: (Np, 3) CUDA tensor (float32/float64); mass: (Np,) or None.
@@ -166,6 +166,8 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     offset: (tiled overwrite only) owned cells are stored as ``sum - offset``, subtracted in double
     before the one rounding to the grid dtype; ``offset="mean"`` uses total mass * scale / nmesh^3,
     i.e. the grid holds rho - mean (only the DC mode changes, which FFTPower discards).
+    hint: "scattered" sizes the tiled overwrite paint's workspace for particles without spatial order in memory
+    (AST_PAINT_SCATTERED).  stats: a dict that receives the list statistics of the tiled overwrite paint.
     """
     L = _lib.lib()
     n = int(nmesh)
@@ -180,7 +182,9 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     npart = pos.shape[0]
     dropped = torch.zeros(1, dtype=torch.int64, device=pos.device)
     ws_bytes = 0
-    tflags = (1 if method == "tiled2" else 0) | (0 if accumulate else 2) | (4 if defer_fold else 0)   # TWO_PASS | OVERWRITE | DEFER_FOLD
+    # TWO_PASS | OVERWRITE | DEFER_FOLD | SCATTERED
+    tflags = (1 if method == "tiled2" else 0) | (0 if accumulate else 2) | (4 if defer_fold else 0) | \
+             (8 if hint == "scattered" and not accumulate and method != "tiled2" else 0)
     if method in ("auto", "tiled", "tiled2") and win != 0 and npart < 2**32 - 1:
         ws_bytes = int(L.ast_paint_tiled_workspace_bytes(win, code, npart, n, nx, tflags))
     if method in ("tiled", "tiled2") and ws_bytes == 0:
@@ -219,6 +223,12 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
         if nd:
             raise _lib.AstrildHipError(f"{nd} deposits fell outside the grid buffer "
                                        f"(x_start={x_start}, nx_alloc={nx})")
+    if stats is not None:
+        st = torch.empty(4, dtype=torch.int64, device=pos.device)
+        if use_tiled and not accumulate and method != "tiled2":
+            check(L.ast_paint_tiled_list_stats(ptr(ws), win, code, npart, n, nx, tflags, ptr(st), stream()),
+                  "ast_paint_tiled_list_stats")
+            stats.update(zip(("groups", "strays", "overflow", "max_strays_per_tile"), st.cpu().tolist()))
     if defer_fold:
         rec = ct.c_void_p()
         check(L.ast_paint_tiled_halo(ptr(ws), win, code, npart, n, nx, tflags, ct.byref(rec)), "ast_paint_tiled_halo")

@@ -136,6 +136,13 @@ int ast_paint(int window, int dtype, const void* pos_d, const void* mass_d, size
  * the grid is complete only after ast_fft_tile_power_3d_halo has read it, which folds the records
  * while its z pass loads the rows (one kernel and ~2 GB of traffic less at 1024^3). */
 #define AST_PAINT_DEFER_FOLD 4
+/* AST_PAINT_SCATTERED (single pass + AST_PAINT_OVERWRITE): a hint that the particles have no spatial order
+ * in memory.  The single-pass overwrite paint groups each 32-particle window by tile (8-byte group records)
+ * and copies the few particles that have no companions in their window ("strays", 16/32 bytes) into their
+ * tile's segment; by default a tile's stray segment holds a quarter of its particle capacity, with this flag
+ * all of it (3.4x the workspace).  Without the hint unordered input still paints correctly - what does not
+ * fit goes through the (slow) overflow list. */
+#define AST_PAINT_SCATTERED 8
 /* offset (AST_PAINT_OVERWRITE only, else 0): every OWNED cell is stored as (sum - offset), the
  * subtraction done in double on the exact fixed-point sum before the single rounding to `dtype`
  * (halo records stay additive).  With offset = total mass * scale / nmesh^3 the grid holds the
@@ -151,6 +158,13 @@ int ast_paint_tiled(int window, int dtype, const void* pos_d, const void* mass_d
  * records inside workspace_d (for ast_fft_tile_power_3d_halo). */
 int ast_paint_tiled_halo(void* workspace_d, int window, int dtype, size_t np, int nmesh, int nx_alloc, int flags,
                          void** rec_out);
+
+/* What the single-pass AST_PAINT_OVERWRITE paint with these parameters left in workspace_d: out_d[0] group records,
+ * out_d[1] stray copies, out_d[2] particles that went through the overflow list, out_d[3] the largest number of
+ * strays a tile asked for (device uint64 x 4).  Diagnostics: a large out_d[2] says the input wants
+ * AST_PAINT_SCATTERED or AST_PAINT_TWO_PASS. */
+int ast_paint_tiled_list_stats(void* workspace_d, int window, int dtype, size_t np, int nmesh, int nx_alloc, int flags,
+                               unsigned long long* out_d, void* stream);
 
 /* dst[i] += src[i] — ghost-plane fold after a slab paint. */
 int ast_accumulate(void* dst_d, const void* src_d, int dtype, size_t count, void* stream);
