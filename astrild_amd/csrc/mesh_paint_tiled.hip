@@ -437,22 +437,23 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
                 if (!valid) key = 0xffffffffu;
                 const bool live = key != 0xffffffffu;
                 if (!PLAINX && valid && !live) ++ndrop;
-                // up to GROUP_ITERS tiles per 32-lane window get a group record: the tile of the first
-                // undecided lane is the candidate; fewer than MINPOP takers -> they are strays
+                // up to GROUP_ITERS tiles per 32-lane window get a group record.  The candidates are the tiles of
+                // three fixed lanes of the window (two v_readlane each, no cross-lane search): in a spatially
+                // coherent input nearly every window is one tile plus a few strays, and the first candidate
+                // settles it.  A candidate with fewer than MINPOP takers leaves them as strays.
                 bool pending = live, stray = false;
 #pragma unroll
                 for (int it = 0; it < GROUP_ITERS; ++it) {
-                    const unsigned long long pend = __ballot(pending);
-                    const uint32_t plo = (uint32_t)pend, phi = (uint32_t)(pend >> 32);
-                    if (__popc(plo) < MINPOP && __popc(phi) < MINPOP) break;            // uniform
-                    const uint32_t mine = half ? phi : plo;
-                    const int cl = mine ? half * 32 + __ffs((int)mine) - 1 : lane;      // candidate lane of my window
-                    const uint32_t ck = (uint32_t)__shfl((int)key, cl, 64);
-                    const bool match = pending && key == ck;
+                    constexpr int cand[3] = {16, 8, 24};
+                    const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, cand[it]);
+                    const uint32_t k1 = (uint32_t)__builtin_amdgcn_readlane((int)key, cand[it] + 32);
+                    const bool match = pending && key == (half ? k1 : k0);
                     const unsigned long long mb = __ballot(match);
-                    const uint32_t mm = half ? (uint32_t)(mb >> 32) : (uint32_t)mb;
-                    if (__popc(mm) >= MINPOP) {
-                        if (lane == cl && match) {
+                    const uint32_t mlo = (uint32_t)mb, mhi = (uint32_t)(mb >> 32);
+                    const uint32_t mm = half ? mhi : mlo;
+                    const bool big = half ? __popc(mhi) >= MINPOP : __popc(mlo) >= MINPOP;
+                    if (big) {
+                        if (match && (lane & 31) == __ffs((int)mm) - 1) {          // the group's first lane
                             const uint32_t first = (uint32_t)p - (uint32_t)(lane & 31);
                             const int slot = slot_of(key);
                             if (slot < 0) {
@@ -472,6 +473,8 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
                         stray = stray || match;
                     }
                     pending = pending && !match;
+                    const unsigned long long pend = __ballot(pending);
+                    if (__popc((uint32_t)pend) < MINPOP && __popc((uint32_t)(pend >> 32)) < MINPOP) break;      // uniform
                 }
                 stray = stray || pending;
                 uint32_t code = CODE_DONE;
@@ -735,7 +738,7 @@ struct WalkLists {
     const unsigned long long* fill64;
     const GroupRec* recs;
     const void* strays;
-    uint32_t rcap, scap;
+    uint32_t rcap, scap, cap;
     size_t np;
 };
 
@@ -793,15 +796,13 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     }
     // quantum: a cell collects at most the particles of two consecutive tiles, each contribution
     // is <= mass_bound * |scale|; keep every sum below 2^SUM_BITS and every term below 2^50
+    // (FMT 1: the bound is the segments' capacity, the same for every column and independent of how the
+    // particles are ordered in memory - the painted grid must not depend on that order)
     uint32_t cmax = 1;
-    for (int tz = 0; tz < g.ntz; ++tz) {
-        const uint32_t t = (uint32_t)((tx * g.nty + ty) * g.ntz + tz);
-        if (FMT == 0) {
-            cmax = max(cmax, wl.tile_count[t]);
-        } else {                              // an upper bound: every record full
-            const unsigned long long f = wl.fill64[t];
-            cmax = max(cmax, min((uint32_t)(f >> 32), wl.rcap) * 32u + min((uint32_t)f, wl.scap));
-        }
+    if (FMT == 0) {
+        for (int tz = 0; tz < g.ntz; ++tz) cmax = max(cmax, wl.tile_count[(uint32_t)((tx * g.nty + ty) * g.ntz + tz)]);
+    } else {
+        cmax = (uint32_t)min(5ull * wl.cap, 0x3fffffffull);      // 32 * rcap + the largest scap = 5 * cap
     }
     const int bits = 33 - __clz((int)min(cmax, 0x3fffffffu));            // 2 * cmax < 2^bits
     const double vmax = mass_bound * fabs(scale) > 0.0 ? mass_bound * fabs(scale) : 1.0;
@@ -822,41 +823,35 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
 #define DEP_U 2
 #endif
     constexpr int U = DEP_U;
-    // kind 0: ids (FMT 0) / group records (FMT 1); kind 1: stray copies (FMT 1).  tz == g.ntz: past the end
-    struct Batch { int tz; uint32_t i0, cnt; size_t off; int kind; };
+    // A tile's work is a list of ENTRIES.  FMT 0: particle ids, one per thread slot.  FMT 1: 32-lane entries, one
+    // per half wave - the tile's nrec group records followed by ceil(nst / 32) blocks of 32 consecutive stray
+    // copies, so records and strays share batches (72 entries, i.e. 4.5 batches, per tile of the bench input).
+    // off: FMT 0 first id of the tile's list; FMT 1 the tile id.  tz == g.ntz: past the end
+    using list_off_t = std::conditional_t<FMT == 1, uint32_t, size_t>;
+    struct Batch { int tz; uint32_t i0, cnt; list_off_t off; uint32_t nrec, nst; };
     // The walk starts at a column-dependent tile and wraps around the periodic z edge (the ring
     // does not care), so concurrently running columns are at different z: in lockstep all of
     // them would store to / gather from addresses a large power of two apart.
     const int tz0 = ablate & 512 ? 0 : (int)(((unsigned)col * 2654435761u >> 16) % (unsigned)g.ntz);
     auto phys = [&](int step) { const int t = tz0 + step; return t >= g.ntz ? t - g.ntz : t; };   // step -> tile
-    auto tile_span = [&](int step, int kind, uint32_t& cnt, size_t& off) {
-        const uint32_t t = (uint32_t)((tx * g.nty + ty) * g.ntz + phys(step));
-        if (FMT == 0) {
-            cnt = wl.tile_count[t];
-            off = (size_t)wl.tile_off[t];
-        } else {
-            const unsigned long long f = wl.fill64[t];
-            cnt = kind == 0 ? min((uint32_t)(f >> 32), wl.rcap) : min((uint32_t)f, wl.scap);
-            off = (size_t)t * (kind == 0 ? wl.rcap : wl.scap);
-        }
-    };
-    // entries of a list one batch covers: 256 * U particles = 8 * U group records
-    auto batch_len = [&](int kind) -> uint32_t { return FMT == 1 && kind == 0 ? 8u * U : 256u * U; };
+    constexpr uint32_t BATCH = FMT == 1 ? 8u * U : 256u * U;      // entries per batch
     auto next_batch = [&](Batch bt) -> Batch {
-        if (bt.tz >= 0 && bt.tz < g.ntz && bt.i0 + batch_len(bt.kind) < bt.cnt) { bt.i0 += batch_len(bt.kind); return bt; }
-        int nt = bt.tz, kind = bt.kind;
-        for (;;) {
-            if (FMT == 1 && kind == 0) kind = 1; else { kind = 0; ++nt; }       // a tile's records, then its strays
-            if (nt >= g.ntz) break;
-            uint32_t cnt;
-            size_t off;
-            tile_span(nt, kind, cnt, off);
-            if (cnt) return Batch{nt, 0u, cnt, off, kind};
+        if (bt.tz >= 0 && bt.tz < g.ntz && bt.i0 + BATCH < bt.cnt) { bt.i0 += BATCH; return bt; }
+        for (int nt = bt.tz + 1; nt < g.ntz; ++nt) {
+            const uint32_t t = (uint32_t)((tx * g.nty + ty) * g.ntz + phys(nt));
+            if (FMT == 0) {
+                const uint32_t cnt = wl.tile_count[t];
+                if (cnt) return Batch{nt, 0u, cnt, (list_off_t)wl.tile_off[t], 0u, 0u};
+            } else {
+                const unsigned long long f = wl.fill64[t];
+                const uint32_t nrec = min((uint32_t)(f >> 32), wl.rcap), nst = min((uint32_t)f, wl.scap);
+                if (nrec + nst) return Batch{nt, 0u, nrec + (nst + 31u) / 32u, (list_off_t)t, nrec, nst};
+            }
         }
-        return Batch{g.ntz, 0u, bt.cnt, bt.off, bt.kind};                  // keeps a loadable span
+        return Batch{g.ntz, 0u, bt.cnt, bt.off, bt.nrec, bt.nst};           // keeps a loadable span
     };
-    // stage 1 of a batch: the particle ids (kind 0) or list positions (kind 1) of this thread's U slots and
-    // which of them hold a particle (bit u of act)
+    // stage 1 of a batch: for each of this thread's U slots the particle id (or the position in the stray
+    // list); bit u of act: the slot holds a particle; bit 8 + u: it is a stray copy
     auto load_idx = [&](const Batch& bt, uint32_t (&idx)[U], uint32_t& act) {
         act = 0;
 #pragma unroll
@@ -865,29 +860,34 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
                 const uint32_t i = bt.i0 + u * 256 + threadIdx.x;
                 idx[u] = wl.index[bt.off + min(i, bt.cnt - 1)];
                 act |= (uint32_t)(i < bt.cnt) << u;
-            } else if (bt.kind == 0) {
-                const uint32_t r = bt.i0 + u * 8 + (threadIdx.x >> 5), b = threadIdx.x & 31;
-                const GroupRec gr = wl.recs[bt.off + min(r, bt.cnt - 1)];
-                idx[u] = (uint32_t)min((size_t)gr.first + b, wl.np - 1);
-                act |= (uint32_t)(r < bt.cnt && ((gr.mask >> b) & 1u)) << u;
             } else {
-                const uint32_t i = bt.i0 + u * 256 + threadIdx.x;
-                idx[u] = min(i, bt.cnt - 1);
-                act |= (uint32_t)(i < bt.cnt) << u;
+                const uint32_t r = bt.i0 + u * 8 + (threadIdx.x >> 5), b = threadIdx.x & 31;
+                const uint32_t rr = min(r, bt.cnt - 1);
+                // unconditional record load (a stray block re-reads the tile's last record, or the segment's
+                // first slot when the tile has none): a predicated load would cost a branch and a full wait
+                const GroupRec gr = wl.recs[(size_t)bt.off * wl.rcap + min(rr, bt.nrec ? bt.nrec - 1 : 0u)];
+                const bool st = rr >= bt.nrec;
+                const uint32_t sidx = (rr - bt.nrec) * 32u + b;
+                idx[u] = st ? min(sidx, bt.nst - 1) : (uint32_t)min((size_t)gr.first + b, wl.np - 1);
+                const bool on = r < bt.cnt && (st ? sidx < bt.nst : ((gr.mask >> b) & 1u) != 0);
+                act |= ((uint32_t)on << u) | ((uint32_t)st << (8 + u));
             }
         }
     };
-    // stage 2: positions and masses (a gather through the ids, or the stray copies themselves)
-    auto load_pos = [&](const Batch& bt, const uint32_t (&idx)[U], T (&p)[3 * U], T (&m)[U]) {
+    // stage 2: positions and masses - a gather through the ids, or the stray copies themselves; one
+    // unconditional load per component through a per-lane base pointer
+    auto load_pos = [&](const Batch& bt, const uint32_t (&idx)[U], uint32_t act, T (&p)[3 * U], T (&m)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (FMT == 1 && bt.kind == 1) {
-                typedef T vec4_t __attribute__((ext_vector_type(4)));
-                const vec4_t v = reinterpret_cast<const vec4_t*>(wl.strays)[bt.off + idx[u]];
-                p[3 * u + 0] = v.x;
-                p[3 * u + 1] = v.y;
-                p[3 * u + 2] = v.z;
-                m[u] = HAS_MASS ? v.w : (T)1;
+            if (FMT == 1) {
+                const bool st = (act >> (8 + u)) & 1u;
+                const T* const sbase = reinterpret_cast<const T*>(wl.strays) + 4 * ((size_t)bt.off * wl.scap);
+                const T* const src = st ? sbase + 4 * (size_t)idx[u] : pos + 3 * (size_t)idx[u];
+                p[3 * u + 0] = src[0];
+                p[3 * u + 1] = src[1];
+                p[3 * u + 2] = src[2];
+                if (HAS_MASS) { const T* const msrc = st ? src + 3 : mass + idx[u]; m[u] = *msrc; }
+                else m[u] = (T)1;
                 continue;
             }
             const size_t q3 = (ablate & 32) ? (size_t)((idx[u] % 1000000u) * 3) : (size_t)idx[u] * 3;
@@ -899,8 +899,8 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
         }                                               // loaded value with a constant and wait for it
     };
 
-    Batch cur = next_batch(Batch{-1, 0u, 0u, 0, 1});
-    Batch nxt = next_batch(cur);
+    Batch nxt = next_batch(Batch{-1, 0u, 0u, 0, 0u, 0u});       // becomes batch k + 1 below
+    int cur_tz = nxt.tz;                                        // tile of batch k, the one being deposited
     int sh = 0;                             // (tz * TZ) mod LZ
     int oz = 0;
     // deposit one batch: positions pc / masses mc of batch `cur`.  CAREFUL = false: every particle
@@ -979,10 +979,11 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     T pA[3 * U], mA[U], pB[3 * U], mB[U];
     uint32_t iX[U], iY[U];
     uint32_t aX = 0, aY = 0, aA = 0, aB = 0;          // occupied slots of the id sets / position sets
-    if (cur.tz < g.ntz) {                   // uniform: the column holds particles
-        load_idx(cur, iY, aA);
+    if (cur_tz < g.ntz) {                   // uniform: the column holds particles
+        load_idx(nxt, iY, aA);
+        load_pos(nxt, iY, aA, pA, mA);
+        nxt = next_batch(nxt);
         load_idx(nxt, iX, aX);
-        load_pos(cur, iY, pA, mA);
     }
     // One loop, two phases with the register sets swapped, so no set is ever copied; tiles are
     // flushed (all the empty ones too: every grid cell gets written) before the first batch of a
@@ -1056,36 +1057,36 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     };
     DSTAMP(0);
     for (;;) {
-        flush_until(cur.tz);
-        if (cur.tz >= g.ntz) break;
-        oz = phys(cur.tz) * TZ;
+        flush_until(cur_tz);
+        if (cur_tz >= g.ntz) break;
+        oz = phys(cur_tz) * TZ;
         {
             DSTAMP(1);
             const Batch nn = next_batch(nxt);
             DSTAMP(2);
-            load_pos(nxt, iX, pB, mB);                    // batch k+1 (a harmless re-load at the end)
+            load_pos(nxt, iX, aX, pB, mB);                // batch k+1 (a harmless re-load at the end)
             aB = aX;
             load_idx(nn, iY, aY);                         // batch k+2
             DSTAMP(3);
             if (careful) deposit(pA, mA, aA, std::true_type{}); else deposit(pA, mA, aA, std::false_type{});
             DSTAMP(4);
-            cur = nxt;
+            cur_tz = nxt.tz;
             nxt = nn;
         }
-        flush_until(cur.tz);
-        if (cur.tz >= g.ntz) break;
-        oz = phys(cur.tz) * TZ;
+        flush_until(cur_tz);
+        if (cur_tz >= g.ntz) break;
+        oz = phys(cur_tz) * TZ;
         {
             DSTAMP(1);
             const Batch nn = next_batch(nxt);
             DSTAMP(2);
-            load_pos(nxt, iY, pA, mA);
+            load_pos(nxt, iY, aY, pA, mA);
             aA = aY;
             load_idx(nn, iX, aX);
             DSTAMP(3);
             if (careful) deposit(pB, mB, aB, std::true_type{}); else deposit(pB, mB, aB, std::false_type{});
             DSTAMP(4);
-            cur = nxt;
+            cur_tz = nxt.tz;
             nxt = nn;
         }
     }
@@ -1324,7 +1325,7 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
         if (overwrite) {
             {
                 AST_PROF("paint_tiled.deposit", s);
-                WalkLists wl{w.index, tile_off, tile_count, w.fill64, w.recs, w.strays, w.rcap, w.scap, np};
+                WalkLists wl{w.index, tile_off, tile_count, w.fill64, w.recs, w.strays, w.rcap, w.scap, w.cap, np};
                 auto launch = [&](auto has_mass, auto fmt) {
                     column_deposit_kernel<T, W, decltype(has_mass)::value, decltype(fmt)::value><<<ncols, 256, 0, s>>>(
                         pos, mass, g, scale, wl, mass ? mass_bound : 1.0, w.col_flags, grid, (T*)w.rec, offset, dropped);
