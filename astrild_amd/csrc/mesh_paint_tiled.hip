@@ -374,6 +374,16 @@ __device__ __noinline__ void place_group_slow(uint32_t key, uint32_t a, uint32_t
     }
 }
 
+// Phases of one interval of 4096 contiguous particles (one workgroup):
+//   1 trips    cell lookup, grouping by ballots; group records and strays (position, tile) are APPENDED to
+//              LDS lists - no table lookups here, so the loop carries no dependent LDS round trips;
+//   2 slots    one thread per list entry: tile -> table slot (CAS) and the entry's offset in the slot;
+//   3 reserve  one thread per used slot: ONE returning 64-bit global atomic per distinct tile;
+//   4 scatter  one thread per entry: 8-byte records and 16-byte stray copies to their final place.
+// A table slot taken by another tile, or a full LDS list, sends the entry through place_group_slow
+// (its global atomics are issued by independent threads, all in flight together).
+constexpr uint32_t LST_CAP = 768;      // strays parked in LDS per interval (the bench input has ~330)
+
 template <typename T, int W, bool PLAINX>
 __global__ void __launch_bounds__(256)
 tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t np, TileGeom g,
@@ -383,17 +393,19 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
                   unsigned long long* dropped) {
     __shared__ uint32_t skey[AGG_SLOTS], srun[AGG_SLOTS], sstray[AGG_SLOTS], sroom_run[AGG_SLOTS], sroom_stray[AGG_SLOTS];
     __shared__ unsigned long long sdst_run[AGG_SLOTS], sdst_stray[AGG_SLOTS];
-    __shared__ uint32_t codes[AGG_TRIPS * IDX_UNROLL][256];           // strays only: slot << 16 | offset, or CODE_DONE
-    __shared__ uint32_t lrec_first[LREC_CAP], lrec_mask[LREC_CAP], lrec_dst[LREC_CAP], lrec_n;
-    constexpr uint32_t MISS_CAP = 512;
-    __shared__ uint32_t smiss_key[MISS_CAP], smiss_a[MISS_CAP], smiss_b[MISS_CAP], smiss_n;
+    // group records: first, mask, tile key (phase 2 turns the key into slot << 16 | offset, DST_NONE = placed already)
+    __shared__ uint32_t lrec_first[LREC_CAP], lrec_mask[LREC_CAP], lrec_key[LREC_CAP], lrec_n;
+    // strays: position, particle id, tile key (same conversion)
+    __shared__ T lst_x[LST_CAP], lst_y[LST_CAP], lst_z[LST_CAP];
+    __shared__ uint32_t lst_p[LST_CAP], lst_key[LST_CAP], lst_n;
+    constexpr uint32_t DST_NONE = 0xffffffffu;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int half = lane >> 5;
     skey[tid] = SLOT_EMPTY;
     srun[tid] = 0;
     sstray[tid] = 0;
-    if (tid == 0) { smiss_n = 0; lrec_n = 0; }
+    if (tid == 0) { lst_n = 0; lrec_n = 0; }
     __syncthreads();
     const size_t per_trip = 256 * IDX_UNROLL;
     const size_t per_interval = per_trip * AGG_TRIPS;
@@ -416,11 +428,6 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
         const uint32_t slot = (key * 2654435761u) >> 24;
         const uint32_t old = atomicCAS(&skey[slot], SLOT_EMPTY, key);
         return (old == SLOT_EMPTY || old == key) ? (int)slot : -1;
-    };
-    auto miss = [&](uint32_t key, uint32_t a, uint32_t mask) {
-        const uint32_t mi = atomicAdd(&smiss_n, 1u);
-        if (mi < MISS_CAP) { smiss_key[mi] = key; smiss_a[mi] = a; smiss_b[mi] = mask; }
-        else slow(key, a, mask);                                   // list full (scattered input)
     };
     static_assert(AGG_TRIPS % 2 == 0, "two register sets");
     T xa[IDX_UNROLL], ya[IDX_UNROLL], za[IDX_UNROLL], xb[IDX_UNROLL], yb[IDX_UNROLL], zb[IDX_UNROLL];
@@ -455,18 +462,13 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
                     if (big) {
                         if (match && (lane & 31) == __ffs((int)mm) - 1) {          // the group's first lane
                             const uint32_t first = (uint32_t)p - (uint32_t)(lane & 31);
-                            const int slot = slot_of(key);
-                            if (slot < 0) {
-                                miss(key, first, mm);
+                            const uint32_t k = atomicAdd(&lrec_n, 1u);
+                            if (k < LREC_CAP) {
+                                lrec_first[k] = first;
+                                lrec_mask[k] = mm;
+                                lrec_key[k] = key;
                             } else {
-                                const uint32_t k = atomicAdd(&lrec_n, 1u);
-                                if (k < LREC_CAP) {
-                                    lrec_first[k] = first;
-                                    lrec_mask[k] = mm;
-                                    lrec_dst[k] = ((uint32_t)slot << 16) | atomicAdd(&srun[slot], 1u);
-                                } else {
-                                    slow(key, first, mm);
-                                }
+                                slow(key, first, mm);
                             }
                         }
                     } else {
@@ -477,13 +479,27 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
                     if (__popc((uint32_t)pend) < MINPOP && __popc((uint32_t)(pend >> 32)) < MINPOP) break;      // uniform
                 }
                 stray = stray || pending;
-                uint32_t code = CODE_DONE;
-                if (stray) {
-                    const int slot = slot_of(key);
-                    if (slot < 0) miss(key, (uint32_t)p, 0u);
-                    else code = ((uint32_t)slot << 16) | atomicAdd(&sstray[slot], 1u);
+                // strays append themselves to the LDS list: one atomic per wave (the first stray lane reserves
+                // for all of them)
+                const unsigned long long sm = __ballot(stray);
+                if (sm) {                                                      // uniform
+                    const int lead = __ffsll((long long)sm) - 1;
+                    uint32_t base = 0;
+                    if (lane == lead) base = atomicAdd(&lst_n, (uint32_t)__popcll(sm));
+                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, lead);
+                    if (stray) {
+                        const uint32_t k = base + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull));
+                        if (k < LST_CAP) {
+                            lst_x[k] = x[u];
+                            lst_y[k] = y[u];
+                            lst_z[k] = z[u];
+                            lst_p[k] = (uint32_t)p;
+                            lst_key[k] = key;
+                        } else {
+                            slow(key, (uint32_t)p, 0u);                        // list full (scattered input)
+                        }
+                    }
                 }
-                codes[trip * IDX_UNROLL + u][tid] = code;
             }
         };
 #pragma unroll
@@ -494,6 +510,22 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
             process(trip + 1, xb, yb, zb);
         }
         __syncthreads();
+        // phase 2: slots
+        const uint32_t nr = min(lrec_n, LREC_CAP), ns = min(lst_n, LST_CAP);
+        for (uint32_t k = tid; k < nr; k += 256) {
+            const uint32_t key = lrec_key[k];
+            const int slot = slot_of(key);
+            if (slot < 0) { slow(key, lrec_first[k], lrec_mask[k]); lrec_key[k] = DST_NONE; }
+            else lrec_key[k] = ((uint32_t)slot << 16) | atomicAdd(&srun[slot], 1u);
+        }
+        for (uint32_t k = tid; k < ns; k += 256) {
+            const uint32_t key = lst_key[k];
+            const int slot = slot_of(key);
+            if (slot < 0) { slow(key, lst_p[k], 0u); lst_key[k] = DST_NONE; }
+            else lst_key[k] = ((uint32_t)slot << 16) | atomicAdd(&sstray[slot], 1u);
+        }
+        __syncthreads();
+        // phase 3: reserve
         if (skey[tid] != SLOT_EMPTY) {
             const uint32_t t = skey[tid], cr = srun[tid], cs = sstray[tid];
             const unsigned long long old = atomicAdd(&fill64[t], ((unsigned long long)cr << 32) | cs);
@@ -503,35 +535,28 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
             sdst_stray[tid] = (unsigned long long)t * scap + bs;
             sroom_stray[tid] = scap - bs;
         }
-        {
-            const uint32_t nm = min(smiss_n, MISS_CAP);
-            for (uint32_t e = tid; e < nm; e += 256) slow(smiss_key[e], smiss_a[e], smiss_b[e]);
-        }
         __syncthreads();
-        {
-            const uint32_t nr = min(lrec_n, LREC_CAP);
-            for (uint32_t k = tid; k < nr; k += 256) {
-                const uint32_t d = lrec_dst[k], slot = d >> 16, at = d & 0xffffu;
-                if (at < sroom_run[slot]) recs[sdst_run[slot] + at] = GroupRec{lrec_first[k], lrec_mask[k]};
-                else for (uint32_t m = lrec_mask[k]; m; m &= m - 1) ovf[atomicAdd(ovf_count, 1ull)] = lrec_first[k] + (uint32_t)__ffs((int)m) - 1u;
-            }
+        // phase 4: scatter
+        for (uint32_t k = tid; k < nr; k += 256) {
+            const uint32_t d = lrec_key[k];
+            if (d == DST_NONE) continue;
+            const uint32_t slot = d >> 16, at = d & 0xffffu;
+            if (at < sroom_run[slot]) recs[sdst_run[slot] + at] = GroupRec{lrec_first[k], lrec_mask[k]};
+            else for (uint32_t m = lrec_mask[k]; m; m &= m - 1) ovf[atomicAdd(ovf_count, 1ull)] = lrec_first[k] + (uint32_t)__ffs((int)m) - 1u;
         }
-#pragma unroll 4
-        for (int j = 0; j < AGG_TRIPS * IDX_UNROLL; ++j) {
-            const uint32_t c = codes[j][tid];
-            if (c == CODE_DONE) continue;
-            const size_t p = p0 + (size_t)j * 256 + tid;
-            const uint32_t slot = c >> 16, at = c & 0xffffu;
-            // the position comes back from L2 (this workgroup read it a moment ago)
-            if (at < sroom_stray[slot]) store_stray(strays, (size_t)(sdst_stray[slot] + at), pos[3 * p], pos[3 * p + 1], pos[3 * p + 2],
-                                                    mass ? mass[p] : (T)1);
-            else ovf[atomicAdd(ovf_count, 1ull)] = (uint32_t)p;
+        for (uint32_t k = tid; k < ns; k += 256) {
+            const uint32_t d = lst_key[k];
+            if (d == DST_NONE) continue;
+            const uint32_t slot = d >> 16, at = d & 0xffffu;
+            if (at < sroom_stray[slot]) store_stray(strays, (size_t)(sdst_stray[slot] + at), lst_x[k], lst_y[k], lst_z[k],
+                                                    mass ? mass[lst_p[k]] : (T)1);
+            else ovf[atomicAdd(ovf_count, 1ull)] = lst_p[k];
         }
-        __syncthreads();                    // everyone is done with the table before it is re-armed
+        __syncthreads();                    // everyone is done with the lists and the table before they are re-armed
         skey[tid] = SLOT_EMPTY;
         srun[tid] = 0;
         sstray[tid] = 0;
-        if (tid == 0) { smiss_n = 0; lrec_n = 0; }
+        if (tid == 0) { lst_n = 0; lrec_n = 0; }
         __syncthreads();
     }
     if (dropped && ndrop) atomicAdd(dropped, ndrop);
@@ -731,13 +756,10 @@ tile_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileG
 // The particle lists a column walk reads.  FMT 0: 4-byte particle ids per tile (exact offsets of the two-pass
 // variant, tile_off / tile_count).  FMT 1: the compact lists of tile_group_kernel (group records + stray copies
 // in fixed-capacity segments, counts in fill64: records in the high word, strays in the low).
-struct WalkLists {
-    const uint32_t* index;
-    const uint32_t* tile_off;
-    const uint32_t* tile_count;
-    const unsigned long long* fill64;
-    const GroupRec* recs;
-    const void* strays;
+// (The list pointers are separate __restrict__ kernel arguments on purpose: read through a struct member the
+// per-tile counts become VECTOR loads followed by s_waitcnt vmcnt(0) - which also waits for every prefetched
+// position - instead of scalar loads.)
+struct WalkCaps {
     uint32_t rcap, scap, cap;
     size_t np;
 };
@@ -745,7 +767,9 @@ struct WalkLists {
 template <typename T, int W, bool HAS_MASS, int FMT>
 __global__ void __launch_bounds__(256)
 column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileGeom g, double scale,
-                      WalkLists wl, double mass_bound,
+                      const uint32_t* __restrict__ wl_index, const uint32_t* __restrict__ wl_tile_off,
+                      const uint32_t* __restrict__ wl_tile_count, const unsigned long long* __restrict__ wl_fill64,
+                      const GroupRec* __restrict__ wl_recs, const T* __restrict__ wl_strays, WalkCaps wl, double mass_bound,
                       const uint32_t* __restrict__ col_flags, T* __restrict__ grid, T* __restrict__ rec,
                       double offset, unsigned long long* dropped) {
     constexpr int LX = TX + W - 1, LY = TY + W - 1, LZ = TZ + W - 1;
@@ -800,7 +824,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     // particles are ordered in memory - the painted grid must not depend on that order)
     uint32_t cmax = 1;
     if (FMT == 0) {
-        for (int tz = 0; tz < g.ntz; ++tz) cmax = max(cmax, wl.tile_count[(uint32_t)((tx * g.nty + ty) * g.ntz + tz)]);
+        for (int tz = 0; tz < g.ntz; ++tz) cmax = max(cmax, wl_tile_count[(uint32_t)((tx * g.nty + ty) * g.ntz + tz)]);
     } else {
         cmax = (uint32_t)min(5ull * wl.cap, 0x3fffffffull);      // 32 * rcap + the largest scap = 5 * cap
     }
@@ -840,62 +864,64 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
         for (int nt = bt.tz + 1; nt < g.ntz; ++nt) {
             const uint32_t t = (uint32_t)((tx * g.nty + ty) * g.ntz + phys(nt));
             if (FMT == 0) {
-                const uint32_t cnt = wl.tile_count[t];
-                if (cnt) return Batch{nt, 0u, cnt, (list_off_t)wl.tile_off[t], 0u, 0u};
+                const uint32_t cnt = wl_tile_count[t];
+                if (cnt) return Batch{nt, 0u, cnt, (list_off_t)wl_tile_off[t], 0u, 0u};
             } else {
-                const unsigned long long f = wl.fill64[t];
+                const unsigned long long f = wl_fill64[t];
                 const uint32_t nrec = min((uint32_t)(f >> 32), wl.rcap), nst = min((uint32_t)f, wl.scap);
                 if (nrec + nst) return Batch{nt, 0u, nrec + (nst + 31u) / 32u, (list_off_t)t, nrec, nst};
             }
         }
         return Batch{g.ntz, 0u, bt.cnt, bt.off, bt.nrec, bt.nst};           // keeps a loadable span
     };
-    // stage 1 of a batch: for each of this thread's U slots the particle id (or the position in the stray
-    // list); bit u of act: the slot holds a particle; bit 8 + u: it is a stray copy
-    auto load_idx = [&](const Batch& bt, uint32_t (&idx)[U], uint32_t& act) {
-        act = 0;
+    // stage 1 of a batch: LOAD ONLY - the id (FMT 0) or the group record (FMT 1) of each of this thread's U
+    // slots.  Nothing may be computed from the loaded values here: that would wait for them on the spot, and with
+    // them for everything else in flight.  (A stray block re-reads the tile's last record, or the segment's first
+    // slot when the tile has none: unconditional loads.)
+    auto load_idx = [&](const Batch& bt, GroupRec (&rec)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (FMT == 0) {
                 const uint32_t i = bt.i0 + u * 256 + threadIdx.x;
-                idx[u] = wl.index[bt.off + min(i, bt.cnt - 1)];
-                act |= (uint32_t)(i < bt.cnt) << u;
+                rec[u].first = wl_index[bt.off + min(i, bt.cnt - 1)];
             } else {
-                const uint32_t r = bt.i0 + u * 8 + (threadIdx.x >> 5), b = threadIdx.x & 31;
-                const uint32_t rr = min(r, bt.cnt - 1);
-                // unconditional record load (a stray block re-reads the tile's last record, or the segment's
-                // first slot when the tile has none): a predicated load would cost a branch and a full wait
-                const GroupRec gr = wl.recs[(size_t)bt.off * wl.rcap + min(rr, bt.nrec ? bt.nrec - 1 : 0u)];
-                const bool st = rr >= bt.nrec;
-                const uint32_t sidx = (rr - bt.nrec) * 32u + b;
-                idx[u] = st ? min(sidx, bt.nst - 1) : (uint32_t)min((size_t)gr.first + b, wl.np - 1);
-                const bool on = r < bt.cnt && (st ? sidx < bt.nst : ((gr.mask >> b) & 1u) != 0);
-                act |= ((uint32_t)on << u) | ((uint32_t)st << (8 + u));
+                const uint32_t r = bt.i0 + u * 8 + (threadIdx.x >> 5);
+                const uint32_t rr = min(min(r, bt.cnt - 1), bt.nrec ? bt.nrec - 1 : 0u);
+                rec[u] = wl_recs[(size_t)bt.off * wl.rcap + rr];
             }
         }
     };
-    // stage 2: positions and masses - a gather through the ids, or the stray copies themselves; one
-    // unconditional load per component through a per-lane base pointer
-    auto load_pos = [&](const Batch& bt, const uint32_t (&idx)[U], uint32_t act, T (&p)[3 * U], T (&m)[U]) {
+    // stage 2, one batch later: ids and occupancy from the records (bit u of act: slot u holds a particle), then
+    // positions and masses - a gather through the ids, or the stray copies themselves; one unconditional load per
+    // component through a per-lane base pointer
+    auto load_pos = [&](const Batch& bt, const GroupRec (&rec)[U], uint32_t& act, T (&p)[3 * U], T (&m)[U]) {
+        act = 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (FMT == 1) {
-                const bool st = (act >> (8 + u)) & 1u;
-                const T* const sbase = reinterpret_cast<const T*>(wl.strays) + 4 * ((size_t)bt.off * wl.scap);
-                const T* const src = st ? sbase + 4 * (size_t)idx[u] : pos + 3 * (size_t)idx[u];
+                const uint32_t r = bt.i0 + u * 8 + (threadIdx.x >> 5), b = threadIdx.x & 31;
+                const bool st = r >= bt.nrec;                                   // uniform per half wave
+                const uint32_t sidx = (r - bt.nrec) * 32u + b;
+                const bool on = st ? (r < bt.cnt && sidx < bt.nst) : ((rec[u].mask >> b) & 1u) != 0;
+                act |= (uint32_t)on << u;
+                const uint32_t idx = st ? min(sidx, bt.nst - 1) : (uint32_t)min((size_t)rec[u].first + b, wl.np - 1);
+                const T* const sbase = wl_strays + 4 * ((size_t)bt.off * wl.scap);
+                const T* const src = st ? sbase + 4 * (size_t)idx : pos + 3 * (size_t)idx;
                 p[3 * u + 0] = src[0];
                 p[3 * u + 1] = src[1];
                 p[3 * u + 2] = src[2];
-                if (HAS_MASS) { const T* const msrc = st ? src + 3 : mass + idx[u]; m[u] = *msrc; }
+                if (HAS_MASS) { const T* const msrc = st ? src + 3 : mass + idx; m[u] = *msrc; }
                 else m[u] = (T)1;
                 continue;
             }
-            const size_t q3 = (ablate & 32) ? (size_t)((idx[u] % 1000000u) * 3) : (size_t)idx[u] * 3;
-            if (ablate & 1024) { p[3 * u + 0] = p[3 * u + 1] = p[3 * u + 2] = (T)idx[u]; continue; }
+            act |= (uint32_t)(bt.i0 + u * 256 + threadIdx.x < bt.cnt) << u;
+            const uint32_t idx = rec[u].first;
+            const size_t q3 = (ablate & 32) ? (size_t)((idx % 1000000u) * 3) : (size_t)idx * 3;
+            if (ablate & 1024) { p[3 * u + 0] = p[3 * u + 1] = p[3 * u + 2] = (T)idx; continue; }
             p[3 * u + 0] = pos[q3 + 0];
             p[3 * u + 1] = pos[q3 + 1];
             p[3 * u + 2] = pos[q3 + 2];
-            m[u] = HAS_MASS ? mass[idx[u]] : (T)1;      // compile time: a run-time choice would merge the
+            m[u] = HAS_MASS ? mass[idx] : (T)1;         // compile time: a run-time choice would merge the
         }                                               // loaded value with a constant and wait for it
     };
 
@@ -977,13 +1003,13 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     // Two register sets, used alternately (a copy at the end of a step would have to wait for
     // the loads it copies): pos/mass A|B of batch k|k+1, indices X|Y of batch k+1|k+2.
     T pA[3 * U], mA[U], pB[3 * U], mB[U];
-    uint32_t iX[U], iY[U];
-    uint32_t aX = 0, aY = 0, aA = 0, aB = 0;          // occupied slots of the id sets / position sets
+    GroupRec iX[U], iY[U];
+    uint32_t aA = 0, aB = 0;                // occupied slots of the position sets
     if (cur_tz < g.ntz) {                   // uniform: the column holds particles
-        load_idx(nxt, iY, aA);
+        load_idx(nxt, iY);
         load_pos(nxt, iY, aA, pA, mA);
         nxt = next_batch(nxt);
-        load_idx(nxt, iX, aX);
+        load_idx(nxt, iX);
     }
     // One loop, two phases with the register sets swapped, so no set is ever copied; tiles are
     // flushed (all the empty ones too: every grid cell gets written) before the first batch of a
@@ -1064,9 +1090,8 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
             DSTAMP(1);
             const Batch nn = next_batch(nxt);
             DSTAMP(2);
-            load_pos(nxt, iX, aX, pB, mB);                // batch k+1 (a harmless re-load at the end)
-            aB = aX;
-            load_idx(nn, iY, aY);                         // batch k+2
+            load_pos(nxt, iX, aB, pB, mB);                // batch k+1 (a harmless re-load at the end)
+            load_idx(nn, iY);                             // batch k+2
             DSTAMP(3);
             if (careful) deposit(pA, mA, aA, std::true_type{}); else deposit(pA, mA, aA, std::false_type{});
             DSTAMP(4);
@@ -1080,9 +1105,8 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
             DSTAMP(1);
             const Batch nn = next_batch(nxt);
             DSTAMP(2);
-            load_pos(nxt, iY, aY, pA, mA);
-            aA = aY;
-            load_idx(nn, iX, aX);
+            load_pos(nxt, iY, aA, pA, mA);
+            load_idx(nn, iX);
             DSTAMP(3);
             if (careful) deposit(pB, mB, aB, std::true_type{}); else deposit(pB, mB, aB, std::false_type{});
             DSTAMP(4);
@@ -1325,10 +1349,11 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
         if (overwrite) {
             {
                 AST_PROF("paint_tiled.deposit", s);
-                WalkLists wl{w.index, tile_off, tile_count, w.fill64, w.recs, w.strays, w.rcap, w.scap, w.cap, np};
+                WalkCaps wl{w.rcap, w.scap, w.cap, np};
                 auto launch = [&](auto has_mass, auto fmt) {
                     column_deposit_kernel<T, W, decltype(has_mass)::value, decltype(fmt)::value><<<ncols, 256, 0, s>>>(
-                        pos, mass, g, scale, wl, mass ? mass_bound : 1.0, w.col_flags, grid, (T*)w.rec, offset, dropped);
+                        pos, mass, g, scale, w.index, tile_off, tile_count, w.fill64, w.recs, (const T*)w.strays, wl,
+                        mass ? mass_bound : 1.0, w.col_flags, grid, (T*)w.rec, offset, dropped);
                 };
                 using I0 = std::integral_constant<int, 0>;
                 using I1 = std::integral_constant<int, 1>;
