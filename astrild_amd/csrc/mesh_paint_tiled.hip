@@ -843,10 +843,12 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     // flight, so the gather latency (and the flush between two tiles) is covered by work of the
     // same wave.  All loads are unconditional (lanes past the end of a batch re-load its last
     // particle): a predicated load costs a branch and a full s_waitcnt each.
-#ifndef DEP_U
-#define DEP_U 2
+    // slots per thread and batch.  A tile's last batch is partly empty (72 entries per tile of the bench input):
+    // 2 wastes less than 4 (deposit 4.49 vs 4.72 ms at 1024^3), 3 is in between
+#ifndef COL_U
+#define COL_U 2
 #endif
-    constexpr int U = DEP_U;
+    constexpr int U = COL_U;
     // A tile's work is a list of ENTRIES.  FMT 0: particle ids, one per thread slot.  FMT 1: 32-lane entries, one
     // per half wave - the tile's nrec group records followed by ceil(nst / 32) blocks of 32 consecutive stray
     // copies, so records and strays share batches (72 entries, i.e. 4.5 batches, per tile of the bench input).

@@ -205,16 +205,35 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
         if offset != "mean":
             raise ValueError(offset)
         offset = total_mass(mass, npart) * float(scale) / float(n) ** 3
+    compact = use_tiled and not accumulate and method != "tiled2"       # single pass + overwrite: group / stray lists
     if use_tiled:
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pos.device)
         mass_bound = 1.0
         if mass is not None and not accumulate and npart:
             lo_hi = torch.empty(2, dtype=torch.float64, device=pos.device)      # bound for the fixed-point tiles
             check(L.ast_minmax(ptr(mass), code, npart, ptr(lo_hi), stream()), "ast_minmax")
             mass_bound = float(lo_hi.abs().max()) or 1.0
-        check(L.ast_paint_tiled(win, code, ptr(pos), ptr(mass), npart, n, float(boxsize), float(scale),
-                                int(x_start), nx, ptr(out), ptr(ws), ws_bytes, ptr(dropped), tflags,
-                                mass_bound, float(offset), stream()), "ast_paint_tiled")
+        while True:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pos.device)
+            check(L.ast_paint_tiled(win, code, ptr(pos), ptr(mass), npart, n, float(boxsize), float(scale),
+                                    int(x_start), nx, ptr(out), ptr(ws), ws_bytes, ptr(dropped), tflags,
+                                    mass_bound, float(offset), stream()), "ast_paint_tiled")
+            st = None
+            if compact and (stats is not None or (check_dropped and not tflags & 8)):
+                st = torch.empty(4, dtype=torch.int64, device=pos.device)
+                check(L.ast_paint_tiled_list_stats(ptr(ws), win, code, npart, n, nx, tflags, ptr(st), stream()),
+                      "ast_paint_tiled_list_stats")
+                st = dict(zip(("groups", "strays", "overflow", "max_strays_per_tile"), st.cpu().tolist()))
+            # particles without spatial order in memory overflow the default stray segments and crawl through
+            # the global-atomic list: paint again with segments sized for that (callers that synchronise anyway)
+            if st is not None and check_dropped and not tflags & 8 and st["overflow"] > npart // 64:
+                tflags |= 8
+                ws_bytes = int(L.ast_paint_tiled_workspace_bytes(win, code, npart, n, nx, tflags))
+                dropped.zero_()
+                del ws
+                continue
+            if stats is not None and st is not None:
+                stats.update(st, scattered=bool(tflags & 8))
+            break
     else:
         check(L.ast_paint(win, code, ptr(pos), ptr(mass), npart, n, float(boxsize), float(scale),
                           int(x_start), nx, ptr(out), ptr(dropped), stream()), "ast_paint")
@@ -223,12 +242,6 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
         if nd:
             raise _lib.AstrildHipError(f"{nd} deposits fell outside the grid buffer "
                                        f"(x_start={x_start}, nx_alloc={nx})")
-    if stats is not None:
-        st = torch.empty(4, dtype=torch.int64, device=pos.device)
-        if use_tiled and not accumulate and method != "tiled2":
-            check(L.ast_paint_tiled_list_stats(ptr(ws), win, code, npart, n, nx, tflags, ptr(st), stream()),
-                  "ast_paint_tiled_list_stats")
-            stats.update(zip(("groups", "strays", "overflow", "max_strays_per_tile"), st.cpu().tolist()))
     if defer_fold:
         rec = ct.c_void_p()
         check(L.ast_paint_tiled_halo(ptr(ws), win, code, npart, n, nx, tflags, ct.byref(rec)), "ast_paint_tiled_halo")
