@@ -906,7 +906,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
                 const uint32_t sidx = (r - bt.nrec) * 32u + b;
                 const bool on = st ? (r < bt.cnt && sidx < bt.nst) : ((rec[u].mask >> b) & 1u) != 0;
                 act |= (uint32_t)on << u;
-                const uint32_t idx = st ? min(sidx, bt.nst - 1) : (uint32_t)min((size_t)rec[u].first + b, wl.np - 1);
+                const uint32_t idx = st ? min(sidx, bt.nst - 1) : min(rec[u].first + b, (uint32_t)(wl.np - 1));    // np < 2^32 - 64: no wrap
                 const T* const sbase = wl_strays + 4 * ((size_t)bt.off * wl.scap);
                 const T* const src = st ? sbase + 4 * (size_t)idx : pos + 3 * (size_t)idx;
                 p[3 * u + 0] = src[0];
@@ -935,6 +935,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     // of the column lies inside the box and the tile does not straddle the periodic x edge, so
     // the unreduced cell (int)floor(s) minus the tile origin is the LDS coordinate (the same
     // expression decided the particle's tile in tile_of(); it raised col_flags otherwise).
+    const double m_unit = (double)(T)scale * invq;         // unit masses: the per-particle factor is a constant
     auto deposit = [&](const T (&pc)[3 * U], const T (&mc)[U], uint32_t act, auto careful_tag) {
         constexpr bool CAREFUL = decltype(careful_tag)::value;
 #pragma unroll
@@ -974,7 +975,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
             Window<W>::weights(fx, wx);
             Window<W>::weights(fy, wy);
             Window<W>::weights(fz, wz);
-            const double m = (double)(T)((double)mc[u] * scale) * invq;
+            const double m = HAS_MASS ? (double)(T)((double)mc[u] * scale) * invq : m_unit;
             unsigned long long* slot[W];          // (lx, ly) row at the ring slots of planes lz + c
             int sl = lz + sh;
             sl = sl >= LZ ? sl - LZ : sl;
@@ -1497,7 +1498,7 @@ extern "C" int ast_paint_tiled(int window, int dtype, const void* pos, const voi
     AST_CHECK_ARG(nmesh > 0 && boxsize > 0.0);
     AST_CHECK_ARG(x_start >= 0 && x_start < nmesh && nx_alloc > 0 && nx_alloc <= nmesh);
     AST_CHECK_ARG(grid != nullptr);
-    AST_CHECK_ARG(np < 0xffffffffull);
+    AST_CHECK_ARG(np < 0xffffffffull - 64);
     if (np == 0) {
         if (flags & AST_PAINT_OVERWRITE)
             AST_CHECK_HIP(hipMemsetAsync(grid, 0, (size_t)nx_alloc * nmesh * nmesh * (dtype == AST_F32 ? 4 : 8),

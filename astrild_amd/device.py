@@ -185,7 +185,7 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     # TWO_PASS | OVERWRITE | DEFER_FOLD | SCATTERED
     tflags = (1 if method == "tiled2" else 0) | (0 if accumulate else 2) | (4 if defer_fold else 0) | \
              (8 if hint == "scattered" and not accumulate and method != "tiled2" else 0)
-    if method in ("auto", "tiled", "tiled2") and win != 0 and npart < 2**32 - 1:
+    if method in ("auto", "tiled", "tiled2") and win != 0 and npart < 2**32 - 65:
         ws_bytes = int(L.ast_paint_tiled_workspace_bytes(win, code, npart, n, nx, tflags))
     if method in ("tiled", "tiled2") and ws_bytes == 0:
         raise _lib.AstrildHipError("tiled paint needs a CIC/TSC window and nmesh a multiple of 32")

@@ -216,19 +216,28 @@ def add_patch(limg, simg, cen_pix):
 
 
 # ------------------------------------------------- synthetic planes + bench leg
-def synth_kappa_planes(nplanes, npix, seed0=4242, rms=0.01, dtype=torch.float64):
-    """Gaussian random fields with P(l) ~ (l + l0)^-2, one per plane.
-    Generated with torch's FFT as bench plumbing (inputs are not part of the path)."""
-    planes = []
+def synth_kappa_plane(p, npix, seed0=4242, rms=0.01, dtype=torch.float64):
+    """Plane p of the synthetic stack: a Gaussian random field with P(l) ~ (l + l0)^-2,
+    seeded by seed0 + p.  Generated with torch's FFT as bench plumbing (inputs are not part of the path)."""
     fy = torch.fft.fftfreq(npix, device="cuda", dtype=torch.float64)[:, None]
     fx = torch.fft.rfftfreq(npix, device="cuda", dtype=torch.float64)[None, :]
     amp = 1.0 / (torch.sqrt(fx * fx + fy * fy) * npix + 10.0)
-    for p in range(nplanes):
-        g = torch.Generator(device="cuda").manual_seed(seed0 + p)
-        white = torch.randn((npix, npix), generator=g, device="cuda", dtype=torch.float64)
-        f = torch.fft.irfft2(torch.fft.rfft2(white) * amp, s=(npix, npix))
-        planes.append((f * (rms / f.std())).to(dtype).contiguous())
-    return planes
+    g = torch.Generator(device="cuda").manual_seed(seed0 + p)
+    white = torch.randn((npix, npix), generator=g, device="cuda", dtype=torch.float64)
+    f = torch.fft.irfft2(torch.fft.rfft2(white) * amp, s=(npix, npix))
+    return (f * (rms / f.std())).to(dtype).contiguous()
+
+
+def synth_kappa_planes(nplanes, npix, seed0=4242, rms=0.01, dtype=torch.float64, ids=None):
+    """The planes `ids` (default: all) of the synthetic stack."""
+    return [synth_kappa_plane(p, npix, seed0, rms, dtype) for p in (range(nplanes) if ids is None else ids)]
+
+
+def synth_plane_weights(nplanes):
+    """(wnum, wden) of the synthetic stack: a 1000 Mpc/h box cut into nplanes slabs, source moved from 1100 to 1000."""
+    mid = (np.arange(nplanes) + 0.5) * (1000.0 / nplanes)
+    half = 0.5 * 1000.0 / nplanes
+    return translate_redshift_weights(mid - half, mid + half, 1100.0, 1000.0)
 
 
 def bench_kappa_pipeline(nplanes=64, npix=4096, steps=3, warmup=1, theta_deg=20.0, sigma_arcmin=1.0):
@@ -236,8 +245,7 @@ def bench_kappa_pipeline(nplanes=64, npix=4096, steps=3, warmup=1, theta_deg=20.
     / c^2 -> Gaussian FFT smoothing -> kappa -> (alpha1, alpha2) -> 100-bin PDF."""
     from . import device as dev
     planes = synth_kappa_planes(nplanes, npix)
-    mid = (np.arange(nplanes) + 0.5) * (1000.0 / nplanes)
-    wnum, wden = translate_redshift_weights(mid - 7.8125, mid + 7.8125, 1100.0, 1000.0)
+    wnum, wden = synth_plane_weights(nplanes)
     bsz = np.deg2rad(theta_deg)
     lp = lens_plan(npix, bsz)
     sp = smooth_plan(npix)

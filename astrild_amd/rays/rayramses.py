@@ -5,9 +5,18 @@ kernel over all selected planes instead of a Python ``+=`` loop.
 
 Deviations from the reference, all of them defects listed in SURVEY.md
 Appendix B: ``_get_box_and_ray_nrs`` is called as a method (rayramses.py:186
-lacks ``self.``); the re-weighting block is unreachable there (:205-222 sits
-behind an unconditional ``raise``) — here it executes when ``z_src_shift`` is
-given, with z_next taken from the snapshot table as the dead code intends.
+lacks ``self.``).  The re-weighting block is unreachable there (:205-222 sits
+behind an unconditional ``raise``): by default this class behaves as the
+reference EXECUTES - ``z_src_shift`` with a selected plane at
+``redshift <= z_src_shift`` raises the same warning, otherwise the planes are
+summed unweighted.  ``reweight=True`` opts into what the dead block intends:
+planes with ``redshift <= z_src_shift`` have ``kappa_2`` multiplied by
+g(x_mid, x_s') / g(x_mid, x_s), z_next by its box rule (:207-210).
+
+Multi-GPU: under an initialised ``torch.distributed`` group of more than one
+rank, plane p of the selection is loaded and summed by rank p mod P and the
+partial maps are combined by ``kappa_shard.kappa_stack_sharded`` (SURVEY.md
+§8e); every rank returns the full result.
 """
 import os
 from typing import Optional
@@ -17,6 +26,16 @@ import pandas as pd
 
 from .. import lensing
 from ..device import as_device
+
+
+def _shard_group(group):
+    """The process group to shard planes over, or None (single process / one rank)."""
+    import torch.distributed as dist
+    if group is None and dist.is_available() and dist.is_initialized():
+        group = dist.group.WORLD
+    if group is not None and dist.get_world_size(group) > 1:
+        return group
+    return None
 
 
 class RayRamsesWarning(BaseException):
@@ -48,21 +67,56 @@ class PlaneStacker:
         return lensing.kappa_stack([t], [num], [den]).cpu().numpy()
 
     @staticmethod
-    def _stack_columns(frames, columns, weights):
-        """frames: list of DataFrames (same index); weights: {column: (num[], den[])} or {}.
-        The first frame is the accumulator, like the reference (rayramses.py:224-232)."""
-        total = frames[0]
+    def _z_next(table, box_nr, ray_nr):
+        """Redshift of the next snapshot along the cone, the rule of the reference's dead block
+        (rayramses.py:207-210, simcoll.py:306-309): at the last output of a light-cone box (the smallest ray
+        number of the box, boxes 1..3) the first output of the next box, else the next row of the box's table."""
+        rows = table.loc[box_nr]
+        ray_nrs = np.asarray(rows.index.values)
+        if ray_nr == ray_nrs.min() and box_nr < 4 and (box_nr + 1, 1) in table.index:
+            return float(table.loc[(box_nr + 1, 1)]["redshift"])
+        ii = int(np.nonzero(ray_nrs == ray_nr)[0][0])
+        if ii + 1 < len(rows):
+            return float(rows.iloc[ii + 1]["redshift"])
+        return float(rows.iloc[ii]["redshift"])
+
+    def _plane_weight(self, table, box_nr, ray_nr, z_src, z_src_shift, reweight, warning):
+        """(numerator, denominator) of one plane's kappa_2 weight, or None when the plane is summed as it is."""
+        if z_src_shift is None:
+            return None
+        z = float(table.loc[(box_nr, ray_nr)]["redshift"])
+        if z > z_src_shift:
+            return (1.0, 1.0) if reweight else None
+        if not reweight:
+            raise warning("Redshift shift has not correct data structure")       # what the reference executes
+        return self._translate_redshift_weight(z, self._z_next(table, box_nr, ray_nr), z_src, z_src_shift)
+
+    @staticmethod
+    def _sum_planes(planes, wn, wd, group):
+        """Device planes -> summed map as numpy; sharded over `group` when given (every rank gets the result)."""
+        if group is None:
+            return lensing.kappa_stack(planes, wn, wd).cpu().numpy()
+        from ..kappa_shard import kappa_stack_sharded
+        return kappa_stack_sharded(planes, wn, wd, group=group, all_ranks=True).cpu().numpy()
+
+    @classmethod
+    def _stack_columns(cls, frames, columns, weights, group=None, template=None):
+        """frames: list of DataFrames (same index) - with `group`, this rank's share of them;
+        weights: {column: (num[], den[])} or {}.  The first frame is the accumulator, like the reference
+        (rayramses.py:224-232); a rank without frames fills `template`'s copy."""
+        total = frames[0] if frames else template
         for column in columns:
             planes = [as_device(np.ascontiguousarray(f[column].values, dtype=np.float64)) for f in frames]
             wn, wd = weights.get(column, (None, None))
-            total[column] = lensing.kappa_stack(planes, wn, wd).cpu().numpy()
+            total[column] = cls._sum_planes(planes, wn, wd, group).reshape(np.shape(total[column].values))
         return total
 
-    @staticmethod
-    def _stack_arrays(arrays, weights=None):
+    @classmethod
+    def _stack_arrays(cls, arrays, weights=None, group=None):
         planes = [as_device(np.ascontiguousarray(a, dtype=np.float64)) for a in arrays]
         wn, wd = weights if weights else (None, None)
-        return lensing.kappa_stack(planes, wn, wd).cpu().numpy()
+        out = cls._sum_planes(planes, wn, wd, group)
+        return out.reshape(np.shape(arrays[0])) if arrays else out
 
 
 class RayRamses(PlaneStacker):
@@ -88,37 +142,45 @@ class RayRamses(PlaneStacker):
 
     def sum_snapshots(self, dir_out: str, columns: list, columns_z_shift: list, integration_range: dict,
                       ray_file_root: str = "Ray_maps_output%05d.h5", sim_folder_root: str = "box%d",
-                      z_src: float = None, z_src_shift: float = None) -> pd.DataFrame:
+                      z_src: float = None, z_src_shift: float = None, reweight: bool = False,
+                      group=None) -> pd.DataFrame:
         """Add ray-tracing outputs between arbitrary redshifts along the light-cone
         (rayramses.py:151-234).  Returns the summed DataFrame (and writes it like the
-        reference when ``dir_out`` is not None)."""
+        reference when ``dir_out`` is not None; rank 0 writes under a process group)."""
         if self.ray_info_df is None:
             self.ray_info_df = self._load_ray_info()
         sim_folder_root = self.dirs["lc"] + sim_folder_root
         box_ray_nrs = self._get_box_and_ray_nrs(integration_range)
-
-        frames, wnum, wden = [], [], []
-        info = self.ray_info_df
-        for ii, (box_nr, ray_nr) in enumerate(box_ray_nrs):
-            sim_info_df = info.loc[(box_nr, ray_nr)]
-            self.dirs["sim"] = sim_folder_root % box_nr + "/"
-            ray_map_df = self._load_ray_map(self.dirs["sim"] + ray_file_root % ray_nr)
-            frames.append(ray_map_df)
-            if z_src_shift is not None:
-                # next snapshot along the cone: next row of the table (rayramses.py:206-210)
-                z_next = info.iloc[min(ii + 1, len(info) - 1)]["redshift"] if ii + 1 < len(box_ray_nrs) \
-                    else sim_info_df["redshift"]
-                n, d = self._translate_redshift_weight(sim_info_df["redshift"], z_next, z_src, z_src_shift)
-                wnum.append(n)
-                wden.append(d)
-        if not frames:
+        if len(box_ray_nrs) == 0:
             raise RayRamsesWarning("no ray-tracing snapshot in the requested range")
+        group = _shard_group(group)
+        rank, world = 0, 1
+        if group is not None:
+            import torch.distributed as dist
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+        info = self.ray_info_df
+        # the weights are decided for every plane on every rank (so all ranks raise alike)
+        plane_w = [self._plane_weight(info, box_nr, ray_nr, z_src, z_src_shift, reweight, RayRamsesWarning)
+                   for box_nr, ray_nr in box_ray_nrs]
+        frames, wnum, wden = [], [], []
+        for ii, (box_nr, ray_nr) in enumerate(box_ray_nrs):
+            if ii % world != rank:
+                continue                                    # plane ii lives on rank ii mod P
+            self.dirs["sim"] = sim_folder_root % box_nr + "/"
+            frames.append(self._load_ray_map(self.dirs["sim"] + ray_file_root % ray_nr))
+            n, d = plane_w[ii] or (1.0, 1.0)
+            wnum.append(n)
+            wden.append(d)
         weights = {}
-        if z_src_shift is not None:
+        if any(w is not None for w in plane_w):
             # "only of kappa but not of iswrs" (rayramses.py:311)
             weights = {c: (wnum, wden) for c in (columns_z_shift or ["kappa_2"]) if c in columns}
-        ray_df_sum = self._stack_columns(frames, columns, weights)
-        if dir_out is not None:
+        template = None
+        if not frames:                                      # more ranks than planes: shape from the first plane
+            self.dirs["sim"] = sim_folder_root % box_ray_nrs[0][0] + "/"
+            template = self._load_ray_map(self.dirs["sim"] + ray_file_root % box_ray_nrs[0][1])
+        ray_df_sum = self._stack_columns(frames, columns, weights, group, template)
+        if dir_out is not None and rank == 0:
             self._merged_snapshots_to_file(ray_df_sum, dir_out, integration_range)
         return ray_df_sum
 

@@ -9,7 +9,7 @@ from typing import Optional
 import numpy as np
 import pandas as pd
 
-from .rays.rayramses import PlaneStacker
+from .rays.rayramses import PlaneStacker, _shard_group
 
 
 class SimulationCollectionWarning(BaseException):
@@ -37,37 +37,47 @@ class SimulationCollection(PlaneStacker):
     def sum_raytracing_snapshots(self, dir_out: str, columns: list, columns_z_shift: list,
                                  integration_range: dict, ray_file_root: str = "Ray_maps_output%05d.h5",
                                  sim_folder_root: str = "box%d", z_src: Optional[float] = None,
-                                 z_src_shift: Optional[float] = None, rm_ray: Optional[dict] = None):
+                                 z_src_shift: Optional[float] = None, rm_ray: Optional[dict] = None,
+                                 reweight: bool = False, group=None):
         """simcoll.py:238-341.  Returns the summed DataFrame (``.h5`` planes) or
-        ndarray (``.npy`` planes)."""
+        ndarray (``.npy`` planes).  ``reweight`` / ``group``: see rays/rayramses.py."""
         box_ray_nrs = self._get_box_and_ray_nrs_for_integration_range(integration_range, rm_ray)
-        maps, wnum, wden = [], [], []
+        selection = []                                      # (sim, box_nr, ray_nr) in the reference's loop order
         for sim_name in self.sim.keys():
-            _sim = self.sim[sim_name]
             box_nr = self._boxnr_from_simname(sim_name)
             if box_nr not in list(box_ray_nrs.keys()):
                 continue
-            ray_nrs = box_ray_nrs[box_nr]
-            for ii, ray_nr in enumerate(ray_nrs):
-                sim_info_df = self.config.loc[(box_nr, ray_nr)]
-                ray_file = glob.glob(
-                    _sim.dirs["sim"] + f"{_sim.file_dsc['root']}_*{ray_nr}." + f"{_sim.file_dsc['extension']}"
-                )[0]
-                maps.append(self._load_ray_map(ray_file))
-                if z_src_shift is not None:
-                    z_next = (self.config.loc[(box_nr, ray_nrs[ii + 1])]["redshift"]
-                              if ii + 1 < len(ray_nrs) else sim_info_df["redshift"])
-                    n, d = self._translate_redshift_weight(sim_info_df["redshift"], z_next, z_src, z_src_shift)
-                    wnum.append(n)
-                    wden.append(d)
-        if not maps:
+            selection += [(self.sim[sim_name], box_nr, ray_nr) for ray_nr in box_ray_nrs[box_nr]]
+        if not selection:
             raise SimulationCollectionWarning("no ray-tracing snapshot in the requested range")
-        if isinstance(maps[0], pd.DataFrame):
+        group = _shard_group(group)
+        rank, world = 0, 1
+        if group is not None:
+            import torch.distributed as dist
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+        plane_w = [self._plane_weight(self.config, box_nr, ray_nr, z_src, z_src_shift, reweight,
+                                      SimulationCollectionWarning) for _, box_nr, ray_nr in selection]
+
+        def ray_file_of(sim, ray_nr):
+            return glob.glob(sim.dirs["sim"] + f"{sim.file_dsc['root']}_*{ray_nr}." + f"{sim.file_dsc['extension']}")[0]
+
+        maps, wnum, wden = [], [], []
+        for ii, (_sim, box_nr, ray_nr) in enumerate(selection):
+            if ii % world != rank:
+                continue                                    # plane ii lives on rank ii mod P
+            maps.append(self._load_ray_map(ray_file_of(_sim, ray_nr)))
+            n, d = plane_w[ii] or (1.0, 1.0)
+            wnum.append(n)
+            wden.append(d)
+        weighted = any(w is not None for w in plane_w)
+        first = maps[0] if maps else self._load_ray_map(ray_file_of(selection[0][0], selection[0][2]))
+        if isinstance(first, pd.DataFrame):
             weights = {}
-            if z_src_shift is not None:
+            if weighted:
                 weights = {c: (wnum, wden) for c in (columns_z_shift or ["kappa_2"]) if c in columns}
-            return self._stack_columns(maps, columns, weights)
-        return self._stack_arrays(maps, (wnum, wden) if z_src_shift is not None else None)
+            return self._stack_columns(maps, columns, weights, group, None if maps else first)
+        out = self._stack_arrays(maps, (wnum, wden) if weighted else None, group)
+        return out.reshape(np.shape(first))
 
     def _get_box_and_ray_nrs_for_integration_range(self, integration_range: dict,
                                                    rm_ray: Optional[dict] = None) -> dict:

@@ -1,0 +1,35 @@
+"""Worker of tests/test_gpu_kappa.py::test_sharded_stack_ranks_share_one_gpu: rank r of a world of P processes,
+all on cuda:0 over gloo, stacks its planes of the synthetic config-D stack with the real HipStackOps and
+kappa_stack_sharded; rank 0 writes the result."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def main():
+    rank, world, port, nplanes, npix, out = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]),
+                                             int(sys.argv[5]), sys.argv[6])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        from astrild_amd import kappa_shard, lensing
+        ids = kappa_shard.my_plane_ids(nplanes)
+        planes = lensing.synth_kappa_planes(nplanes, npix, ids=ids)
+        wnum, wden = lensing.synth_plane_weights(nplanes)
+        res = kappa_shard.kappa_stack_sharded(planes, wnum[ids], wden[ids])
+        res2 = kappa_shard.kappa_stack_sharded(planes, wnum[ids], wden[ids])
+        if rank == 0:
+            assert torch.equal(res, res2)                   # fixed summation order: bit-reproducible
+            np.save(out, res.cpu().numpy())
+        else:
+            assert res is None
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -225,16 +225,34 @@ def test_rayramses_sum_snapshots_plain_and_reweighted():
     sel = [(1, 2), (1, 3), (2, 1)]
     for col in ("kappa_2", "isw_rs"):
         assert np.array_equal(out[col].values, ok.kappa_stack([frames[s][col].values for s in sel]))
-    # whole light-cone with the source moved from z=0.4 to z=0.22: kappa_2 re-weighted, isw_rs not
+    # z_src_shift with planes at redshift <= z_src_shift: the reference raises (rayramses.py:201-205) - the default
+    rr = MemRay({"lc": "/lc/"}, cosmology=FlatCosmology(), ray_info_df=_ray_table())
+    with pytest.raises(BaseException, match="Redshift shift has not correct data structure"):
+        rr.sum_snapshots(None, ["kappa_2", "isw_rs"], ["kappa_2"], {"z": [], "box": [0], "ray": [0]},
+                         z_src=0.4, z_src_shift=0.22)
+    # ... and sums unweighted when every selected plane lies beyond the shifted source
+    rr = MemRay({"lc": "/lc/"}, cosmology=FlatCosmology(), ray_info_df=_ray_table())
+    out = rr.sum_snapshots(None, ["kappa_2"], ["kappa_2"], {"z": [0.17, 0.3], "box": [0], "ray": [0]},
+                           z_src=0.4, z_src_shift=0.16)
+    assert np.array_equal(out["kappa_2"].values, ok.kappa_stack([frames[s]["kappa_2"].values for s in [(2, 1), (2, 2)]]))
+    # reweight=True, whole light-cone, source moved from z=0.4 to z=0.22: what the dead block intends.  Planes with
+    # z <= 0.22 are re-weighted (kappa_2 only, isw_rs never); z_next by the box rule of :207-210: (1,1) is the
+    # smallest ray number of box 1 -> first output of box 2; (1,2) -> next row; (1,3), last row -> itself;
+    # (2,1): no box 3 in the table -> next row; (2,2) at z = 0.25 > 0.22 keeps weight 1
     rr = MemRay({"lc": "/lc/"}, cosmology=FlatCosmology(), ray_info_df=_ray_table())
     out = rr.sum_snapshots(None, ["kappa_2", "isw_rs"], ["kappa_2"], {"z": [], "box": [0], "ray": [0]},
-                           z_src=0.4, z_src_shift=0.22)
-    zs = _ray_table()["redshift"].values
-    z_next = np.append(zs[1:], zs[-1])
-    ref = ok.kappa_stack([frames[s]["kappa_2"].values for s in _ray_table().index],
-                         3000.0 * zs, 3000.0 * z_next, 3000.0 * 0.4, 3000.0 * 0.22)
+                           z_src=0.4, z_src_shift=0.22, reweight=True)
+    order = list(_ray_table().index)
+    z_near = {(1, 1): 0.05, (1, 2): 0.10, (1, 3): 0.15, (2, 1): 0.20}
+    z_next = {(1, 1): 0.20, (1, 2): 0.15, (1, 3): 0.15, (2, 1): 0.25}
+    ref = None
+    for s_ in order:
+        q = frames[s_]["kappa_2"].values.astype(np.float64)
+        if s_ in z_near:
+            q = ok.translate_redshift(q, 3000.0 * z_near[s_], 3000.0 * z_next[s_], 3000.0 * 0.4, 3000.0 * 0.22)
+        ref = q.copy() if ref is None else ref + q
     assert np.array_equal(out["kappa_2"].values, ref)
-    assert np.array_equal(out["isw_rs"].values, ok.kappa_stack([frames[s]["isw_rs"].values for s in _ray_table().index]))
+    assert np.array_equal(out["isw_rs"].values, ok.kappa_stack([frames[s_]["isw_rs"].values for s_ in order]))
 
 
 def test_simulation_collection_sum_npy_planes(tmp_path):

@@ -193,3 +193,31 @@ def test_add_galaxy_shape_noise(lens, dev):
     gsn = ok.galaxy_shape_noise(64, 34077)
     got = lens.add(dev.as_device(kap), dev.as_device(gsn)).cpu().numpy()
     assert np.array_equal(got, kap + gsn)
+
+
+@pytest.mark.parametrize("world,nplanes,npix", [(2, 9, 512), (4, 64, 4096)])
+def test_sharded_stack_ranks_share_one_gpu(hip, tmp_path, world, nplanes, npix):
+    """Config D rehearsal: `world` processes on cuda:0 over gloo, plane p on rank p mod P, HipStackOps + the
+    all-to-all chunk exchange of kappa_shard, against the single-GPU sequential stack (64 planes x 4096^2 fp64
+    at the stated size).  Re-association only: <= P ulp of the sum of |planes|."""
+    import socket
+    import subprocess
+    import sys
+    import torch
+    from astrild_amd import lensing
+    torch.cuda.set_device(0)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "stack.npy")
+    worker = os.path.join(os.path.dirname(__file__), "kappa_gpu_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(nplanes), str(npix), out])
+             for r in range(world)]
+    assert [p.wait(timeout=600) for p in procs] == [0] * world
+    got = np.load(out).reshape(npix, npix)
+    planes = lensing.synth_kappa_planes(nplanes, npix)
+    wnum, wden = lensing.synth_plane_weights(nplanes)
+    seq = lensing.kappa_stack(planes, wnum, wden).cpu().numpy()
+    bound = sum(abs(float(wnum[p] / wden[p])) * float(planes[p].abs().max()) for p in range(nplanes))
+    npt.assert_allclose(got, seq, rtol=0, atol=world * 2.0 ** -52 * bound)
+    assert np.abs(got - seq).max() <= 1e-15 * np.abs(seq).max() * 4
