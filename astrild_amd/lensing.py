@@ -171,6 +171,58 @@ def histogram(t, nbins, range=None, density=False):
     return counts, edges
 
 
+def order_statistics(t, ks):
+    """Exact k-th smallest elements (0-based) of a device tensor - radix select on the GPU (ast_order_statistics)."""
+    ks = [int(k) for k in ks]
+    karr = (ct.c_size_t * len(ks))(*ks)
+    out = (ct.c_double * len(ks))()
+    scratch = torch.empty(2048, dtype=torch.int64, device=t.device)
+    check(_lib.lib().ast_order_statistics(ptr(t), real_code(t), t.numel(), karr, len(ks), out, ptr(scratch), stream()),
+          "ast_order_statistics")
+    return [float(v) for v in out]
+
+
+def percentile(t, qs):
+    """np.percentile(t, q) (default "linear" method) for each q, from exact order statistics:
+    numpy's virtual index n*q + (1 - q) - 1, gamma = its fractional part and numpy's two-sided lerp."""
+    n = t.numel()
+    res = []
+    for q in qs:
+        qf = np.true_divide(q, 100)
+        vi = n * qf + (1 + qf * (1 - 1 - 1)) - 1
+        prev = int(np.floor(vi))
+        gamma = vi - prev
+        prev = min(max(prev, 0), n - 1)
+        a, b = order_statistics(t, [prev, min(prev + 1, n - 1)])
+        diff = b - a
+        v = a + diff * gamma
+        if gamma >= 0.5:
+            v = b - diff * (1 - gamma)
+        res.append(float(v))
+    return res
+
+
+def peak_find(t, lo=-np.inf, hi=np.inf):
+    """Heights and flat pixel indices of the strict 8-neighbour local maxima of the interior of a square map with
+    lo <= height < hi, in row-major scan order (lenstools ConvergenceMap.locatePeaks; numpy arrays)."""
+    assert t.dim() == 2 and t.shape[0] == t.shape[1] and t.is_contiguous()
+    npix = t.shape[0]
+    cap = max(1024, t.numel() // 8)
+    while True:
+        values = torch.empty(cap, dtype=t.dtype, device=t.device)
+        index = torch.empty(cap, dtype=torch.int64, device=t.device)
+        count = torch.zeros(1, dtype=torch.int64, device=t.device)
+        check(_lib.lib().ast_peak_find(ptr(t), real_code(t), npix, float(lo), float(hi), cap, ptr(values), ptr(index),
+                                       ptr(count), stream()), "ast_peak_find")
+        n = int(count.item())
+        if n <= cap:
+            break
+        cap = n                                   # a strict maximum excludes its neighbours: n <= numel / 4 in any case
+    values, index = values[:n].cpu().numpy(), index[:n].cpu().numpy()
+    order = np.argsort(index, kind="stable")
+    return values[order], index[order]
+
+
 def add(a, b, out=None):
     out = torch.empty_like(a) if out is None else out
     check(_lib.lib().ast_add(ptr(a), ptr(b), ptr(out), real_code(a), a.numel(), stream()), "ast_add")
@@ -240,43 +292,80 @@ def synth_plane_weights(nplanes):
     return translate_redshift_weights(mid - half, mid + half, 1100.0, 1000.0)
 
 
-def bench_kappa_pipeline(nplanes=64, npix=4096, steps=3, warmup=1, theta_deg=20.0, sigma_arcmin=1.0):
+def bench_kappa_pipeline(nplanes=64, npix=4096, steps=3, warmup=1, theta_deg=20.0, sigma_arcmin=1.0, group=None):
     """kappa-maps/s at npix^2 for one full map: stack nplanes planes (weighted) ->
-    / c^2 -> Gaussian FFT smoothing -> kappa -> (alpha1, alpha2) -> 100-bin PDF."""
+    / c^2 -> Gaussian FFT smoothing -> kappa -> (alpha1, alpha2) -> 100-bin PDF.
+    With a process group of P > 1 ranks the planes are sharded (plane p on rank p mod P,
+    kappa_shard.kappa_stack_sharded) and rank 0 runs the single-map stages; the time is the
+    slowest rank's, between barriers."""
     from . import device as dev
-    planes = synth_kappa_planes(nplanes, npix)
+    world, rank = 1, 0
+    if group is not None:
+        import torch.distributed as dist
+        from . import kappa_shard
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    ids = list(range(rank, nplanes, world))
+    planes = synth_kappa_planes(nplanes, npix, ids=ids)
     wnum, wden = synth_plane_weights(nplanes)
+    wnum, wden = wnum[ids], wden[ids]
     bsz = np.deg2rad(theta_deg)
-    lp = lens_plan(npix, bsz)
-    sp = smooth_plan(npix)
     sigma_px = sigma_arcmin / 60.0 * npix / theta_deg
-    out = torch.empty_like(planes[0])
+    lp = sp = None
+    if rank == 0:
+        lp = lens_plan(npix, bsz)
+        sp = smooth_plan(npix)
+    out = torch.empty((npix, npix), dtype=torch.float64, device="cuda")
 
     def step():
-        kappa_stack(planes, wnum, wden, out=out)
+        if world > 1:
+            res = kappa_shard.kappa_stack_sharded(planes, wnum, wden, group=group, root=0)
+            if rank != 0:
+                return None
+            out.view(-1).copy_(res)
+        else:
+            kappa_stack(planes, wnum, wden, out=out)
         convert_code_to_phy_units("kappa_2", out)
         sp.gaussian(out, sigma_px, "gaussianFFT")
         a1, a2 = lp.alphas(out)
         return histogram(out, 100, density=True), a1, a2
 
+    def barrier():
+        if world > 1:
+            dist.barrier(group)
+        torch.cuda.synchronize()
+
     for _ in range(warmup):
         step()
-    torch.cuda.synchronize()
+    barrier()
     dev.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    torch.cuda.synchronize()
+    barrier()
     dt = (time.perf_counter() - t0) / steps
     prof = dev.profile_report()
     dev.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
+        dt = float(tmax.item())
     stack_ms = prof.get("kappa_stack", (0, 0.0))[1] / steps
-    stack_bytes = (nplanes + 1) * npix * npix * 8
-    return {
+    nloc = len(ids)
+    stack_bytes = (nloc + 1) * npix * npix * 8 + (0 if world == 1 else 2 * npix * npix * 8)     # + chunk sums
+    # SURVEY.md §8(d) algorithmic bytes of the whole per-map pipeline: stack (P + 1) maps, FFT smoothing 8 map
+    # passes, kappa -> alpha 12 passes over the padded (2 npix)^2 array + pad/crop
+    px = npix * npix * 8
+    pipeline_bytes = (nplanes + 1) * px + 8 * px + (12 * 4 * px + 6 * px)
+    res = {
         "metric": f"kappa-maps/s at {npix}^2 ({nplanes}-plane weighted stack + smoothing + kappa->alpha + PDF, fp64)",
-        "value": 1.0 / dt, "unit": "maps/s", "ms_per_map": dt * 1e3,
+        "value": 1.0 / dt, "unit": "maps/s", "ms_per_map": dt * 1e3, "n_gpus": world,
+        "planes_per_rank": nloc,
         "stack": {"ms": round(stack_ms, 4), "alg_GB": round(stack_bytes / 1e9, 3),
                   "GBps": round(stack_bytes / stack_ms / 1e6, 1) if stack_ms else None,
                   "frac": round(stack_bytes / stack_ms / 1e6 / 8000.0, 4) if stack_ms else None},
+        "roofline": {"bound": "hbm", "scope": "whole per-map pipeline, all GPUs", "alg_GB": round(pipeline_bytes / 1e9, 3),
+                     "achieved": round(pipeline_bytes / dt / 1e9, 1), "peak": 8000.0 * world, "unit": "GB/s",
+                     "frac": round(pipeline_bytes / dt / 1e9 / (8000.0 * world), 4)},
         "kernels_ms": {k: round(v[1] / steps, 4) for k, v in prof.items()},
     }
+    return res

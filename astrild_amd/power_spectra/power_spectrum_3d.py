@@ -50,64 +50,52 @@ class PowerSpectrum3D:
         dir_out: Optional[str] = None,
         save: bool = True,
     ) -> Union[None, dict]:
-        """Power spectrum of particle quantities (power_spectrum_3d.py:33-81)."""
-        if snap_nrs:
-            if not set(snap_nrs) < set(self.sim.dir_nrs):
-                raise PowerSpectrum3DWarning(
-                    f"Some of the snapshots {snap_nrs} do not exist in:\n{self.sim.dir_nrs}"
-                )
-            _file_paths1 = self.sim.get_file_paths(file_dsc[0], file_dsc[0]["path"], "max")
-            if len(file_dsc) > 1:
-                _file_paths2 = self.sim.get_file_paths(file_dsc[1], file_dsc[1]["path"], "max")
-        else:
-            _file_path = file_dsc[0].pop("path")
-            _file_dsc = file_dsc[0]
-            snap_nrs = self.sim.get_file_nrs(_file_dsc, _file_path, "max")
-            _file_paths1 = self.sim.get_file_paths(_file_dsc, _file_path, "max")
-            if len(file_dsc) > 1:
-                _file_path = file_dsc[1].pop("path")
-                _file_dsc = file_dsc[1]
-                _file_paths2 = self.sim.get_file_paths(_file_dsc, _file_path, "max")
-
-        snap_nrs = np.sort(snap_nrs)
-        if len(file_dsc) > 1:
-            pk = self._cross_power_spectra(quantities, snap_nrs, _file_paths1, _file_paths2)
-        else:
-            pk = self._auto_power_spectra(quantities, snap_nrs, _file_paths1)
-
+        """Power spectrum of particle quantities, same call as power_spectrum_3d.py:33-81: one file
+        description -> auto spectra, two -> cross spectra of the paired files; one spectrum per snapshot.
+        Returns {"k": {snap_%d: k}, "P": {snap_%d: P}} when ``save`` is False, else writes pk_<quantities>.h5."""
+        jobs = self._jobs(file_dsc, snap_nrs)
+        pk = self._spectra(quantities, jobs, cross=len(file_dsc) > 1)
         if save:
             self._save_results(quantities, pk)
-        else:
-            return pk
-
-    def _auto_power_spectra(self, quantity, snap_nrs, _file_paths) -> dict:
-        pk = {"k": {}, "P": {}}
-        for snap_nr, file_path in zip(snap_nrs, _file_paths):
-            value_map = self._read_data(file_path, quantity)
-            if len(value_map.shape) != 3:
-                raise PowerSpectrum3DWarning(f"{len(value_map.shape)}D is not supported :-(")
-            k, Pk = self._power_spectrum_3d(value_map)
-            pk["k"]["snap_%d" % snap_nr] = k
-            pk["P"]["snap_%d" % snap_nr] = Pk
-        if len(_file_paths) > 1:
-            _columns = list(pk["k"].keys())
-            assert np.sum(pk["k"][_columns[0]]) == np.sum(pk["k"][_columns[1]])
+            return None
         return pk
+
+    def _jobs(self, file_dsc, snap_nrs):
+        """[(snap_nr, (path,) or (path1, path2))] sorted by snapshot: the reference's file resolution
+        (:48-71; an explicit snapshot list must be a subset of the simulation's directories, without one
+        the file numbers of the first description are used and "path" is popped from the descriptions)."""
+        explicit = bool(snap_nrs)
+        if explicit and not set(snap_nrs) < set(self.sim.dir_nrs):
+            raise PowerSpectrum3DWarning(
+                f"Some of the snapshots {snap_nrs} do not exist in:\n{self.sim.dir_nrs}")
+        columns = []
+        for i, dsc in enumerate(file_dsc[:2]):
+            path = dsc["path"] if explicit else dsc.pop("path")
+            if i == 0 and not explicit:
+                snap_nrs = self.sim.get_file_nrs(dsc, path, "max")
+            columns.append(self.sim.get_file_paths(dsc, path, "max"))
+        return list(zip(np.sort(snap_nrs), zip(*columns)))
+
+    def _spectra(self, quantity, jobs, cross) -> dict:
+        """One spectrum per job.  Auto: the ``quantity`` column of the file; cross: both files as they are
+        (the reference passes quantity=None there, :120-121)."""
+        pk = {"k": {}, "P": {}}
+        for snap_nr, paths in jobs:
+            maps = [self._read_data(p, None if cross else quantity) for p in paths]
+            if maps[0].dim() != 3:
+                raise PowerSpectrum3DWarning(f"{maps[0].dim()}D is not supported :-(")
+            pk["k"]["snap_%d" % snap_nr], pk["P"]["snap_%d" % snap_nr] = self._power_spectrum_3d(*maps)
+        ks = list(pk["k"].values())
+        if len(ks) > 1:                     # the reference's check that snapshots share their wavenumbers
+            assert np.sum(ks[0]) == np.sum(ks[1])
+        return pk
+
+    # the reference's two entry points, kept for callers that use them directly
+    def _auto_power_spectra(self, quantity, snap_nrs, _file_paths) -> dict:
+        return self._spectra(quantity, list(zip(snap_nrs, ((p,) for p in _file_paths))), cross=False)
 
     def _cross_power_spectra(self, quantity, snap_nrs, _file_paths1, _file_paths2) -> dict:
-        pk = {"k": {}, "P": {}}
-        for snap_nr, file_path1, file_path2 in zip(snap_nrs, _file_paths1, _file_paths2):
-            value_map1 = self._read_data(file_path1, None)
-            value_map2 = self._read_data(file_path2, None)
-            if len(value_map1.shape) != 3:
-                raise PowerSpectrum3DWarning(f"{len(value_map1.shape)}D is not supported :-(")
-            k, Pk = self._power_spectrum_3d(value_map1, value_map2)
-            pk["k"]["snap_%d" % snap_nr] = k
-            pk["P"]["snap_%d" % snap_nr] = Pk
-        if len(_file_paths1) > 1:
-            _columns = list(pk["k"].keys())
-            assert np.sum(pk["k"][_columns[0]]) == np.sum(pk["k"][_columns[1]])
-        return pk
+        return self._spectra(quantity, list(zip(snap_nrs, zip(_file_paths1, _file_paths2))), cross=True)
 
     def _read_data(self, file_in: str, quantity=None):
         """NGP scatter-assign of a DataFrame column, or a pre-gridded .npy

@@ -3,8 +3,8 @@ unit conversion + reshape, PDF, filters, galaxy shape noise, kappa -> deflection
 crop / division / merge.  ``self.data`` holds numpy arrays like the reference;
 the arithmetic runs on the GPU through libastrild_hip.so.
 
-Not carried over (out of scope): wl_peak_counts (lenstools), create_cmb
-(broken in the reference, sky_array.py:735-739), resize (skimage)."""
+Not carried over (out of scope): create_cmb (broken in the reference,
+sky_array.py:735-739), resize (skimage)."""
 import copy
 from typing import Dict, List, Optional, Tuple, Union
 
@@ -108,6 +108,29 @@ class SkyArray:
         t = as_device(np.ascontiguousarray(self.data[of], dtype=np.float64))
         _pdf["values"], _pdf["bins"] = lensing.histogram(t, nbins, density=True)
         return _pdf
+
+    def wl_peak_counts(self, nbins: int, field_conversion: str, of: str = "orig",
+                       limits: Optional[tuple] = None) -> pd.DataFrame:
+        """Signal peak counts (sky_array.py:435-472): heights of the 8-neighbour local maxima between the map's
+        5th and 95th percentile (or ``limits``), histogrammed into ``nbins`` bins; DataFrame(kappa = bin centres,
+        counts).  The 3 x 3 stencil over the map and the percentile selection run on the GPU; lenstools'
+        ``locatePeaks`` semantics: interior pixels, strictly larger than all 8 neighbours, thresholds[0] <= height
+        < thresholds[-1].  ("normalize" subtracts the mean of the map itself; the reference reads a non-existent
+        ``self.skymap`` there.)"""
+        data = np.ascontiguousarray(self.data[of], dtype=np.float64)
+        t = as_device(data)
+        if limits is None:
+            lower_bound, upper_bound = lensing.percentile(t, [5, 95])
+        else:
+            lower_bound, upper_bound = min(limits), max(limits)
+        map_bins = np.arange(lower_bound, upper_bound, (upper_bound - lower_bound) / nbins)
+        heights, _ = lensing.peak_find(t)
+        if field_conversion == "normalize":
+            heights = heights - np.mean(data)          # the peak heights of (map - mean): same subtraction, same operands
+        _kappa = heights[(heights >= map_bins[0]) & (heights < map_bins[-1])]
+        _hist, _kappa = np.histogram(_kappa, bins=nbins, density=False)
+        _kappa = (_kappa[1:] + _kappa[:-1]) / 2
+        return pd.DataFrame(data={"kappa": _kappa, "counts": _hist})
 
     def crop(self, xlimit, ylimit, of: Optional[str] = None, img: Optional[np.ndarray] = None,
              rtn: bool = False, orig_data: str = None) -> Union[np.ndarray, None]:

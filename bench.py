@@ -119,10 +119,12 @@ def bispectrum_leg(dev, n=512, width=8):
             "ntri_total": int(np.sum(res["ntri"])), "kernels_ms": {k: round(v[1], 3) for k, v in prof.items()}}
 
 
-def kappa_leg(dev, steps, warmup):
-    """64 planes x 4096^2 fp64 -> stack -> Gaussian FFT smoothing -> kappa->alpha (config D)."""
+def kappa_leg(dev, steps, warmup, group=None):
+    """64 planes x 4096^2 fp64 -> stack -> Gaussian FFT smoothing -> kappa->alpha (config D);
+    with a process group the planes are sharded over its ranks."""
     from astrild_amd import lensing
-    return lensing.bench_kappa_pipeline(nplanes=64, npix=4096, steps=max(2, min(steps, 5)), warmup=min(warmup, 2))
+    return lensing.bench_kappa_pipeline(nplanes=64, npix=4096, steps=max(2, min(steps, 5)), warmup=min(warmup, 2),
+                                        group=group)
 
 
 def main():
@@ -215,6 +217,13 @@ def main():
             torch.cuda.empty_cache()
         if args.kappa:
             out["kappa"] = kappa_leg(dev, args.steps, args.warmup)
+    if use_slab and world > 1 and args.kappa:
+        # config D on N GPUs: lens planes sharded over the ranks (every rank takes part)
+        del leg
+        torch.cuda.empty_cache()
+        kl = kappa_leg(dev, args.steps, args.warmup, group=dist.group.WORLD)
+        if rank == 0:
+            out["kappa"] = kl
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

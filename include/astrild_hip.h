@@ -330,6 +330,20 @@ int ast_smooth_plan_destroy(ast_smooth_plan* plan);
 int ast_gaussian_smooth(ast_smooth_plan* plan, double* img_d, double sigma_px, int mode,
                         void* stream);
 
+/* Local maxima of an npix x npix map (SkyArray.wl_peak_counts, rays/skys/sky_array.py:435-472 ->
+ * lenstools ConvergenceMap.locatePeaks): interior pixels strictly larger than their 8 neighbours with a
+ * value in [lo, hi).  Heights go to values_d (dtype), flat row-major pixel indices to index_d, at most
+ * `cap` of each; *count_d (device uint64) receives the number FOUND (may exceed cap).  The order in the
+ * output arrays is not defined (sort by index for lenstools' scan order). */
+int ast_peak_find(const void* img_d, int dtype, int npix, double lo, double hi, size_t cap, void* values_d,
+                  long long* index_d, unsigned long long* count_d, void* stream);
+
+/* Exact order statistics: out_host[j] = the ks_host[j]-th smallest element (0-based) of buf_d - what
+ * np.percentile interpolates between (sky_array.py:452-457).  Radix select on order-preserving keys, six
+ * passes over the buffer per k; SYNCHRONOUS (host arrays in and out).  scratch_d: 2048 uint64 on the device. */
+int ast_order_statistics(const void* buf_d, int dtype, size_t count, const size_t* ks_host, int nk,
+                         double* out_host, unsigned long long* scratch_d, void* stream);
+
 /* Sum of a buffer in double, fixed summation order (bit-reproducible): out_d[0]; out_d must hold
  * 1 + AST_SUM_PARTS doubles (the rest is scratch). */
 #define AST_SUM_PARTS 1024

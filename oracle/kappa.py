@@ -98,6 +98,38 @@ def pdf(img, nbins):
     return np.histogram(img, bins=nbins, density=True)
 
 
+def locate_peaks(img, thresholds):
+    """lenstools ``ConvergenceMap.locatePeaks(thresholds)`` as called at rays/skys/sky_array.py:465-466
+    (lenstools is un-vendored and unpinned; its peak finder restated): interior pixels strictly larger than all
+    8 neighbours, height in [thresholds[0], thresholds[-1]); heights and (y, x) in row-major scan order."""
+    a = np.asarray(img, dtype=np.float64)
+    c = a[1:-1, 1:-1]
+    peak = np.ones(c.shape, dtype=bool)
+    n0, n1 = a.shape
+    for dy in (0, 1, 2):
+        for dx in (0, 1, 2):
+            if dy == 1 and dx == 1:
+                continue
+            peak &= c > a[dy:n0 - 2 + dy, dx:n1 - 2 + dx]
+    peak &= (c >= thresholds[0]) & (c < thresholds[-1])
+    ys, xs = np.nonzero(peak)
+    return c[ys, xs], np.stack([ys + 1, xs + 1], axis=1)
+
+
+def wl_peak_counts(img, nbins, field_conversion="", limits=None):
+    """rays/skys/sky_array.py:435-472 (the mean of the map itself where the reference reads ``self.skymap``)."""
+    img = np.asarray(img, dtype=np.float64)
+    _map = img - np.mean(img) if field_conversion == "normalize" else img
+    if limits is None:
+        lower_bound, upper_bound = np.percentile(img, 5), np.percentile(img, 95)
+    else:
+        lower_bound, upper_bound = min(limits), max(limits)
+    map_bins = np.arange(lower_bound, upper_bound, (upper_bound - lower_bound) / nbins)
+    _kappa, _ = locate_peaks(_map, map_bins)
+    _hist, _kappa = np.histogram(_kappa, bins=nbins, density=False)
+    return (_kappa[1:] + _kappa[:-1]) / 2, _hist
+
+
 # ----------------------------------------------------- a-9 kappa -> alpha, phi
 def _iso_kernel(ncc, dcell, which):
     """kernel_alphas_iso / kernel_phi_iso, rays/skys/lib_so_cgls/lensing_funcs.c:45-83,117-148."""

@@ -221,3 +221,28 @@ def test_sharded_stack_ranks_share_one_gpu(hip, tmp_path, world, nplanes, npix):
     bound = sum(abs(float(wnum[p] / wden[p])) * float(planes[p].abs().max()) for p in range(nplanes))
     npt.assert_allclose(got, seq, rtol=0, atol=world * 2.0 ** -52 * bound)
     assert np.abs(got - seq).max() <= 1e-15 * np.abs(seq).max() * 4
+
+
+@pytest.mark.parametrize("npix,conv,limits", [(64, "", None), (257, "normalize", None), (512, "", (-0.5, 1.5))])
+def test_wl_peak_counts_bit_exact(lens, dev, npix, conv, limits):
+    """SkyArray.wl_peak_counts: peak set, percentile bounds and histogram counts identical to the oracle."""
+    import torch
+    from astrild_amd.rays import SkyMap
+    rng = np.random.default_rng(npix)
+    img = ok.gaussian_smooth(rng.standard_normal((npix, npix)), 10.0, 2.0, kind="gaussianFFT")
+    img[5, 7] = img[5, 8] = img.max() + 1.0                       # a plateau: not a peak
+    t = dev.as_device(img)
+    for q in (5, 95, 50, 0, 100, 33.3):
+        assert lens.percentile(t, [q])[0] == np.percentile(img, q)
+    ks = [0, 1, npix * npix // 3, npix * npix - 1]
+    assert lens.order_statistics(t, ks) == np.sort(img.ravel())[ks].tolist()
+    assert lens.order_statistics(dev.as_device(img.astype(np.float32)), ks) == \\
+        np.sort(img.astype(np.float32).ravel())[ks].astype(np.float64).tolist()
+    vals, idx = lens.peak_find(t)
+    rv, rp = ok.locate_peaks(img, np.array([-np.inf, np.inf]))
+    assert np.array_equal(vals, rv) and np.array_equal(idx, rp[:, 0] * npix + rp[:, 1])
+    sky = SkyMap.from_array(img, npix, 10.0, "kappa_2", "/tmp/")
+    df = sky.wl_peak_counts(12, conv, limits=limits)
+    centres, counts = ok.wl_peak_counts(img, 12, conv, limits)
+    assert np.array_equal(df["counts"].values, counts)            # integer counts: exact
+    assert np.array_equal(df["kappa"].values, centres)

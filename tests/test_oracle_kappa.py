@@ -129,3 +129,25 @@ def test_dgd3_window_matches_reference_test(dt_map):
         x_slice, y_slice = f[:, len(f) // 2], f[len(f) // 2, :]
         assert x_slice.max() == case["x_slice_max"]
         npt.assert_almost_equal(y_slice.max() * 1e7, case["y_slice_max_times_1e7"], decimal=case["decimal"])
+
+
+def test_locate_peaks_hand_made_map():
+    """Strict 8-neighbour maxima of the interior only; plateaus and border pixels are not peaks."""
+    a = np.zeros((6, 6))
+    a[2, 2] = 1.0                     # isolated peak
+    a[4, 3] = a[4, 4] = 0.7           # plateau: neither is strictly larger than the other
+    a[0, 5] = 9.0                     # on the border: never a peak
+    a[1, 4] = 0.5                     # interior, but its neighbour (0, 5) is larger
+    vals, pos = ok.locate_peaks(a, np.array([-1.0, 0.0, 2.0]))
+    assert vals.tolist() == [1.0] and pos.tolist() == [[2, 2]]
+    vals, _ = ok.locate_peaks(a, np.array([-1.0, 1.0]))       # upper threshold is exclusive
+    assert vals.size == 0
+    rng = np.random.default_rng(3)
+    img = rng.standard_normal((40, 40))
+    vals, pos = ok.locate_peaks(img, np.array([-10.0, 10.0]))
+    for v, (y, x) in zip(vals, pos):
+        nb = img[y - 1:y + 2, x - 1:x + 2].copy()
+        nb[1, 1] = -np.inf
+        assert v == img[y, x] and v > nb.max()
+    centres, counts = ok.wl_peak_counts(img, 8, "normalize")
+    assert counts.sum() <= vals.size and len(centres) == 8 and np.all(np.diff(centres) > 0)
