@@ -34,9 +34,9 @@ SIGNATURES = {
     "ast_divide": (_i, [_vp, _i, _sz, _d, _vp]),
     "ast_synth_lattice_particles": (_i, [_vp, _i, _sz, _sz, _i, _d, _d, _u64, _u64, _vp]),
     "ast_ngp_assign": (_i, [_vp, _vp, _vp, _vp, _i, _sz, _i, _vp, _vp, _vp, _vp]),
-    "ast_paint": (_i, [_i, _i, _vp, _vp, _sz, _i, _d, _d, _i, _i, _vp, _vp, _vp]),
+    "ast_paint": (_i, [_i, _i, _vp, _vp, _sz, _i, _d, _d, _i, _i, _vp, _vp, _d, _vp]),
     "ast_paint_tiled_workspace_bytes": (_sz, [_i, _i, _sz, _i, _i, _i]),
-    "ast_paint_tiled": (_i, [_i, _i, _vp, _vp, _sz, _i, _d, _d, _i, _i, _vp, _vp, _sz, _vp, _i, _d, _d, _vp]),
+    "ast_paint_tiled": (_i, [_i, _i, _vp, _vp, _sz, _i, _d, _d, _i, _i, _vp, _vp, _sz, _vp, _i, _d, _d, _d, _vp]),
     "ast_paint_tiled_list_stats": (_i, [_vp, _i, _i, _sz, _i, _i, _i, _vp, _vp]),
     "ast_accumulate": (_i, [_vp, _vp, _i, _sz, _vp]),
     "ast_fft_plan_create": (_i, [ct.POINTER(_vp), _i, _i, _i, ct.POINTER(_sz), _sz, _d, _i]),
@@ -56,6 +56,7 @@ SIGNATURES = {
     "ast_fft_tile_power_3d_halo": (_i, [_vp, _vp, _i, _vp, _sz, _i, _sz, _d, _d, _vp, _vp]),
     "ast_paint_tiled_halo": (_i, [_vp, _i, _i, _sz, _i, _i, _i, ct.POINTER(ct.c_void_p)]),
     "ast_power_bin_1d": (_i, [_vp, _vp, _i, _i, _d, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ast_interlace_compensate": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ast_shell_filter": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ast_triple_product_sum": (_i, [_vp, _vp, _vp, _i, _sz, _vp, _vp]),
     "ast_slab_pack": (_i, [_vp, _vp, _i, _sz, _sz, _sz, _i, _vp]),

@@ -19,16 +19,16 @@ using ast::Window;
 template <typename T, int W>
 __global__ void __launch_bounds__(256)
 paint_direct_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t np, int n,
-                    double inv_dx, double scale, int x_start, int nx_alloc, T* __restrict__ grid,
+                    double inv_dx, double shift, double scale, int x_start, int nx_alloc, T* __restrict__ grid,
                     unsigned long long* dropped) {
     constexpr int LO = Window<W>::LO;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     unsigned long long ndrop = 0;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += stride) {
         double fx, fy, fz;
-        const int bx = ast::locate<W>((double)pos[3 * p + 0] * inv_dx, n, fx);
-        const int by = ast::locate<W>((double)pos[3 * p + 1] * inv_dx, n, fy);
-        const int bz = ast::locate<W>((double)pos[3 * p + 2] * inv_dx, n, fz);
+        const int bx = ast::locate<W>(__fma_rn((double)pos[3 * p + 0], inv_dx, shift), n, fx);
+        const int by = ast::locate<W>(__fma_rn((double)pos[3 * p + 1], inv_dx, shift), n, fy);
+        const int bz = ast::locate<W>(__fma_rn((double)pos[3 * p + 2], inv_dx, shift), n, fz);
         const T m = (T)((mass ? (double)mass[p] : 1.0) * scale);
         T wx[W], wy[W], wz[W];
         Window<W>::weights(fx, wx);
@@ -100,19 +100,19 @@ __global__ void ngp_write_kernel(const T* x, const T* y, const T* z, const T* v,
 template <typename T>
 int launch_paint(int window, const T* pos, const T* mass, size_t np, int n, double boxsize,
                  double scale, int x_start, int nx_alloc, T* grid, unsigned long long* dropped,
-                 hipStream_t s) {
+                 double shift_cells, hipStream_t s) {
     const double inv_dx = (double)n / boxsize;
     unsigned g = ast::stream_grid(np, 256);
     AST_PROF("paint_direct", s);
     switch (window) {
         case AST_WIN_NGP:
-            paint_direct_kernel<T, 1><<<g, 256, 0, s>>>(pos, mass, np, n, inv_dx, scale, x_start, nx_alloc, grid, dropped);
+            paint_direct_kernel<T, 1><<<g, 256, 0, s>>>(pos, mass, np, n, inv_dx, shift_cells, scale, x_start, nx_alloc, grid, dropped);
             break;
         case AST_WIN_CIC:
-            paint_direct_kernel<T, 2><<<g, 256, 0, s>>>(pos, mass, np, n, inv_dx, scale, x_start, nx_alloc, grid, dropped);
+            paint_direct_kernel<T, 2><<<g, 256, 0, s>>>(pos, mass, np, n, inv_dx, shift_cells, scale, x_start, nx_alloc, grid, dropped);
             break;
         default:
-            paint_direct_kernel<T, 3><<<g, 256, 0, s>>>(pos, mass, np, n, inv_dx, scale, x_start, nx_alloc, grid, dropped);
+            paint_direct_kernel<T, 3><<<g, 256, 0, s>>>(pos, mass, np, n, inv_dx, shift_cells, scale, x_start, nx_alloc, grid, dropped);
             break;
     }
     AST_CHECK_LAUNCH();
@@ -123,7 +123,7 @@ int launch_paint(int window, const T* pos, const T* mass, size_t np, int n, doub
 
 extern "C" int ast_paint(int window, int dtype, const void* pos, const void* mass, size_t np, int nmesh,
                          double boxsize, double scale, int x_start, int nx_alloc, void* grid,
-                         unsigned long long* dropped, void* stream) {
+                         unsigned long long* dropped, double shift_cells, void* stream) {
     AST_CHECK_ARG(window == AST_WIN_NGP || window == AST_WIN_CIC || window == AST_WIN_TSC);
     AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
     AST_CHECK_ARG(nmesh > 0 && boxsize > 0.0);
@@ -134,9 +134,9 @@ extern "C" int ast_paint(int window, int dtype, const void* pos, const void* mas
     hipStream_t s = ast::as_stream(stream);
     if (dtype == AST_F32)
         return launch_paint<float>(window, (const float*)pos, (const float*)mass, np, nmesh, boxsize, scale,
-                                   x_start, nx_alloc, (float*)grid, dropped, s);
+                                   x_start, nx_alloc, (float*)grid, dropped, shift_cells, s);
     return launch_paint<double>(window, (const double*)pos, (const double*)mass, np, nmesh, boxsize, scale,
-                                x_start, nx_alloc, (double*)grid, dropped, s);
+                                x_start, nx_alloc, (double*)grid, dropped, shift_cells, s);
 }
 
 extern "C" int ast_ngp_assign(const void* x, const void* y, const void* z, const void* values, int dtype,

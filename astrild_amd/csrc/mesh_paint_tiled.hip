@@ -86,7 +86,11 @@ struct TileGeom {
     int n, x_start, nx_alloc;
     int ntx, nty, ntz;
     double inv_dx;
+    double shift;        // added to every coordinate in grid units (interlacing paints at +1/2 cell)
 };
+
+// position -> grid units: x * n/L + shift as ONE fma (for shift = 0 exactly the rounded product)
+template <typename T> __device__ inline double grid_coord(T x, const TileGeom& g) { return __fma_rn((double)x, g.inv_dx, g.shift); }
 
 // base cell (window centre for TSC, lower corner for CIC) -> tile id, or 0xffffffff when the
 // base plane is outside the buffer.  The common case is a position inside the box: cell =
@@ -96,7 +100,7 @@ struct TileGeom {
 // PLAINX: the buffer is the whole periodic grid (x_start = 0, nx_alloc = n).
 template <typename T, int W, bool PLAINX>
 __device__ inline uint32_t tile_of(T x, T y, T z, const TileGeom& g, uint32_t* __restrict__ col_flags) {
-    const double sx = (double)x * g.inv_dx, sy = (double)y * g.inv_dx, sz = (double)z * g.inv_dx;
+    const double sx = grid_coord(x, g), sy = grid_coord(y, g), sz = grid_coord(z, g);
     int cx = (int)floor(W == 2 ? sx : sx + 0.5);
     int cy = (int)floor(W == 2 ? sy : sy + 0.5);
     int cz = (int)floor(W == 2 ? sz : sz + 0.5);
@@ -576,9 +580,9 @@ overflow_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, c
          i += (unsigned long long)gridDim.x * blockDim.x) {
         const size_t p = ovf[i];
         double fx, fy, fz;
-        const int bx = ast::locate<W>((double)pos[3 * p + 0] * g.inv_dx, g.n, fx);
-        const int by = ast::locate<W>((double)pos[3 * p + 1] * g.inv_dx, g.n, fy);
-        const int bz = ast::locate<W>((double)pos[3 * p + 2] * g.inv_dx, g.n, fz);
+        const int bx = ast::locate<W>(grid_coord(pos[3 * p + 0], g), g.n, fx);
+        const int by = ast::locate<W>(grid_coord(pos[3 * p + 1], g), g.n, fy);
+        const int bz = ast::locate<W>(grid_coord(pos[3 * p + 2], g), g.n, fz);
         T wx[W], wy[W], wz[W];
         Window<W>::weights(fx, wx);
         Window<W>::weights(fy, wy);
@@ -697,11 +701,11 @@ tile_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileG
         for (int u = 0; u < U; ++u) {
             if (!on[u]) continue;
             double fx, fy, fz;
-            int bx = ast::locate<W>((double)px[u] * g.inv_dx, g.n, fx) - g.x_start;
+            int bx = ast::locate<W>(grid_coord(px[u], g), g.n, fx) - g.x_start;
             if (bx < 0) bx += g.n;
             const int lx = bx - ox;                               // 0..TX-1 by construction of the index
-            const int ly = ast::locate<W>((double)py[u] * g.inv_dx, g.n, fy) - oy;
-            const int lz = ast::locate<W>((double)pz[u] * g.inv_dx, g.n, fz) - oz;
+            const int ly = ast::locate<W>(grid_coord(py[u], g), g.n, fy) - oy;
+            const int lz = ast::locate<W>(grid_coord(pz[u], g), g.n, fz) - oz;
             T wx[W], wy[W], wz[W];
             Window<W>::weights(fx, wx);
             Window<W>::weights(fy, wy);
@@ -945,8 +949,8 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
             double fx, fy, fz;
             int lx, ly, lz;
             if (!CAREFUL) {
-                const double sx = (double)pc[3 * u + 0] * g.inv_dx, sy = (double)pc[3 * u + 1] * g.inv_dx,
-                             sz = (double)pc[3 * u + 2] * g.inv_dx;
+                const double sx = grid_coord(pc[3 * u + 0], g), sy = grid_coord(pc[3 * u + 1], g),
+                             sz = grid_coord(pc[3 * u + 2], g);
                 const double flx = floor(W == 2 ? sx : sx + 0.5), fly = floor(W == 2 ? sy : sy + 0.5),
                              flz = floor(W == 2 ? sz : sz + 0.5);
                 fx = sx - flx;
@@ -956,16 +960,16 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
                 ly = (int)fly - oy;
                 lz = (int)flz - oz;
             } else {
-                lx = ast::locate_rel<W>((double)pc[3 * u + 0] * g.inv_dx, g.n, orx, fx);
-                ly = ast::locate_rel<W>((double)pc[3 * u + 1] * g.inv_dx, g.n, oy, fy);
-                lz = ast::locate_rel<W>((double)pc[3 * u + 2] * g.inv_dx, g.n, oz, fz);
+                lx = ast::locate_rel<W>(grid_coord(pc[3 * u + 0], g), g.n, orx, fx);
+                ly = ast::locate_rel<W>(grid_coord(pc[3 * u + 1], g), g.n, oy, fy);
+                lz = ast::locate_rel<W>(grid_coord(pc[3 * u + 2], g), g.n, oz, fz);
                 if ((unsigned)lx >= ex || (unsigned)ly >= ey || (unsigned)lz >= ez) {
                     // more than a box length outside the box: the general reduction
-                    int bx = ast::locate<W>((double)pc[3 * u + 0] * g.inv_dx, g.n, fx) - g.x_start;
+                    int bx = ast::locate<W>(grid_coord(pc[3 * u + 0], g), g.n, fx) - g.x_start;
                     if (bx < 0) bx += g.n;
                     lx = bx - ox;
-                    ly = ast::locate<W>((double)pc[3 * u + 1] * g.inv_dx, g.n, fy) - oy;
-                    lz = ast::locate<W>((double)pc[3 * u + 2] * g.inv_dx, g.n, fz) - oz;
+                    ly = ast::locate<W>(grid_coord(pc[3 * u + 1], g), g.n, fy) - oy;
+                    lz = ast::locate<W>(grid_coord(pc[3 * u + 2], g), g.n, fz) - oz;
                     if ((unsigned)lx >= ex || (unsigned)ly >= ey || (unsigned)lz >= ez) continue;   // not in this tile: cannot happen
                 }
             }
@@ -1492,7 +1496,7 @@ extern "C" int ast_paint_tiled_list_stats(void* workspace, int window, int dtype
 extern "C" int ast_paint_tiled(int window, int dtype, const void* pos, const void* mass, size_t np, int nmesh,
                                double boxsize, double scale, int x_start, int nx_alloc, void* grid,
                                void* workspace, size_t workspace_bytes, unsigned long long* dropped,
-                               int flags, double mass_bound, double offset, void* stream) {
+                               int flags, double mass_bound, double offset, double shift_cells, void* stream) {
     AST_CHECK_ARG(window == AST_WIN_CIC || window == AST_WIN_TSC);
     AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
     AST_CHECK_ARG(nmesh > 0 && boxsize > 0.0);
@@ -1517,6 +1521,7 @@ extern "C" int ast_paint_tiled(int window, int dtype, const void* pos, const voi
     }
     g.x_start = x_start;
     g.inv_dx = (double)nmesh / boxsize;
+    g.shift = shift_cells;
     const size_t need = carve(nullptr, np, ntiles, (uint32_t)(g.ntx * g.nty), flags, dtype == AST_F32 ? 4 : 8,
                               record_bytes(window, g, dtype == AST_F32 ? 4 : 8, flags)).bytes;
     if (workspace_bytes < need) {

@@ -128,6 +128,62 @@ shell_filter_kernel(const C* __restrict__ in, C* __restrict__ out, int n, long l
     }
 }
 
+
+// f-1: interlacing + window compensation of a catalogue-painted mesh (nbodykit CatalogMesh with interlaced=True /
+// compensated=True, the parameters astrild writes at power_spectrum_3d.py:197-212; nbodykit is un-vendored, its
+// published formulas restated).  c1 is the spectrum of the plain paint, c2 of the paint shifted by half a cell
+// (ast_paint shift_cells = 0.5); w_i = 2 pi m_i / N is the circular frequency of axis i:
+//   interlaced:   c1 <- (c1 + c2 * exp(i (wx + wy + wz) / 2)) / 2        (Sefusatti et al. 2016: odd images cancel)
+//   compensated:  c1 <- c1 / prod_i W(w_i),
+//     interlaced:      W = sinc(w/2)^p                     (CompensateCIC p = 2, CompensateTSC p = 3)
+//     not interlaced:  W = sqrt(1 - 2/3 s) (CIC),  sqrt(1 - s + 2/15 s^2) (TSC),  s = sin^2(w/2)
+//                                                          (Compensate*Shotnoise: aliased shot noise, Jing 2005)
+// All factors in double for both dtypes.
+template <typename C>
+__global__ void __launch_bounds__(256)
+interlace_compensate_kernel(C* __restrict__ c1, const C* __restrict__ c2, int n, int window, int compensate,
+                            int i0_start, int i0_count, int i1_start, int i1_count) {
+    using R = typename cplx_traits<C>::real;
+    const int nz = n / 2 + 1;
+    const size_t total = (size_t)i0_count * i1_count * nz;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const double dw = 2.0 * M_PI / (double)n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int iz = (int)(i % nz);
+        const size_t row = i / nz;
+        const double w[3] = {dw * freq(i0_start + (int)(row / i1_count), n), dw * freq(i1_start + (int)(row % i1_count), n),
+                             dw * iz};
+        double re = (double)c1[i].x, im = (double)c1[i].y;
+        if (c2) {
+            double sn, cs;
+            sincos(0.5 * (w[0] + w[1] + w[2]), &sn, &cs);
+            const double re2 = (double)c2[i].x, im2 = (double)c2[i].y;
+            re = 0.5 * re + 0.5 * (re2 * cs - im2 * sn);
+            im = 0.5 * im + 0.5 * (re2 * sn + im2 * cs);
+        }
+        if (compensate) {
+            double f = 1.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double h = 0.5 * w[a], sh = sin(h);
+                if (c2) {
+                    const double sc = h == 0.0 ? 1.0 : sh / h;
+                    f *= window == AST_WIN_TSC ? sc * sc * sc : sc * sc;
+                } else {
+                    const double s2 = sh * sh;
+                    f *= window == AST_WIN_TSC ? sqrt(1.0 - s2 + 2.0 / 15.0 * s2 * s2) : sqrt(1.0 - 2.0 / 3.0 * s2);
+                }
+            }
+            re /= f;
+            im /= f;
+        }
+        C o;
+        o.x = (R)re;
+        o.y = (R)im;
+        c1[i] = o;
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 triple_sum_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c, size_t n, double* out) {
@@ -216,6 +272,29 @@ extern "C" int ast_shell_filter(const void* in, void* out, int dtype, int nmesh,
         shell_filter_kernel<float2><<<g, 256, 0, s>>>((const float2*)in, (float2*)out, nmesh, lo2, hi2, i0_start, i0_count, i1_start, i1_count);
     else
         shell_filter_kernel<double2><<<g, 256, 0, s>>>((const double2*)in, (double2*)out, nmesh, lo2, hi2, i0_start, i0_count, i1_start, i1_count);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+extern "C" int ast_interlace_compensate(void* c1, const void* c2, int dtype, int nmesh, int window, int compensate,
+                                        int i0_start, int i0_count, int i1_start, int i1_count, void* stream) {
+    AST_CHECK_ARG(c1 != nullptr && (c2 != nullptr || compensate));
+    AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
+    AST_CHECK_ARG(window == AST_WIN_CIC || window == AST_WIN_TSC);
+    AST_CHECK_ARG(nmesh >= 4 && nmesh % 2 == 0);
+    AST_CHECK_ARG(i0_start >= 0 && i0_count >= 0 && i0_start + i0_count <= nmesh);
+    AST_CHECK_ARG(i1_start >= 0 && i1_count >= 0 && i1_start + i1_count <= nmesh);
+    const size_t total = (size_t)i0_count * i1_count * (nmesh / 2 + 1);
+    if (total == 0) return AST_OK;
+    unsigned g = ast::stream_grid(total, 256);
+    hipStream_t s = ast::as_stream(stream);
+    AST_PROF("interlace_compensate", s);
+    if (dtype == AST_F32)
+        interlace_compensate_kernel<float2><<<g, 256, 0, s>>>((float2*)c1, (const float2*)c2, nmesh, window, compensate != 0,
+                                                             i0_start, i0_count, i1_start, i1_count);
+    else
+        interlace_compensate_kernel<double2><<<g, 256, 0, s>>>((double2*)c1, (const double2*)c2, nmesh, window, compensate != 0,
+                                                              i0_start, i0_count, i1_start, i1_count);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }

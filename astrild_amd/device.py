@@ -152,7 +152,7 @@ class PaintHalo:
 
 def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="auto",
           x_start=0, nx_alloc=None, check_dropped=True, accumulate=None, defer_fold=False, offset=0.0,
-          hint=None, stats=None):
+          hint=None, stats=None, shift=0.0):
     """pmesh ``ParticleMesh.paint(pos, mass=, resampler=)`` on the GPU.
 
     pos: (Np, 3) CUDA tensor (float32/float64); mass: (Np,) or None.
@@ -168,6 +168,7 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     i.e. the grid holds rho - mean (only the DC mode changes, which FFTPower discards).
     hint: "scattered" sizes the tiled overwrite paint's workspace for particles without spatial order in memory
     (AST_PAINT_SCATTERED).  stats: a dict that receives the list statistics of the tiled overwrite paint.
+    shift: added to every coordinate in grid units (0.5 paints the second mesh of an interlaced pair).
     """
     L = _lib.lib()
     n = int(nmesh)
@@ -216,7 +217,7 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pos.device)
             check(L.ast_paint_tiled(win, code, ptr(pos), ptr(mass), npart, n, float(boxsize), float(scale),
                                     int(x_start), nx, ptr(out), ptr(ws), ws_bytes, ptr(dropped), tflags,
-                                    mass_bound, float(offset), stream()), "ast_paint_tiled")
+                                    mass_bound, float(offset), float(shift), stream()), "ast_paint_tiled")
             st = None
             if compact and (stats is not None or (check_dropped and not tflags & 8)):
                 st = torch.empty(4, dtype=torch.int64, device=pos.device)
@@ -236,7 +237,7 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
             break
     else:
         check(L.ast_paint(win, code, ptr(pos), ptr(mass), npart, n, float(boxsize), float(scale),
-                          int(x_start), nx, ptr(out), ptr(dropped), stream()), "ast_paint")
+                          int(x_start), nx, ptr(out), ptr(dropped), float(shift), stream()), "ast_paint")
     if check_dropped:
         nd = int(dropped.item())
         if nd:
@@ -396,6 +397,55 @@ def fftpower_1d(field1, boxsize, field2=None, fused=True):
     s1 = r2c(field1)
     s2 = None if field2 is None else r2c(field2)
     return finish_power(*power_bin_1d(s1, s2, n, boxsize))
+
+
+# ------------------------------------------ catalogue meshes: interlacing + compensation
+def interlace_compensate(c1, c2, nmesh, window, compensated=True, i0=None, i1=None):
+    """In place on c1 (half spectrum of the plain paint): combine with c2 (spectrum of the paint shifted by half
+    a cell, or None) and divide by the mass-assignment window - nbodykit CatalogMesh, interlaced / compensated."""
+    n = int(nmesh)
+    i0 = (0, n) if i0 is None else tuple(i0)
+    i1 = (0, n) if i1 is None else tuple(i1)
+    assert c1.is_cuda and c1.is_contiguous() and c1.numel() == i0[1] * i1[1] * (n // 2 + 1)
+    assert c2 is None or (c2.dtype == c1.dtype and c2.numel() == c1.numel() and c2.is_contiguous())
+    if c2 is None and not compensated:
+        return c1
+    check(_lib.lib().ast_interlace_compensate(ptr(c1), ptr(c2), _CPLX[c1.dtype], n, _lib.WIN[window.lower()],
+                                              int(bool(compensated)), int(i0[0]), int(i0[1]), int(i1[0]), int(i1[1]),
+                                              stream()), "ast_interlace_compensate")
+    return c1
+
+
+def catalog_mesh_complex(pos, mass, nmesh, boxsize, window="tsc", interlaced=True, compensated=True):
+    """delta_k of a particle catalogue like nbodykit ``CatalogMesh(..., Nmesh, BoxSize, window=, interlaced=,
+    compensated=).compute(mode="complex")``: the painted field is normalised to 1 + delta (mean weight per cell 1),
+    transformed with pmesh's 1/Ng convention, interlaced with a second paint shifted by half a cell and divided
+    by the window.  Returns (half spectrum, shotnoise = L^3 sum w^2 / (sum w)^2)."""
+    n = int(nmesh)
+    wsum = total_mass(mass, pos.shape[0])
+    scale = float(n) ** 3 / wsum
+    c1 = r2c(paint(pos, mass, n, boxsize, window, scale=scale))
+    c2 = r2c(paint(pos, mass, n, boxsize, window, scale=scale, shift=0.5)) if interlaced else None
+    interlace_compensate(c1, c2, n, window, compensated)
+    if mass is None:
+        w2 = float(pos.shape[0])
+    else:
+        w2 = float(triple_product_sum(mass, mass, torch.ones_like(mass)).item())
+    return c1, float(boxsize) ** 3 * w2 / wsum ** 2
+
+
+def catalog_power_1d(pos1, mass1, nmesh, boxsize, window="tsc", interlaced=True, compensated=True, pos2=None, mass2=None):
+    """``FFTPower(CatalogMesh(cat1, ...), mode="1d", kmin=2 pi / L[, second=CatalogMesh(cat2, ...)])``: dict(k, power,
+    modes, shotnoise); the shot noise is reported, not subtracted (auto: L^3 sum w^2 / (sum w)^2; cross: 0)."""
+    n = int(nmesh)
+    c1, sn = catalog_mesh_complex(pos1, mass1, n, boxsize, window, interlaced, compensated)
+    c2 = None
+    if pos2 is not None:
+        c2, _ = catalog_mesh_complex(pos2, mass2, n, boxsize, window, interlaced, compensated)
+        sn = 0.0
+    res = finish_power(*power_bin_1d(c1, c2, n, boxsize))
+    res["shotnoise"] = sn
+    return res
 
 
 # ----------------------------------------------------------------- bispectrum

@@ -129,6 +129,18 @@ class PowerSpectrum3D:
         print("Pk wavenumber ------>", np.nanmin(k), np.nanmax(k))
         return k, Pk
 
+    def _power_spectrum_3d_catalog(self, pos1, mass1=None, pos2=None, mass2=None, window: str = "tsc",
+                                   interlaced: bool = True, compensated: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+        """The cross (or auto) spectrum of PARTICLE catalogues with the mesh parameters the reference writes in its
+        cross branch (power_spectrum_3d.py:197-212: ``compensated=True, interlaced=True, window='TSC'``).  There they
+        decorate an ``ArrayMesh`` and do nothing; for a catalogue source they mean: paint with the window, paint again
+        half a cell shifted, combine the two spectra and divide by the window.  Positions in box
+        units, ``(Np, 3)``; returns ``(k, P - shotnoise)`` like ``_power_spectrum_3d``."""
+        as_dev = lambda a: None if a is None else dev.as_device(np.ascontiguousarray(a), self.dtype)
+        r = dev.catalog_power_1d(as_dev(pos1), as_dev(mass1), int(self.sim.domain_level), self.sim.boxsize, window,
+                                 interlaced, compensated, pos2=as_dev(pos2), mass2=as_dev(mass2))
+        return np.array(r["k"]), np.array(r["power"] - r["shotnoise"])
+
     def _save_results(self, quantity: List[str], pk: dict) -> None:
         """DataFrame(index=k, columns=snap_%d) -> pk_<quantity>.h5 (power_spectrum_3d.py:228-249)."""
         _columns = list(pk["k"].keys())

@@ -109,11 +109,14 @@ int ast_ngp_assign(const void* x_d, const void* y_d, const void* z_d, const void
  *           nx_alloc = nmesh.  Slab-decomposed: the rank's owned planes plus
  *           its ghost planes.  Deposits falling outside the buffer are
  *           counted in *dropped_d (device uint64, may be NULL) and skipped.
+ *   shift_cells: added to every coordinate in GRID units, s = x * nmesh/boxsize + shift_cells (one fma;
+ *           0 = plain paint).  Interlacing (nbodykit CatalogMesh, interlaced=True) paints a second
+ *           mesh with shift_cells = 0.5, see ast_interlace_compensate.
  * Index/fraction arithmetic is float64 for both dtypes; the accumulation is
  * in `dtype` with hardware atomics (sum order is not reproducible). */
 int ast_paint(int window, int dtype, const void* pos_d, const void* mass_d, size_t np,
               int nmesh, double boxsize, double scale, int x_start, int nx_alloc,
-              void* grid_d, unsigned long long* dropped_d, void* stream);
+              void* grid_d, unsigned long long* dropped_d, double shift_cells, void* stream);
 
 /* Same result as ast_paint, for the CIC/TSC windows, through LDS-resident
  * grid tiles: particles are run-length grouped by the tile of their base
@@ -153,7 +156,7 @@ int ast_paint_tiled(int window, int dtype, const void* pos_d, const void* mass_d
                     int nmesh, double boxsize, double scale, int x_start, int nx_alloc,
                     void* grid_d, void* workspace_d, size_t workspace_bytes,
                     unsigned long long* dropped_d, int flags, double mass_bound, double offset,
-                    void* stream);
+                    double shift_cells, void* stream);
 /* Where a paint with AST_PAINT_OVERWRITE | AST_PAINT_DEFER_FOLD and these parameters left its halo
  * records inside workspace_d (for ast_fft_tile_power_3d_halo). */
 int ast_paint_tiled_halo(void* workspace_d, int window, int dtype, size_t np, int nmesh, int nx_alloc, int flags,
@@ -165,6 +168,18 @@ int ast_paint_tiled_halo(void* workspace_d, int window, int dtype, size_t np, in
  * AST_PAINT_SCATTERED or AST_PAINT_TWO_PASS. */
 int ast_paint_tiled_list_stats(void* workspace_d, int window, int dtype, size_t np, int nmesh, int nx_alloc, int flags,
                                unsigned long long* out_d, void* stream);
+
+/* Interlacing and window compensation of a catalogue-painted mesh in Fourier space - what nbodykit's
+ * CatalogMesh does for the parameters astrild writes at power_spectra/power_spectrum_3d.py:197-212
+ * (compensated=True, interlaced=True, window='TSC'; they are inert for the ArrayMesh inputs the reference
+ * passes, real for particle catalogues).  c1_d: half spectrum (block [i0, i1, nmesh/2+1], like
+ * ast_power_bin_1d) of the plain paint, updated in place; c2_d: spectrum of the paint with shift_cells = 0.5,
+ * or NULL (no interlacing):
+ *   c1 <- (c1 + c2 exp(i (wx+wy+wz)/2)) / 2,   w = 2 pi m / nmesh;
+ *   compensate != 0:  c1 <- c1 / prod_axes W(w):  sinc(w/2)^p (p = 2 CIC, 3 TSC) with interlacing,
+ *   sqrt(1 - 2/3 s) / sqrt(1 - s + 2/15 s^2), s = sin^2(w/2), without (nbodykit's Compensate*Shotnoise). */
+int ast_interlace_compensate(void* c1_d, const void* c2_d, int dtype, int nmesh, int window, int compensate,
+                             int i0_start, int i0_count, int i1_start, int i1_count, void* stream);
 
 /* dst[i] += src[i] — ghost-plane fold after a slab paint. */
 int ast_accumulate(void* dst_d, const void* src_d, int dtype, size_t count, void* stream);

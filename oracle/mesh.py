@@ -65,13 +65,15 @@ def window_1d(s, window):
     return i0.astype(np.int64), w
 
 
-def paint(pos, mass, nmesh, boxsize, window="cic", out=None):
+def paint(pos, mass, nmesh, boxsize, window="cic", out=None, shift=0.0):
     """Mass-weighted scatter-add of particles onto a periodic ``nmesh**3`` grid.
 
     pos: (Np, 3) in box units [0, boxsize) (any real value wraps);
     mass: (Np,) or None (unit mass).  Returns the float64 grid (C order,
     axis 0 slowest), NOT divided by the cell volume — the caller does the
-    ``/dx**3`` of stats_subfind.py:132.
+    ``/dx**3`` of stats_subfind.py:132.  ``shift`` is added to the coordinates in
+    grid units (pmesh's affine transform ``s = pos * Nmesh/BoxSize + shift``; nbodykit's
+    interlacing paints its second mesh with shift = 0.5).
     """
     pos = np.asarray(pos, dtype=np.float64)
     n = int(nmesh)
@@ -81,7 +83,7 @@ def paint(pos, mass, nmesh, boxsize, window="cic", out=None):
     i0 = []
     w = []
     for d in range(3):
-        a, b = window_1d(pos[:, d] * inv_dx, window)
+        a, b = window_1d(pos[:, d] * inv_dx + shift, window)
         i0.append(a)
         w.append(b)
     support = w[0].shape[0]

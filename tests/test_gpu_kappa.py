@@ -236,7 +236,7 @@ def test_wl_peak_counts_bit_exact(lens, dev, npix, conv, limits):
         assert lens.percentile(t, [q])[0] == np.percentile(img, q)
     ks = [0, 1, npix * npix // 3, npix * npix - 1]
     assert lens.order_statistics(t, ks) == np.sort(img.ravel())[ks].tolist()
-    assert lens.order_statistics(dev.as_device(img.astype(np.float32)), ks) == \\
+    assert lens.order_statistics(dev.as_device(img.astype(np.float32)), ks) == \
         np.sort(img.astype(np.float32).ravel())[ks].astype(np.float64).tolist()
     vals, idx = lens.peak_find(t)
     rv, rp = ok.locate_peaks(img, np.array([-np.inf, np.inf]))

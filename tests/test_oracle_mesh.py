@@ -147,3 +147,61 @@ def test_integer_vs_float64_binning_differ_only_on_exact_edges():
     assert mi.sum() == fftpower.brute_force_mode_counts(n).sum()
     # any disagreement is confined to lattice vectors with perfect-square |m|^2
     assert abs(int(mi.sum()) - int(mf.sum())) <= 6 * 2      # outermost edge modes only
+
+
+def _sinusoidal_catalogue(n, L, m, amp, per_cell=4):
+    """A density 1 + amp cos(2 pi m.x / L) carried by a regular lattice of `per_cell`^3 particles per cell with
+    sinusoidal weights: fine enough that only the window, not the sampling, shapes the measured mode."""
+    g = (np.arange(n * per_cell) + 0.5) * (L / (n * per_cell))
+    x, y, z = np.meshgrid(g, g, g, indexing="ij")
+    pos = np.stack([x.ravel(), y.ravel(), z.ravel()], axis=1)
+    mass = 1.0 + amp * np.cos(2 * np.pi * (m[0] * pos[:, 0] + m[1] * pos[:, 1] + m[2] * pos[:, 2]) / L)
+    return pos, mass
+
+
+@pytest.mark.parametrize("window", ["cic", "tsc"])
+def test_compensation_restores_a_plane_wave_amplitude(window):
+    """delta = A cos(k.x): painting multiplies the mode by the window, sinc(k_i H / 2)^p per axis; dividing by it
+    (compensated + interlaced) gives back P = A^2 L^3 / 4 in the mode's shell; uncompensated the power is W^2 lower."""
+    n, L, amp, m = 16, 100.0, 0.2, (3, -2, 4)
+    pos, mass = _sinusoidal_catalogue(n, L, m, amp, per_cell=8)      # images of the particle lattice: (u / (u - 8))^p
+    shell = int(np.floor(np.sqrt(sum(v * v for v in m)))) - 1
+    full = fftpower.catalog_power_1d(pos, mass, n, L, window, interlaced=True, compensated=True)
+    raw = fftpower.catalog_power_1d(pos, mass, n, L, window, interlaced=False, compensated=False)
+    exact = 2 * (amp ** 2 / 4) * L ** 3 / full["modes"][shell]
+    # what is left is the particle lattice's own images, (u / (u - 8))^p of the amplitude per axis: 0.6 % (CIC)
+    tol = 8e-3 if window == "cic" else 1e-3
+    assert full["power"][shell].real == pytest.approx(exact, rel=tol)
+    p = 3 if window == "tsc" else 2
+    w = np.prod([np.sinc(v / n) ** p for v in m])
+    assert raw["power"][shell].real == pytest.approx(exact * w * w, rel=tol)
+    others = np.delete(full["power"].real, shell)
+    assert np.abs(others).max() < 1e-3 * exact
+
+
+def test_interlacing_cancels_the_first_alias():
+    """A weight pattern at m = (N - 3, 0, 0) - beyond the Nyquist frequency - aliases onto m = -3 on the grid.  The
+    image comes with the sign (-1)^(sum of the alias vector) relative to the half-cell shifted paint, so the
+    interlaced combination cancels it (Sefusatti et al. 2016)."""
+    n, L, amp = 16, 100.0, 0.2
+    pos, mass = _sinusoidal_catalogue(n, L, (n - 3, 0, 0), amp, per_cell=4)
+    plain = fftpower.catalog_power_1d(pos, mass, n, L, "tsc", interlaced=False, compensated=False)
+    inter = fftpower.catalog_power_1d(pos, mass, n, L, "tsc", interlaced=True, compensated=False)
+    shell = 3 - 1
+    w = np.sinc((n - 3) / n) ** 3                                   # the TSC window at the pattern's own frequency
+    expect = 2 * (amp ** 2 / 4) * L ** 3 * w * w / plain["modes"][shell]
+    assert plain["power"][shell].real == pytest.approx(expect, rel=0.05)     # the alias is there ...
+    assert inter["power"][shell].real < 1e-6 * plain["power"][shell].real     # ... and interlacing removes it
+
+
+def test_catalogue_shot_noise_level():
+    """Poisson catalogue: P(k) = L^3 / N on every shell once the window is divided out (interlaced + compensated)."""
+    rng = np.random.default_rng(2)
+    n, L, npart = 32, 200.0, 200000
+    pos = rng.uniform(0, L, size=(npart, 3))
+    r = fftpower.catalog_power_1d(pos, None, n, L, "tsc", interlaced=True, compensated=True)
+    assert r["shotnoise"] == pytest.approx(L ** 3 / npart)
+    ratio = r["power"].real / r["shotnoise"]
+    # exponentially distributed mode powers: the shell mean scatters by 1 / sqrt(independent modes)
+    assert np.all(np.abs(ratio - 1) < 4.5 / np.sqrt(r["modes"] / 2.0))
+    assert abs(np.average(ratio, weights=r["modes"]) - 1) < 0.02
