@@ -73,6 +73,8 @@ SIGNATURES = {
     "ast_gaussian_smooth": (_i, [_vp, _vp, _d, _i, _vp]),
     "ast_minmax": (_i, [_vp, _i, _sz, _vp, _vp]),
     "ast_sum": (_i, [_vp, _i, _sz, _vp, _vp]),
+    "ast_flat_power_bin": (_i, [_vp, _vp, _i, _d, _vp, _i, _vp, _vp, _vp]),
+    "ast_ring_filter_2d": (_i, [_vp, _vp, _i, _d, _d, _d, _vp]),
     "ast_peak_find": (_i, [_vp, _i, _i, _d, _d, _sz, _vp, _vp, _vp, _vp]),
     "ast_order_statistics": (_i, [_vp, _i, _sz, ct.POINTER(_sz), _i, ct.POINTER(_d), _vp, _vp]),
     "ast_histogram": (_i, [_vp, _i, _sz, _d, _d, _i, _vp, _vp]),

@@ -20,12 +20,13 @@ class Bispectrum3DWarning(BaseException):
 
 class Bispectrum3D(PowerSpectrum3D):
     def _bispectrum_3d(self, value_map, shell_width: int = 1, m_min: int = 1, m_max: Optional[int] = None,
-                       triangles: Optional[Sequence[Tuple[int, int, int]]] = None) -> dict:
+                       triangles: Optional[Sequence[Tuple[int, int, int]]] = None, group=None) -> dict:
         """Matter bispectrum B(k1, k2, k3) by FFT triangle counting.
 
         Shells are [m, m + shell_width) in units of k_F = 2*pi/L on integer |m|;
         ``triangles`` lists shell-index triplets (default: equilateral).  Returns
-        dict(k (ntri, 3), B, ntri) with exact integer triangle counts."""
+        dict(k (ntri, 3), B, ntri) with exact integer triangle counts.  ``group``: a torch.distributed
+        process group whose ranks all call this with the same grid; the triangle bins are split over them."""
         n = int(self.sim.domain_level)
         m_max = n // 2 if m_max is None else m_max
         edges = list(range(m_min, m_max + 1, shell_width))
@@ -37,6 +38,9 @@ class Bispectrum3D(PowerSpectrum3D):
         f = dev.as_device(value_map, self.dtype)
         if tuple(f.shape) != (n, n, n):
             raise Bispectrum3DWarning(f"value_map shape {tuple(f.shape)} does not match Nmesh={n}")
+        if group is not None:              # triangle bins spread over the ranks of a torch.distributed group
+            from ..bispec_shard import bispectrum_sharded
+            return bispectrum_sharded(f, self.sim.boxsize, edges, triangles, group=group)
         return dev.bispectrum(f, self.sim.boxsize, edges, triangles)
 
     def compute_bispectrum(self, quantities: List[str], file_paths: List[str], **kwargs) -> dict:

@@ -223,6 +223,66 @@ def peak_find(t, lo=-np.inf, hi=np.inf):
     return values[order], index[order]
 
 
+# --------------------------------------------- f-3 flat-sky spectra (lenstools restated)
+def _rfft2(t):
+    from . import device as dev
+    n = t.shape[0]
+    out = torch.empty((n, n // 2 + 1), dtype=torch.complex128, device=t.device)
+    dev.fft_plan(_lib.FFT_R2C, F64, (n, n), 1, 1.0, False).execute(t, out)
+    return out
+
+
+def flat_power_spectrum(img, angle_deg, l_edges, img2=None):
+    """lenstools ``ConvergenceMap.powerSpectrum(l_edges)`` (angular_power_spectrum.py:38-53): (l, P_l) with l the bin
+    centres; bins (l_k, l_k+1], mean of |rfft2|^2 over the bin's half-plane pixels times (angle / npix^2)^2; empty
+    bins are 0 like lenstools' (it only divides where there are hits)."""
+    l_edges = np.asarray(l_edges, dtype=np.float64)
+    nb = len(l_edges) - 1
+    t = as_device(np.ascontiguousarray(img, dtype=np.float64)) if not isinstance(img, torch.Tensor) else img
+    n = t.shape[0]
+    assert t.dim() == 2 and t.shape[1] == n and t.dtype == torch.float64
+    ft1 = _rfft2(t.contiguous())
+    ft2 = None if img2 is None else _rfft2(as_device(np.ascontiguousarray(img2, dtype=np.float64)))
+    angle = np.deg2rad(angle_deg)
+    edges = as_device(l_edges)
+    psum = torch.zeros(nb, dtype=torch.float64, device=t.device)
+    hits = torch.zeros(nb, dtype=torch.int64, device=t.device)
+    check(_lib.lib().ast_flat_power_bin(ptr(ft1), ptr(ft2), n, float(angle), ptr(edges), nb, ptr(psum), ptr(hits),
+                                        stream()), "ast_flat_power_bin")
+    psum, hits = psum.cpu().numpy(), hits.cpu().numpy()
+    power = np.where(hits > 0, psum / np.maximum(hits, 1), psum) * (angle / float(n) ** 2) ** 2
+    return 0.5 * (l_edges[:-1] + l_edges[1:]), power
+
+
+def flat_bispectrum_equilateral(img, angle_deg, l_edges):
+    """lenstools ``ConvergenceMap.bispectrum(l_edges, configuration="equilateral")`` (bispectrum_2d.py:33-50) by the
+    FFT estimator: per bin ring-filter the spectrum, transform back, sum the cube; triangle counts from the bare
+    rings.  B = angle^4 / npix^6 * <ft ft ft> over closed triangles with all sides in the bin; bins without a
+    closed triangle are 0.  Returns (l, B_l, integer triangle counts)."""
+    from . import device as dev
+    l_edges = np.asarray(l_edges, dtype=np.float64)
+    nb = len(l_edges) - 1
+    t = as_device(np.ascontiguousarray(img, dtype=np.float64)) if not isinstance(img, torch.Tensor) else img
+    n = t.shape[0]
+    ft = _rfft2(t.contiguous())
+    ring = torch.empty_like(ft)
+    field = torch.empty((n, n), dtype=torch.float64, device=t.device)
+    angle = float(np.deg2rad(angle_deg))
+    c2r = dev.fft_plan(_lib.FFT_C2R, F64, (n, n), 1, 1.0, False)
+    num, den = np.zeros(nb), np.zeros(nb)
+    for k in range(nb):
+        for src, acc in ((ft, num), (None, den)):
+            check(_lib.lib().ast_ring_filter_2d(ptr(src), ptr(ring), n, angle, float(l_edges[k]), float(l_edges[k + 1]),
+                                                stream()), "ast_ring_filter_2d")
+            c2r.execute(ring, field)
+            acc[k] = float(dev.triple_product_sum(field, field, field).item())
+    npx = float(n) ** 2
+    ntri = np.rint(den / npx).astype(np.int64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        b = np.where(ntri > 0, (num / npx) / np.maximum(ntri, 1), 0.0) * angle ** 4 / float(n) ** 6
+    return 0.5 * (l_edges[:-1] + l_edges[1:]), b, ntri
+
+
 def add(a, b, out=None):
     out = torch.empty_like(a) if out is None else out
     check(_lib.lib().ast_add(ptr(a), ptr(b), ptr(out), real_code(a), a.numel(), stream()), "ast_add")

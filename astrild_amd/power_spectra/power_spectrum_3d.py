@@ -107,6 +107,10 @@ class PowerSpectrum3D:
                                   fields[column].values, self.sim.npar, dtype=self.dtype)
         elif ".npy" in file_in:
             return dev.as_device(np.load(file_in), self.dtype)
+        elif file_in.endswith((".a_den", ".a_vel", ".a_velDiv", ".den", ".dtfe")):
+            # a DTFE grid binary (what dtfe.py:70-80 / powmes.py:21-23 turn into the .npy above): straight to the device
+            from ..formats import read_density_grid
+            return read_density_grid(file_in, dtype=self.dtype)[1]
         return dev.as_device(np.zeros((self.sim.npar,) * 3), self.dtype)
 
     def _get_vector_magnitude(self, value_map: np.ndarray) -> np.ndarray:

@@ -140,6 +140,35 @@ class RayRamses(PlaneStacker):
     def _load_ray_map(self, ray_file: str) -> pd.DataFrame:
         return pd.read_hdf(ray_file)
 
+    def compress_snapshot(self, fields: list, dir_out: str = None, convert: bool = False, cosmo=None,
+                          save: bool = True, cpu_files: Optional[dict] = None):
+        """Combine the ray-tracing outputs of the individual CPUs of each snapshot into one pandas .h5 file
+        (rayramses.py:69-148).  ``cpu_files``: {ray_nr: [per-CPU ASCII files]}; by default every
+        ``<root>_<ray_nr>*`` file group found in ``dirs["sim"]`` (the reference asks its Simulation base class,
+        which is outside the hot path).  Returns {ray_nr: DataFrame} when ``save`` is False."""
+        import glob
+        import re
+        from ..formats import compress_rayramses_outputs
+        self.cosmology = cosmo if cosmo is not None else self.cosmology
+        root = self.file_dsc["root"]
+        if cpu_files is None:
+            cpu_files = {}
+            for path in sorted(glob.glob(self.dirs["sim"] + f"{root}_*")):
+                m = re.search(r"(\d+)", os.path.basename(path)[len(root):])
+                if m and not path.endswith(".h5"):
+                    cpu_files.setdefault(int(m.group(1)), []).append(path)
+        h = None
+        if convert:
+            h = float(self.cosmology.H0.value) / 100 if hasattr(self.cosmology.H0, "value") else float(self.cosmology.H0) / 100
+        out = {}
+        for ray_nr in sorted(cpu_files):
+            table = compress_rayramses_outputs(cpu_files[ray_nr], fields, convert, h)
+            if save:
+                table.to_hdf((dir_out or self.dirs["sim"]) + "%s_output%05d.h5" % (root, ray_nr), key="df", mode="w")
+            else:
+                out[ray_nr] = table
+        return None if save else out
+
     def sum_snapshots(self, dir_out: str, columns: list, columns_z_shift: list, integration_range: dict,
                       ray_file_root: str = "Ray_maps_output%05d.h5", sim_folder_root: str = "box%d",
                       z_src: float = None, z_src_shift: float = None, reweight: bool = False,

@@ -345,6 +345,17 @@ int ast_smooth_plan_destroy(ast_smooth_plan* plan);
 int ast_gaussian_smooth(ast_smooth_plan* plan, double* img_d, double sigma_px, int mode,
                         void* stream);
 
+/* Flat-sky angular power spectrum binning (power_spectra/angular_power_spectrum.py:38-53 -> lenstools
+ * ConvergenceMap.powerSpectrum, restated): ft1_d / ft2_d (or NULL = auto) are rfft2 half planes (npix x (npix/2+1),
+ * complex128, unnormalised); pixel (i, j) has |l| = 2 pi / angle * sqrt(min(i, npix-i)^2 + j^2) and falls into bin k
+ * when edges[k] < |l| <= edges[k+1].  psum_d[k] += sum Re(ft1 conj ft2), hits_d[k] += pixels (device uint64);
+ * P(k) = psum / hits * (angle / npix^2)^2 on the host.  edges_d: nbins + 1 doubles on the device, ascending. */
+int ast_flat_power_bin(const void* ft1_d, const void* ft2_d, int npix, double angle_rad, const double* edges_d,
+                       int nbins, double* psum_d, unsigned long long* hits_d, void* stream);
+/* out = in * 1[l_lo < |l| <= l_hi] on the same half plane (in_d = NULL: the indicator itself) - the ring fields of the
+ * FFT estimator of the equilateral flat-sky bispectrum (bispectra/bispectrum_2d.py:33-50). */
+int ast_ring_filter_2d(const void* in_d, void* out_d, int npix, double angle_rad, double l_lo, double l_hi, void* stream);
+
 /* Local maxima of an npix x npix map (SkyArray.wl_peak_counts, rays/skys/sky_array.py:435-472 ->
  * lenstools ConvergenceMap.locatePeaks): interior pixels strictly larger than their 8 neighbours with a
  * value in [lo, hi).  Heights go to values_d (dtype), flat row-major pixel indices to index_d, at most

@@ -130,6 +130,62 @@ def wl_peak_counts(img, nbins, field_conversion="", limits=None):
     return (_kappa[1:] + _kappa[:-1]) / 2, _hist
 
 
+# ------------------------------------------------ f-3 flat-sky spectra (lenstools)
+def _pixel_l(npix, angle_rad):
+    i = np.arange(npix)
+    lx = np.minimum(i, npix - i) * 2.0 * np.pi / angle_rad
+    ly = np.arange(npix // 2 + 1) * 2.0 * np.pi / angle_rad
+    return np.sqrt(lx[:, None] ** 2 + ly[None, :] ** 2)
+
+
+def flat_power_spectrum(img, angle_deg, l_edges, img2=None):
+    """lenstools ``ConvergenceMap.powerSpectrum`` as called at power_spectra/angular_power_spectrum.py:48-52
+    (un-vendored, unpinned; its rfft2 + azimuthal average restated): bins (l_k, l_k+1], mean of Re(ft1 conj ft2)
+    over the half-plane pixels of the bin, times (angle / npix^2)^2."""
+    img = np.asarray(img, dtype=np.float64)
+    n = img.shape[0]
+    angle = np.deg2rad(angle_deg)
+    f1 = np.fft.rfft2(img)
+    f2 = f1 if img2 is None else np.fft.rfft2(np.asarray(img2, dtype=np.float64))
+    l = _pixel_l(n, angle)
+    p = (f1 * np.conj(f2)).real
+    l_edges = np.asarray(l_edges, dtype=np.float64)
+    out = np.zeros(len(l_edges) - 1)
+    for k in range(len(out)):
+        sel = (l > l_edges[k]) & (l <= l_edges[k + 1])
+        if sel.any():
+            out[k] = p[sel].mean()
+    return 0.5 * (l_edges[:-1] + l_edges[1:]), out * (angle / n ** 2) ** 2
+
+
+def flat_bispectrum_equilateral_brute(img, angle_deg, l_edges):
+    """Equilateral flat-sky bispectrum by direct enumeration of the closed triangles of the FULL Fourier plane
+    (tiny maps only): B_k = angle^4 / npix^6 * mean of ft(l1) ft(l2) ft(l3) over l1 + l2 + l3 = 0 with every
+    |l_i| in (l_k, l_k+1] - what lenstools' ``bispectrum(configuration="equilateral")`` averages
+    (bispectra/bispectrum_2d.py:45-49)."""
+    img = np.asarray(img, dtype=np.float64)
+    n = img.shape[0]
+    angle = np.deg2rad(angle_deg)
+    ft = np.fft.fft2(img)
+    m = np.arange(n)
+    m = np.minimum(m, n - m)
+    lmod = np.sqrt(m[:, None] ** 2 + m[None, :] ** 2) * 2.0 * np.pi / angle
+    ii, jj = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    l_edges = np.asarray(l_edges, dtype=np.float64)
+    b, ntri = np.zeros(len(l_edges) - 1), np.zeros(len(l_edges) - 1, dtype=np.int64)
+    for k in range(len(b)):
+        sel = (lmod > l_edges[k]) & (lmod <= l_edges[k + 1])
+        a_i, a_j = ii[sel], jj[sel]
+        i3 = (-(a_i[:, None] + a_i[None, :])) % n
+        j3 = (-(a_j[:, None] + a_j[None, :])) % n
+        ok_ = sel[i3, j3]
+        ntri[k] = int(ok_.sum())
+        if ntri[k]:
+            prod = ft[a_i, a_j][:, None] * ft[a_i, a_j][None, :] * ft[i3, j3]
+            b[k] = prod[ok_].real.sum() / ntri[k] * angle ** 4 / float(n) ** 6
+    return 0.5 * (l_edges[:-1] + l_edges[1:]), b, ntri
+
+
 # ----------------------------------------------------- a-9 kappa -> alpha, phi
 def _iso_kernel(ncc, dcell, which):
     """kernel_alphas_iso / kernel_phi_iso, rays/skys/lib_so_cgls/lensing_funcs.c:45-83,117-148."""

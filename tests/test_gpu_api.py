@@ -272,3 +272,31 @@ def test_simulation_collection_sum_npy_planes(tmp_path):
                                       rm_ray={1: [2]})
     order = [(1, 1), (1, 3), (2, 1), (2, 2)]
     assert np.array_equal(tot, ok.kappa_stack([planes[o] for o in order]))
+
+
+def test_sharded_bispectrum_ranks_share_one_gpu(tmp_path):
+    """SURVEY.md §8e row 2 rehearsal: 3 processes on cuda:0 over gloo, triangle bins split over the ranks, grid
+    broadcast from rank 0; against the single-GPU estimator on the same grid (same kernels: identical numbers)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    import torch
+    from astrild_amd import device as dev
+    torch.cuda.set_device(0)
+    world, n = 3, 128
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "bispec.npz")
+    worker = os.path.join(os.path.dirname(__file__), "bispec_gpu_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(n), out]) for r in range(world)]
+    assert [p.wait(timeout=600) for p in procs] == [0] * world
+    got = np.load(out)
+    pos = dev.synth_lattice_particles(n, n, 1000.0, seed=3, dtype=torch.float32)
+    field = dev.paint(pos, None, n, 1000.0, "cic")
+    edges = list(range(1, n // 2 + 1, 4))
+    ref = dev.bispectrum(field, 1000.0, edges, [tuple(t) for t in got["tri"]])
+    assert np.array_equal(got["ntri"], ref["ntri"])
+    ok_ = ref["ntri"] > 0
+    npt.assert_allclose(got["B"][ok_], ref["B"][ok_], rtol=1e-12)

@@ -246,3 +246,39 @@ def test_wl_peak_counts_bit_exact(lens, dev, npix, conv, limits):
     centres, counts = ok.wl_peak_counts(img, 12, conv, limits)
     assert np.array_equal(df["counts"].values, counts)            # integer counts: exact
     assert np.array_equal(df["kappa"].values, centres)
+
+
+def test_flat_sky_power_and_bispectrum_vs_oracle(lens, dev):
+    """AngularPowerSpectrum.from_array and Bispectrum2D.from_skymap (lenstools restated) -
+    annulus membership and pixel counts exact, P_l to 1e-12; the FFT-estimator bispectrum against the
+    brute-force triangle enumeration, triangle counts exact."""
+    from astrild_amd.rays import SkyMap
+    from astrild_amd.power_spectra import AngularPowerSpectrum
+    from astrild_amd.bispectra import Bispectrum2D
+    rng = np.random.default_rng(12)
+    npix, theta = 256, 10.0
+    img = ok.gaussian_smooth(rng.standard_normal((npix, npix)), theta, 6.0, kind="gaussianFFT")
+    img = img + 0.5 * img ** 2
+    sky = SkyMap.from_array(img, npix, theta, "kappa_2", "/tmp/")
+    lf = 2 * np.pi / np.deg2rad(theta)
+    edges = np.concatenate([lf * np.arange(0.5, 40.0, 3.0), [lf * 100.0, lf * 400.0]])   # incl. integer-radius edges
+    edges[3] = lf * 5.0                                                                  # an edge ON a lattice radius
+    aps = AngularPowerSpectrum.from_array(sky, "orig", edges)
+    l, p = ok.flat_power_spectrum(img, theta, edges)
+    assert np.array_equal(aps.ell, l)
+    npt.assert_allclose(aps.P, p, rtol=1e-12, atol=1e-14 * p.max())
+    assert aps.P[-1] == 0.0                                                              # beyond the corner: empty
+    # cross power of two maps
+    img2 = np.roll(img, 3, axis=0)
+    l2, p2 = lens.flat_power_spectrum(img, theta, edges, img2=img2)
+    npt.assert_allclose(p2, ok.flat_power_spectrum(img, theta, edges, img2=img2)[1], rtol=1e-11, atol=1e-13 * p.max())
+    # bispectrum on a small map, brute force
+    n2 = 32
+    small = img[:n2, :n2].copy()
+    sky2 = SkyMap.from_array(small, n2, 2.0, "kappa_2", "/tmp/")
+    lf2 = 2 * np.pi / np.deg2rad(2.0)
+    e2 = lf2 * np.array([1.5, 3.5, 6.0, 9.2, 14.0])
+    bs = Bispectrum2D.from_skymap(sky2, "orig", e2)
+    lb, bb, nb = ok.flat_bispectrum_equilateral_brute(small, 2.0, e2)
+    assert np.array_equal(bs.ntri, nb)
+    npt.assert_allclose(bs.B, bb, rtol=1e-9, atol=1e-12 * np.abs(bb).max())

@@ -151,3 +151,39 @@ def test_locate_peaks_hand_made_map():
         assert v == img[y, x] and v > nb.max()
     centres, counts = ok.wl_peak_counts(img, 8, "normalize")
     assert counts.sum() <= vals.size and len(centres) == 8 and np.all(np.diff(centres) > 0)
+
+
+def test_flat_power_spectrum_known_answers():
+    """White noise of variance s^2 per pixel: P_l = s^2 * pixel area on every annulus; a single plane wave of
+    amplitude A lands in one annulus with P = A^2 * area / 4 / (pixels of the annulus) per occupied pixel."""
+    rng = np.random.default_rng(6)
+    n, theta = 128, 5.0
+    img = rng.standard_normal((n, n)) * 0.3
+    area = np.deg2rad(theta) ** 2
+    lf = 2 * np.pi / np.deg2rad(theta)
+    edges = lf * np.arange(4.5, 60.0, 5.0)
+    l, p = ok.flat_power_spectrum(img, theta, edges)
+    npt.assert_allclose(p, 0.09 * area / n ** 2, rtol=0.12)
+    assert np.allclose(l, 0.5 * (edges[:-1] + edges[1:]))
+    y, x = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    wave = 0.2 * np.cos(2 * np.pi * (7 * y + 3 * x) / n)
+    l, p = ok.flat_power_spectrum(wave, theta, edges)
+    k = np.searchsorted(edges, lf * np.sqrt(58.0)) - 1
+    pix = ((ok._pixel_l(n, np.deg2rad(theta)) > edges[k]) & (ok._pixel_l(n, np.deg2rad(theta)) <= edges[k + 1])).sum()
+    npt.assert_allclose(p[k], (0.2 / 2 * n * n) ** 2 / pix * (np.deg2rad(theta) / n ** 2) ** 2, rtol=1e-10)
+    assert np.abs(np.delete(p, k)).max() < 1e-20
+
+
+def test_flat_bispectrum_brute_force_counts_triangles():
+    """Three plane waves closing a triangle give a bispectrum only in the bin holding all three sides."""
+    n, theta = 24, 4.0
+    y, x = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    m1, m2 = (5, 0), (-2, 4)
+    m3 = (-(m1[0] + m2[0]), -(m1[1] + m2[1]))                              # (-3, -4): |m| = 5, 4.47, 5
+    img = sum(np.cos(2 * np.pi * (a * y + b * x) / n) for a, b in (m1, m2, m3))
+    lf = 2 * np.pi / np.deg2rad(theta)
+    l, b, ntri = ok.flat_bispectrum_equilateral_brute(img, theta, lf * np.array([2.5, 4.2, 5.5, 8.0]))
+    assert ntri[1] > 0 and b[1] > 0 and abs(b[0]) < 1e-12 * b[1] and abs(b[2]) < 1e-12 * b[1]
+    # every ordered closed triangle built from +-(m1, m2, m3): 3! orderings x 2 signs, each (n^2/2)^3
+    expect = 12 * (n * n / 2.0) ** 3 / ntri[1] * np.deg2rad(theta) ** 4 / float(n) ** 6
+    npt.assert_allclose(b[1], expect, rtol=1e-10)
