@@ -810,6 +810,8 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     // 0 = an owned plane the buffer does not hold (last x tile of a slab buffer with
     // nx_alloc % TX != 0): deposits there are counted as dropped
     __shared__ unsigned long long dest[LX * LY];
+    // exact sums of the first H planes the walk flushes: the periodic wrap at the end of the walk lands on them
+    __shared__ unsigned long long first_planes[LX * LY * H];
     for (int ab = threadIdx.x; ab < LX * LY; ab += 256) {
         const int b = ab % LY, a = ab / LY;
         const int px = ox + a - LO;
@@ -1057,6 +1059,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
                     const unsigned long long raw = tile[ab * LZ + sl[i]];
                     tile[ab * LZ + sl[i]] = BIAS;
                     any |= raw != BIAS;
+                    if (ftz == 0 && c0 + i < H) first_planes[ab * H + c0 + i] = raw;     // (stored below, rewritten at the end)
                     if (RAW) {
                         const unsigned long long dbits = (raw & 0x0000ffffffffffffull) | 0x4330000000000000ull;
                         v[i] = (T)((__longlong_as_double((long long)dbits) - 4644337115725824.0) * q - sub);      // 2^52 + 2^47
@@ -1124,34 +1127,34 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     DSTAMP(9);
     DSTAMP_END;
 
-    // the H planes still in the ring hold z = n - LO + k (k < H), i.e. the periodic wrap onto planes
-    // this workgroup stored at its first tile: add them where they were stored
-    // The stores being added to were issued by this workgroup and are in its XCD's L2, where the
-    // atomics execute: draining the workgroup's stores is all the ordering needed.  (A
-    // __threadfence() here is a buffer_wbl2 + buffer_inv of the whole L2 per wave.)
+    // The H planes still in the ring hold z = n - LO + k (k < H): the periodic wrap onto the first planes this
+    // workgroup flushed.  Their exact sums were kept in first_planes, so the cells are REWRITTEN with the one
+    // correctly rounded total (exact integer sum of both parts, offset subtracted in double) - plain stores, no
+    // read-modify-write.  The earlier stores to the same cells are this workgroup's own: draining them (a
+    // workgroup-scope release; a __threadfence() here is a buffer_wbl2 + buffer_inv of the whole L2 per wave)
+    // and the barrier order the two.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     for (int i = threadIdx.x; i < LX * LY * H; i += 256) {
-        const int k = i % H, ab = i / H, b = ab % LY, a = ab / LY;
+        const int k = i % H, ab = i / H;
         int sl = k + sh;
         sl = sl >= LZ ? sl - LZ : sl;
-        const unsigned long long raw = tile[ab * LZ + sl];
+        const unsigned long long raw = first_planes[i] + tile[ab * LZ + sl] - BIAS;
+        const unsigned long long d = dest[ab];
+        const double sub = (d & 2ull) ? offset : 0.0;
         T v;
+        bool any;
         if (RAW) {
-            const unsigned long long dbits = (raw & 0x0000ffffffffffffull) | 0x4330000000000000ull;
-            v = (T)((__longlong_as_double((long long)dbits) - 4644337115725824.0) * q);
+            const unsigned long long low = raw & 0x0000ffffffffffffull;
+            any = low != BIAS;
+            v = (T)((__longlong_as_double((long long)(low | 0x4330000000000000ull)) - 4644337115725824.0) * q - sub);
         } else {
-            v = (T)((double)(long long)raw * q);
+            any = raw != 0ull;
+            v = (T)((double)(long long)raw * q - sub);
         }
-        if (v == (T)0) continue;
-        const int z = ast::wrap1(tz0 * TZ + k - LO, g.n);
-        if (RM::owned(a, TX) && RM::owned(b, TY)) {
-            const int px = ox + a - LO;
-            if (px < g.nx_alloc) atomicAdd(&grid[((size_t)px * g.n + oy + b - LO) * g.n + z], v);
-            else ++ndrop;                   // owned plane the buffer does not hold
-        } else {
-            atomicAdd(&rec[((size_t)col * RM::COUNT + RM::cell(a, b)) * g.n + z], v);
-        }
+        if (d == 0ull) { ndrop += any; continue; }      // owned plane the buffer does not hold
+        typedef __attribute__((address_space(1))) T gT;
+        ((gT*)(d & ~3ull))[ast::wrap1(tz0 * TZ + k - LO, g.n)] = v;
     }
     if (dropped && ndrop) atomicAdd(dropped, ndrop);
 }

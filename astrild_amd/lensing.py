@@ -184,12 +184,12 @@ def order_statistics(t, ks):
 
 def percentile(t, qs):
     """np.percentile(t, q) (default "linear" method) for each q, from exact order statistics:
-    numpy's virtual index n*q + (1 - q) - 1, gamma = its fractional part and numpy's two-sided lerp."""
+    numpy's virtual index (n - 1) * q, gamma = its fractional part and numpy's two-sided lerp."""
     n = t.numel()
     res = []
     for q in qs:
         qf = np.true_divide(q, 100)
-        vi = n * qf + (1 + qf * (1 - 1 - 1)) - 1
+        vi = (n - 1) * qf
         prev = int(np.floor(vi))
         gamma = vi - prev
         prev = min(max(prev, 0), n - 1)
