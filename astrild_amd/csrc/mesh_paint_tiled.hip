@@ -941,7 +941,8 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     // of the column lies inside the box and the tile does not straddle the periodic x edge, so
     // the unreduced cell (int)floor(s) minus the tile origin is the LDS coordinate (the same
     // expression decided the particle's tile in tile_of(); it raised col_flags otherwise).
-    const double m_unit = (double)(T)scale * invq;         // unit masses: the per-particle factor is a constant
+    // mass * scale / quantum in double (no intermediate rounding to T); unit masses: a constant
+    const double scale_invq = scale * invq, m_unit = scale_invq;
     auto deposit = [&](const T (&pc)[3 * U], const T (&mc)[U], uint32_t act, auto careful_tag) {
         constexpr bool CAREFUL = decltype(careful_tag)::value;
 #pragma unroll
@@ -981,7 +982,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
             Window<W>::weights(fx, wx);
             Window<W>::weights(fy, wy);
             Window<W>::weights(fz, wz);
-            const double m = HAS_MASS ? (double)(T)((double)mc[u] * scale) * invq : m_unit;
+            const double m = HAS_MASS ? (double)mc[u] * scale_invq : m_unit;
             unsigned long long* slot[W];          // (lx, ly) row at the ring slots of planes lz + c
             int sl = lz + sh;
             sl = sl >= LZ ? sl - LZ : sl;
