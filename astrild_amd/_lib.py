@@ -51,9 +51,9 @@ SIGNATURES = {
     "ast_fft_tile_rows_r2c": (_i, [_vp, _vp, _i, _sz, _sz, _sz, _sz, _d, _vp]),
     "ast_fft_tile_r2c_3d": (_i, [_vp, _vp, _i, _sz, _d, _vp]),
     "ast_fft_tile_power_scratch_bytes": (_sz, [_sz]),
-    "ast_fft_tile_power_3d": (_i, [_vp, _vp, _sz, _i, _sz, _d, _d, _vp, _vp]),
+    "ast_fft_tile_power_3d": (_i, [_vp, _vp, _sz, _i, _sz, _d, _d, _i, _vp, _vp]),
     "ast_fft_tile_isqrt_table": (_i, [_vp, _i, _vp]),
-    "ast_fft_tile_power_3d_halo": (_i, [_vp, _vp, _i, _vp, _sz, _i, _sz, _d, _d, _vp, _vp]),
+    "ast_fft_tile_power_3d_halo": (_i, [_vp, _vp, _i, _vp, _sz, _i, _sz, _d, _d, _i, _vp, _vp]),
     "ast_paint_tiled_halo": (_i, [_vp, _i, _i, _sz, _i, _i, _i, ct.POINTER(ct.c_void_p)]),
     "ast_power_bin_1d": (_i, [_vp, _vp, _i, _i, _d, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ast_interlace_compensate": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

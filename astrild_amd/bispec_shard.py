@@ -47,6 +47,8 @@ def bispectrum_sharded(field, boxsize, edges, triangles, group=None, root_has_fi
     dict(B, ntri, k) in the order of ``triangles``."""
     ops = ops or HipBispecOps()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    from .slab import comm_ready
+    comm_ready(group)
     if root_has_field and world > 1:
         dist.broadcast(field, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     tri = [tuple(int(v) for v in t) for t in triangles]

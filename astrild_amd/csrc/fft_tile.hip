@@ -236,7 +236,8 @@ shell_partials_stage1_kernel(const double* __restrict__ partial, size_t nwg, int
 }
 // 8 bins per block: 32 row groups x 8 bins, each thread adds REDUCE_ROWS / 32 rows, then the groups in order
 __global__ void __launch_bounds__(256)
-shell_partials_stage2_kernel(const double* __restrict__ partial2, int nb, double pnorm, double* __restrict__ psum) {
+shell_partials_stage2_kernel(const double* __restrict__ partial2, int nb, double pnorm, int first_bin,
+                             double* __restrict__ psum) {
     __shared__ double part[32][8];
     const int b8 = threadIdx.x & 7, grp = threadIdx.x >> 3;
     const int bin = blockIdx.x * 8 + b8;
@@ -247,7 +248,7 @@ shell_partials_stage2_kernel(const double* __restrict__ partial2, int nb, double
     }
     part[grp][b8] = acc;
     __syncthreads();
-    if (grp == 0 && bin < nb) {
+    if (grp == 0 && bin < nb && bin >= first_bin) {       // bins below first_bin come from the low-k channel
         double t = 0.0;
         for (int k = 0; k < 32; ++k) t += part[k][b8];
         psum[bin] += pnorm * t;
@@ -365,6 +366,132 @@ rows_r2c_kernel(const float* __restrict__ in, float2* __restrict__ out, const fl
         orow[k] = make_float2((e.x + t.y) * scale, (e.y - t.x) * scale);
         orow[M - k] = make_float2((e.x - t.y) * scale, (-e.y - t.x) * scale);
     }
+}
+
+// -------------------------------------------------- low-k side channel in double
+// The fp32 transform leaves a white round-off floor of ~1e-7 of the field's rms amplitude on every mode.  A
+// spectrum with a large dynamic range (the cold lattice of the bench: the lowest shells hold 1e-5 of the peak
+// power) then misses the 1e-6 target on its lowest shells by 2e-6 / |m|^2.  The few modes with |m_i| <= MLOW are
+// therefore ALSO evaluated as plain DFT sums in double - one more read of the grid, ~12 fp64 FMA per cell - and
+// the shells they fill completely (|m| < MLOW + 1) take their sums from here:
+//   z  one wave per (x, y) row: lane l holds z = l + 64 j; the j sum uses the (N/64)-th roots of unity as
+//      compile-time constants, one twiddle e^{-2 pi i kz l / N} per lane and kz, then a fixed xor-shuffle tree;
+//   y  per x plane, sums over y for ky = -MLOW..MLOW;   x  sums over x for kx = -MLOW..MLOW, then the shells.
+// Deterministic (fixed summation trees).  The grid may hold rho or rho - mean: only the unused DC mode differs.
+constexpr int MLOW = 5;                  // shells |m| in [1, 6) are taken from the double-precision sums
+// e^{-2 pi i r / 16} = (kC16[r], kS16[r])
+__device__ constexpr double kC16[16] = {1.0, 0.92387953251128674, 0.70710678118654752, 0.38268343236508977, 0.0,
+                                        -0.38268343236508977, -0.70710678118654752, -0.92387953251128674, -1.0,
+                                        -0.92387953251128674, -0.70710678118654752, -0.38268343236508977, 0.0,
+                                        0.38268343236508977, 0.70710678118654752, 0.92387953251128674};
+__device__ constexpr double kS16[16] = {0.0, -0.38268343236508977, -0.70710678118654752, -0.92387953251128674, -1.0,
+                                        -0.92387953251128674, -0.70710678118654752, -0.38268343236508977, 0.0,
+                                        0.38268343236508977, 0.70710678118654752, 0.92387953251128674, 1.0,
+                                        0.92387953251128674, 0.70710678118654752, 0.38268343236508977};
+
+template <int NJ, int FOLDW>
+__global__ void __launch_bounds__(256)
+lowk_z_kernel(const float* __restrict__ grid, const float* __restrict__ rec, int n, double2* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);        // n^2 is a multiple of 4
+    const float* in = grid + row * (size_t)n;
+    const float* src[3] = {nullptr, nullptr, nullptr};
+    int ns = 0;
+    if (FOLDW != 0) {
+        constexpr int W = FOLDW != 0 ? FOLDW : 2;
+        ns = ast::halo_sources<float, W>(rec, (int)(row / n), (int)(row % n), n, n / ast::TX, n / ast::TY, src);
+    }
+    double f[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) f[j] = (double)in[lane + 64 * j];
+    if (ns > 0) {                                        // the records first, then onto the row: the fold's order
+        float h[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) h[j] = src[0][lane + 64 * j];
+        if (ns > 1) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) h[j] += src[1][lane + 64 * j];
+        }
+        if (ns > 2) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) h[j] += src[2][lane + 64 * j];
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) f[j] = (double)(in[lane + 64 * j] + h[j]);       // the fp32 value the FFT's z pass sees
+    }
+    double2 acc[MLOW + 1];
+#pragma unroll
+    for (int kz = 0; kz <= MLOW; ++kz) {
+        double re = 0.0, im = 0.0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            constexpr int step = 16 / NJ;
+            const int r = ((kz * j) % NJ) * step;        // e^{-2 pi i (kz j) / NJ}: a compile-time constant after unrolling
+            re += f[j] * kC16[r];
+            im += f[j] * kS16[r];
+        }
+        double ts, tc;
+        sincospi(-2.0 * (double)((kz * lane) % n) / (double)n, &ts, &tc);
+        acc[kz] = make_double2(re * tc - im * ts, re * ts + im * tc);
+    }
+#pragma unroll
+    for (int kz = 0; kz <= MLOW; ++kz) {
+        double re = acc[kz].x, im = acc[kz].y;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            re += __shfl_xor(re, o, 64);
+            im += __shfl_xor(im, o, 64);
+        }
+        if (lane == 0) out[row * (MLOW + 1) + kz] = make_double2(re, im);
+    }
+}
+
+// in[(outer * n + t) * inner + i], t < n summed with e^{-2 pi i k t / n} for k = -MLOW..MLOW:
+// out[(outer * (2 MLOW + 1) + k + MLOW) * inner + i].  One workgroup per `outer`; used for y (outer = x, inner = MLOW+1)
+// and x (outer = 1, inner = (2 MLOW + 1)(MLOW + 1)).
+__global__ void __launch_bounds__(256)
+lowk_axis_kernel(const double2* __restrict__ in, int n, int inner, double2* __restrict__ out) {
+    extern __shared__ double2 tw[];                       // e^{-2 pi i t / n}
+    for (int t = threadIdx.x; t < n; t += 256) {
+        double sn, cs;
+        sincospi(-2.0 * (double)t / (double)n, &sn, &cs);
+        tw[t] = make_double2(cs, sn);
+    }
+    __syncthreads();
+    const size_t outer = blockIdx.x;
+    const int nout = (2 * MLOW + 1) * inner;
+    for (int o = threadIdx.x; o < nout; o += 256) {
+        const int k = o / inner - MLOW, i = o % inner;
+        double re = 0.0, im = 0.0;
+        for (int t = 0; t < n; ++t) {
+            const double2 v = in[(outer * n + t) * inner + i];
+            const double2 w = tw[(unsigned)(k * t) & (unsigned)(n - 1)];       // n is a power of two
+            re += v.x * w.x - v.y * w.y;
+            im += v.x * w.y + v.y * w.x;
+        }
+        out[(outer * (2 * MLOW + 1) + k + MLOW) * inner + i] = make_double2(re, im);
+    }
+}
+
+// modes[kx + MLOW][ky + MLOW][kz] -> sums[shell] = pnorm * sum w |delta_k|^2 for the shells |m| in [s + 1, s + 2),
+// s < MLOW, each shell added up by one thread in a fixed order
+__global__ void lowk_shell_kernel(const double2* __restrict__ modes, double pnorm, double* __restrict__ sums) {
+    const int s = threadIdx.x;
+    if (s >= MLOW) return;
+    double acc = 0.0;
+    for (int a = -MLOW; a <= MLOW; ++a)
+        for (int b = -MLOW; b <= MLOW; ++b)
+            for (int c = 0; c <= MLOW; ++c) {
+                const int m2 = a * a + b * b + c * c;
+                if (m2 < (s + 1) * (s + 1) || m2 >= (s + 2) * (s + 2)) continue;
+                const double2 v = modes[((a + MLOW) * (2 * MLOW + 1) + b + MLOW) * (MLOW + 1) + c];
+                acc += (c > 0 ? 2.0 : 1.0) * (v.x * v.x + v.y * v.y);
+            }
+    sums[s] = acc * pnorm;
+}
+
+__global__ void lowk_patch_kernel(const double* __restrict__ sums, int count, double* __restrict__ psum) {
+    if ((int)threadIdx.x < count) psum[threadIdx.x] += sums[threadIdx.x];
 }
 
 // ------------------------------------------------------------------ host side
@@ -515,32 +642,41 @@ extern "C" int ast_fft_tile_r2c_3d(const void* in, void* out, int dtype, size_t 
 extern "C" size_t ast_fft_tile_power_scratch_bytes(size_t n) {
     const size_t nzp = ((n / 2 + 1) + 15) / 16 * 16;
     const size_t tiles = (n / 2 + 1 + 15) / 16;
-    return n * n * nzp * sizeof(float2) + n * tiles * (n / 2 - 1) * sizeof(double);
+    return n * n * nzp * sizeof(float2) + n * tiles * (n / 2 - 1) * sizeof(double) + 64 * sizeof(double);     // + low-k sums
 }
 
 // FFTPower's shell sums of an (n, n, n) real grid without ever writing the spectrum:
 // z pass (R2C) and y pass into `scratch`, x pass fused with the shell binning.
 // psum_d[shell] += L^3 * sum_modes w |delta_k|^2, delta_k = rfftn(grid)/n^3  (auto power only).
 static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, int dtype, size_t n, double boxsize,
-                         double mean, double* psum, const void* rec, int window, void* stream);
+                         double mean, double* psum, const void* rec, int window, int lowk, void* stream);
 
 extern "C" int ast_fft_tile_power_3d(const void* grid, void* scratch, size_t scratch_bytes, int dtype, size_t n,
-                                     double boxsize, double mean, double* psum, void* stream) {
-    return power_3d_impl(grid, scratch, scratch_bytes, dtype, n, boxsize, mean, psum, nullptr, 0, stream);
+                                     double boxsize, double mean, int lowk, double* psum, void* stream) {
+    return power_3d_impl(grid, scratch, scratch_bytes, dtype, n, boxsize, mean, psum, nullptr, 0, lowk, stream);
 }
 
 // The same for a grid painted with AST_PAINT_OVERWRITE | AST_PAINT_DEFER_FOLD: `halo_rec` (from
 // ast_paint_tiled_halo) is folded into the border rows as the z pass loads them.
 extern "C" int ast_fft_tile_power_3d_halo(const void* grid, const void* halo_rec, int window, void* scratch,
                                           size_t scratch_bytes, int dtype, size_t n, double boxsize, double mean,
-                                          double* psum, void* stream) {
+                                          int lowk, double* psum, void* stream) {
     AST_CHECK_ARG(halo_rec != nullptr && (window == AST_WIN_CIC || window == AST_WIN_TSC));
-    return power_3d_impl(grid, scratch, scratch_bytes, dtype, n, boxsize, mean, psum, halo_rec, window, stream);
+    return power_3d_impl(grid, scratch, scratch_bytes, dtype, n, boxsize, mean, psum, halo_rec, window, lowk, stream);
+}
+
+template <int NJ>
+static void launch_lowk_z(const float* grid, const float* rec, int window, int n, double2* out, hipStream_t s) {
+    const unsigned blocks = (unsigned)((size_t)n * n / 4);
+    if (rec == nullptr) lowk_z_kernel<NJ, 0><<<blocks, 256, 0, s>>>(grid, rec, n, out);
+    else if (window == AST_WIN_CIC) lowk_z_kernel<NJ, 2><<<blocks, 256, 0, s>>>(grid, rec, n, out);
+    else lowk_z_kernel<NJ, 3><<<blocks, 256, 0, s>>>(grid, rec, n, out);
 }
 
 static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, int dtype, size_t n, double boxsize,
-                         double mean, double* psum, const void* rec, int window, void* stream) {
+                         double mean, double* psum, const void* rec, int window, int lowk, void* stream) {
     AST_CHECK_ARG(grid != nullptr && scratch != nullptr && psum != nullptr && boxsize > 0.0);
+    AST_CHECK_ARG(lowk == 0 || lowk == 1);
     AST_CHECK_ARG(ast_fft_tile_supported(dtype, n));
     AST_CHECK_ARG(scratch_bytes >= ast_fft_tile_power_scratch_bytes(n));
     const size_t nz = n / 2 + 1, nzp = (nz + 15) / 16 * 16, tiles = (nz + 15) / 16;
@@ -549,6 +685,22 @@ static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, 
     const float2* tw = g_tw.get((int)n);
     if (!tw) { ast::set_error("ast_fft_tile_power_3d: twiddle table allocation failed"); return AST_ERR_HIP; }
     hipStream_t s = ast::as_stream(stream);
+    double* lowk_sums = (double*)((char*)scratch + ast_fft_tile_power_scratch_bytes(n)) - 64;
+    if (lowk) {
+        // the modes |m_i| <= MLOW as DFT sums in double, through the (still unused) spectrum scratch
+        AST_PROF("fft_tile.lowk", s);
+        double2* lowz = (double2*)scratch;                                   // [x][y][kz <= MLOW]
+        double2* lowy = lowz + n * n * (MLOW + 1);                           // [x][ky][kz]
+        double2* modes = lowy + n * (2 * MLOW + 1) * (MLOW + 1);             // [kx][ky][kz]
+        if (n == 1024) launch_lowk_z<16>((const float*)grid, (const float*)rec, window, (int)n, lowz, s);
+        else if (n == 512) launch_lowk_z<8>((const float*)grid, (const float*)rec, window, (int)n, lowz, s);
+        else launch_lowk_z<4>((const float*)grid, (const float*)rec, window, (int)n, lowz, s);
+        lowk_axis_kernel<<<(unsigned)n, 256, n * sizeof(double2), s>>>(lowz, (int)n, MLOW + 1, lowy);
+        lowk_axis_kernel<<<1, 256, n * sizeof(double2), s>>>(lowy, (int)n, (2 * MLOW + 1) * (MLOW + 1), modes);
+        const double ng = (double)n * (double)n * (double)n;
+        lowk_shell_kernel<<<1, 64, 0, s>>>(modes, boxsize * boxsize * boxsize / (ng * ng), lowk_sums);
+        AST_CHECK_LAUNCH();
+    }
     int rc = rows_r2c_impl(grid, spec, dtype, n, n * n, n, nzp, 1.0, mean, stream, rec, window);      // z
     if (rc != AST_OK) return rc;
     rc = ast_fft_tile_c2c(spec, dtype, n, nzp, nz, n, n * nzp, 1.0, stream);                          // y, per x-plane
@@ -563,7 +715,8 @@ static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, 
     const int nb = (int)(n / 2 - 1);
     double* partial2 = (double*)scratch;                   // the spectrum scratch is dead after the x pass
     shell_partials_stage1_kernel<<<REDUCE_ROWS, 256, 0, s>>>(partial, n * tiles, nb, partial2);
-    shell_partials_stage2_kernel<<<(nb + 7) / 8, 256, 0, s>>>(partial2, nb, boxsize * boxsize * boxsize, psum);
+    shell_partials_stage2_kernel<<<(nb + 7) / 8, 256, 0, s>>>(partial2, nb, boxsize * boxsize * boxsize, lowk ? MLOW : 0, psum);
+    if (lowk) lowk_patch_kernel<<<1, 64, 0, s>>>(lowk_sums, MLOW, psum);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }

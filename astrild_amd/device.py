@@ -341,11 +341,13 @@ def finish_power(ksum, psum, nmodes):
 _power_scratch = {}
 
 
-def power_sums_fused(field, boxsize, psum=None, mean=0.0, halo=None):
+def power_sums_fused(field, boxsize, psum=None, mean=0.0, halo=None, lowk=True):
     """(ksum, psum, nmodes) of the auto power of an fp32 cube of side 256/512/1024 through
     the fused tile-FFT + shell-binning path (the spectrum is never written to HBM).
     ``mean`` is subtracted from the cells on load: it only touches the discarded DC mode
-    and keeps fp32 round-off from scaling with the mean density (pass total_mass/Ng)."""
+    and keeps fp32 round-off from scaling with the mean density (pass total_mass/Ng).
+    ``lowk``: the five lowest shells come from double-precision DFT sums of the modes |m_i| <= 5 (one more read
+    of the grid): the fp32 transform's round-off floor would otherwise cap them at ~2e-6 / |m|^2."""
     n = field.shape[0]
     L = _lib.lib()
     key = (torch.cuda.current_device(), n)
@@ -359,11 +361,11 @@ def power_sums_fused(field, boxsize, psum=None, mean=0.0, halo=None):
     ksum, nmodes = shell_geometry(n, boxsize)
     if halo is not None:                      # grid from paint(..., defer_fold=True)
         check(L.ast_fft_tile_power_3d_halo(ptr(field), halo.rec_ptr, halo.window_code, ptr(scratch), scratch.numel(),
-                                           real_code(field), n, float(boxsize), float(mean), ptr(psum), stream()),
+                                           real_code(field), n, float(boxsize), float(mean), int(bool(lowk)), ptr(psum), stream()),
               "ast_fft_tile_power_3d_halo")
         return ksum, psum, nmodes
     check(L.ast_fft_tile_power_3d(ptr(field), ptr(scratch), scratch.numel(), real_code(field), n, float(boxsize),
-                                  float(mean), ptr(psum), stream()), "ast_fft_tile_power_3d")
+                                  float(mean), int(bool(lowk)), ptr(psum), stream()), "ast_fft_tile_power_3d")
     return ksum, psum, nmodes
 
 

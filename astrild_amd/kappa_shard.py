@@ -75,8 +75,11 @@ def kappa_stack_sharded(planes, wnum=None, wden=None, group=None, root=0, all_ra
     if world == 1:
         return send[:n]
     recv = ops.empty(world * chunk)
+    from .slab import comm_ready
+    comm_ready(group)
     dist.all_to_all_single(recv, send, group=group)       # chunk j of every rank -> rank j
     mine = ops.stack([recv[s * chunk:(s + 1) * chunk] for s in range(world)])      # rank order: fixed
+    comm_ready(group)
     if all_ranks:
         full = ops.empty(world * chunk)
         dist.all_gather_into_tensor(full, mine, group=group)

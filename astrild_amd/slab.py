@@ -102,6 +102,14 @@ class HipSlabOps:
                                                 first=first, count=count)
 
 
+def comm_ready(group=None):
+    """RCCL orders a collective after the kernels already queued on the current stream.  The gloo backend (CPU tests,
+    and the one-GPU rehearsals that put several ranks on one card) reads device buffers from its own threads: there
+    the producers have to be finished first."""
+    if torch.cuda.is_available() and torch.cuda.is_initialized() and dist.get_backend(group) != "nccl":
+        torch.cuda.synchronize()
+
+
 def ghost_fold(buf, nloc, gl, gh, ops, group=None):
     """Step 2.  buf: (gl + nloc + gh, N, N) with the owned planes in the middle.
     Lower ghosts belong to rank r-1 (its top gl planes), upper ghosts to rank r+1
@@ -113,6 +121,7 @@ def ghost_fold(buf, nloc, gl, gh, ops, group=None):
     upper = buf[gl + nloc:].contiguous()
     from_right = torch.empty_like(lower)       # right neighbour's lower ghosts -> my top planes
     from_left = torch.empty_like(upper)        # left neighbour's upper ghosts -> my bottom planes
+    comm_ready(group)
     reqs = dist.batch_isend_irecv([
         dist.P2POp(dist.isend, lower, left, group),
         dist.P2POp(dist.isend, upper, right, group),
@@ -134,6 +143,7 @@ def exchange_chunk(packed_c, block, chunk, pc, nloc, group=None):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     ops_list = []
+    comm_ready(group)
     for s in range(world):
         dst = block[s * nloc + chunk * pc: s * nloc + (chunk + 1) * pc]
         if s == rank:
@@ -213,5 +223,6 @@ class SlabPowerPipeline:
     def step(self, check=False):
         block = self.forward_fft(self.paint(check))
         self.ops.power_bin(block, self.n, self.L, self.i0, self.i1, self.psum)
+        comm_ready(self.group)
         dist.all_reduce(self.psum, group=self.group)
         return self.ksum, self.psum, self.nmodes

@@ -237,14 +237,17 @@ int ast_fft_tile_isqrt_table(int* out_d, int count, void* stream);
 /* `mean`: a constant subtracted from every cell as it is loaded (0 = none).  It only
  * changes the DC mode, which FFTPower discards, but with it the fp32 round-off of all
  * other modes no longer scales with the O(1) mean density (cold low-k shells gain). */
+/* `lowk` = 1: the modes with |m_i| <= 5 are ALSO evaluated as DFT sums in double (one more read of the grid) and the
+ * five lowest shells, |m| in [1, 6), take their sums from there: the fp32 transform's white round-off floor
+ * (~1e-7 of the rms amplitude per mode) otherwise limits shells that hold 1e-5 of the peak power to ~2e-6 / |m|^2. */
 int ast_fft_tile_power_3d(const void* grid_d, void* scratch_d, size_t scratch_bytes, int dtype, size_t n,
-                          double boxsize, double mean, double* psum_d, void* stream);
+                          double boxsize, double mean, int lowk, double* psum_d, void* stream);
 /* The same for a grid painted with AST_PAINT_OVERWRITE | AST_PAINT_DEFER_FOLD (fp32, whole periodic grid):
  * halo_rec_d comes from ast_paint_tiled_halo on the paint's workspace; the records are added to the border
  * rows as the z pass loads them, in the order the paint's own fold kernel uses (bit-identical result). */
 int ast_fft_tile_power_3d_halo(const void* grid_d, const void* halo_rec_d, int window, void* scratch_d,
                                size_t scratch_bytes, int dtype, size_t n, double boxsize, double mean,
-                               double* psum_d, void* stream);
+                               int lowk, double* psum_d, void* stream);
 
 /* ---------------------------------------------- a-5: k-shell power binning */
 
