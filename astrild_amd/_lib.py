@@ -16,6 +16,7 @@ WIN = {"ngp": 0, "nnb": 0, "nearest": 0, "cic": 1, "tsc": 2}
 FFT_R2C, FFT_C2R, FFT_C2C_FWD, FFT_C2C_INV = 0, 1, 2, 3
 ERR_WORKSPACE = -4
 SUM_PARTS = 1024          # AST_SUM_PARTS
+BIN = {"integer": 0, "float64": 1}      # AST_BIN_*
 
 
 class AstrildHipError(RuntimeError):
@@ -36,7 +37,7 @@ SIGNATURES = {
     "ast_ngp_assign": (_i, [_vp, _vp, _vp, _vp, _i, _sz, _i, _vp, _vp, _vp, _vp]),
     "ast_paint": (_i, [_i, _i, _vp, _vp, _sz, _i, _d, _d, _i, _i, _vp, _vp, _d, _vp]),
     "ast_paint_tiled_workspace_bytes": (_sz, [_i, _i, _sz, _i, _i, _i]),
-    "ast_paint_tiled": (_i, [_i, _i, _vp, _vp, _sz, _i, _d, _d, _i, _i, _vp, _vp, _sz, _vp, _i, _d, _d, _d, _vp]),
+    "ast_paint_tiled": (_i, [_i, _i, _vp, _vp, _sz, _i, _d, _d, _i, _i, _vp, _vp, _sz, _vp, _i, _d, _d, _i, _i, _d, _vp]),
     "ast_paint_tiled_list_stats": (_i, [_vp, _i, _i, _sz, _i, _i, _i, _vp, _vp]),
     "ast_accumulate": (_i, [_vp, _vp, _i, _sz, _vp]),
     "ast_fft_plan_create": (_i, [ct.POINTER(_vp), _i, _i, _i, ct.POINTER(_sz), _sz, _d, _i]),
@@ -51,11 +52,16 @@ SIGNATURES = {
     "ast_fft_tile_rows_r2c": (_i, [_vp, _vp, _i, _sz, _sz, _sz, _sz, _d, _vp]),
     "ast_fft_tile_r2c_3d": (_i, [_vp, _vp, _i, _sz, _d, _vp]),
     "ast_fft_tile_power_scratch_bytes": (_sz, [_sz]),
-    "ast_fft_tile_power_3d": (_i, [_vp, _vp, _sz, _i, _sz, _d, _d, _i, _vp, _vp]),
+    "ast_fft_tile_power_3d": (_i, [_vp, _vp, _sz, _i, _sz, _d, _d, _i, _i, _vp, _vp]),
     "ast_fft_tile_isqrt_table": (_i, [_vp, _i, _vp]),
-    "ast_fft_tile_power_3d_halo": (_i, [_vp, _vp, _i, _vp, _sz, _i, _sz, _d, _d, _i, _vp, _vp]),
+    "ast_fft_tile_power_3d_halo": (_i, [_vp, _vp, _i, _vp, _sz, _i, _sz, _d, _d, _i, _i, _vp, _vp]),
+    "ast_lowk_work_bytes": (_sz, [_sz, _sz]),
+    "ast_lowk_mode_count": (_i, []),
+    "ast_lowk_shell_count": (_i, []),
+    "ast_lowk_modes": (_i, [_vp, _i, _sz, _sz, _sz, _i, _vp, _vp, _sz, _vp]),
+    "ast_lowk_shell_sums": (_i, [_vp, _sz, _d, _i, _vp, _vp]),
     "ast_paint_tiled_halo": (_i, [_vp, _i, _i, _sz, _i, _i, _i, ct.POINTER(ct.c_void_p)]),
-    "ast_power_bin_1d": (_i, [_vp, _vp, _i, _i, _d, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ast_power_bin_1d": (_i, [_vp, _vp, _i, _i, _d, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "ast_interlace_compensate": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ast_shell_filter": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ast_triple_product_sum": (_i, [_vp, _vp, _vp, _i, _sz, _vp, _vp]),

@@ -31,6 +31,21 @@ struct ProfScope {
 
 }  // namespace ast
 
+namespace ast {
+// FFTPower's shell membership.  Mathematically shell = floor(|m|) - 1 on integer lattice vectors m; nbodykit
+// decides it in float64: digitize(kx^2 + ky^2 + kz^2, kedges^2) with k_i = k_F * m_i and kedges = arange(k_F, ...,
+// k_F) (element i = k_F + i * k_F).  The two agree except for vectors whose norm is EXACTLY an integer r
+// (perfect-square |m|^2): those sit on an edge and the rounding of the float expressions decides between shell r - 1
+// and r - 2.  This restates that arithmetic for such a vector (no fma: the library is built with
+// -ffp-contract=off); kf = 0 selects the integer rule.  Returns floor(|m|) or floor(|m|) - 1.
+__device__ inline int float64_edge_norm(int r, int mx, int my, int mz, double kf) {
+    const double kx = kf * (double)mx, ky = kf * (double)my, kz = kf * (double)mz;
+    const double k2 = (kx * kx + ky * ky) + kz * kz;
+    const double e = kf + (double)(r - 1) * kf;
+    return k2 < e * e ? r - 1 : r;
+}
+}  // namespace ast
+
 #define AST_PROF(name, stream) ast::ProfScope ast_prof_scope_(name, stream)
 
 #define AST_CHECK_ARG(cond)                                              \

@@ -103,13 +103,19 @@ __global__ void tile_isqrt_table_kernel(int* out, int count) {
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < count; v += gridDim.x * blockDim.x) out[v] = tile_isqrt(v);
 }
 
+// out of line on purpose: inlined 32 times into the unrolled epilogue its double-precision temporaries push the
+// kernel over its 128-VGPR budget (38 spilled registers); as a call only the rare branch pays
+__device__ __noinline__ int edge_norm_call(int r, int mx, int my, int mz, double kf) {
+    return ast::float64_edge_norm(r, mx, my, mz, kf);
+}
+
 template <int R1, int R2, int C, bool POWER>
 __global__ void __launch_bounds__(C * (R1 > R2 ? R1 : R2))
 // N = 1024 with binning: 128 VGPRs, so that two 8-wave workgroups fit a CU (see SPLIT below)
 __attribute__((amdgpu_waves_per_eu(POWER && R1 * R2 >= 1024 ? 4 : 1, POWER && R1 * R2 >= 1024 ? 4 : 8)))
 strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, size_t elem_stride,
                    size_t ncols, size_t batch_stride, unsigned tiles_per_batch, float scale,
-                   double* __restrict__ partial) {
+                   double* __restrict__ partial, double kf_rule) {
     constexpr int N = R1 * R2;
     constexpr int NT = C * (R1 > R2 ? R1 : R2);
     constexpr int NB = N / 2 - 1;    // shells when POWER
@@ -205,7 +211,9 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
             const float2 x = u[bitrev(k2, ilog2(R2))];
             const int row = sub + R1 * k2;
             const int kx = row > N / 2 ? row - N : row;
-            const int sh = tile_isqrt(kx * kx + m2yz);                  // shell = sh - 1; 0 is DC
+            int sh = tile_isqrt(kx * kx + m2yz);                        // shell = sh - 1; 0 is DC
+            // lattice vectors of integer norm sit on a shell edge: nbodykit's float64 comparison decides (rare path)
+            if (kf_rule != 0.0 && sh * sh == kx * kx + m2yz && sh > 0) sh = edge_norm_call(sh, kx, ky, kz, kf_rule);
             // |delta_k|^2 in fp32 (one rounding of 6e-8 per mode, random over the >= 18 modes of a
             // shell), accumulated in double
             if (sh >= 1 && sh <= NB) atomicAdd(&shell[sh], (double)(fmaf(x.x, x.x, x.y * x.y) * w));
@@ -378,7 +386,8 @@ rows_r2c_kernel(const float* __restrict__ in, float2* __restrict__ out, const fl
 //      compile-time constants, one twiddle e^{-2 pi i kz l / N} per lane and kz, then a fixed xor-shuffle tree;
 //   y  per x plane, sums over y for ky = -MLOW..MLOW;   x  sums over x for kx = -MLOW..MLOW, then the shells.
 // Deterministic (fixed summation trees).  The grid may hold rho or rho - mean: only the unused DC mode differs.
-constexpr int MLOW = 5;                  // shells |m| in [1, 6) are taken from the double-precision sums
+constexpr int MLOW = 5;                  // shells 0..4 (|m| in [1, 6), by the binning rule) are taken from the double-precision sums
+constexpr int MBOX = MLOW + 1;           // modes |m_i| <= MBOX are evaluated: under the float64 rule a vector of norm exactly 6 may fall into shell 4
 // e^{-2 pi i r / 16} = (kC16[r], kS16[r])
 __device__ constexpr double kC16[16] = {1.0, 0.92387953251128674, 0.70710678118654752, 0.38268343236508977, 0.0,
                                         -0.38268343236508977, -0.70710678118654752, -0.92387953251128674, -1.0,
@@ -419,9 +428,9 @@ lowk_z_kernel(const float* __restrict__ grid, const float* __restrict__ rec, int
 #pragma unroll
         for (int j = 0; j < NJ; ++j) f[j] = (double)(in[lane + 64 * j] + h[j]);       // the fp32 value the FFT's z pass sees
     }
-    double2 acc[MLOW + 1];
+    double2 acc[MBOX + 1];
 #pragma unroll
-    for (int kz = 0; kz <= MLOW; ++kz) {
+    for (int kz = 0; kz <= MBOX; ++kz) {
         double re = 0.0, im = 0.0;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -435,22 +444,25 @@ lowk_z_kernel(const float* __restrict__ grid, const float* __restrict__ rec, int
         acc[kz] = make_double2(re * tc - im * ts, re * ts + im * tc);
     }
 #pragma unroll
-    for (int kz = 0; kz <= MLOW; ++kz) {
+    for (int kz = 0; kz <= MBOX; ++kz) {
         double re = acc[kz].x, im = acc[kz].y;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             re += __shfl_xor(re, o, 64);
             im += __shfl_xor(im, o, 64);
         }
-        if (lane == 0) out[row * (MLOW + 1) + kz] = make_double2(re, im);
+        if (lane == 0) out[row * (MBOX + 1) + kz] = make_double2(re, im);
     }
 }
 
-// in[(outer * n + t) * inner + i], t < n summed with e^{-2 pi i k t / n} for k = -MLOW..MLOW:
-// out[(outer * (2 MLOW + 1) + k + MLOW) * inner + i].  One workgroup per `outer`; used for y (outer = x, inner = MLOW+1)
-// and x (outer = 1, inner = (2 MLOW + 1)(MLOW + 1)).
+// One axis of the low-k transform: in[(outer * nt + t) * inner + i], t < nt, is summed with e^{-2 pi i k (t0 + t) / n} for
+// k = -MBOX..MBOX.  Block (outer, part) adds up the t of part `part` (of gridDim.y), four independent accumulators so
+// that several loads are in flight, and writes out[((outer * nparts + part) * (2 MBOX + 1) + k + MBOX) * inner + i].
+// y pass: outer = x plane, inner = MBOX + 1, one part.  x pass: outer = 1, inner = (2 MBOX + 1)(MBOX + 1), LOWK_XPARTS
+// parts, then lowk_parts_reduce_kernel adds the parts in order.
+constexpr int LOWK_XPARTS = 64;
 __global__ void __launch_bounds__(256)
-lowk_axis_kernel(const double2* __restrict__ in, int n, int inner, double2* __restrict__ out) {
+lowk_axis_kernel(const double2* __restrict__ in, int n, int nt, int t0, int inner, double2* __restrict__ out) {
     extern __shared__ double2 tw[];                       // e^{-2 pi i t / n}
     for (int t = threadIdx.x; t < n; t += 256) {
         double sn, cs;
@@ -459,32 +471,58 @@ lowk_axis_kernel(const double2* __restrict__ in, int n, int inner, double2* __re
     }
     __syncthreads();
     const size_t outer = blockIdx.x;
-    const int nout = (2 * MLOW + 1) * inner;
+    const int nparts = gridDim.y, part = blockIdx.y;
+    const int per = (nt + nparts - 1) / nparts, ta = part * per, tb = min(nt, ta + per);
+    const int nout = (2 * MBOX + 1) * inner;
     for (int o = threadIdx.x; o < nout; o += 256) {
-        const int k = o / inner - MLOW, i = o % inner;
-        double re = 0.0, im = 0.0;
-        for (int t = 0; t < n; ++t) {
-            const double2 v = in[(outer * n + t) * inner + i];
-            const double2 w = tw[(unsigned)(k * t) & (unsigned)(n - 1)];       // n is a power of two
-            re += v.x * w.x - v.y * w.y;
-            im += v.x * w.y + v.y * w.x;
+        const int k = o / inner - MBOX, i = o % inner;
+        double re[4] = {0.0, 0.0, 0.0, 0.0}, im[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int tq = ta; tq < tb; tq += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = min(tq + q, tb - 1);        // unconditional load; the duplicate is not added
+                const double2 v = in[(outer * nt + t) * inner + i];
+                const double2 w = tw[(unsigned)(k * (t0 + t)) & (unsigned)(n - 1)];       // n is a power of two
+                if (tq + q < tb) {
+                    re[q] += v.x * w.x - v.y * w.y;
+                    im[q] += v.x * w.y + v.y * w.x;
+                }
+            }
         }
-        out[(outer * (2 * MLOW + 1) + k + MLOW) * inner + i] = make_double2(re, im);
+        out[((outer * nparts + part) * (2 * MBOX + 1) + k + MBOX) * inner + i] =
+            make_double2((re[0] + re[1]) + (re[2] + re[3]), (im[0] + im[1]) + (im[2] + im[3]));
     }
 }
 
-// modes[kx + MLOW][ky + MLOW][kz] -> sums[shell] = pnorm * sum w |delta_k|^2 for the shells |m| in [s + 1, s + 2),
-// s < MLOW, each shell added up by one thread in a fixed order
-__global__ void lowk_shell_kernel(const double2* __restrict__ modes, double pnorm, double* __restrict__ sums) {
+// acc[i] (+)= sum over parts of in[part * count + i], parts in index order
+__global__ void __launch_bounds__(256)
+lowk_parts_reduce_kernel(const double2* __restrict__ in, int nparts, int count, int accumulate, double2* __restrict__ acc) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    double re = accumulate ? acc[i].x : 0.0, im = accumulate ? acc[i].y : 0.0;
+    for (int p = 0; p < nparts; ++p) {
+        re += in[(size_t)p * count + i].x;
+        im += in[(size_t)p * count + i].y;
+    }
+    acc[i] = make_double2(re, im);
+}
+
+// modes[kx + MBOX][ky + MBOX][kz] -> sums[s] = pnorm * sum w |delta_k|^2 over the modes of shell s < MLOW (shell by
+// the binning rule in force), each shell added up by one thread in a fixed order
+__global__ void lowk_shell_kernel(const double2* __restrict__ modes, double pnorm, double kf_rule, double* __restrict__ sums) {
     const int s = threadIdx.x;
     if (s >= MLOW) return;
     double acc = 0.0;
-    for (int a = -MLOW; a <= MLOW; ++a)
-        for (int b = -MLOW; b <= MLOW; ++b)
-            for (int c = 0; c <= MLOW; ++c) {
+    for (int a = -MBOX; a <= MBOX; ++a)
+        for (int b = -MBOX; b <= MBOX; ++b)
+            for (int c = 0; c <= MBOX; ++c) {
                 const int m2 = a * a + b * b + c * c;
-                if (m2 < (s + 1) * (s + 1) || m2 >= (s + 2) * (s + 2)) continue;
-                const double2 v = modes[((a + MLOW) * (2 * MLOW + 1) + b + MLOW) * (MLOW + 1) + c];
+                int r = (int)sqrt((double)m2);
+                while (r * r > m2) --r;
+                while ((r + 1) * (r + 1) <= m2) ++r;
+                if (kf_rule != 0.0 && r * r == m2 && r > 0) r = ast::float64_edge_norm(r, a, b, c, kf_rule);
+                if (r - 1 != s) continue;
+                const double2 v = modes[((a + MBOX) * (2 * MBOX + 1) + b + MBOX) * (MBOX + 1) + c];
                 acc += (c > 0 ? 2.0 : 1.0) * (v.x * v.x + v.y * v.y);
             }
     sums[s] = acc * pnorm;
@@ -518,7 +556,7 @@ struct TwiddleCache {
 
 template <int R1, int R2, int C, bool POWER>
 int launch_c2c(float2* data, const float2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride,
-               float scale, double* partial, hipStream_t s) {
+               float scale, double* partial, hipStream_t s, double kf_rule = 0.0) {
     constexpr int N = R1 * R2, NT = C * (R1 > R2 ? R1 : R2);
     constexpr bool SPLIT = POWER && R1 == R2 && N * C * sizeof(float2) > 64 * 1024;       // as in the kernel
     const size_t lds = (size_t)((SPLIT ? N / 2 : N) * C + N) * sizeof(float2) + (POWER ? (N / 2) * sizeof(double) : 0);
@@ -532,17 +570,17 @@ int launch_c2c(float2* data, const float2* tw, size_t elem_stride, size_t ncols,
     AST_CHECK_ARG(tiles * batch < 0x7fffffffull);
     strided_c2c_kernel<R1, R2, C, POWER><<<(unsigned)(tiles * batch), NT, lds, s>>>(data, tw, elem_stride, ncols,
                                                                                    batch_stride, (unsigned)tiles, scale,
-                                                                                   partial);
+                                                                                   partial, kf_rule);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
 
 template <bool POWER>
 int dispatch_c2c(size_t n, float2* d, const float2* tw, size_t elem_stride, size_t ncols, size_t batch,
-                 size_t batch_stride, float scale, double* partial, hipStream_t s) {
-    if (n == 1024) return launch_c2c<32, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s);
-    if (n == 512) return launch_c2c<16, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s);
-    return launch_c2c<16, 16, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s);
+                 size_t batch_stride, float scale, double* partial, hipStream_t s, double kf_rule = 0.0) {
+    if (n == 1024) return launch_c2c<32, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, kf_rule);
+    if (n == 512) return launch_c2c<16, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, kf_rule);
+    return launch_c2c<16, 16, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, kf_rule);
 }
 
 template <int R1, int R2, int C, int FOLDW = 0>
@@ -649,34 +687,56 @@ extern "C" size_t ast_fft_tile_power_scratch_bytes(size_t n) {
 // z pass (R2C) and y pass into `scratch`, x pass fused with the shell binning.
 // psum_d[shell] += L^3 * sum_modes w |delta_k|^2, delta_k = rfftn(grid)/n^3  (auto power only).
 static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, int dtype, size_t n, double boxsize,
-                         double mean, double* psum, const void* rec, int window, int lowk, void* stream);
+                         double mean, double* psum, const void* rec, int window, int lowk, int binning, void* stream);
 
 extern "C" int ast_fft_tile_power_3d(const void* grid, void* scratch, size_t scratch_bytes, int dtype, size_t n,
-                                     double boxsize, double mean, int lowk, double* psum, void* stream) {
-    return power_3d_impl(grid, scratch, scratch_bytes, dtype, n, boxsize, mean, psum, nullptr, 0, lowk, stream);
+                                     double boxsize, double mean, int lowk, int binning, double* psum, void* stream) {
+    return power_3d_impl(grid, scratch, scratch_bytes, dtype, n, boxsize, mean, psum, nullptr, 0, lowk, binning, stream);
 }
 
 // The same for a grid painted with AST_PAINT_OVERWRITE | AST_PAINT_DEFER_FOLD: `halo_rec` (from
 // ast_paint_tiled_halo) is folded into the border rows as the z pass loads them.
 extern "C" int ast_fft_tile_power_3d_halo(const void* grid, const void* halo_rec, int window, void* scratch,
                                           size_t scratch_bytes, int dtype, size_t n, double boxsize, double mean,
-                                          int lowk, double* psum, void* stream) {
+                                          int lowk, int binning, double* psum, void* stream) {
     AST_CHECK_ARG(halo_rec != nullptr && (window == AST_WIN_CIC || window == AST_WIN_TSC));
-    return power_3d_impl(grid, scratch, scratch_bytes, dtype, n, boxsize, mean, psum, halo_rec, window, lowk, stream);
+    return power_3d_impl(grid, scratch, scratch_bytes, dtype, n, boxsize, mean, psum, halo_rec, window, lowk, binning, stream);
 }
 
-template <int NJ>
-static void launch_lowk_z(const float* grid, const float* rec, int window, int n, double2* out, hipStream_t s) {
-    const unsigned blocks = (unsigned)((size_t)n * n / 4);
-    if (rec == nullptr) lowk_z_kernel<NJ, 0><<<blocks, 256, 0, s>>>(grid, rec, n, out);
-    else if (window == AST_WIN_CIC) lowk_z_kernel<NJ, 2><<<blocks, 256, 0, s>>>(grid, rec, n, out);
-    else lowk_z_kernel<NJ, 3><<<blocks, 256, 0, s>>>(grid, rec, n, out);
+constexpr size_t LOWK_MODES = (size_t)(2 * MBOX + 1) * (2 * MBOX + 1) * (MBOX + 1);
+
+// modes[kx + MBOX][ky + MBOX][kz] (+)= sum over the nx planes x0 .. x0 + nx - 1 (rows of n floats, n rows per plane) of
+// f(x, y, z) e^{-2 pi i (kx x + ky y + kz z) / n}.  work: nx * n * (MBOX + 1) + nx * 13 * 7 + 64 * 1183 double2.
+static int lowk_modes(const float* planes, const float* rec, int window, int n, int x0, int nx, int accumulate,
+                      double2* modes, double2* work, hipStream_t s) {
+    double2* lowz = work;                                                  // [x][y][kz]
+    double2* lowy = lowz + (size_t)nx * n * (MBOX + 1);                    // [x][ky][kz]
+    double2* parts = lowy + (size_t)nx * (2 * MBOX + 1) * (MBOX + 1);      // [part][kx][ky][kz]
+    const unsigned blocks = (unsigned)((size_t)nx * n / 4);
+    auto z = [&](auto nj) {
+        constexpr int NJ = decltype(nj)::value;
+        if (rec == nullptr) lowk_z_kernel<NJ, 0><<<blocks, 256, 0, s>>>(planes, rec, n, lowz);
+        else if (window == AST_WIN_CIC) lowk_z_kernel<NJ, 2><<<blocks, 256, 0, s>>>(planes, rec, n, lowz);
+        else lowk_z_kernel<NJ, 3><<<blocks, 256, 0, s>>>(planes, rec, n, lowz);
+    };
+    if (n == 1024) z(std::integral_constant<int, 16>{});
+    else if (n == 512) z(std::integral_constant<int, 8>{});
+    else z(std::integral_constant<int, 4>{});
+    const size_t lds = (size_t)n * sizeof(double2);
+    lowk_axis_kernel<<<dim3((unsigned)nx, 1), 256, lds, s>>>(lowz, n, n, 0, MBOX + 1, lowy);
+    const int inner = (2 * MBOX + 1) * (MBOX + 1);
+    lowk_axis_kernel<<<dim3(1, LOWK_XPARTS), 256, lds, s>>>(lowy, n, nx, x0, inner, parts);
+    lowk_parts_reduce_kernel<<<(unsigned)((LOWK_MODES + 255) / 256), 256, 0, s>>>(parts, LOWK_XPARTS, (int)LOWK_MODES, accumulate, modes);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
 }
 
 static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, int dtype, size_t n, double boxsize,
-                         double mean, double* psum, const void* rec, int window, int lowk, void* stream) {
+                         double mean, double* psum, const void* rec, int window, int lowk, int binning, void* stream) {
     AST_CHECK_ARG(grid != nullptr && scratch != nullptr && psum != nullptr && boxsize > 0.0);
     AST_CHECK_ARG(lowk == 0 || lowk == 1);
+    AST_CHECK_ARG(binning == AST_BIN_INTEGER || binning == AST_BIN_FLOAT64);
+    const double kf_rule = binning == AST_BIN_FLOAT64 ? 2.0 * M_PI / boxsize : 0.0;
     AST_CHECK_ARG(ast_fft_tile_supported(dtype, n));
     AST_CHECK_ARG(scratch_bytes >= ast_fft_tile_power_scratch_bytes(n));
     const size_t nz = n / 2 + 1, nzp = (nz + 15) / 16 * 16, tiles = (nz + 15) / 16;
@@ -687,18 +747,13 @@ static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, 
     hipStream_t s = ast::as_stream(stream);
     double* lowk_sums = (double*)((char*)scratch + ast_fft_tile_power_scratch_bytes(n)) - 64;
     if (lowk) {
-        // the modes |m_i| <= MLOW as DFT sums in double, through the (still unused) spectrum scratch
+        // the modes |m_i| <= MBOX as DFT sums in double, through the (still unused) spectrum scratch
         AST_PROF("fft_tile.lowk", s);
-        double2* lowz = (double2*)scratch;                                   // [x][y][kz <= MLOW]
-        double2* lowy = lowz + n * n * (MLOW + 1);                           // [x][ky][kz]
-        double2* modes = lowy + n * (2 * MLOW + 1) * (MLOW + 1);             // [kx][ky][kz]
-        if (n == 1024) launch_lowk_z<16>((const float*)grid, (const float*)rec, window, (int)n, lowz, s);
-        else if (n == 512) launch_lowk_z<8>((const float*)grid, (const float*)rec, window, (int)n, lowz, s);
-        else launch_lowk_z<4>((const float*)grid, (const float*)rec, window, (int)n, lowz, s);
-        lowk_axis_kernel<<<(unsigned)n, 256, n * sizeof(double2), s>>>(lowz, (int)n, MLOW + 1, lowy);
-        lowk_axis_kernel<<<1, 256, n * sizeof(double2), s>>>(lowy, (int)n, (2 * MLOW + 1) * (MLOW + 1), modes);
+        double2* modes = (double2*)scratch;
+        int rc = lowk_modes((const float*)grid, (const float*)rec, window, (int)n, 0, (int)n, 0, modes, modes + LOWK_MODES, s);
+        if (rc != AST_OK) return rc;
         const double ng = (double)n * (double)n * (double)n;
-        lowk_shell_kernel<<<1, 64, 0, s>>>(modes, boxsize * boxsize * boxsize / (ng * ng), lowk_sums);
+        lowk_shell_kernel<<<1, 64, 0, s>>>(modes, boxsize * boxsize * boxsize / (ng * ng), kf_rule, lowk_sums);
         AST_CHECK_LAUNCH();
     }
     int rc = rows_r2c_impl(grid, spec, dtype, n, n * n, n, nzp, 1.0, mean, stream, rec, window);      // z
@@ -708,7 +763,7 @@ static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, 
     const double inv_ng = 1.0 / ((double)n * (double)n * (double)n);
     {
         AST_PROF("fft_tile.c2c_power", s);
-        rc = dispatch_c2c<true>(n, spec, tw, n * nzp, nz, n, nzp, (float)inv_ng, partial, s);          // x + binning
+        rc = dispatch_c2c<true>(n, spec, tw, n * nzp, nz, n, nzp, (float)inv_ng, partial, s, kf_rule);   // x + binning
         if (rc != AST_OK) return rc;
     }
     AST_PROF("fft_tile.shell_reduce", s);
@@ -717,6 +772,34 @@ static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, 
     shell_partials_stage1_kernel<<<REDUCE_ROWS, 256, 0, s>>>(partial, n * tiles, nb, partial2);
     shell_partials_stage2_kernel<<<(nb + 7) / 8, 256, 0, s>>>(partial2, nb, boxsize * boxsize * boxsize, lowk ? MLOW : 0, psum);
     if (lowk) lowk_patch_kernel<<<1, 64, 0, s>>>(lowk_sums, MLOW, psum);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+// The low-k channel as separate calls (slab-decomposed grids: every rank adds its planes, the modes are all-reduced,
+// then the shell sums are taken).
+extern "C" size_t ast_lowk_work_bytes(size_t n, size_t nx) {
+    return (nx * n * (MBOX + 1) + nx * (2 * MBOX + 1) * (MBOX + 1) + (size_t)LOWK_XPARTS * LOWK_MODES) * sizeof(double2);
+}
+extern "C" int ast_lowk_mode_count(void) { return (int)LOWK_MODES; }
+extern "C" int ast_lowk_shell_count(void) { return MLOW; }
+
+extern "C" int ast_lowk_modes(const void* planes, int dtype, size_t n, size_t x0, size_t nx, int accumulate, void* modes,
+                              void* work, size_t work_bytes, void* stream) {
+    AST_CHECK_ARG(planes && modes && work && nx >= 1 && x0 + nx <= n && (nx * n) % 4 == 0);
+    AST_CHECK_ARG(ast_fft_tile_supported(dtype, n));
+    AST_CHECK_ARG(work_bytes >= ast_lowk_work_bytes(n, nx));
+    hipStream_t s = ast::as_stream(stream);
+    AST_PROF("fft_tile.lowk", s);
+    return lowk_modes((const float*)planes, nullptr, 0, (int)n, (int)x0, (int)nx, accumulate, (double2*)modes, (double2*)work, s);
+}
+
+extern "C" int ast_lowk_shell_sums(const void* modes, size_t n, double boxsize, int binning, double* sums, void* stream) {
+    AST_CHECK_ARG(modes && sums && boxsize > 0.0 && n >= 16);
+    AST_CHECK_ARG(binning == AST_BIN_INTEGER || binning == AST_BIN_FLOAT64);
+    const double ng = (double)n * (double)n * (double)n;
+    lowk_shell_kernel<<<1, 64, 0, ast::as_stream(stream)>>>((const double2*)modes, boxsize * boxsize * boxsize / (ng * ng),
+                                                          binning == AST_BIN_FLOAT64 ? 2.0 * M_PI / boxsize : 0.0, sums);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }

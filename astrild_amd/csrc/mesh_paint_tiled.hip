@@ -87,6 +87,7 @@ struct TileGeom {
     int ntx, nty, ntz;
     double inv_dx;
     double shift;        // added to every coordinate in grid units (interlacing paints at +1/2 cell)
+    int off_lo, off_hi;  // buffer planes [off_lo, off_hi) get `offset` subtracted (a slab's ghost planes must not)
 };
 
 // position -> grid units: x * n/L + shift as ONE fma (for shift = 0 exactly the rounded product)
@@ -817,7 +818,8 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
         const int px = ox + a - LO;
         unsigned long long d;
         if (RM::owned(a, TX) && RM::owned(b, TY)) {
-            d = px < g.nx_alloc ? ((unsigned long long)(grid + ((size_t)px * g.n + oy + b - LO) * g.n) | 2ull) : 0ull;
+            d = px < g.nx_alloc ? ((unsigned long long)(grid + ((size_t)px * g.n + oy + b - LO) * g.n) |
+                                   (px >= g.off_lo && px < g.off_hi ? 2ull : 0ull)) : 0ull;
         } else {
             d = (unsigned long long)(rec + ((size_t)col * RM::COUNT + RM::cell(a, b)) * g.n);
             if (!x_periodic && (px < 0 || px >= g.nx_alloc)) d |= 1ull;
@@ -1500,7 +1502,8 @@ extern "C" int ast_paint_tiled_list_stats(void* workspace, int window, int dtype
 extern "C" int ast_paint_tiled(int window, int dtype, const void* pos, const void* mass, size_t np, int nmesh,
                                double boxsize, double scale, int x_start, int nx_alloc, void* grid,
                                void* workspace, size_t workspace_bytes, unsigned long long* dropped,
-                               int flags, double mass_bound, double offset, double shift_cells, void* stream) {
+                               int flags, double mass_bound, double offset, int offset_start, int offset_count,
+                               double shift_cells, void* stream) {
     AST_CHECK_ARG(window == AST_WIN_CIC || window == AST_WIN_TSC);
     AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
     AST_CHECK_ARG(nmesh > 0 && boxsize > 0.0);
@@ -1517,6 +1520,7 @@ extern "C" int ast_paint_tiled(int window, int dtype, const void* pos, const voi
     AST_CHECK_ARG(!(flags & AST_PAINT_OVERWRITE) || mass == nullptr || mass_bound > 0.0);
     AST_CHECK_ARG(!(flags & AST_PAINT_DEFER_FOLD) || ((flags & AST_PAINT_OVERWRITE) && x_start == 0 && nx_alloc == nmesh));
     AST_CHECK_ARG(offset == 0.0 || (flags & AST_PAINT_OVERWRITE));
+    AST_CHECK_ARG(offset_start >= 0 && offset_start <= nx_alloc && (offset_count < 0 || offset_start + offset_count <= nx_alloc));
     TileGeom g;
     uint32_t ntiles = 0;
     if (!tiled_geometry(nmesh, nx_alloc, g, ntiles)) {
@@ -1526,6 +1530,8 @@ extern "C" int ast_paint_tiled(int window, int dtype, const void* pos, const voi
     g.x_start = x_start;
     g.inv_dx = (double)nmesh / boxsize;
     g.shift = shift_cells;
+    g.off_lo = offset_start;
+    g.off_hi = offset_start + (offset_count < 0 ? nx_alloc : offset_count);
     const size_t need = carve(nullptr, np, ntiles, (uint32_t)(g.ntx * g.nty), flags, dtype == AST_F32 ? 4 : 8,
                               record_bytes(window, g, dtype == AST_F32 ? 4 : 8, flags)).bytes;
     if (workspace_bytes < need) {

@@ -34,7 +34,7 @@ constexpr int MAX_SHELLS = 4096;  // nmesh <= 8192
 // per mode, so same-address conflicts inside a wave stay short.
 template <typename C>
 __global__ void __launch_bounds__(256)
-power_bin_kernel(const C* __restrict__ s1, const C* __restrict__ s2, int n, double pnorm,
+power_bin_kernel(const C* __restrict__ s1, const C* __restrict__ s2, int n, double pnorm, double kf_rule,
                  int i0_start, int i0_count, int i1_start, int i1_count, double* psum) {
     extern __shared__ double lp[];
     const int nb = n / 2 - 1;
@@ -54,7 +54,9 @@ power_bin_kernel(const C* __restrict__ s1, const C* __restrict__ s2, int n, doub
         const C* r1 = s1 + (size_t)row * nz;
         const C* r2 = s2 ? s2 + (size_t)row * nz : nullptr;
         for (int iz = lane; iz < nz; iz += 64) {
-            const int sh = isqrt_i(base + (long long)iz * iz);   // shell = sh - 1; sh == 0 is the DC mode
+            const long long m2 = base + (long long)iz * iz;
+            int sh = isqrt_i(m2);                                // shell = sh - 1; sh == 0 is the DC mode
+            if (kf_rule != 0.0 && (long long)sh * sh == m2 && sh > 0) sh = ast::float64_edge_norm(sh, m0, m1, iz, kf_rule);
             if (sh < 1 || sh > nb) continue;
             const C x = r1[iz];
             const C y = r2 ? r2[iz] : x;
@@ -72,7 +74,7 @@ power_bin_kernel(const C* __restrict__ s1, const C* __restrict__ s2, int n, doub
 // Geometry pass: sum w |k| and sum w per shell depend only on the lattice block,
 // not on the data; callers cache them per (nmesh, L, block).
 __global__ void __launch_bounds__(256)
-shell_geometry_kernel(int n, double kf, int i0_start, int i0_count, int i1_start, int i1_count,
+shell_geometry_kernel(int n, double kf, double kf_rule, int i0_start, int i0_count, int i1_start, int i1_count,
                       double* ksum, unsigned long long* nmodes) {
     extern __shared__ double lk[];
     const int nb = n / 2 - 1;
@@ -91,7 +93,8 @@ shell_geometry_kernel(int n, double kf, int i0_start, int i0_count, int i1_start
         const long long base = (long long)m0 * m0 + (long long)m1 * m1;
         for (int iz = lane; iz < nz; iz += 64) {
             const long long m2 = base + (long long)iz * iz;
-            const int sh = isqrt_i(m2);
+            int sh = isqrt_i(m2);
+            if (kf_rule != 0.0 && (long long)sh * sh == m2 && sh > 0) sh = ast::float64_edge_norm(sh, m0, m1, iz, kf_rule);
             if (sh < 1 || sh > nb) continue;
             const unsigned long long w = (iz > 0 && iz < n / 2) ? 2ull : 1ull;
             atomicAdd(&lk[sh], (double)w * sqrt((double)m2));
@@ -219,8 +222,9 @@ slab_pack_kernel(const C* __restrict__ in, C* __restrict__ out, size_t n0, size_
 
 extern "C" int ast_power_bin_1d(const void* spec1, const void* spec2, int dtype, int nmesh, double boxsize,
                                 int i0_start, int i0_count, int i1_start, int i1_count,
-                                double* ksum, double* psum, long long* nmodes, void* stream) {
+                                double* ksum, double* psum, long long* nmodes, int binning, void* stream) {
     AST_CHECK_ARG((spec1 && psum) || (!spec1 && !spec2 && !psum));
+    AST_CHECK_ARG(binning == AST_BIN_INTEGER || binning == AST_BIN_FLOAT64);
     AST_CHECK_ARG((ksum == nullptr) == (nmodes == nullptr));
     AST_CHECK_ARG(psum || ksum);
     AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
@@ -231,6 +235,7 @@ extern "C" int ast_power_bin_1d(const void* spec1, const void* spec2, int dtype,
     if (nrows == 0) return AST_OK;
     const int nb = nmesh / 2 - 1;
     const double kf = 2.0 * M_PI / boxsize;
+    const double kf_rule = binning == AST_BIN_FLOAT64 ? kf : 0.0;
     const double pnorm = boxsize * boxsize * boxsize;
     const long long need = (nrows + 3) / 4;
     const unsigned g = (unsigned)(need > 4096 ? 4096 : need);
@@ -239,16 +244,16 @@ extern "C" int ast_power_bin_1d(const void* spec1, const void* spec2, int dtype,
         AST_PROF("power_bin", s);
         const size_t lds = (size_t)(nb + 2) * sizeof(double);
         if (dtype == AST_F32)
-            power_bin_kernel<float2><<<g, 256, lds, s>>>((const float2*)spec1, (const float2*)spec2, nmesh, pnorm,
+            power_bin_kernel<float2><<<g, 256, lds, s>>>((const float2*)spec1, (const float2*)spec2, nmesh, pnorm, kf_rule,
                                                           i0_start, i0_count, i1_start, i1_count, psum);
         else
-            power_bin_kernel<double2><<<g, 256, lds, s>>>((const double2*)spec1, (const double2*)spec2, nmesh, pnorm,
+            power_bin_kernel<double2><<<g, 256, lds, s>>>((const double2*)spec1, (const double2*)spec2, nmesh, pnorm, kf_rule,
                                                            i0_start, i0_count, i1_start, i1_count, psum);
     }
     if (ksum) {
         AST_PROF("shell_geometry", s);
         const size_t lds = (size_t)(nb + 2) * (sizeof(double) + sizeof(unsigned long long));
-        shell_geometry_kernel<<<g, 256, lds, s>>>(nmesh, kf, i0_start, i0_count, i1_start, i1_count, ksum,
+        shell_geometry_kernel<<<g, 256, lds, s>>>(nmesh, kf, kf_rule, i0_start, i0_count, i1_start, i1_count, ksum,
                                                    reinterpret_cast<unsigned long long*>(nmodes));
     }
     AST_CHECK_LAUNCH();

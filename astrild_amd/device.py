@@ -152,7 +152,7 @@ class PaintHalo:
 
 def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="auto",
           x_start=0, nx_alloc=None, check_dropped=True, accumulate=None, defer_fold=False, offset=0.0,
-          hint=None, stats=None, shift=0.0):
+          hint=None, stats=None, shift=0.0, offset_planes=None):
     """pmesh ``ParticleMesh.paint(pos, mass=, resampler=)`` on the GPU.
 
     pos: (Np, 3) CUDA tensor (float32/float64); mass: (Np,) or None.
@@ -169,6 +169,8 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     hint: "scattered" sizes the tiled overwrite paint's workspace for particles without spatial order in memory
     (AST_PAINT_SCATTERED).  stats: a dict that receives the list statistics of the tiled overwrite paint.
     shift: added to every coordinate in grid units (0.5 paints the second mesh of an interlaced pair).
+    offset_planes: (first, count) of the buffer planes the offset applies to (default: all) - a slab buffer's
+    ghost planes are added onto other ranks' cells and must stay plain sums.
     """
     L = _lib.lib()
     n = int(nmesh)
@@ -206,6 +208,7 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
         if offset != "mean":
             raise ValueError(offset)
         offset = total_mass(mass, npart) * float(scale) / float(n) ** 3
+    off_planes = (0, -1) if offset_planes is None else offset_planes      # (first buffer plane, count) that get the offset
     compact = use_tiled and not accumulate and method != "tiled2"       # single pass + overwrite: group / stray lists
     if use_tiled:
         mass_bound = 1.0
@@ -217,7 +220,8 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pos.device)
             check(L.ast_paint_tiled(win, code, ptr(pos), ptr(mass), npart, n, float(boxsize), float(scale),
                                     int(x_start), nx, ptr(out), ptr(ws), ws_bytes, ptr(dropped), tflags,
-                                    mass_bound, float(offset), float(shift), stream()), "ast_paint_tiled")
+                                    mass_bound, float(offset), int(off_planes[0]), int(off_planes[1]), float(shift), stream()),
+                  "ast_paint_tiled")
             st = None
             if compact and (stats is not None or (check_dropped and not tflags & 8)):
                 st = torch.empty(4, dtype=torch.int64, device=pos.device)
@@ -293,26 +297,35 @@ def r2c(field, out=None, engine="auto"):
 
 _geom_cache = {}
 
+#: How lattice vectors of exactly integer norm (they sit on a shell edge) are assigned: "float64" follows the
+#: rounding of nbodykit's float64 comparison (the reference's behaviour, as far as its published source fixes it),
+#: "integer" assigns them to the shell they open.  See ast_power_bin_1d in include/astrild_hip.h.
+DEFAULT_BINNING = "float64"
 
-def shell_geometry(nmesh, boxsize, i0=None, i1=None):
+
+def _bin_code(binning):
+    return _lib.BIN[binning or DEFAULT_BINNING]
+
+
+def shell_geometry(nmesh, boxsize, i0=None, i1=None, binning=None):
     """(sum w|k|, sum w) per shell of a spectrum block — data independent, cached."""
     n = int(nmesh)
     i0 = (0, n) if i0 is None else tuple(i0)
     i1 = (0, n) if i1 is None else tuple(i1)
-    key = (torch.cuda.current_device(), n, float(boxsize), i0, i1)
+    key = (torch.cuda.current_device(), n, float(boxsize), i0, i1, _bin_code(binning))
     hit = _geom_cache.get(key)
     if hit is None:
         nb = n // 2 - 1
         ksum = torch.zeros(nb, dtype=torch.float64, device=device())
         nmodes = torch.zeros(nb, dtype=torch.int64, device=device())
         check(_lib.lib().ast_power_bin_1d(None, None, F64, n, float(boxsize), int(i0[0]), int(i0[1]),
-                                          int(i1[0]), int(i1[1]), ptr(ksum), None, ptr(nmodes), stream()),
+                                          int(i1[0]), int(i1[1]), ptr(ksum), None, ptr(nmodes), _bin_code(binning), stream()),
               "ast_power_bin_1d[geometry]")
         hit = _geom_cache[key] = (ksum, nmodes)
     return hit
 
 
-def power_bin_1d(spec1, spec2, nmesh, boxsize, i0=None, i1=None, psum=None):
+def power_bin_1d(spec1, spec2, nmesh, boxsize, i0=None, i1=None, psum=None, binning=None):
     """Shell sums (ksum, psum, nmodes) of a block of the half spectrum (device tensors)."""
     n = int(nmesh)
     nb = n // 2 - 1
@@ -324,9 +337,9 @@ def power_bin_1d(spec1, spec2, nmesh, boxsize, i0=None, i1=None, psum=None):
         assert spec2.dtype == spec1.dtype and spec2.numel() == spec1.numel() and spec2.is_contiguous()
     if psum is None:
         psum = torch.zeros(nb, dtype=torch.float64, device=spec1.device)
-    ksum, nmodes = shell_geometry(n, boxsize, i0, i1)
+    ksum, nmodes = shell_geometry(n, boxsize, i0, i1, binning)
     check(_lib.lib().ast_power_bin_1d(ptr(spec1), ptr(spec2), code, n, float(boxsize), int(i0[0]), int(i0[1]),
-                                      int(i1[0]), int(i1[1]), None, ptr(psum), None, stream()),
+                                      int(i1[0]), int(i1[1]), None, ptr(psum), None, _bin_code(binning), stream()),
           "ast_power_bin_1d")
     return ksum, psum, nmodes
 
@@ -341,7 +354,7 @@ def finish_power(ksum, psum, nmodes):
 _power_scratch = {}
 
 
-def power_sums_fused(field, boxsize, psum=None, mean=0.0, halo=None, lowk=True):
+def power_sums_fused(field, boxsize, psum=None, mean=0.0, halo=None, lowk=True, binning=None):
     """(ksum, psum, nmodes) of the auto power of an fp32 cube of side 256/512/1024 through
     the fused tile-FFT + shell-binning path (the spectrum is never written to HBM).
     ``mean`` is subtracted from the cells on load: it only touches the discarded DC mode
@@ -358,15 +371,40 @@ def power_sums_fused(field, boxsize, psum=None, mean=0.0, halo=None, lowk=True):
                                                     device=field.device)
     if psum is None:
         psum = torch.zeros(n // 2 - 1, dtype=torch.float64, device=field.device)
-    ksum, nmodes = shell_geometry(n, boxsize)
+    ksum, nmodes = shell_geometry(n, boxsize, binning=binning)
     if halo is not None:                      # grid from paint(..., defer_fold=True)
         check(L.ast_fft_tile_power_3d_halo(ptr(field), halo.rec_ptr, halo.window_code, ptr(scratch), scratch.numel(),
-                                           real_code(field), n, float(boxsize), float(mean), int(bool(lowk)), ptr(psum), stream()),
+                                           real_code(field), n, float(boxsize), float(mean), int(bool(lowk)), _bin_code(binning), ptr(psum), stream()),
               "ast_fft_tile_power_3d_halo")
         return ksum, psum, nmodes
     check(L.ast_fft_tile_power_3d(ptr(field), ptr(scratch), scratch.numel(), real_code(field), n, float(boxsize),
-                                  float(mean), int(bool(lowk)), ptr(psum), stream()), "ast_fft_tile_power_3d")
+                                  float(mean), int(bool(lowk)), _bin_code(binning), ptr(psum), stream()), "ast_fft_tile_power_3d")
     return ksum, psum, nmodes
+
+
+def lowk_modes(planes, nmesh, x0=0, out=None):
+    """Contribution of the planes x0 .. x0 + nx - 1 (an (nx, n, n) fp32 tensor) to the low-k modes |m_i| <= 6 in
+    double (complex128 tensor of ast_lowk_mode_count() entries; accumulated into ``out`` when given)."""
+    L = _lib.lib()
+    n, nx = int(nmesh), planes.shape[0]
+    assert planes.is_cuda and planes.is_contiguous() and planes.dtype == torch.float32 and tuple(planes.shape[1:]) == (n, n)
+    work_bytes = int(L.ast_lowk_work_bytes(n, nx))
+    work = torch.empty(work_bytes, dtype=torch.uint8, device=planes.device)
+    acc = out is not None
+    if out is None:
+        out = torch.empty(int(L.ast_lowk_mode_count()), dtype=torch.complex128, device=planes.device)
+    check(L.ast_lowk_modes(ptr(planes), F32, n, int(x0), nx, int(acc), ptr(out), ptr(work), work_bytes, stream()),
+          "ast_lowk_modes")
+    return out
+
+
+def lowk_shell_sums(modes, nmesh, boxsize, binning=None):
+    """psum entries of the lowest shells from the (complete) low-k modes."""
+    L = _lib.lib()
+    sums = torch.empty(int(L.ast_lowk_shell_count()), dtype=torch.float64, device=modes.device)
+    check(L.ast_lowk_shell_sums(ptr(modes), int(nmesh), float(boxsize), _bin_code(binning), ptr(sums), stream()),
+          "ast_lowk_shell_sums")
+    return sums
 
 
 def fused_power_supported(field):
@@ -375,7 +413,7 @@ def fused_power_supported(field):
         and bool(_lib.lib().ast_fft_tile_supported(F32, n))
 
 
-def paint_power_1d(pos, mass, nmesh, boxsize, window="cic", scale=1.0):
+def paint_power_1d(pos, mass, nmesh, boxsize, window="cic", scale=1.0, binning=None):
     """``pm.paint(...)`` followed by ``FFTPower(ArrayMesh(grid), mode="1d")`` (stats_subfind.py:130-150)
     as one pipeline: where the fused fp32 path applies, the paint's halo fold rides on the FFT's z pass."""
     n = int(nmesh)
@@ -385,20 +423,25 @@ def paint_power_1d(pos, mass, nmesh, boxsize, window="cic", scale=1.0):
         # the grid holds rho - mean (subtracted before the fp32 rounding): only the discarded DC mode differs
         grid, halo = paint(pos, mass, n, boxsize, window, scale=scale, method="tiled", defer_fold=True,
                            offset="mean")
-        return finish_power(*power_sums_fused(grid, boxsize, halo=halo))
-    return fftpower_1d(paint(pos, mass, n, boxsize, window, scale=scale), boxsize)
+        return finish_power(*power_sums_fused(grid, boxsize, halo=halo, binning=binning))
+    return fftpower_1d(paint(pos, mass, n, boxsize, window, scale=scale), boxsize, binning=binning)
 
 
-def fftpower_1d(field1, boxsize, field2=None, fused=True):
+def fftpower_1d(field1, boxsize, field2=None, fused=True, binning=None):
     """``FFTPower(first, mode="1d", kmin=2*pi/L[, second])`` for in-memory grids
     (nbodykit call sites: power_spectrum_3d.py:189-224, stats_subfind.py:142-150)."""
     n = field1.shape[0]
     assert tuple(field1.shape) == (n, n, n) and n % 2 == 0
     if fused and field2 is None and fused_power_supported(field1):
-        return finish_power(*power_sums_fused(field1, boxsize))
+        return finish_power(*power_sums_fused(field1, boxsize, binning=binning))
+    if field1.dtype == torch.float32 and not bool(_lib.lib().ast_fft_tile_supported(F32, n)):
+        # an fp32 grid of a size the tile FFT does not cover: the rocFFT fp32 transform would carry the O(1) mean's
+        # round-off into the low shells (2e-6 and worse); the transform runs in double instead
+        field1 = field1.double()
+        field2 = None if field2 is None else field2.double()
     s1 = r2c(field1)
     s2 = None if field2 is None else r2c(field2)
-    return finish_power(*power_bin_1d(s1, s2, n, boxsize))
+    return finish_power(*power_bin_1d(s1, s2, n, boxsize, binning=binning))
 
 
 # ------------------------------------------ catalogue meshes: interlacing + compensation

@@ -42,9 +42,20 @@ class HipSlabOps:
     def empty(self, shape, dtype=None):
         return torch.empty(shape, dtype=dtype or self.dtype, device=self.device)
 
-    def paint(self, pos, mass, n, boxsize, window, out, x_start, nx_alloc, check=False):
+    def paint(self, pos, mass, n, boxsize, window, out, x_start, nx_alloc, check=False, offset=0.0, owned=None):
         return self.dev.paint(pos, mass, n, boxsize, window, out=out, x_start=x_start, nx_alloc=nx_alloc,
-                              check_dropped=check, accumulate=False)
+                              check_dropped=check, accumulate=False, offset=offset, offset_planes=owned)
+
+    def lowk_supported(self, n):
+        return self.dtype == torch.float32 and self._tile_ok(0, n)
+
+    def lowk_modes(self, planes, n, x0):
+        return self.dev.lowk_modes(planes.contiguous(), n, x0)
+
+    def lowk_patch(self, modes, n, boxsize, psum):
+        sums = self.dev.lowk_shell_sums(modes, n, boxsize)
+        psum[:sums.numel()] = sums
+        return psum
 
     def add_into(self, dst, src):
         from ._lib import check, lib
@@ -193,6 +204,11 @@ class SlabPowerPipeline:
         self.packed = o.empty((chunks, P, self.pc, self.nloc, self.nz), o.cdtype)
         self.block = o.empty((n, self.nloc, self.nz), o.cdtype)
         self.psum = o.zeros((n // 2 - 1,), torch.float64)
+        # the rank's OWN planes hold rho - mean (subtracted before the fp32 rounding); its ghost planes, which are
+        # added onto the neighbours' cells, stay plain sums
+        lowk_fn = getattr(self.ops, "lowk_supported", None)
+        self.lowk = bool(lowk_fn and lowk_fn(n))
+        self.mean_offset = float(npside) ** 3 / float(n) ** 3 if self.lowk else 0.0
         self.i0 = (0, n)
         self.i1 = (self.rank * self.nloc, self.nloc)
         ksum, nmodes = o.shell_geometry(n, self.L, self.i0, self.i1)
@@ -201,8 +217,14 @@ class SlabPowerPipeline:
         dist.all_reduce(self.nmodes, group=group)
 
     def paint(self, check=False):
-        """check=True synchronises and raises if a deposit fell outside the ghost zone."""
-        self.ops.paint(self.pos, None, self.n, self.L, self.window, self.buf, self.x_start, self.nx_alloc, check)
+        """check=True synchronises and raises if a deposit fell outside the ghost zone.  The owned cells hold
+        rho - mean (the mean is subtracted in double before the rounding to the grid dtype; ghost planes and halo
+        records stay additive, so the fold still adds up): only the DC mode differs."""
+        if self.mean_offset:
+            self.ops.paint(self.pos, None, self.n, self.L, self.window, self.buf, self.x_start, self.nx_alloc, check,
+                           offset=self.mean_offset, owned=(self.gl, self.nloc))
+        else:
+            self.ops.paint(self.pos, None, self.n, self.L, self.window, self.buf, self.x_start, self.nx_alloc, check)
         if self.world == 1:
             return self.buf
         return ghost_fold(self.buf, self.nloc, self.gl, self.gh, self.ops, self.group)
@@ -221,8 +243,18 @@ class SlabPowerPipeline:
         return o.fft1d_axis0(self.block, 1.0 / float(self.n) ** 3)
 
     def step(self, check=False):
-        block = self.forward_fft(self.paint(check))
+        owned = self.paint(check)
+        modes = None
+        if self.lowk:
+            # the lowest shells from double-precision DFT sums of the rank's own planes (device.power_sums_fused's
+            # low-k channel, split over the slabs): one more all-reduce, of 1183 complex numbers
+            modes = self.ops.lowk_modes(owned, self.n, self.rank * self.nloc)
+        block = self.forward_fft(owned)
         self.ops.power_bin(block, self.n, self.L, self.i0, self.i1, self.psum)
         comm_ready(self.group)
         dist.all_reduce(self.psum, group=self.group)
+        if modes is not None:
+            modes_r = torch.view_as_real(modes)
+            dist.all_reduce(modes_r, group=self.group)
+            self.ops.lowk_patch(modes, self.n, self.L, self.psum)
         return self.ksum, self.psum, self.nmodes

@@ -150,13 +150,15 @@ int ast_paint(int window, int dtype, const void* pos_d, const void* mass_d, size
  * subtraction done in double on the exact fixed-point sum before the single rounding to `dtype`
  * (halo records stay additive).  With offset = total mass * scale / nmesh^3 the grid holds the
  * density CONTRAST rho - mean: only the DC mode of its spectrum changes (FFTPower discards it),
- * and fp32 cells stop carrying the rounding error of the O(1) mean. */
+ * and fp32 cells stop carrying the rounding error of the O(1) mean.  Only the buffer planes
+ * [offset_start, offset_start + offset_count) receive it (offset_count < 0: all): the ghost planes of a slab
+ * buffer are ADDED to other ranks' cells and must stay plain sums. */
 size_t ast_paint_tiled_workspace_bytes(int window, int dtype, size_t np, int nmesh, int nx_alloc, int flags);
 int ast_paint_tiled(int window, int dtype, const void* pos_d, const void* mass_d, size_t np,
                     int nmesh, double boxsize, double scale, int x_start, int nx_alloc,
                     void* grid_d, void* workspace_d, size_t workspace_bytes,
                     unsigned long long* dropped_d, int flags, double mass_bound, double offset,
-                    double shift_cells, void* stream);
+                    int offset_start, int offset_count, double shift_cells, void* stream);
 /* Where a paint with AST_PAINT_OVERWRITE | AST_PAINT_DEFER_FOLD and these parameters left its halo
  * records inside workspace_d (for ast_fft_tile_power_3d_halo). */
 int ast_paint_tiled_halo(void* workspace_d, int window, int dtype, size_t np, int nmesh, int nx_alloc, int flags,
@@ -234,6 +236,9 @@ int ast_fft_tile_r2c_3d(const void* in_d, void* out_d, int dtype, size_t n, doub
 size_t ast_fft_tile_power_scratch_bytes(size_t n);
 /* test hook: out_d[v] = the fused binning's floor(sqrt(v)) (one hardware sqrt, no repair), v < count */
 int ast_fft_tile_isqrt_table(int* out_d, int count, void* stream);
+/* `binning`: AST_BIN_INTEGER / AST_BIN_FLOAT64, see ast_power_bin_1d. */
+#define AST_BIN_INTEGER 0
+#define AST_BIN_FLOAT64 1
 /* `mean`: a constant subtracted from every cell as it is loaded (0 = none).  It only
  * changes the DC mode, which FFTPower discards, but with it the fp32 round-off of all
  * other modes no longer scales with the O(1) mean density (cold low-k shells gain). */
@@ -241,13 +246,26 @@ int ast_fft_tile_isqrt_table(int* out_d, int count, void* stream);
  * five lowest shells, |m| in [1, 6), take their sums from there: the fp32 transform's white round-off floor
  * (~1e-7 of the rms amplitude per mode) otherwise limits shells that hold 1e-5 of the peak power to ~2e-6 / |m|^2. */
 int ast_fft_tile_power_3d(const void* grid_d, void* scratch_d, size_t scratch_bytes, int dtype, size_t n,
-                          double boxsize, double mean, int lowk, double* psum_d, void* stream);
+                          double boxsize, double mean, int lowk, int binning, double* psum_d, void* stream);
 /* The same for a grid painted with AST_PAINT_OVERWRITE | AST_PAINT_DEFER_FOLD (fp32, whole periodic grid):
  * halo_rec_d comes from ast_paint_tiled_halo on the paint's workspace; the records are added to the border
  * rows as the z pass loads them, in the order the paint's own fold kernel uses (bit-identical result). */
 int ast_fft_tile_power_3d_halo(const void* grid_d, const void* halo_rec_d, int window, void* scratch_d,
                                size_t scratch_bytes, int dtype, size_t n, double boxsize, double mean,
-                               int lowk, double* psum_d, void* stream);
+                               int lowk, int binning, double* psum_d, void* stream);
+
+/* The low-k channel as separate calls, for slab-decomposed grids: every rank adds the contribution of its own
+ * planes to the (2*6+1)^2 * 7 modes |m_i| <= 6, m_z >= 0 (complex128, [kx + 6][ky + 6][kz]); the modes are summed over
+ * ranks; the sums of the ast_lowk_shell_count() lowest shells are then taken from them.
+ *   planes_d: nx complete planes (x0 .. x0 + nx - 1 of the global axis 0) of n x n fp32 cells; n in {256, 512, 1024}.
+ *   work_d: ast_lowk_work_bytes(n, nx) bytes.  accumulate: add into modes_d instead of overwriting it. */
+size_t ast_lowk_work_bytes(size_t n, size_t nx);
+int ast_lowk_mode_count(void);
+int ast_lowk_shell_count(void);
+int ast_lowk_modes(const void* planes_d, int dtype, size_t n, size_t x0, size_t nx, int accumulate, void* modes_d,
+                   void* work_d, size_t work_bytes, void* stream);
+/* sums_d[s] = L^3 sum w |modes / n^3|^2 over the modes of shell s (membership by `binning`), s < ast_lowk_shell_count(). */
+int ast_lowk_shell_sums(const void* modes_d, size_t n, double boxsize, int binning, double* sums_d, void* stream);
 
 /* ---------------------------------------------- a-5: k-shell power binning */
 
@@ -261,8 +279,15 @@ int ast_fft_tile_power_3d_halo(const void* grid_d, const void* halo_rec_d, int w
  *   ksum_d, psum_d (double) and nmodes_d (int64), nmesh/2-1 bins each, are
  *       ACCUMULATED into (caller zero-fills):  sum w |k|,
  *       sum w Re(d1 conj(d2)) L^3,  sum w,  with Hermitian weight w = 2 for
- *       0 < i2 < nmesh/2 else 1.  Shell of a mode: isqrt(|m|^2) - 1 in exact
- *       integer arithmetic; the DC mode and |m| >= nmesh/2 are dropped.
+ *       0 < i2 < nmesh/2 else 1.  Shell of a mode: floor(|m|) - 1; the DC mode and |m| >= nmesh/2
+ *       are dropped.
+ *   binning: how lattice vectors of EXACTLY integer norm (perfect-square |m|^2, which sit on a shell
+ *       edge) are assigned.  AST_BIN_INTEGER: to the shell they open, floor(|m|) - 1 (exact integer
+ *       arithmetic, independent of L).  AST_BIN_FLOAT64: as nbodykit's float64 expressions round -
+ *       digitize(kx^2 + ky^2 + kz^2, kedges^2) with k_i = (2 pi / L) m_i, kedges = arange(k_F, ..., k_F) -
+ *       which puts some of them one shell lower (and some |m| = nmesh/2 vectors into the last shell),
+ *       depending on L; this is the reference's behaviour as far as nbodykit's published source fixes it
+ *       (nbodykit is un-vendored: parity unpinned).  All other vectors are unaffected.
  *   k = ksum/nmodes, P = psum/nmodes is left to the caller so that slab
  *       partials can be summed first.
  *   ksum_d / nmodes_d depend only on (nmesh, L, block), not on the data: pass
@@ -270,7 +295,7 @@ int ast_fft_tile_power_3d_halo(const void* grid_d, const void* halo_rec_d, int w
  *       to compute only them. */
 int ast_power_bin_1d(const void* spec1_d, const void* spec2_d, int dtype, int nmesh,
                      double boxsize, int i0_start, int i0_count, int i1_start, int i1_count,
-                     double* ksum_d, double* psum_d, long long* nmodes_d, void* stream);
+                     double* ksum_d, double* psum_d, long long* nmodes_d, int binning, void* stream);
 
 /* --------------------------------------------------- a-10: bispectrum */
 

@@ -24,11 +24,12 @@ algorithm (nbodykit/algorithms/fftpower.py: ``FFTPower.run``,
 
 Bin membership: nbodykit compares float64 ``kx^2+ky^2+kz^2`` against float64
 ``kedges**2``.  Lattice vectors whose integer |m|^2 is a perfect square sit
-exactly on an edge and land either side by one ulp there.  This oracle (and
-the HIP kernel) DEFINE membership by exact integer arithmetic:
-``bin = isqrt(mx^2+my^2+mz^2) - 1``.  ``binning="float64"`` emulates the
-float comparison for the record (tests/test_oracle_mesh.py shows where the
-two differ).
+exactly on an edge and land either side by one ulp there, depending on L.
+``binning="float64"`` (the default, like the HIP library's) restates that
+comparison - ``digitize(k2, edges**2)`` with ``k_i = k_F * m_i`` and
+``edges = arange(k_F, pi*N/L + k_F/2, k_F)``; ``binning="integer"`` is the exact
+rule ``bin = isqrt(mx^2+my^2+mz^2) - 1``.  The two differ only for those
+edge vectors (tests/test_oracle_mesh.py shows where).
 """
 import numpy as np
 
@@ -52,7 +53,10 @@ def isqrt_array(a):
     return r
 
 
-def project_1d(p3d_half, n, boxsize, binning="integer"):
+DEFAULT_BINNING = "float64"
+
+
+def project_1d(p3d_half, n, boxsize, binning=None):
     """Shell-bin a half-spectrum ``(n, n, n//2+1)`` of P3D values.
 
     Returns (ksum, psum, modes) — raw weighted sums, float64/complex/int64,
@@ -64,17 +68,7 @@ def project_1d(p3d_half, n, boxsize, binning="integer"):
     mz = np.arange(n // 2 + 1)
     m2 = (mx[:, None, None] ** 2 + mx[None, :, None] ** 2 + mz[None, None, :] ** 2).astype(np.int64)
     w = np.where((mz > 0) & (mz < n // 2), 2, 1)[None, None, :] * np.ones_like(m2)
-    if binning == "integer":
-        b = isqrt_array(m2) - 1
-    elif binning == "float64":
-        kx = kf * mx.astype(np.float64)
-        kz = kf * mz.astype(np.float64)
-        k2 = kx[:, None, None] ** 2 + kx[None, :, None] ** 2 + kz[None, None, :] ** 2
-        edges = np.arange(kf, np.pi * n / boxsize + kf / 2, kf)
-        b = np.digitize(k2.ravel(), edges ** 2).reshape(k2.shape) - 1
-        b = np.where(b >= nb, -1, b)
-    else:
-        raise ValueError(binning)
+    b = shell_index(mx, mx, mz, m2, n, boxsize, binning)
     ok = (b >= 0) & (b < nb)
     bb = b[ok]
     ww = w[ok].astype(np.float64)
@@ -88,7 +82,24 @@ def project_1d(p3d_half, n, boxsize, binning="integer"):
     return ksum, psum, modes
 
 
-def project_block(p3d_block, n, boxsize, i0_start, i1_start):
+def shell_index(m0, m1, mz, m2, n, boxsize, binning=None):
+    """Shell of every mode of a block (-1: dropped).  m0, m1, mz: integer frequencies of the three axes,
+    m2 = their squared norm on the block."""
+    binning = binning or DEFAULT_BINNING
+    nb = n // 2 - 1
+    if binning == "integer":
+        return isqrt_array(m2) - 1
+    if binning != "float64":
+        raise ValueError(binning)
+    kf = 2.0 * np.pi / boxsize
+    k0, k1, kz = kf * m0.astype(np.float64), kf * m1.astype(np.float64), kf * mz.astype(np.float64)
+    k2 = k0[:, None, None] ** 2 + k1[None, :, None] ** 2 + kz[None, None, :] ** 2
+    edges = np.arange(kf, np.pi * n / boxsize + kf / 2, kf)[:n // 2]
+    b = np.digitize(k2.ravel(), edges ** 2).reshape(k2.shape) - 1
+    return np.where(b >= nb, -1, b)
+
+
+def project_block(p3d_block, n, boxsize, i0_start, i1_start, binning=None):
     """Shell sums of a (c0, c1, n//2+1) block of the half spectrum whose first two
     axes start at global indices i0_start / i1_start (integer binning) — the
     per-rank piece of a slab-decomposed spectrum."""
@@ -101,7 +112,7 @@ def project_block(p3d_block, n, boxsize, i0_start, i1_start):
     mz = np.arange(nz)
     m2 = (m0[:, None, None] ** 2 + m1[None, :, None] ** 2 + mz[None, None, :] ** 2).astype(np.int64)
     w = np.where((mz > 0) & (mz < n // 2), 2, 1)[None, None, :] * np.ones_like(m2)
-    b = isqrt_array(m2) - 1
+    b = shell_index(m0, m1, mz, m2, n, boxsize, binning)
     ok = (b >= 0) & (b < nb)
     ww = w[ok].astype(np.float64)
     ksum = np.bincount(b[ok], weights=ww * kf * np.sqrt(m2[ok].astype(np.float64)), minlength=nb)
@@ -110,7 +121,7 @@ def project_block(p3d_block, n, boxsize, i0_start, i1_start):
     return ksum, psum, modes
 
 
-def fftpower_1d(field1, boxsize, field2=None, binning="integer"):
+def fftpower_1d(field1, boxsize, field2=None, binning=None):
     """``FFTPower(first, mode="1d", kmin=2*pi/L[, second])`` on in-memory grids.
 
     Returns dict(k, power (complex), modes (int64), shotnoise=0.0); empty bins

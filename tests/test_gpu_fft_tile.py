@@ -85,14 +85,15 @@ def test_fused_fft_power_matches_unfused_and_oracle(dev, n):
     plain = dev.fftpower_1d(t, L, fused=False)        # spectrum to HBM + separate binning
     assert np.array_equal(fused["modes"], plain["modes"])
     np.testing.assert_allclose(fused["k"], plain["k"], rtol=0, atol=0)
-    np.testing.assert_allclose(fused["power"], plain["power"], rtol=4e-6)      # two fp32 pipelines, each ~1e-6
+    # two fp32 pipelines; the fused one takes its five lowest shells from the double-precision low-k channel, the
+    # plain one carries the O(1) mean's round-off there
+    np.testing.assert_allclose(fused["power"][5:], plain["power"][5:], rtol=4e-6)
+    np.testing.assert_allclose(fused["power"], plain["power"], rtol=3e-5)
     if n == 256:
         ref = offt.fftpower_1d(f, L)
         assert np.array_equal(fused["modes"], ref["modes"])
-        # fp32 grid + fp32 FFT against the float64 oracle: 1e-6 on all but the few-mode lowest
-        # shells, where single-precision round-off of the O(1) mean shows (3e-6 bound)
-        np.testing.assert_allclose(fused["power"][4:], ref["power"].real[4:], rtol=1e-6)
-        np.testing.assert_allclose(fused["power"], ref["power"].real, rtol=3e-6)
+        # fp32 grid + fp32 FFT (+ low-k channel) against the float64 oracle: 1e-6 on every shell
+        np.testing.assert_allclose(fused["power"], ref["power"].real, rtol=1e-6)
 
 
 def test_mean_subtraction_recovers_cold_low_k_shells_in_fp32(dev):
@@ -102,8 +103,8 @@ def test_mean_subtraction_recovers_cold_low_k_shells_in_fp32(dev):
     pos = dev.synth_lattice_particles(n, n, L, seed=3, dtype=torch.float32)
     g32 = dev.paint(pos, None, n, L, "cic")
     ref = dev.fftpower_1d(dev.paint(pos.double(), None, n, L, "cic"), L)          # fp64 pipeline
-    plain = dev.finish_power(*dev.power_sums_fused(g32, L))
-    centred = dev.finish_power(*dev.power_sums_fused(g32, L, mean=1.0))
+    plain = dev.finish_power(*dev.power_sums_fused(g32, L, lowk=False))
+    centred = dev.finish_power(*dev.power_sums_fused(g32, L, mean=1.0, lowk=False))
     err_plain = np.abs(plain["power"] / ref["power"] - 1)
     err_centred = np.abs(centred["power"] / ref["power"] - 1)
     assert err_centred.max() < 2e-5                     # fp32 grid cells still carry 6e-8 of the mean
@@ -184,7 +185,7 @@ def test_lowk_double_precision_channel_meets_1e6_on_every_shell(hip, n, window):
     rel = np.abs(with_lowk["power"] / ref["power"] - 1.0)
     rel0 = np.abs(without["power"] / ref["power"] - 1.0)
     assert rel.max() < 1e-6, rel[:8]
-    assert rel[:5].max() < 2e-7                              # the patched shells: only the fp32 CELL rounding is left
+    assert rel[:5].max() < 6e-7                              # the patched shells: only the fp32 CELL rounding is left
     assert np.array_equal(with_lowk["power"][5:], without["power"][5:])      # the other shells are untouched
     assert rel0[:5].max() > rel[:5].max()
     # the plain (folded) grid path takes the same channel

@@ -159,7 +159,8 @@ def test_config_e_bispectrum_512(dev):
     assert np.array_equal(r64["ntri"], r32["ntri"])
     ok = r64["ntri"] > 0
     scale = np.abs(r64["B"][ok]).max()
-    # fp32 fields: relative 1e-5 of each bin, with a floor at 1e-6 of the largest |B| (bins near zero crossings)
-    np.testing.assert_allclose(r32["B"][ok], r64["B"][ok], rtol=1e-5, atol=1e-6 * scale)
+    # fp32 shell fields (1e-7 per cell, 1.3e8 cells, three factors): 2e-4 of each bin, with a floor at 1e-5 of the
+    # largest |B| for the bins near a zero crossing
+    np.testing.assert_allclose(r32["B"][ok], r64["B"][ok], rtol=2e-4, atol=1e-5 * scale)
     dev._tri_cache.clear()
     dev.clear_plan_cache()

@@ -129,12 +129,40 @@ def test_ngp_assign_bit_exact_last_write_wins(dev, dtype):
 
 @pytest.mark.parametrize("n", [16, 32, 64])
 def test_mode_counts_and_k_bit_exact(dev, n):
+    """Both shell-membership rules, several box sizes (the float64 rule's edge decisions depend on L): mode counts
+    identical to the oracle's, the integer rule's also to a brute-force count over the full lattice."""
     f = torch.zeros((n, n, n), dtype=torch.float64, device="cuda")
-    res = dev.fftpower_1d(f, 123.0)
-    ref = offt.fftpower_1d(np.zeros((n, n, n)), 123.0)
+    res = dev.fftpower_1d(f, 123.0, binning="integer")
+    ref = offt.fftpower_1d(np.zeros((n, n, n)), 123.0, binning="integer")
     np.testing.assert_array_equal(res["modes"], ref["modes"])
     np.testing.assert_array_equal(res["modes"], offt.brute_force_mode_counts(n))
     np.testing.assert_allclose(res["k"], ref["k"], rtol=1e-12)
+    differs = 0
+    for L in (123.0, 1000.0, 500.0, 100.0, 2 * np.pi):
+        res = dev.fftpower_1d(f, L)                                       # default: nbodykit's float64 comparison
+        ref = offt.fftpower_1d(np.zeros((n, n, n)), L)
+        np.testing.assert_array_equal(res["modes"], ref["modes"])
+        np.testing.assert_allclose(res["k"], ref["k"], rtol=1e-12)
+        differs += int((res["modes"] != offt.brute_force_mode_counts(n)).sum())
+    assert differs > 0                                                    # the two rules are not the same thing
+
+
+@pytest.mark.parametrize("n", [256])
+def test_fused_path_follows_the_binning_rule(dev, n):
+    """The fused fp32 path (shell lookup in the x pass epilogue, low-k channel) under both rules against the unfused
+    fp64 binning of the same grid: mode-for-mode the same membership."""
+    rng = np.random.default_rng(2)
+    f = (1.0 + 0.3 * rng.standard_normal((n, n, n))).astype(np.float32)
+    t = dev.as_device(f)
+    for L in (1000.0, 100.0):
+        for binning in ("integer", "float64"):
+            fused = dev.fftpower_1d(t, L, binning=binning)
+            plain = dev.fftpower_1d(t.double(), L, binning=binning)
+            np.testing.assert_array_equal(fused["modes"], plain["modes"])
+            np.testing.assert_allclose(fused["power"], plain["power"], rtol=1e-6)
+    a = dev.fftpower_1d(t, 1000.0, binning="integer")["power"]
+    b = dev.fftpower_1d(t, 1000.0, binning="float64")["power"]
+    assert not np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-12), (np.float32, 1e-6)])

@@ -105,14 +105,15 @@ def test_slab_pipeline_object_on_one_gpu_over_nccl(hip):
         ref = dev.fftpower_1d(dev.paint(pos, None, n, L, "cic"), L)
         assert np.array_equal(res["modes"], ref["modes"])
         np.testing.assert_allclose(res["k"], ref["k"], rtol=1e-12)
-        np.testing.assert_allclose(res["power"], ref["power"], rtol=5e-6)
+        np.testing.assert_allclose(res["power"], ref["power"], rtol=2e-6)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,dt,rtol", [(2, 64, "f64", 1e-9), (4, 256, "f32", 3e-5),
+@pytest.mark.parametrize("world,n,dt,rtol", [(2, 64, "f64", 1e-9), (4, 256, "f32", 2e-6),
                                              # config C rehearsal at its stated size: the 1024^3 problem on 2 / 4 ranks
-                                             (2, 1024, "f32", 3e-5), (4, 1024, "f32", 3e-5)])
+                                             # (fp32 slabs hold rho - mean, lowest shells from the low-k channel)
+                                             (2, 1024, "f32", 2e-6), (4, 1024, "f32", 2e-6)])
 def test_ranks_share_one_gpu_over_gloo(hip, tmp_path, world, n, dt, rtol):
     """The real multi-rank data flow (ghost fold, chunked exchange, all-reduces) with HipSlabOps:
     `world` processes, all on cuda:0, gloo instead of RCCL (one GPU here), against the single-GPU path."""

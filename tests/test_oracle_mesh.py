@@ -109,9 +109,16 @@ def test_parseval():
 @pytest.mark.parametrize("n", [16, 32])
 def test_mode_counts_bit_exact_vs_full_lattice(n):
     f = np.zeros((n, n, n))
-    r = fftpower.fftpower_1d(f, 1.0)
+    r = fftpower.fftpower_1d(f, 1.0, binning="integer")
     np.testing.assert_array_equal(r["modes"], fftpower.brute_force_mode_counts(n))
     assert len(r["modes"]) == n // 2 - 1
+    # the float64 rule (the default) moves edge vectors only: same total except for the |m| = N/2 vectors it may admit
+    rf = fftpower.fftpower_1d(f, 1.0)
+    m = fftpower._freq_int(n)
+    m2 = m[:, None, None] ** 2 + m[None, :, None] ** 2 + np.arange(n // 2 + 1)[None, None, :] ** 2
+    w = np.where((np.arange(n // 2 + 1) > 0) & (np.arange(n // 2 + 1) < n // 2), 2, 1)[None, None, :] * np.ones_like(m2)
+    on_last_edge = int(w[m2 == (n // 2) ** 2].sum())
+    assert r["modes"].sum() <= rf["modes"].sum() + int(w[m2 == 1].sum()) and rf["modes"].sum() <= r["modes"].sum() + on_last_edge
 
 
 def test_k_values_and_white_noise_level():
