@@ -39,6 +39,8 @@ SIGNATURES = {
     "ast_paint_tiled_workspace_bytes": (_sz, [_i, _i, _sz, _i, _i, _i]),
     "ast_paint_tiled": (_i, [_i, _i, _vp, _vp, _sz, _i, _d, _d, _i, _i, _vp, _vp, _sz, _vp, _i, _d, _d, _i, _i, _d, _vp]),
     "ast_paint_tiled_list_stats": (_i, [_vp, _i, _i, _sz, _i, _i, _i, _vp, _vp]),
+    "ast_route_count": (_i, [_vp, _i, _sz, _i, _d, _i, _i, _vp, _vp]),
+    "ast_route_scatter": (_i, [_vp, _vp, _i, _sz, _i, _d, _i, _i, _vp, _vp, _vp, _vp]),
     "ast_accumulate": (_i, [_vp, _vp, _i, _sz, _vp]),
     "ast_fft_plan_create": (_i, [ct.POINTER(_vp), _i, _i, _i, ct.POINTER(_sz), _sz, _d, _i]),
     "ast_fft_plan_create_strided_1d": (_i, [ct.POINTER(_vp), _i, _i, _sz, _sz, _sz, _sz, _d]),

@@ -342,3 +342,102 @@ extern "C" int ast_synth_lattice_particles(void* pos, int dtype, size_t first, s
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
+
+// ---- particle routing for slab-decomposed paints ----
+// Destination of a particle = the slab that owns its base plane (the cell floor(s) for CIC, the nearest grid
+// point floor(s + 1/2) for NGP / TSC, wrapped into the box), slabs of nloc = nmesh / nparts planes.
+namespace {
+constexpr int ROUTE_MAX_PARTS = 64;
+
+template <typename T>
+__device__ inline int route_dest(T x, double inv_dx, double half, int n, int nloc) {
+    const double fl = floor((double)x * inv_dx + half);
+    const double dn = (double)n;
+    double r = fl - floor(fl / dn) * dn;
+    r = r >= dn ? r - dn : r;
+    r = r < 0.0 ? r + dn : r;
+    return (int)r / nloc;
+}
+
+// MODE 0: counts[part] += particles; MODE 1: scatter to out at cursor[part] (reserved per block through LDS counts)
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256)
+route_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t np, double inv_dx, double half, int n, int nloc,
+             int nparts, unsigned long long* __restrict__ counts, T* __restrict__ out_pos, T* __restrict__ out_mass) {
+    __shared__ unsigned int lcount[ROUTE_MAX_PARTS];
+    __shared__ unsigned long long lbase[ROUTE_MAX_PARTS];
+    const size_t per_block = 256 * 8;
+    for (size_t b0 = (size_t)blockIdx.x * per_block; b0 < np; b0 += (size_t)gridDim.x * per_block) {
+        if (threadIdx.x < ROUTE_MAX_PARTS) lcount[threadIdx.x] = 0;
+        __syncthreads();
+        int dest[8];
+        unsigned int slot[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const size_t p = b0 + (size_t)u * 256 + threadIdx.x;
+            dest[u] = -1;
+            if (p < np) {
+                dest[u] = route_dest(pos[3 * p], inv_dx, half, n, nloc);
+                slot[u] = atomicAdd(&lcount[dest[u]], 1u);
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < nparts && lcount[threadIdx.x])
+            lbase[threadIdx.x] = atomicAdd(&counts[threadIdx.x], (unsigned long long)lcount[threadIdx.x]);
+        if (MODE == 1) {
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (dest[u] < 0) continue;
+                const size_t p = b0 + (size_t)u * 256 + threadIdx.x;
+                const size_t q = (size_t)(lbase[dest[u]] + slot[u]);
+                out_pos[3 * q + 0] = pos[3 * p + 0];
+                out_pos[3 * q + 1] = pos[3 * p + 1];
+                out_pos[3 * q + 2] = pos[3 * p + 2];
+                if (mass) out_mass[q] = mass[p];
+            }
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+
+// counts_d[part] (uint64, caller zero-fills) += number of particles whose base plane belongs to slab `part`.
+extern "C" int ast_route_count(const void* pos, int dtype, size_t np, int nmesh, double boxsize, int window, int nparts,
+                               unsigned long long* counts, void* stream) {
+    AST_CHECK_ARG(counts && (pos || np == 0) && nmesh > 0 && boxsize > 0.0);
+    AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
+    AST_CHECK_ARG(nparts >= 1 && nparts <= ROUTE_MAX_PARTS && nmesh % nparts == 0);
+    if (np == 0) return AST_OK;
+    const double half = window == AST_WIN_CIC ? 0.0 : 0.5;
+    const unsigned g = ast::stream_grid((np + 7) / 8, 256);
+    hipStream_t s = ast::as_stream(stream);
+    if (dtype == AST_F32)
+        route_kernel<float, 0><<<g, 256, 0, s>>>((const float*)pos, nullptr, np, nmesh / boxsize, half, nmesh, nmesh / nparts, nparts, counts, nullptr, nullptr);
+    else
+        route_kernel<double, 0><<<g, 256, 0, s>>>((const double*)pos, nullptr, np, nmesh / boxsize, half, nmesh, nmesh / nparts, nparts, counts, nullptr, nullptr);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+// Particles grouped by destination slab: slab `part` occupies out[cursor_d[part] ...) where cursor_d holds the
+// exclusive prefix sums of ast_route_count on entry (it is advanced; order inside a slab's range is not defined).
+extern "C" int ast_route_scatter(const void* pos, const void* mass, int dtype, size_t np, int nmesh, double boxsize,
+                                 int window, int nparts, unsigned long long* cursor, void* out_pos, void* out_mass,
+                                 void* stream) {
+    AST_CHECK_ARG(cursor && (pos || np == 0) && (out_pos || np == 0) && nmesh > 0 && boxsize > 0.0);
+    AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
+    AST_CHECK_ARG((mass == nullptr) == (out_mass == nullptr));
+    AST_CHECK_ARG(nparts >= 1 && nparts <= ROUTE_MAX_PARTS && nmesh % nparts == 0);
+    if (np == 0) return AST_OK;
+    const double half = window == AST_WIN_CIC ? 0.0 : 0.5;
+    const unsigned g = ast::stream_grid((np + 7) / 8, 256);
+    hipStream_t s = ast::as_stream(stream);
+    AST_PROF("route_scatter", s);
+    if (dtype == AST_F32)
+        route_kernel<float, 1><<<g, 256, 0, s>>>((const float*)pos, (const float*)mass, np, nmesh / boxsize, half, nmesh, nmesh / nparts, nparts, cursor, (float*)out_pos, (float*)out_mass);
+    else
+        route_kernel<double, 1><<<g, 256, 0, s>>>((const double*)pos, (const double*)mass, np, nmesh / boxsize, half, nmesh, nmesh / nparts, nparts, cursor, (double*)out_pos, (double*)out_mass);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}

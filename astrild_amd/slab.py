@@ -108,6 +108,23 @@ class HipSlabOps:
         self.dev.power_bin_1d(block, None, n, boxsize, i0, i1, psum=psum)
         return psum
 
+    def route_count(self, pos, n, boxsize, window, parts):
+        from ._lib import WIN, check, lib
+        counts = torch.zeros(parts, dtype=torch.int64, device=self.device)
+        check(lib().ast_route_count(self.dev.ptr(pos), self.dev.real_code(pos), pos.shape[0], n, float(boxsize),
+                                    WIN[window.lower()], parts, self.dev.ptr(counts), self.dev.stream()), "ast_route_count")
+        return counts
+
+    def route_scatter(self, pos, mass, n, boxsize, window, parts, counts):
+        from ._lib import WIN, check, lib
+        cursor = torch.cumsum(counts, 0) - counts                  # exclusive prefix sums (P values)
+        out_pos = torch.empty_like(pos)
+        out_mass = None if mass is None else torch.empty_like(mass)
+        check(lib().ast_route_scatter(self.dev.ptr(pos), self.dev.ptr(mass), self.dev.real_code(pos), pos.shape[0], n,
+                                      float(boxsize), WIN[window.lower()], parts, self.dev.ptr(cursor), self.dev.ptr(out_pos),
+                                      self.dev.ptr(out_mass), self.dev.stream()), "ast_route_scatter")
+        return out_pos, out_mass
+
     def synth(self, npside, n, boxsize, seed, shuffle, first, count):
         return self.dev.synth_lattice_particles(npside, n, boxsize, seed=seed, shuffle=shuffle, dtype=self.dtype,
                                                 first=first, count=count)
@@ -166,11 +183,34 @@ def exchange_chunk(packed_c, block, chunk, pc, nloc, group=None):
     return dist.batch_isend_irecv(ops_list) if ops_list else []
 
 
+def route_particles(pos, mass, n, boxsize, window, ops, group=None):
+    """particles that are not partitioned by slab go to the rank that owns their base plane -
+    count per destination, group by destination on the device, one all-to-all of the counts and one all-to-all-v of
+    the 12-16 B per particle (positions, then masses).  Returns this rank's (pos, mass); a deposit then reaches at
+    most the window's own width beyond the slab (ghost = 0)."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return pos, mass
+    counts = ops.route_count(pos, n, boxsize, window, world)
+    spos, smass = ops.route_scatter(pos, mass, n, boxsize, window, world, counts)
+    incoming = torch.empty_like(counts)
+    comm_ready(group)
+    dist.all_to_all_single(incoming, counts, group=group)
+    send, recv = [int(v) for v in counts.tolist()], [int(v) for v in incoming.tolist()]
+    out_pos = spos.new_empty((sum(recv), 3))
+    dist.all_to_all_single(out_pos, spos, output_split_sizes=recv, input_split_sizes=send, group=group)
+    out_mass = None
+    if mass is not None:
+        out_mass = smass.new_empty((sum(recv),))
+        dist.all_to_all_single(out_mass, smass, output_split_sizes=recv, input_split_sizes=send, group=group)
+    return out_pos, out_mass
+
+
 class SlabPowerPipeline:
     """CIC/TSC + slab FFT + P(k) for the synthetic lattice workload of bench.py."""
 
     def __init__(self, n, boxsize, npside, window="cic", dtype=torch.float32, seed=20240601, shuffle=False,
-                 ghost=4, ops=None, group=None, pos=None, chunks=None):
+                 ghost=4, ops=None, group=None, pos=None, chunks=None, route=False):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -179,6 +219,10 @@ class SlabPowerPipeline:
             raise ValueError(f"grid {n} and particle lattice {npside} must be divisible by the number of ranks {P}")
         self.n, self.L, self.window = n, float(boxsize), window
         self.ops = ops or HipSlabOps(dtype)
+        if route:
+            # arbitrary input (`pos`, or the synthetic set in shuffled order): every particle goes to the rank that
+            # owns its base plane first, so the deposits reach no further than the window itself
+            ghost = 0
         self.nloc = n // P
         self.nz = n // 2 + 1
         # particles jitter across slab boundaries: ghost planes take base cells up to
@@ -192,6 +236,9 @@ class SlabPowerPipeline:
         self.nx_alloc = self.nloc + self.gl + self.gh
         ppr = npside ** 3 // P
         self.pos = pos if pos is not None else self.ops.synth(npside, n, self.L, seed, shuffle, self.rank * ppr, ppr)
+        self.npart_total = float(npside) ** 3
+        if route:
+            self.pos, _ = route_particles(self.pos, None, n, self.L, window, self.ops, group)
         o = self.ops
         self.buf = o.empty((self.nx_alloc, n, n))
         self.spec2d = o.empty((self.nloc, n, self.nz), o.cdtype)
@@ -208,7 +255,10 @@ class SlabPowerPipeline:
         # added onto the neighbours' cells, stay plain sums
         lowk_fn = getattr(self.ops, "lowk_supported", None)
         self.lowk = bool(lowk_fn and lowk_fn(n))
-        self.mean_offset = float(npside) ** 3 / float(n) ** 3 if self.lowk else 0.0
+        total = torch.tensor([float(self.pos.shape[0])], dtype=torch.float64, device=self.pos.device)
+        comm_ready(group)
+        dist.all_reduce(total, group=group)
+        self.mean_offset = float(total.item()) / float(n) ** 3 if self.lowk else 0.0
         self.i0 = (0, n)
         self.i1 = (self.rank * self.nloc, self.nloc)
         ksum, nmodes = o.shell_geometry(n, self.L, self.i0, self.i1)

@@ -183,6 +183,17 @@ int ast_paint_tiled_list_stats(void* workspace_d, int window, int dtype, size_t 
 int ast_interlace_compensate(void* c1_d, const void* c2_d, int dtype, int nmesh, int window, int compensate,
                              int i0_start, int i0_count, int i1_start, int i1_count, void* stream);
 
+/* Particle routing for input that is not partitioned by slab: the destination of a particle is
+ * the slab (nmesh / nparts planes of axis 0) that owns its base plane - floor(s) for CIC, floor(s + 1/2) for NGP/TSC,
+ * s = x nmesh / boxsize, wrapped.  ast_route_count: counts_d[part] (device uint64, caller zero-fills) += particles per
+ * slab.  ast_route_scatter: cursor_d holds the exclusive prefix sums of the counts on entry (it is advanced); slab
+ * `part`'s particles are written contiguously to out_pos_d (and out_mass_d when mass_d is given) from its cursor on,
+ * ready for an all-to-all-v with the counts as split sizes.  nparts <= 64. */
+int ast_route_count(const void* pos_d, int dtype, size_t np, int nmesh, double boxsize, int window, int nparts,
+                    unsigned long long* counts_d, void* stream);
+int ast_route_scatter(const void* pos_d, const void* mass_d, int dtype, size_t np, int nmesh, double boxsize, int window,
+                      int nparts, unsigned long long* cursor_d, void* out_pos_d, void* out_mass_d, void* stream);
+
 /* dst[i] += src[i] — ghost-plane fold after a slab paint. */
 int ast_accumulate(void* dst_d, const void* src_d, int dtype, size_t count, void* stream);
 

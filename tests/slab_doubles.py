@@ -52,3 +52,16 @@ class NumpySlabOps:
         _, ps, _ = offt.project_block(p3d, n, boxsize, i0[0], i1[0])
         psum.copy_(torch.from_numpy(ps))
         return psum
+
+    @staticmethod
+    def _dest(pos, n, boxsize, window, parts):
+        sgrid = pos.numpy()[:, 0] * (n / boxsize)
+        base = np.floor(sgrid if window == "cic" else sgrid + 0.5)
+        return (np.mod(base, n).astype(np.int64)) // (n // parts)
+
+    def route_count(self, pos, n, boxsize, window, parts):
+        return torch.from_numpy(np.bincount(self._dest(pos, n, boxsize, window, parts), minlength=parts).astype(np.int64))
+
+    def route_scatter(self, pos, mass, n, boxsize, window, parts, counts):
+        order = np.argsort(self._dest(pos, n, boxsize, window, parts), kind="stable")
+        return pos[torch.from_numpy(order)].contiguous(), None if mass is None else mass[torch.from_numpy(order)].contiguous()
