@@ -17,6 +17,7 @@
 // independent 8-byte loads in flight.
 #include "ast_common.h"
 #include "paint_tile_geom.h"
+#include <algorithm>
 #include <cmath>
 #include <mutex>
 #include <vector>
@@ -103,19 +104,13 @@ __global__ void tile_isqrt_table_kernel(int* out, int count) {
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < count; v += gridDim.x * blockDim.x) out[v] = tile_isqrt(v);
 }
 
-// out of line on purpose: inlined 32 times into the unrolled epilogue its double-precision temporaries push the
-// kernel over its 128-VGPR budget (38 spilled registers); as a call only the rare branch pays
-__device__ __noinline__ int edge_norm_call(int r, int mx, int my, int mz, double kf) {
-    return ast::float64_edge_norm(r, mx, my, mz, kf);
-}
-
 template <int R1, int R2, int C, bool POWER>
 __global__ void __launch_bounds__(C * (R1 > R2 ? R1 : R2))
 // N = 1024 with binning: 128 VGPRs, so that two 8-wave workgroups fit a CU (see SPLIT below)
 __attribute__((amdgpu_waves_per_eu(POWER && R1 * R2 >= 1024 ? 4 : 1, POWER && R1 * R2 >= 1024 ? 4 : 8)))
 strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, size_t elem_stride,
                    size_t ncols, size_t batch_stride, unsigned tiles_per_batch, float scale,
-                   double* __restrict__ partial, double kf_rule) {
+                   double* __restrict__ partial, const unsigned* __restrict__ edge_fall) {
     constexpr int N = R1 * R2;
     constexpr int NT = C * (R1 > R2 ? R1 : R2);
     constexpr int NB = N / 2 - 1;    // shells when POWER
@@ -138,7 +133,11 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
     const int c = threadIdx.x % C, sub = threadIdx.x / C;
     const bool col_ok = c0 + c < ncols;
     float2* base = data + (size_t)b * batch_stride + c0 + c;
-
+    // AST_BIN_FLOAT64: bit k2 of this thread's word says that its epilogue mode (row sub + R1 * k2, column c) has an
+    // integer norm AND nbodykit's float64 comparison puts it one shell lower.  The words are data independent and
+    // come precomputed (edge_fall_kernel): one register, no double-precision code in this register-tight kernel.
+    unsigned fallmask = 0;
+    if (POWER && edge_fall) fallmask = edge_fall[(size_t)blockIdx.x * NT + threadIdx.x];
     float2 u[R2];
     {                                                 // stage 1: task (c, n2 = sub)
         const bool task1 = sub < R2;
@@ -213,7 +212,7 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
             const int kx = row > N / 2 ? row - N : row;
             int sh = tile_isqrt(kx * kx + m2yz);                        // shell = sh - 1; 0 is DC
             // lattice vectors of integer norm sit on a shell edge: nbodykit's float64 comparison decides (rare path)
-            if (kf_rule != 0.0 && sh * sh == kx * kx + m2yz && sh > 0) sh = edge_norm_call(sh, kx, ky, kz, kf_rule);
+            sh -= (int)((fallmask >> k2) & 1u);
             // |delta_k|^2 in fp32 (one rounding of 6e-8 per mode, random over the >= 18 modes of a
             // shell), accumulated in double
             if (sh >= 1 && sh <= NB) atomicAdd(&shell[sh], (double)(fmaf(x.x, x.x, x.y * x.y) * w));
@@ -400,58 +399,62 @@ __device__ constexpr double kS16[16] = {0.0, -0.38268343236508977, -0.7071067811
 
 template <int NJ, int FOLDW>
 __global__ void __launch_bounds__(256)
-lowk_z_kernel(const float* __restrict__ grid, const float* __restrict__ rec, int n, double2* __restrict__ out) {
+lowk_z_kernel(const float* __restrict__ grid, const float* __restrict__ rec, int n, size_t nrows, double2* __restrict__ out) {
     const int lane = threadIdx.x & 63;
-    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);        // n^2 is a multiple of 4
-    const float* in = grid + row * (size_t)n;
-    const float* src[3] = {nullptr, nullptr, nullptr};
-    int ns = 0;
-    if (FOLDW != 0) {
-        constexpr int W = FOLDW != 0 ? FOLDW : 2;
-        ns = ast::halo_sources<float, W>(rec, (int)(row / n), (int)(row % n), n, n / ast::TX, n / ast::TY, src);
-    }
-    double f[NJ];
+    // the lane's twiddles e^{-2 pi i kz lane / n}: once per wave, which then walks many rows
+    double twc[MBOX + 1], tws[MBOX + 1];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) f[j] = (double)in[lane + 64 * j];
-    if (ns > 0) {                                        // the records first, then onto the row: the fold's order
-        float h[NJ];
+    for (int kz = 0; kz <= MBOX; ++kz) sincospi(-2.0 * (double)((kz * lane) % n) / (double)n, &tws[kz], &twc[kz]);
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    for (size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < nrows; row += nwaves) {
+        const float* in = grid + row * (size_t)n;
+        float fr[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) h[j] = src[0][lane + 64 * j];
-        if (ns > 1) {
+        for (int j = 0; j < NJ; ++j) fr[j] = in[lane + 64 * j];
+        if (FOLDW != 0) {
+            constexpr int W = FOLDW != 0 ? FOLDW : 2;
+            const float* src[3];
+            const int ns = ast::halo_sources<float, W>(rec, (int)(row / n), (int)(row % n), n, n / ast::TX, n / ast::TY, src);
+            if (ns > 0) {                                // the records first, then onto the row: the fold's order,
+                float h[NJ];                             // i.e. the fp32 value the FFT's z pass sees
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) h[j] += src[1][lane + 64 * j];
+                for (int j = 0; j < NJ; ++j) h[j] = src[0][lane + 64 * j];
+                if (ns > 1) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) h[j] += src[1][lane + 64 * j];
+                }
+                if (ns > 2) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) h[j] += src[2][lane + 64 * j];
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fr[j] += h[j];
+            }
         }
-        if (ns > 2) {
+        double f[NJ];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) h[j] += src[2][lane + 64 * j];
+        for (int j = 0; j < NJ; ++j) f[j] = (double)fr[j];
+#pragma unroll
+        for (int kz = 0; kz <= MBOX; ++kz) {
+            double re = 0.0, im = 0.0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                constexpr int step = 16 / NJ;
+                const int r = ((kz * j) % NJ) * step;    // e^{-2 pi i (kz j) / NJ}: a compile-time constant after unrolling
+                if (r == 0) re += f[j];
+                else if (r == 4) im -= f[j];
+                else if (r == 8) re -= f[j];
+                else if (r == 12) im += f[j];
+                else { re += f[j] * kC16[r]; im += f[j] * kS16[r]; }
+            }
+            double pr = re * twc[kz] - im * tws[kz], pi = re * tws[kz] + im * twc[kz];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                pr += __shfl_xor(pr, o, 64);
+                pi += __shfl_xor(pi, o, 64);
+            }
+            if (lane == 0) out[row * (MBOX + 1) + kz] = make_double2(pr, pi);
         }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) f[j] = (double)(in[lane + 64 * j] + h[j]);       // the fp32 value the FFT's z pass sees
-    }
-    double2 acc[MBOX + 1];
-#pragma unroll
-    for (int kz = 0; kz <= MBOX; ++kz) {
-        double re = 0.0, im = 0.0;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            constexpr int step = 16 / NJ;
-            const int r = ((kz * j) % NJ) * step;        // e^{-2 pi i (kz j) / NJ}: a compile-time constant after unrolling
-            re += f[j] * kC16[r];
-            im += f[j] * kS16[r];
-        }
-        double ts, tc;
-        sincospi(-2.0 * (double)((kz * lane) % n) / (double)n, &ts, &tc);
-        acc[kz] = make_double2(re * tc - im * ts, re * ts + im * tc);
-    }
-#pragma unroll
-    for (int kz = 0; kz <= MBOX; ++kz) {
-        double re = acc[kz].x, im = acc[kz].y;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            re += __shfl_xor(re, o, 64);
-            im += __shfl_xor(im, o, 64);
-        }
-        if (lane == 0) out[row * (MBOX + 1) + kz] = make_double2(re, im);
     }
 }
 
@@ -533,6 +536,53 @@ __global__ void lowk_patch_kernel(const double* __restrict__ sums, int count, do
 }
 
 // ------------------------------------------------------------------ host side
+// The fall words of the fused x pass (see strided_c2c_kernel): for workgroup (ky = b, kz tile) and thread (c, sub) bit k2
+// covers the mode (kx row sub + R1 k2, ky, kz = 16 tile + c).  Same thread geometry as launch_c2c<.., true>.
+template <int R1, int R2, int C>
+__global__ void edge_fall_kernel(unsigned* __restrict__ out, unsigned tiles_per_batch, int ncols, double kf) {
+    constexpr int N = R1 * R2;
+    const unsigned tile = blockIdx.x % tiles_per_batch, b = blockIdx.x / tiles_per_batch;
+    const int c = threadIdx.x % C, sub = threadIdx.x / C;
+    const int kz = (int)(tile * C + c), ky = (int)b > N / 2 ? (int)b - N : (int)b;
+    unsigned word = 0;
+    if (sub < R1 && kz < ncols) {
+        for (int k2 = 0; k2 < R2; ++k2) {
+            const int row = sub + R1 * k2, kx = row > N / 2 ? row - N : row;
+            const int m2 = kx * kx + ky * ky + kz * kz;
+            int r = (int)sqrt((double)m2);
+            while (r * r > m2) --r;
+            while ((r + 1) * (r + 1) <= m2) ++r;
+            if (r * r == m2 && r > 0 && ast::float64_edge_norm(r, kx, ky, kz, kf) != r) word |= 1u << k2;
+        }
+    }
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = word;
+}
+
+struct EdgeFallCache {
+    std::mutex m;
+    struct Entry { int dev; size_t n; double boxsize; unsigned* words; };
+    std::vector<Entry> tabs;
+    const unsigned* get(size_t n, double boxsize, hipStream_t s) {
+        std::lock_guard<std::mutex> lock(m);
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+        for (auto& t : tabs) if (t.dev == dev && t.n == n && t.boxsize == boxsize) return t.words;
+        const size_t nz = n / 2 + 1, tiles = (nz + 15) / 16;
+        const unsigned nt = n == 256 ? 256 : 512;                 // threads of launch_c2c<R1, R2, 16, true>
+        unsigned* d = nullptr;
+        if (hipMalloc(&d, n * tiles * nt * sizeof(unsigned)) != hipSuccess) return nullptr;
+        const double kf = 2.0 * M_PI / boxsize;
+        const unsigned blocks = (unsigned)(n * tiles);
+        if (n == 1024) edge_fall_kernel<32, 32, 16><<<blocks, nt, 0, s>>>(d, (unsigned)tiles, (int)nz, kf);
+        else if (n == 512) edge_fall_kernel<16, 32, 16><<<blocks, nt, 0, s>>>(d, (unsigned)tiles, (int)nz, kf);
+        else edge_fall_kernel<16, 16, 16><<<blocks, nt, 0, s>>>(d, (unsigned)tiles, (int)nz, kf);
+        if (hipGetLastError() != hipSuccess) return nullptr;
+        if (tabs.size() >= 4) { (void)hipFree(tabs.front().words); tabs.erase(tabs.begin()); }      // a few (N, L) at most
+        tabs.push_back({dev, n, boxsize, d});
+        return d;
+    }
+} g_edge;
+
 struct TwiddleCache {
     std::mutex m;
     std::vector<std::pair<std::pair<int, int>, float2*>> tabs;   // (device, N) -> table
@@ -556,7 +606,7 @@ struct TwiddleCache {
 
 template <int R1, int R2, int C, bool POWER>
 int launch_c2c(float2* data, const float2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride,
-               float scale, double* partial, hipStream_t s, double kf_rule = 0.0) {
+               float scale, double* partial, hipStream_t s, const unsigned* edge_fall = nullptr) {
     constexpr int N = R1 * R2, NT = C * (R1 > R2 ? R1 : R2);
     constexpr bool SPLIT = POWER && R1 == R2 && N * C * sizeof(float2) > 64 * 1024;       // as in the kernel
     const size_t lds = (size_t)((SPLIT ? N / 2 : N) * C + N) * sizeof(float2) + (POWER ? (N / 2) * sizeof(double) : 0);
@@ -570,17 +620,17 @@ int launch_c2c(float2* data, const float2* tw, size_t elem_stride, size_t ncols,
     AST_CHECK_ARG(tiles * batch < 0x7fffffffull);
     strided_c2c_kernel<R1, R2, C, POWER><<<(unsigned)(tiles * batch), NT, lds, s>>>(data, tw, elem_stride, ncols,
                                                                                    batch_stride, (unsigned)tiles, scale,
-                                                                                   partial, kf_rule);
+                                                                                   partial, edge_fall);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
 
 template <bool POWER>
 int dispatch_c2c(size_t n, float2* d, const float2* tw, size_t elem_stride, size_t ncols, size_t batch,
-                 size_t batch_stride, float scale, double* partial, hipStream_t s, double kf_rule = 0.0) {
-    if (n == 1024) return launch_c2c<32, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, kf_rule);
-    if (n == 512) return launch_c2c<16, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, kf_rule);
-    return launch_c2c<16, 16, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, kf_rule);
+                 size_t batch_stride, float scale, double* partial, hipStream_t s, const unsigned* edge_fall = nullptr) {
+    if (n == 1024) return launch_c2c<32, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall);
+    if (n == 512) return launch_c2c<16, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall);
+    return launch_c2c<16, 16, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall);
 }
 
 template <int R1, int R2, int C, int FOLDW = 0>
@@ -712,12 +762,13 @@ static int lowk_modes(const float* planes, const float* rec, int window, int n, 
     double2* lowz = work;                                                  // [x][y][kz]
     double2* lowy = lowz + (size_t)nx * n * (MBOX + 1);                    // [x][ky][kz]
     double2* parts = lowy + (size_t)nx * (2 * MBOX + 1) * (MBOX + 1);      // [part][kx][ky][kz]
-    const unsigned blocks = (unsigned)((size_t)nx * n / 4);
+    const size_t nrows = (size_t)nx * n;
+    const unsigned blocks = (unsigned)std::min<size_t>((nrows + 3) / 4, 256 * 12);      // waves walk many rows each
     auto z = [&](auto nj) {
         constexpr int NJ = decltype(nj)::value;
-        if (rec == nullptr) lowk_z_kernel<NJ, 0><<<blocks, 256, 0, s>>>(planes, rec, n, lowz);
-        else if (window == AST_WIN_CIC) lowk_z_kernel<NJ, 2><<<blocks, 256, 0, s>>>(planes, rec, n, lowz);
-        else lowk_z_kernel<NJ, 3><<<blocks, 256, 0, s>>>(planes, rec, n, lowz);
+        if (rec == nullptr) lowk_z_kernel<NJ, 0><<<blocks, 256, 0, s>>>(planes, rec, n, nrows, lowz);
+        else if (window == AST_WIN_CIC) lowk_z_kernel<NJ, 2><<<blocks, 256, 0, s>>>(planes, rec, n, nrows, lowz);
+        else lowk_z_kernel<NJ, 3><<<blocks, 256, 0, s>>>(planes, rec, n, nrows, lowz);
     };
     if (n == 1024) z(std::integral_constant<int, 16>{});
     else if (n == 512) z(std::integral_constant<int, 8>{});
@@ -763,7 +814,12 @@ static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, 
     const double inv_ng = 1.0 / ((double)n * (double)n * (double)n);
     {
         AST_PROF("fft_tile.c2c_power", s);
-        rc = dispatch_c2c<true>(n, spec, tw, n * nzp, nz, n, nzp, (float)inv_ng, partial, s, kf_rule);   // x + binning
+        const unsigned* edge_fall = nullptr;
+        if (kf_rule != 0.0) {
+            edge_fall = g_edge.get(n, boxsize, s);
+            if (!edge_fall) { ast::set_error("ast_fft_tile_power_3d: edge table allocation failed"); return AST_ERR_HIP; }
+        }
+        rc = dispatch_c2c<true>(n, spec, tw, n * nzp, nz, n, nzp, (float)inv_ng, partial, s, edge_fall);   // x + binning
         if (rc != AST_OK) return rc;
     }
     AST_PROF("fft_tile.shell_reduce", s);

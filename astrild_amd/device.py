@@ -433,7 +433,10 @@ def fftpower_1d(field1, boxsize, field2=None, fused=True, binning=None):
     n = field1.shape[0]
     assert tuple(field1.shape) == (n, n, n) and n % 2 == 0
     if fused and field2 is None and fused_power_supported(field1):
-        return finish_power(*power_sums_fused(field1, boxsize, binning=binning))
+        # the grid's mean is removed as the z pass loads the cells (it only feeds the discarded DC mode): an fp32
+        # transform of an O(1) mean would leave its round-off on every shell
+        mean = total_mass(field1.reshape(-1), 0) / float(field1.numel())
+        return finish_power(*power_sums_fused(field1, boxsize, mean=mean, binning=binning))
     if field1.dtype == torch.float32 and not bool(_lib.lib().ast_fft_tile_supported(F32, n)):
         # an fp32 grid of a size the tile FFT does not cover: the rocFFT fp32 transform would carry the O(1) mean's
         # round-off into the low shells (2e-6 and worse); the transform runs in double instead

@@ -102,7 +102,7 @@ def test_slab_pipeline_object_on_one_gpu_over_nccl(hip):
         ks, ps, nm = pipe.step(check=True)
         res = dev.finish_power(ks, ps, nm)
         pos = dev.synth_lattice_particles(n, n, L, seed=5, dtype=torch.float32)
-        ref = dev.fftpower_1d(dev.paint(pos, None, n, L, "cic"), L)
+        ref = dev.paint_power_1d(pos, None, n, L, "cic")
         assert np.array_equal(res["modes"], ref["modes"])
         np.testing.assert_allclose(res["k"], ref["k"], rtol=1e-12)
         np.testing.assert_allclose(res["power"], ref["power"], rtol=2e-6)
@@ -134,7 +134,7 @@ def test_ranks_share_one_gpu_over_gloo(hip, tmp_path, world, n, dt, rtol):
     got = np.load(out)
     dtype = torch.float64 if dt == "f64" else torch.float32
     pos = dev.synth_lattice_particles(n, n, 1000.0, seed=5, dtype=dtype)
-    ref = dev.fftpower_1d(dev.paint(pos, None, n, 1000.0, "cic"), 1000.0)
+    ref = dev.paint_power_1d(pos, None, n, 1000.0, "cic")       # fp32: rho - mean grid, fused FFT + low-k channel
     assert np.array_equal(got["modes"], ref["modes"])
     np.testing.assert_allclose(got["k"], ref["k"], rtol=1e-12)
     np.testing.assert_allclose(got["power"], ref["power"], rtol=rtol)
