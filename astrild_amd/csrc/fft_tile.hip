@@ -397,63 +397,92 @@ __device__ constexpr double kS16[16] = {0.0, -0.38268343236508977, -0.7071067811
                                         0.38268343236508977, 0.70710678118654752, 0.92387953251128674, 1.0,
                                         0.92387953251128674, 0.70710678118654752, 0.38268343236508977};
 
+// One level of a TRANSPOSED wave reduction: the lanes whose `mask` bit is clear keep the lower half of the `count`
+// running sums, the others the upper half, and each adds its partner's half - half the work of a plain xor tree at
+// every level (56 element steps for 28 sums instead of 168).
+template <int COUNT>
+__device__ inline void reduce_level(double (&v)[28], int lane, int mask) {
+    const bool upper = (lane & mask) != 0;
+#pragma unroll
+    for (int i = 0; i < COUNT / 2; ++i) {
+        const double keep = upper ? v[i + COUNT / 2] : v[i];
+        const double send = upper ? v[i] : v[i + COUNT / 2];
+        v[i] = keep + __shfl_xor(send, mask, 64);
+    }
+}
+
 template <int NJ, int FOLDW>
 __global__ void __launch_bounds__(256)
 lowk_z_kernel(const float* __restrict__ grid, const float* __restrict__ rec, int n, size_t nrows, double2* __restrict__ out) {
+    static_assert(MBOX == 6, "the reduction below is laid out for 2 rows x 7 kz x (re, im) = 28 sums");
     const int lane = threadIdx.x & 63;
-    // the lane's twiddles e^{-2 pi i kz lane / n}: once per wave, which then walks many rows
+    // the lane's twiddles e^{-2 pi i kz lane / n}: once per wave, which then walks many row pairs
     double twc[MBOX + 1], tws[MBOX + 1];
 #pragma unroll
     for (int kz = 0; kz <= MBOX; ++kz) sincospi(-2.0 * (double)((kz * lane) % n) / (double)n, &tws[kz], &twc[kz]);
-    const size_t nwaves = (size_t)gridDim.x * 4;
-    for (size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < nrows; row += nwaves) {
-        const float* in = grid + row * (size_t)n;
-        float fr[NJ];
+    const size_t npairs = nrows / 2, nwaves = (size_t)gridDim.x * 4;          // nrows is even
+    for (size_t pair = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); pair < npairs; pair += nwaves) {
+        double v[28];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) fr[j] = in[lane + 64 * j];
-        if (FOLDW != 0) {
-            constexpr int W = FOLDW != 0 ? FOLDW : 2;
-            const float* src[3];
-            const int ns = ast::halo_sources<float, W>(rec, (int)(row / n), (int)(row % n), n, n / ast::TX, n / ast::TY, src);
-            if (ns > 0) {                                // the records first, then onto the row: the fold's order,
-                float h[NJ];                             // i.e. the fp32 value the FFT's z pass sees
+        for (int rr = 0; rr < 2; ++rr) {
+            const size_t row = 2 * pair + rr;
+            const float* in = grid + row * (size_t)n;
+            float fr[NJ];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) h[j] = src[0][lane + 64 * j];
-                if (ns > 1) {
+            for (int j = 0; j < NJ; ++j) fr[j] = in[lane + 64 * j];
+            if (FOLDW != 0) {
+                constexpr int W = FOLDW != 0 ? FOLDW : 2;
+                const float* src[3];
+                const int ns = ast::halo_sources<float, W>(rec, (int)(row / n), (int)(row % n), n, n / ast::TX, n / ast::TY, src);
+                if (ns > 0) {                            // the records first, then onto the row: the fold's order,
+                    float h[NJ];                         // i.e. the fp32 value the FFT's z pass sees
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) h[j] += src[1][lane + 64 * j];
+                    for (int j = 0; j < NJ; ++j) h[j] = src[0][lane + 64 * j];
+                    if (ns > 1) {
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) h[j] += src[1][lane + 64 * j];
+                    }
+                    if (ns > 2) {
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) h[j] += src[2][lane + 64 * j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) fr[j] += h[j];
                 }
-                if (ns > 2) {
+            }
+            double f[NJ];
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) h[j] += src[2][lane + 64 * j];
+            for (int j = 0; j < NJ; ++j) f[j] = (double)fr[j];
+#pragma unroll
+            for (int kz = 0; kz <= MBOX; ++kz) {
+                double re = 0.0, im = 0.0;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    constexpr int step = 16 / NJ;
+                    const int r = ((kz * j) % NJ) * step;    // e^{-2 pi i (kz j) / NJ}: a compile-time constant after unrolling
+                    if (r == 0) re += f[j];
+                    else if (r == 4) im -= f[j];
+                    else if (r == 8) re -= f[j];
+                    else if (r == 12) im += f[j];
+                    else { re += f[j] * kC16[r]; im += f[j] * kS16[r]; }
                 }
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) fr[j] += h[j];
+                v[rr * 14 + 2 * kz] = re * twc[kz] - im * tws[kz];
+                v[rr * 14 + 2 * kz + 1] = re * tws[kz] + im * twc[kz];
             }
         }
-        double f[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) f[j] = (double)fr[j];
-#pragma unroll
-        for (int kz = 0; kz <= MBOX; ++kz) {
-            double re = 0.0, im = 0.0;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                constexpr int step = 16 / NJ;
-                const int r = ((kz * j) % NJ) * step;    // e^{-2 pi i (kz j) / NJ}: a compile-time constant after unrolling
-                if (r == 0) re += f[j];
-                else if (r == 4) im -= f[j];
-                else if (r == 8) re -= f[j];
-                else if (r == 12) im += f[j];
-                else { re += f[j] * kC16[r]; im += f[j] * kS16[r]; }
-            }
-            double pr = re * twc[kz] - im * tws[kz], pi = re * tws[kz] + im * twc[kz];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                pr += __shfl_xor(pr, o, 64);
-                pi += __shfl_xor(pi, o, 64);
-            }
-            if (lane == 0) out[row * (MBOX + 1) + kz] = make_double2(pr, pi);
+        // 28 sums over the 64 lanes: 28 -> 14 -> 7 (+1 zero) -> 4 -> 2 -> 1, then the last pair
+        reduce_level<28>(v, lane, 32);
+        reduce_level<14>(v, lane, 16);
+        v[7] = 0.0;
+        reduce_level<8>(v, lane, 8);
+        reduce_level<4>(v, lane, 4);
+        reduce_level<2>(v, lane, 2);
+        v[0] += __shfl_xor(v[0], 1, 64);
+        // lane bits 5..1 say which sum it holds: element 14 b5 + 7 b4 + (4 b3 + 2 b2 + b1), the last term 7 being the pad
+        const int sub = ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+        if ((lane & 1) == 0 && sub < 7) {
+            const int e = ((lane >> 5) & 1) * 14 + ((lane >> 4) & 1) * 7 + sub;      // = row-in-pair * 14 + 2 kz + (re | im)
+            reinterpret_cast<double*>(out)[(2 * pair + e / 14) * (size_t)(2 * (MBOX + 1)) + e % 14] = v[0];
         }
     }
 }
@@ -511,24 +540,31 @@ lowk_parts_reduce_kernel(const double2* __restrict__ in, int nparts, int count, 
 }
 
 // modes[kx + MBOX][ky + MBOX][kz] -> sums[s] = pnorm * sum w |delta_k|^2 over the modes of shell s < MLOW (shell by
-// the binning rule in force), each shell added up by one thread in a fixed order
-__global__ void lowk_shell_kernel(const double2* __restrict__ modes, double pnorm, double kf_rule, double* __restrict__ sums) {
-    const int s = threadIdx.x;
-    if (s >= MLOW) return;
-    double acc = 0.0;
-    for (int a = -MBOX; a <= MBOX; ++a)
-        for (int b = -MBOX; b <= MBOX; ++b)
-            for (int c = 0; c <= MBOX; ++c) {
-                const int m2 = a * a + b * b + c * c;
-                int r = (int)sqrt((double)m2);
-                while (r * r > m2) --r;
-                while ((r + 1) * (r + 1) <= m2) ++r;
-                if (kf_rule != 0.0 && r * r == m2 && r > 0) r = ast::float64_edge_norm(r, a, b, c, kf_rule);
-                if (r - 1 != s) continue;
-                const double2 v = modes[((a + MBOX) * (2 * MBOX + 1) + b + MBOX) * (MBOX + 1) + c];
-                acc += (c > 0 ? 2.0 : 1.0) * (v.x * v.x + v.y * v.y);
-            }
-    sums[s] = acc * pnorm;
+// the binning rule in force): one thread per mode works out (shell, weighted power), then one thread per shell adds
+// its modes in index order
+__global__ void __launch_bounds__(256)
+lowk_shell_kernel(const double2* __restrict__ modes, double pnorm, double kf_rule, double* __restrict__ sums) {
+    constexpr int NM = (2 * MBOX + 1) * (2 * MBOX + 1) * (MBOX + 1);
+    __shared__ double val[NM];
+    __shared__ signed char sh[NM];
+    for (int i = threadIdx.x; i < NM; i += 256) {
+        const int c = i % (MBOX + 1), b = (i / (MBOX + 1)) % (2 * MBOX + 1) - MBOX, a = i / ((MBOX + 1) * (2 * MBOX + 1)) - MBOX;
+        const int m2 = a * a + b * b + c * c;
+        int r = (int)sqrt((double)m2);
+        while (r * r > m2) --r;
+        while ((r + 1) * (r + 1) <= m2) ++r;
+        if (kf_rule != 0.0 && r * r == m2 && r > 0) r = ast::float64_edge_norm(r, a, b, c, kf_rule);
+        const double2 v = modes[i];
+        sh[i] = (signed char)(r - 1 < MLOW ? r - 1 : -1);
+        val[i] = (c > 0 ? 2.0 : 1.0) * (v.x * v.x + v.y * v.y);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < MLOW) {
+        double acc = 0.0;
+        for (int i = 0; i < NM; ++i)
+            if (sh[i] == (int)threadIdx.x) acc += val[i];
+        sums[threadIdx.x] = acc * pnorm;
+    }
 }
 
 __global__ void lowk_patch_kernel(const double* __restrict__ sums, int count, double* __restrict__ psum) {
@@ -763,7 +799,7 @@ static int lowk_modes(const float* planes, const float* rec, int window, int n, 
     double2* lowy = lowz + (size_t)nx * n * (MBOX + 1);                    // [x][ky][kz]
     double2* parts = lowy + (size_t)nx * (2 * MBOX + 1) * (MBOX + 1);      // [part][kx][ky][kz]
     const size_t nrows = (size_t)nx * n;
-    const unsigned blocks = (unsigned)std::min<size_t>((nrows + 3) / 4, 256 * 12);      // waves walk many rows each
+    const unsigned blocks = (unsigned)std::min<size_t>((nrows / 2 + 3) / 4, 256 * 12);  // waves walk many row pairs each
     auto z = [&](auto nj) {
         constexpr int NJ = decltype(nj)::value;
         if (rec == nullptr) lowk_z_kernel<NJ, 0><<<blocks, 256, 0, s>>>(planes, rec, n, nrows, lowz);
@@ -804,7 +840,7 @@ static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, 
         int rc = lowk_modes((const float*)grid, (const float*)rec, window, (int)n, 0, (int)n, 0, modes, modes + LOWK_MODES, s);
         if (rc != AST_OK) return rc;
         const double ng = (double)n * (double)n * (double)n;
-        lowk_shell_kernel<<<1, 64, 0, s>>>(modes, boxsize * boxsize * boxsize / (ng * ng), kf_rule, lowk_sums);
+        lowk_shell_kernel<<<1, 256, 0, s>>>(modes, boxsize * boxsize * boxsize / (ng * ng), kf_rule, lowk_sums);
         AST_CHECK_LAUNCH();
     }
     int rc = rows_r2c_impl(grid, spec, dtype, n, n * n, n, nzp, 1.0, mean, stream, rec, window);      // z
@@ -854,7 +890,7 @@ extern "C" int ast_lowk_shell_sums(const void* modes, size_t n, double boxsize, 
     AST_CHECK_ARG(modes && sums && boxsize > 0.0 && n >= 16);
     AST_CHECK_ARG(binning == AST_BIN_INTEGER || binning == AST_BIN_FLOAT64);
     const double ng = (double)n * (double)n * (double)n;
-    lowk_shell_kernel<<<1, 64, 0, ast::as_stream(stream)>>>((const double2*)modes, boxsize * boxsize * boxsize / (ng * ng),
+    lowk_shell_kernel<<<1, 256, 0, ast::as_stream(stream)>>>((const double2*)modes, boxsize * boxsize * boxsize / (ng * ng),
                                                           binning == AST_BIN_FLOAT64 ? 2.0 * M_PI / boxsize : 0.0, sums);
     AST_CHECK_LAUNCH();
     return AST_OK;
