@@ -506,6 +506,41 @@ lowk_axis_kernel(const double2* __restrict__ in, int n, int nt, int t0, int inne
     const int nparts = gridDim.y, part = blockIdx.y;
     const int per = (nt + nparts - 1) / nparts, ta = part * per, tb = min(nt, ta + per);
     const int nout = (2 * MBOX + 1) * inner;
+    if (nout <= 128) {
+        // few outputs (the y pass: 91): 256 / nout thread groups share the t range, interleaved, and their partial
+        // sums are added in group order
+        __shared__ double2 part_sum[256];
+        const int groups = 256 / nout, o = threadIdx.x % nout, gq = threadIdx.x / nout;
+        double re = 0.0, im = 0.0, re2 = 0.0, im2 = 0.0;
+        if (gq < groups) {
+            const int k = o / inner - MBOX, i = o % inner;
+            int t = ta + gq;
+            for (; t + groups < tb; t += 2 * groups) {           // two loads in flight
+                const double2 v = in[(outer * nt + t) * inner + i], v2 = in[(outer * nt + t + groups) * inner + i];
+                const double2 w = tw[(unsigned)(k * (t0 + t)) & (unsigned)(n - 1)];
+                const double2 w2 = tw[(unsigned)(k * (t0 + t + groups)) & (unsigned)(n - 1)];
+                re += v.x * w.x - v.y * w.y;
+                im += v.x * w.y + v.y * w.x;
+                re2 += v2.x * w2.x - v2.y * w2.y;
+                im2 += v2.x * w2.y + v2.y * w2.x;
+            }
+            if (t < tb) {
+                const double2 v = in[(outer * nt + t) * inner + i];
+                const double2 w = tw[(unsigned)(k * (t0 + t)) & (unsigned)(n - 1)];
+                re += v.x * w.x - v.y * w.y;
+                im += v.x * w.y + v.y * w.x;
+            }
+        }
+        part_sum[threadIdx.x] = make_double2(re + re2, im + im2);
+        __syncthreads();
+        if (gq == 0) {
+            double sr = 0.0, si = 0.0;
+            for (int q = 0; q < groups; ++q) { sr += part_sum[q * nout + o].x; si += part_sum[q * nout + o].y; }
+            const int k = o / inner - MBOX, i = o % inner;
+            out[((outer * nparts + part) * (2 * MBOX + 1) + k + MBOX) * inner + i] = make_double2(sr, si);
+        }
+        return;
+    }
     for (int o = threadIdx.x; o < nout; o += 256) {
         const int k = o / inner - MBOX, i = o % inner;
         double re[4] = {0.0, 0.0, 0.0, 0.0}, im[4] = {0.0, 0.0, 0.0, 0.0};
