@@ -21,7 +21,7 @@ paint = sum(v["corrected_GB"] for k, v in kernels.items()
                                     "overflow_deposit_kernel", "tile_deposit_kernel")))
 out = {
     "_doc": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 bench.py --cpu-sample 0 --kappa 0 --bispec 0 "
-            "--steps 2 --warmup 1` on MI355X. Counter values are KiB per launch (mean over launches). Corrected bytes = "
+            "--legs 0 --steps 2 --warmup 1` on MI355X. Counter values are KiB per launch (mean over launches). Corrected bytes = "
             "(2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B). Calibration: the "
             "synth kernel writes the 12.885 GB of positions exactly once (WRITE_SIZE exact); the index kernel reads them once and "
             "2*FETCH_SIZE*1024 matches for 4/12-byte-per-lane loads. For 8/16-byte-per-lane loads (fft_tile, fold) the x2 "

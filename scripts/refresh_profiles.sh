@@ -3,15 +3,16 @@
 # command; everything lands in gpurun_out/profiles_<tag>/ for copying into profiles/.
 # usage: scripts/refresh_profiles.sh <tag>
 set -e
-tag=${1:-r01}
+tag=${1:-r02}
 R=$PWD
 out=$R/gpurun_out/profiles_$tag
 mkdir -p $out
 python3 bench.py > $out/${tag}_bench_1gpu.json 2> $out/bench.stderr
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python3 $R/bench.py --cpu-sample 0 --kappa 0 --bispec 0 > $out/${tag}_bench_under_rocprof.json 2> $out/rocprof_stats.stderr
-rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch -o f --output-format csv -- python3 $R/bench.py --cpu-sample 0 --kappa 0 --bispec 0 --steps 2 --warmup 1 > /dev/null 2> $out/pmc_fetch.stderr
-rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write -o w --output-format csv -- python3 $R/bench.py --cpu-sample 0 --kappa 0 --bispec 0 --steps 2 --warmup 1 > /dev/null 2> $out/pmc_write.stderr
+lean="--cpu-sample 0 --kappa 0 --bispec 0 --legs 0"
+rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python3 $R/bench.py $lean > $out/${tag}_bench_under_rocprof.json 2> $out/rocprof_stats.stderr
+rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch -o f --output-format csv -- python3 $R/bench.py $lean --steps 2 --warmup 1 > /dev/null 2> $out/pmc_fetch.stderr
+rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write -o w --output-format csv -- python3 $R/bench.py $lean --steps 2 --warmup 1 > /dev/null 2> $out/pmc_write.stderr
 cd $R
 python3 scripts/pmc_traffic_json.py $out/pmc_fetch $out/pmc_write $out/${tag}_pmc_traffic.json
 find $out/stats -name "*kernel_stats.csv" -exec cp {} $out/${tag}_bench_kernel_stats.csv \;
