@@ -567,6 +567,182 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
     if (dropped && ndrop) atomicAdd(dropped, ndrop);
 }
 
+// ------------------------------------------------------------------------------------
+// AST_PAINT_SCATTERED: particles WITHOUT spatial order in memory.  The grouping kernel above degenerates there
+// (every particle is a stray of a tile no neighbour shares: one returning global atomic and one 16-byte scattered
+// store per particle, 74 ms at 1024^3).  Two radix levels instead, every workgroup handling 16384 records so that a
+// bucket receives a run of records (16 at the first level, 32 at the second) for ONE reservation atomic:
+//   count     records per coarse bucket (SC_BUCKETS buckets of tpb consecutive tiles), exclusive scan -> bucket starts;
+//   level A   particle -> 16-byte record {x, y, z, m} in its bucket's range of a staging array;
+//   level B   bucket by bucket, record -> the stray segment of its tile (the format the column walk reads), slots
+//             reserved per (workgroup, tile) from the tile's fill64 counter.
+// The walk then finds only stray copies (no group records) and reads them contiguously.  A record that does not fit
+// its tile's segment (strongly clustered input) is deposited on the spot with global atomics.
+constexpr int SC_THREADS = 1024, SC_PER_THREAD = 16, SC_CHUNK = SC_THREADS * SC_PER_THREAD;
+constexpr uint32_t SC_BUCKETS = 1024, SC_TPB_MAX = 2048;        // buckets; most tiles per bucket (LDS counters of level B)
+
+template <typename T, int W, bool PLAINX>
+__global__ void __launch_bounds__(SC_THREADS)
+scatter_count_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t tpb, unsigned long long* __restrict__ bcount,
+                     uint32_t* __restrict__ col_flags, unsigned long long* dropped) {
+    __shared__ uint32_t cnt[SC_BUCKETS];
+    const int tid = threadIdx.x;
+    cnt[tid] = 0;
+    __syncthreads();
+    unsigned long long ndrop = 0;
+    const size_t p0 = (size_t)blockIdx.x * SC_CHUNK;
+#pragma unroll 4
+    for (int u = 0; u < SC_PER_THREAD; ++u) {
+        const size_t p = p0 + (size_t)u * SC_THREADS + tid;
+        if (p >= np) break;
+        const uint32_t key = tile_of<T, W, PLAINX>(pos[3 * p], pos[3 * p + 1], pos[3 * p + 2], g, col_flags);
+        if (key == 0xffffffffu) { ++ndrop; continue; }
+        atomicAdd(&cnt[key / tpb], 1u);
+    }
+    __syncthreads();
+    if (cnt[tid]) atomicAdd(&bcount[tid], (unsigned long long)cnt[tid]);
+    if (dropped && ndrop) atomicAdd(dropped, ndrop);
+}
+
+// bstart[b] = exclusive prefix sum of bcount; cursor[b] = the same (level A advances it)
+__global__ void __launch_bounds__(SC_BUCKETS)
+scatter_scan_kernel(const unsigned long long* __restrict__ bcount, unsigned long long* __restrict__ bstart,
+                    unsigned long long* __restrict__ cursor) {
+    __shared__ unsigned long long s[SC_BUCKETS];
+    const int tid = threadIdx.x;
+    s[tid] = bcount[tid];
+    __syncthreads();
+    for (int o = 1; o < (int)SC_BUCKETS; o <<= 1) {
+        const unsigned long long add = tid >= o ? s[tid - o] : 0ull;
+        __syncthreads();
+        s[tid] += add;
+        __syncthreads();
+    }
+    const unsigned long long ex = s[tid] - bcount[tid];
+    bstart[tid] = ex;
+    cursor[tid] = ex;
+    if (tid == (int)SC_BUCKETS - 1) bstart[SC_BUCKETS] = s[tid];
+}
+
+template <typename T, int W, bool PLAINX>
+__global__ void __launch_bounds__(SC_THREADS)
+scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t np, TileGeom g, uint32_t tpb,
+                       unsigned long long* __restrict__ cursor, T* __restrict__ staging) {
+    __shared__ uint32_t cnt[SC_BUCKETS];
+    __shared__ unsigned long long base[SC_BUCKETS];
+    const int tid = threadIdx.x;
+    cnt[tid] = 0;
+    __syncthreads();
+    const size_t p0 = (size_t)blockIdx.x * SC_CHUNK;
+    T x[SC_PER_THREAD], y[SC_PER_THREAD], z[SC_PER_THREAD];
+    uint32_t where[SC_PER_THREAD];                   // bucket << 16 | rank inside the workgroup's run (< 16384)
+#pragma unroll
+    for (int u = 0; u < SC_PER_THREAD; ++u) {
+        const size_t p = min(p0 + (size_t)u * SC_THREADS + tid, np - 1);       // unconditional loads
+        x[u] = pos[3 * p];
+        y[u] = pos[3 * p + 1];
+        z[u] = pos[3 * p + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < SC_PER_THREAD; ++u) {
+        const size_t p = p0 + (size_t)u * SC_THREADS + tid;
+        where[u] = 0xffffffffu;
+        if (p < np) {
+            const uint32_t key = tile_of<T, W, PLAINX>(x[u], y[u], z[u], g, nullptr);
+            if (key != 0xffffffffu) {
+                const uint32_t b = key / tpb;
+                where[u] = (b << 16) | atomicAdd(&cnt[b], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (cnt[tid]) base[tid] = atomicAdd(&cursor[tid], (unsigned long long)cnt[tid]);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < SC_PER_THREAD; ++u) {
+        if (where[u] == 0xffffffffu) continue;
+        const size_t p = p0 + (size_t)u * SC_THREADS + tid;
+        store_stray(staging, (size_t)(base[where[u] >> 16] + (where[u] & 0xffffu)), x[u], y[u], z[u], mass ? mass[p] : (T)1);
+    }
+}
+
+// one record deposited with global atomics (a full tile segment): overflow_deposit_kernel's body
+template <typename T, int W>
+__device__ __noinline__ void deposit_record_global(T x, T y, T z, T m, const TileGeom& g, double scale, T* __restrict__ grid,
+                                                   unsigned long long* dropped) {
+    constexpr int LO = Window<W>::LO;
+    double fx, fy, fz;
+    const int bx = ast::locate<W>(grid_coord(x, g), g.n, fx);
+    const int by = ast::locate<W>(grid_coord(y, g), g.n, fy);
+    const int bz = ast::locate<W>(grid_coord(z, g), g.n, fz);
+    T wx[W], wy[W], wz[W];
+    Window<W>::weights(fx, wx);
+    Window<W>::weights(fy, wy);
+    Window<W>::weights(fz, wz);
+    const T mm = (T)((double)m * scale);
+    for (int a = 0; a < W; ++a) {
+        int px = ast::wrap1(bx - LO + a, g.n) - g.x_start;
+        if (px < 0) px += g.n;
+        if (px >= g.nx_alloc) { if (dropped) atomicAdd(dropped, 1ull); continue; }
+        for (int b = 0; b < W; ++b) {
+            T* row = grid + ((size_t)px * g.n + ast::wrap1(by - LO + b, g.n)) * g.n;
+            for (int c = 0; c < W; ++c) atomicAdd(row + ast::wrap1(bz - LO + c, g.n), mm * wx[a] * wy[b] * wz[c]);
+        }
+    }
+}
+
+template <typename T, int W, bool PLAINX>
+__global__ void __launch_bounds__(SC_THREADS)
+scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* __restrict__ bstart, TileGeom g, uint32_t tpb,
+                       unsigned long long* __restrict__ fill64, T* __restrict__ strays, uint32_t scap, double scale,
+                       T* __restrict__ grid, unsigned long long* __restrict__ late, unsigned long long* dropped) {
+    __shared__ uint32_t cnt[SC_TPB_MAX], room[SC_TPB_MAX];
+    __shared__ unsigned long long base[SC_TPB_MAX];
+    const int tid = threadIdx.x;
+    const uint32_t bucket = blockIdx.x;
+    const size_t b0 = (size_t)bstart[bucket], b1 = (size_t)bstart[bucket + 1];
+    typedef T vec4_t __attribute__((ext_vector_type(4)));
+    const vec4_t* recs = reinterpret_cast<const vec4_t*>(staging);
+    for (size_t c0 = b0 + (size_t)blockIdx.y * SC_CHUNK; c0 < b1; c0 += (size_t)gridDim.y * SC_CHUNK) {
+        for (uint32_t t = tid; t < tpb; t += SC_THREADS) cnt[t] = 0;
+        __syncthreads();
+        vec4_t r[SC_PER_THREAD];
+        uint32_t where[SC_PER_THREAD];               // tile in bucket << 16 | rank (< 16384)
+#pragma unroll
+        for (int u = 0; u < SC_PER_THREAD; ++u) r[u] = recs[min(c0 + (size_t)u * SC_THREADS + tid, b1 - 1)];
+#pragma unroll
+        for (int u = 0; u < SC_PER_THREAD; ++u) {
+            where[u] = 0xffffffffu;
+            if (c0 + (size_t)u * SC_THREADS + tid < b1) {
+                const uint32_t lt = tile_of<T, W, PLAINX>(r[u].x, r[u].y, r[u].z, g, nullptr) - bucket * tpb;
+                where[u] = (lt << 16) | atomicAdd(&cnt[lt], 1u);
+            }
+        }
+        __syncthreads();
+        for (uint32_t t = tid; t < tpb; t += SC_THREADS) {
+            if (!cnt[t]) continue;
+            const uint32_t tile = bucket * tpb + t;
+            const uint32_t old = (uint32_t)atomicAdd(&fill64[tile], (unsigned long long)cnt[t]);
+            const uint32_t bs = min(old, scap);
+            base[t] = (unsigned long long)tile * scap + bs;
+            room[t] = scap - bs;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < SC_PER_THREAD; ++u) {
+            if (where[u] == 0xffffffffu) continue;
+            const uint32_t lt = where[u] >> 16, at = where[u] & 0xffffu;
+            if (at < room[lt]) {
+                *reinterpret_cast<vec4_t*>(strays + 4 * (size_t)(base[lt] + at)) = r[u];
+            } else {
+                atomicAdd(late, 1ull);
+                deposit_record_global<T, W>(r[u].x, r[u].y, r[u].z, r[u].w, g, scale, grid, dropped);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Particles that did not fit their tile's segment in the single-pass variant: plain
 // global-atomic deposit (the direct kernel's inner loop over an index list).
 template <typename T, int W>
@@ -1268,6 +1444,13 @@ struct Workspace {
     GroupRec* recs;                  // [tile][rcap]
     void* strays;                    // [tile][scap] x {x, y, z, m}
     uint32_t rcap, scap;
+    // AST_PAINT_SCATTERED: two-level bucket scatter
+    unsigned long long* bcount;      // [SC_BUCKETS] records per coarse bucket
+    unsigned long long* bstart;      // [SC_BUCKETS + 1] their exclusive scan
+    unsigned long long* bcursor;     // [SC_BUCKETS] level A's write cursors
+    unsigned long long* late;        // records that found their tile's segment full (deposited on the spot)
+    void* staging;                   // [np] x {x, y, z, m}, bucket-major
+    uint32_t tpb;                    // tiles per bucket (0: the scatter path does not apply)
     size_t bytes;
 };
 
@@ -1296,14 +1479,22 @@ Workspace carve(void* base, size_t np, uint32_t ntiles, uint32_t ncols, int flag
     w.tile_count = (uint32_t*)take((size_t)ntiles * 4);
     w.tile_fill = (uint32_t*)take((size_t)ntiles * 4);
     w.fill64 = (unsigned long long*)take(compact ? (size_t)ntiles * 8 : 0);
+    const bool scattered = compact && (flags & AST_PAINT_SCATTERED);
+    w.tpb = scattered ? (ntiles + SC_BUCKETS - 1) / SC_BUCKETS : 0;
+    if (w.tpb > SC_TPB_MAX || np < (size_t)SC_CHUNK) w.tpb = 0;      // huge grids / tiny inputs: the grouping kernel does it
+    w.bcount = (unsigned long long*)take(w.tpb ? SC_BUCKETS * 8 : 0);
+    w.late = (unsigned long long*)take(w.tpb ? 8 : 0);
     w.tile_off = (uint32_t*)take((size_t)ntiles * 4);
     w.block_sums = (uint32_t*)take((size_t)((ntiles + 1023) / 1024 + 1) * 4);
     w.cap = two_pass ? 0 : tile_capacity(np, ntiles);
-    w.rcap = compact ? (w.cap + MINPOP - 1) / MINPOP : 0;
+    w.rcap = compact && !w.tpb ? (w.cap + MINPOP - 1) / MINPOP : 0;       // the scatter path writes stray copies only
     w.scap = compact ? ((flags & AST_PAINT_SCATTERED) ? w.cap : (w.cap + 3) / 4) : 0;
     w.index = (uint32_t*)take(two_pass ? np * 4 : compact ? 0 : (size_t)ntiles * w.cap * 4);
     w.recs = (GroupRec*)take((size_t)ntiles * w.rcap * sizeof(GroupRec));
     w.strays = take((size_t)ntiles * w.scap * 4 * esz);
+    w.bstart = (unsigned long long*)take(w.tpb ? (SC_BUCKETS + 1) * 8 : 0);
+    w.bcursor = (unsigned long long*)take(w.tpb ? SC_BUCKETS * 8 : 0);
+    w.staging = take(w.tpb ? np * 4 * esz : 0);
     w.ovf = (uint32_t*)take(two_pass ? 0 : np * 4);
     w.rec = take(rec_bytes);
     w.bytes = off;
@@ -1399,6 +1590,21 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
             index_pass(std::integral_constant<int, 1>{}, nullptr, w.tile_off, w.tile_fill, w.index, 0, nullptr, nullptr, nullptr);
         }
         deposit_pass(w.tile_off, w.tile_count, 0);
+    } else if (overwrite && w.tpb) {
+        {
+            AST_PROF("paint_tiled.fill", s);
+            const unsigned nchunks = (unsigned)((np + SC_CHUNK - 1) / SC_CHUNK);
+            auto run = [&](auto px) {
+                constexpr bool PX = decltype(px)::value;
+                scatter_count_kernel<T, W, PX><<<nchunks, SC_THREADS, 0, s>>>(pos, np, g, w.tpb, w.bcount, w.col_flags, dropped);
+                scatter_scan_kernel<<<1, SC_BUCKETS, 0, s>>>(w.bcount, w.bstart, w.bcursor);
+                scatter_level_a_kernel<T, W, PX><<<nchunks, SC_THREADS, 0, s>>>(pos, mass, np, g, w.tpb, w.bcursor, (T*)w.staging);
+                scatter_level_b_kernel<T, W, PX><<<dim3(SC_BUCKETS, 32), SC_THREADS, 0, s>>>(
+                    (const T*)w.staging, w.bstart, g, w.tpb, w.fill64, (T*)w.strays, w.scap, scale, grid, w.late, dropped);
+            };
+            if (plainx) run(std::true_type{}); else run(std::false_type{});
+        }
+        deposit_pass(nullptr, nullptr, 0);
     } else if (overwrite) {
         {
             AST_PROF("paint_tiled.fill", s);
@@ -1494,7 +1700,7 @@ extern "C" int ast_paint_tiled_list_stats(void* workspace, int window, int dtype
     const Workspace w = carve(workspace, np, ntiles, (uint32_t)(g.ntx * g.nty), flags, esz, record_bytes(window, g, esz, flags));
     hipStream_t s = ast::as_stream(stream);
     AST_CHECK_HIP(hipMemsetAsync(out, 0, 4 * sizeof(unsigned long long), s));
-    list_stats_kernel<<<256, 256, 0, s>>>(w.fill64, ntiles, w.rcap, w.scap, w.ovf_count, out);
+    list_stats_kernel<<<256, 256, 0, s>>>(w.fill64, ntiles, w.rcap, w.scap, w.tpb ? w.late : w.ovf_count, out);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
