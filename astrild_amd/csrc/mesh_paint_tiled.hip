@@ -578,7 +578,7 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
 //             reserved per (workgroup, tile) from the tile's fill64 counter.
 // The walk then finds only stray copies (no group records) and reads them contiguously.  A record that does not fit
 // its tile's segment (strongly clustered input) is deposited on the spot with global atomics.
-constexpr int SC_THREADS = 1024, SC_PER_THREAD = 16, SC_CHUNK = SC_THREADS * SC_PER_THREAD;
+constexpr int SC_THREADS = 1024, SC_PER_THREAD = 8, SC_CHUNK = SC_THREADS * SC_PER_THREAD;      // 16 per thread spills (128 VGPRs at 1024 threads)
 constexpr uint32_t SC_BUCKETS = 1024, SC_TPB_MAX = 2048;        // buckets; most tiles per bucket (LDS counters of level B)
 
 template <typename T, int W, bool PLAINX>
@@ -624,17 +624,75 @@ scatter_scan_kernel(const unsigned long long* __restrict__ bcount, unsigned long
     if (tid == (int)SC_BUCKETS - 1) bstart[SC_BUCKETS] = s[tid];
 }
 
+// Exclusive scan of cnt[0 .. table) into lstart[] by the whole workgroup (SC_THREADS threads, table <= 2 * SC_THREADS);
+// returns the total.  wsum: 16 words of LDS.
+__device__ inline uint32_t block_exclusive_scan(const uint32_t* cnt, uint32_t* lstart, uint32_t table, uint32_t* wsum) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t i0 = 2u * tid, a = i0 < table ? cnt[i0] : 0u, b = i0 + 1 < table ? cnt[i0 + 1] : 0u;
+    uint32_t inc = a + b;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+    for (int k = 0; k < SC_THREADS / 64; ++k) { if (k < wave) woff += wsum[k]; total += wsum[k]; }
+    const uint32_t ex = woff + inc - (a + b);
+    if (i0 < table) lstart[i0] = ex;
+    if (i0 + 1 < table) lstart[i0 + 1] = ex + a;
+    __syncthreads();
+    return total;
+}
+
+// The records of one workgroup leave through LDS in DESTINATION order, a quarter at a time: consecutive lanes then
+// store consecutive 16-byte records of the same run, so a run reaches L2 as whole lines in one instruction.  (Stored
+// straight from the registers, each record is a lone 16-byte piece of a line that other workgroups' pieces reach much
+// later: with ~500 workgroups x 1024 open runs the lines leave L2 partly filled - 0.75 TB/s.)
+// where[u] = table entry << 16 | rank of record u among the workgroup's records of that entry (0xffffffff: none);
+// lstart[]: the entries' first slots in the workgroup's destination order, base[]: their first index in `out`,
+// room[] (or null): how many records of an entry `out` still takes - the rest is not stored (the caller deposits them).
+template <typename T>
+__device__ inline void staged_store(const T (&rx)[SC_PER_THREAD], const T (&ry)[SC_PER_THREAD], const T (&rz)[SC_PER_THREAD],
+                                    const T (&rm)[SC_PER_THREAD], const uint32_t (&where)[SC_PER_THREAD],
+                                    const uint32_t* lstart, const unsigned long long* base, const uint32_t* room,
+                                    uint32_t total, T* __restrict__ out, T* stage /* [4096 * 4] */,
+                                    unsigned long long* sidx /* [4096] */) {
+    typedef T vec4_t __attribute__((ext_vector_type(4)));
+    constexpr uint32_t ROUND = 4096;
+    for (uint32_t q0 = 0; q0 < total; q0 += ROUND) {
+#pragma unroll
+        for (int u = 0; u < SC_PER_THREAD; ++u) {
+            if (where[u] == 0xffffffffu) continue;
+            const uint32_t e = where[u] >> 16, r = where[u] & 0xffffu;
+            const uint32_t sl = lstart[e] + r - q0;           // unsigned: slots of other rounds fail the test
+            if (sl < ROUND) {
+                reinterpret_cast<vec4_t*>(stage)[sl] = vec4_t{rx[u], ry[u], rz[u], rm[u]};
+                sidx[sl] = (room == nullptr || r < room[e]) ? base[e] + r : ~0ull;
+            }
+        }
+        __syncthreads();
+        const uint32_t here = min(ROUND, total - q0);
+        for (uint32_t i = threadIdx.x; i < here; i += SC_THREADS) {
+            const unsigned long long d = sidx[i];
+            if (d != ~0ull) *reinterpret_cast<vec4_t*>(out + 4 * (size_t)d) = reinterpret_cast<const vec4_t*>(stage)[i];
+        }
+        __syncthreads();
+    }
+}
+
 template <typename T, int W, bool PLAINX>
 __global__ void __launch_bounds__(SC_THREADS)
 scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t np, TileGeom g, uint32_t tpb,
                        unsigned long long* __restrict__ cursor, T* __restrict__ staging) {
-    __shared__ uint32_t cnt[SC_BUCKETS];
+    __shared__ uint32_t cnt[SC_BUCKETS], lstart[SC_BUCKETS], wsum[16];
     __shared__ unsigned long long base[SC_BUCKETS];
+    extern __shared__ unsigned long long dyn[];          // stage: 4096 records, then their 4096 destinations
+    T* stage = reinterpret_cast<T*>(dyn);
+    unsigned long long* sidx = dyn + 4096 * 4 * sizeof(T) / sizeof(unsigned long long);
     const int tid = threadIdx.x;
     cnt[tid] = 0;
     __syncthreads();
     const size_t p0 = (size_t)blockIdx.x * SC_CHUNK;
-    T x[SC_PER_THREAD], y[SC_PER_THREAD], z[SC_PER_THREAD];
+    T x[SC_PER_THREAD], y[SC_PER_THREAD], z[SC_PER_THREAD], m[SC_PER_THREAD];
     uint32_t where[SC_PER_THREAD];                   // bucket << 16 | rank inside the workgroup's run (< 16384)
 #pragma unroll
     for (int u = 0; u < SC_PER_THREAD; ++u) {
@@ -642,6 +700,7 @@ scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, si
         x[u] = pos[3 * p];
         y[u] = pos[3 * p + 1];
         z[u] = pos[3 * p + 2];
+        m[u] = mass ? mass[p] : (T)1;
     }
 #pragma unroll
     for (int u = 0; u < SC_PER_THREAD; ++u) {
@@ -657,13 +716,8 @@ scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, si
     }
     __syncthreads();
     if (cnt[tid]) base[tid] = atomicAdd(&cursor[tid], (unsigned long long)cnt[tid]);
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < SC_PER_THREAD; ++u) {
-        if (where[u] == 0xffffffffu) continue;
-        const size_t p = p0 + (size_t)u * SC_THREADS + tid;
-        store_stray(staging, (size_t)(base[where[u] >> 16] + (where[u] & 0xffffu)), x[u], y[u], z[u], mass ? mass[p] : (T)1);
-    }
+    const uint32_t total = block_exclusive_scan(cnt, lstart, SC_BUCKETS, wsum);
+    staged_store<T>(x, y, z, m, where, lstart, base, nullptr, total, staging, stage, sidx);
 }
 
 // one record deposited with global atomics (a full tile segment): overflow_deposit_kernel's body
@@ -691,13 +745,29 @@ __device__ __noinline__ void deposit_record_global(T x, T y, T z, T m, const Til
     }
 }
 
+// the late list of level B (records whose tile segment was full), deposited with global atomics
+template <typename T, int W>
+__global__ void __launch_bounds__(256)
+late_deposit_kernel(const T* __restrict__ late_list, const unsigned long long* __restrict__ late, unsigned long long late_cap,
+                    TileGeom g, double scale, T* __restrict__ grid, unsigned long long* dropped) {
+    const unsigned long long n = min(*late, late_cap);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x)
+        deposit_record_global<T, W>(late_list[4 * i], late_list[4 * i + 1], late_list[4 * i + 2], late_list[4 * i + 3], g, scale,
+                                    grid, dropped);
+}
+
 template <typename T, int W, bool PLAINX>
 __global__ void __launch_bounds__(SC_THREADS)
 scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* __restrict__ bstart, TileGeom g, uint32_t tpb,
-                       unsigned long long* __restrict__ fill64, T* __restrict__ strays, uint32_t scap, double scale,
-                       T* __restrict__ grid, unsigned long long* __restrict__ late, unsigned long long* dropped) {
-    __shared__ uint32_t cnt[SC_TPB_MAX], room[SC_TPB_MAX];
+                       unsigned long long* __restrict__ fill64, T* __restrict__ strays, uint32_t scap,
+                       T* __restrict__ late_list, unsigned long long late_cap, unsigned long long* __restrict__ late,
+                       unsigned long long* dropped) {
+    __shared__ uint32_t cnt[SC_TPB_MAX], room[SC_TPB_MAX], lstart[SC_TPB_MAX], wsum[16];
     __shared__ unsigned long long base[SC_TPB_MAX];
+    extern __shared__ unsigned long long dyn[];
+    T* stage = reinterpret_cast<T*>(dyn);
+    unsigned long long* sidx = dyn + 4096 * 4 * sizeof(T) / sizeof(unsigned long long);
     const int tid = threadIdx.x;
     const uint32_t bucket = blockIdx.x;
     const size_t b0 = (size_t)bstart[bucket], b1 = (size_t)bstart[bucket + 1];
@@ -706,15 +776,18 @@ scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* 
     for (size_t c0 = b0 + (size_t)blockIdx.y * SC_CHUNK; c0 < b1; c0 += (size_t)gridDim.y * SC_CHUNK) {
         for (uint32_t t = tid; t < tpb; t += SC_THREADS) cnt[t] = 0;
         __syncthreads();
-        vec4_t r[SC_PER_THREAD];
+        T x[SC_PER_THREAD], y[SC_PER_THREAD], z[SC_PER_THREAD], m[SC_PER_THREAD];
         uint32_t where[SC_PER_THREAD];               // tile in bucket << 16 | rank (< 16384)
 #pragma unroll
-        for (int u = 0; u < SC_PER_THREAD; ++u) r[u] = recs[min(c0 + (size_t)u * SC_THREADS + tid, b1 - 1)];
+        for (int u = 0; u < SC_PER_THREAD; ++u) {
+            const vec4_t r = recs[min(c0 + (size_t)u * SC_THREADS + tid, b1 - 1)];
+            x[u] = r.x; y[u] = r.y; z[u] = r.z; m[u] = r.w;
+        }
 #pragma unroll
         for (int u = 0; u < SC_PER_THREAD; ++u) {
             where[u] = 0xffffffffu;
             if (c0 + (size_t)u * SC_THREADS + tid < b1) {
-                const uint32_t lt = tile_of<T, W, PLAINX>(r[u].x, r[u].y, r[u].z, g, nullptr) - bucket * tpb;
+                const uint32_t lt = tile_of<T, W, PLAINX>(x[u], y[u], z[u], g, nullptr) - bucket * tpb;
                 where[u] = (lt << 16) | atomicAdd(&cnt[lt], 1u);
             }
         }
@@ -727,19 +800,16 @@ scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* 
             base[t] = (unsigned long long)tile * scap + bs;
             room[t] = scap - bs;
         }
-        __syncthreads();
+        const uint32_t total = block_exclusive_scan(cnt, lstart, tpb, wsum);
 #pragma unroll
-        for (int u = 0; u < SC_PER_THREAD; ++u) {
-            if (where[u] == 0xffffffffu) continue;
-            const uint32_t lt = where[u] >> 16, at = where[u] & 0xffffu;
-            if (at < room[lt]) {
-                *reinterpret_cast<vec4_t*>(strays + 4 * (size_t)(base[lt] + at)) = r[u];
-            } else {
-                atomicAdd(late, 1ull);
-                deposit_record_global<T, W>(r[u].x, r[u].y, r[u].z, r[u].w, g, scale, grid, dropped);
+        for (int u = 0; u < SC_PER_THREAD; ++u) {         // a full tile segment (rare): the record goes to the late list
+            if (where[u] != 0xffffffffu && (where[u] & 0xffffu) >= room[where[u] >> 16]) {
+                const unsigned long long k = atomicAdd(late, 1ull);
+                if (k < late_cap) reinterpret_cast<vec4_t*>(late_list)[k] = vec4_t{x[u], y[u], z[u], m[u]};
+                else if (dropped) atomicAdd(dropped, 1ull);            // more than a quarter of all particles: reported, not lost silently
             }
         }
-        __syncthreads();
+        staged_store<T>(x, y, z, m, where, lstart, base, room, total, strays, stage, sidx);
     }
 }
 
@@ -1598,13 +1668,18 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
                 constexpr bool PX = decltype(px)::value;
                 scatter_count_kernel<T, W, PX><<<nchunks, SC_THREADS, 0, s>>>(pos, np, g, w.tpb, w.bcount, w.col_flags, dropped);
                 scatter_scan_kernel<<<1, SC_BUCKETS, 0, s>>>(w.bcount, w.bstart, w.bcursor);
-                scatter_level_a_kernel<T, W, PX><<<nchunks, SC_THREADS, 0, s>>>(pos, mass, np, g, w.tpb, w.bcursor, (T*)w.staging);
-                scatter_level_b_kernel<T, W, PX><<<dim3(SC_BUCKETS, 32), SC_THREADS, 0, s>>>(
-                    (const T*)w.staging, w.bstart, g, w.tpb, w.fill64, (T*)w.strays, w.scap, scale, grid, w.late, dropped);
+                const size_t stage_lds = 4096 * (4 * sizeof(T) + sizeof(unsigned long long));
+                scatter_level_a_kernel<T, W, PX><<<nchunks, SC_THREADS, stage_lds, s>>>(pos, mass, np, g, w.tpb, w.bcursor, (T*)w.staging);
+                const unsigned long long late_cap = np / 4 * sizeof(uint32_t) / sizeof(T);       // the overflow list's room
+                scatter_level_b_kernel<T, W, PX><<<dim3(SC_BUCKETS, 32), SC_THREADS, stage_lds, s>>>(
+                    (const T*)w.staging, w.bstart, g, w.tpb, w.fill64, (T*)w.strays, w.scap, (T*)w.ovf, late_cap, w.late, dropped);
             };
             if (plainx) run(std::true_type{}); else run(std::false_type{});
         }
         deposit_pass(nullptr, nullptr, 0);
+        AST_PROF("paint_tiled.overflow", s);
+        late_deposit_kernel<T, W><<<1024, 256, 0, s>>>((const T*)w.ovf, w.late, np / 4 * sizeof(uint32_t) / sizeof(T), g, scale, grid,
+                                                       dropped);
     } else if (overwrite) {
         {
             AST_PROF("paint_tiled.fill", s);
