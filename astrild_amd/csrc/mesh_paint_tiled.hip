@@ -624,6 +624,9 @@ scatter_scan_kernel(const unsigned long long* __restrict__ bcount, unsigned long
     if (tid == (int)SC_BUCKETS - 1) bstart[SC_BUCKETS] = s[tid];
 }
 
+// records staged per round: 96 KB of LDS either way
+template <typename T> constexpr uint32_t sc_round() { return sizeof(T) == 4 ? 4096u : 2048u; }
+
 // Exclusive scan of cnt[0 .. table) into lstart[] by the whole workgroup (SC_THREADS threads, table <= 2 * SC_THREADS);
 // returns the total.  wsum: 16 words of LDS.
 __device__ inline uint32_t block_exclusive_scan(const uint32_t* cnt, uint32_t* lstart, uint32_t table, uint32_t* wsum) {
@@ -654,10 +657,10 @@ template <typename T>
 __device__ inline void staged_store(const T (&rx)[SC_PER_THREAD], const T (&ry)[SC_PER_THREAD], const T (&rz)[SC_PER_THREAD],
                                     const T (&rm)[SC_PER_THREAD], const uint32_t (&where)[SC_PER_THREAD],
                                     const uint32_t* lstart, const unsigned long long* base, const uint32_t* room,
-                                    uint32_t total, T* __restrict__ out, T* stage /* [4096 * 4] */,
-                                    unsigned long long* sidx /* [4096] */) {
+                                    uint32_t total, T* __restrict__ out, T* stage /* [SC_ROUND * 4] */,
+                                    unsigned long long* sidx /* [SC_ROUND] */) {
     typedef T vec4_t __attribute__((ext_vector_type(4)));
-    constexpr uint32_t ROUND = 4096;
+    constexpr uint32_t ROUND = sc_round<T>();
     for (uint32_t q0 = 0; q0 < total; q0 += ROUND) {
 #pragma unroll
         for (int u = 0; u < SC_PER_THREAD; ++u) {
@@ -687,7 +690,7 @@ scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, si
     __shared__ unsigned long long base[SC_BUCKETS];
     extern __shared__ unsigned long long dyn[];          // stage: 4096 records, then their 4096 destinations
     T* stage = reinterpret_cast<T*>(dyn);
-    unsigned long long* sidx = dyn + 4096 * 4 * sizeof(T) / sizeof(unsigned long long);
+    unsigned long long* sidx = dyn + sc_round<T>() * 4 * sizeof(T) / sizeof(unsigned long long);
     const int tid = threadIdx.x;
     cnt[tid] = 0;
     __syncthreads();
@@ -767,7 +770,7 @@ scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* 
     __shared__ unsigned long long base[SC_TPB_MAX];
     extern __shared__ unsigned long long dyn[];
     T* stage = reinterpret_cast<T*>(dyn);
-    unsigned long long* sidx = dyn + 4096 * 4 * sizeof(T) / sizeof(unsigned long long);
+    unsigned long long* sidx = dyn + sc_round<T>() * 4 * sizeof(T) / sizeof(unsigned long long);
     const int tid = threadIdx.x;
     const uint32_t bucket = blockIdx.x;
     const size_t b0 = (size_t)bstart[bucket], b1 = (size_t)bstart[bucket + 1];
@@ -1664,17 +1667,27 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
         {
             AST_PROF("paint_tiled.fill", s);
             const unsigned nchunks = (unsigned)((np + SC_CHUNK - 1) / SC_CHUNK);
-            auto run = [&](auto px) {
+            auto run = [&](auto px) -> int {
                 constexpr bool PX = decltype(px)::value;
                 scatter_count_kernel<T, W, PX><<<nchunks, SC_THREADS, 0, s>>>(pos, np, g, w.tpb, w.bcount, w.col_flags, dropped);
                 scatter_scan_kernel<<<1, SC_BUCKETS, 0, s>>>(w.bcount, w.bstart, w.bcursor);
-                const size_t stage_lds = 4096 * (4 * sizeof(T) + sizeof(unsigned long long));
+                const size_t stage_lds = sc_round<T>() * (4 * sizeof(T) + sizeof(unsigned long long));
+                static bool attr_set = false;           // > 64 KB of dynamic LDS needs the attribute (per template instance)
+                if (!attr_set) {
+                    AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_level_a_kernel<T, W, PX>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds));
+                    AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_level_b_kernel<T, W, PX>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds));
+                    attr_set = true;
+                }
                 scatter_level_a_kernel<T, W, PX><<<nchunks, SC_THREADS, stage_lds, s>>>(pos, mass, np, g, w.tpb, w.bcursor, (T*)w.staging);
                 const unsigned long long late_cap = np / 4 * sizeof(uint32_t) / sizeof(T);       // the overflow list's room
                 scatter_level_b_kernel<T, W, PX><<<dim3(SC_BUCKETS, 32), SC_THREADS, stage_lds, s>>>(
                     (const T*)w.staging, w.bstart, g, w.tpb, w.fill64, (T*)w.strays, w.scap, (T*)w.ovf, late_cap, w.late, dropped);
+                return AST_OK;
             };
-            if (plainx) run(std::true_type{}); else run(std::false_type{});
+            const int rc = plainx ? run(std::true_type{}) : run(std::false_type{});
+            if (rc != AST_OK) return rc;
         }
         deposit_pass(nullptr, nullptr, 0);
         AST_PROF("paint_tiled.overflow", s);

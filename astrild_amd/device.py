@@ -223,18 +223,24 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
                                     mass_bound, float(offset), int(off_planes[0]), int(off_planes[1]), float(shift), stream()),
                   "ast_paint_tiled")
             st = None
-            if compact and (stats is not None or (check_dropped and not tflags & 8)):
+            if compact and (stats is not None or check_dropped):
                 st = torch.empty(4, dtype=torch.int64, device=pos.device)
                 check(L.ast_paint_tiled_list_stats(ptr(ws), win, code, npart, n, nx, tflags, ptr(st), stream()),
                       "ast_paint_tiled_list_stats")
                 st = dict(zip(("groups", "strays", "overflow", "max_strays_per_tile"), st.cpu().tolist()))
-            # particles without spatial order in memory overflow the default stray segments and crawl through
-            # the global-atomic list: paint again with segments sized for that (callers that synchronise anyway)
-            if st is not None and check_dropped and not tflags & 8 and st["overflow"] > npart // 64:
-                tflags |= 8
-                ws_bytes = int(L.ast_paint_tiled_workspace_bytes(win, code, npart, n, nx, tflags))
+            # Too much went through the overflow list.  Particles without spatial order in memory overflow the
+            # default stray segments: paint again with the two-level bucket scatter (AST_PAINT_SCATTERED).  If that
+            # still overflows, the input is strongly CLUSTERED (tiles far above twice the mean occupancy): the exact
+            # two-pass variant has no capacity limit.  (Callers that synchronise anyway.)
+            if st is not None and check_dropped and st["overflow"] > npart // 64:
                 dropped.zero_()
                 del ws
+                if not tflags & 8:
+                    tflags |= 8
+                elif not tflags & 1:
+                    tflags = (tflags & ~8) | 1
+                    compact = False
+                ws_bytes = int(L.ast_paint_tiled_workspace_bytes(win, code, npart, n, nx, tflags))
                 continue
             if stats is not None and st is not None:
                 stats.update(st, scattered=bool(tflags & 8))
