@@ -416,3 +416,34 @@ def test_power_spectrum_3d_catalogue_branch(dev, tmp_path):
     k, pk = ps._power_spectrum_3d_catalog(pos1, None)
     ref = offt.catalog_power_1d(pos1, None, n, L, "tsc", True, True)
     np.testing.assert_allclose(pk, ref["power"].real - ref["shotnoise"], rtol=1e-9, atol=1e-9 * np.abs(ref["power"]).max())
+
+
+@pytest.mark.parametrize("window,dtype", [("cic", np.float32), ("tsc", np.float64)])
+def test_scattered_path_two_level_bucket_scatter(dev, window, dtype):
+    """AST_PAINT_SCATTERED (hint="scattered"): count, scan, particle -> bucket staging, bucket -> tile stray segments,
+    column walk over stray copies only.  Unordered uniform input with masses against the oracle; a clustered blob
+    on top exercises the late list (tile segments full) and, through the API's retry, the exact two-pass variant."""
+    rng = np.random.default_rng(41)
+    n, L, npart = 64, 200.0, 150000
+    pos = rng.uniform(-0.4 * L, 1.4 * L, size=(npart, 3)).astype(dtype)
+    mass = rng.uniform(0.5, 2.0, size=npart).astype(dtype)
+    st = {}
+    got = dev.paint(dev.as_device(pos), dev.as_device(mass), n, L, window, method="tiled", accumulate=False,
+                    hint="scattered", stats=st).cpu().numpy()
+    assert st["scattered"] and st["groups"] == 0 and st["strays"] == npart and st["overflow"] == 0
+    ref = omesh.paint(pos, mass, n, L, window)
+    tol = 1e-11 if dtype == np.float64 else 2e-6
+    np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * ref.max())
+    blob = np.concatenate([rng.normal(0.3 * L, 0.01 * L, size=(npart // 50, 3)), pos[: npart - npart // 50]]).astype(dtype)
+    rng.shuffle(blob)
+    st = {}
+    got = dev.paint(dev.as_device(blob), None, n, L, window, method="tiled", accumulate=False, hint="scattered",
+                    check_dropped=False, stats=st).cpu().numpy()
+    assert 0 < st["overflow"] < npart // 64                       # a few thousand records take the late list
+    ref = omesh.paint(blob, None, n, L, window)
+    np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * ref.max())
+    heavy = np.concatenate([rng.normal(0.3 * L, 0.01 * L, size=(npart // 2, 3)), pos[: npart // 2]]).astype(dtype)
+    rng.shuffle(heavy)
+    got = dev.paint(dev.as_device(heavy), None, n, L, window, method="tiled", accumulate=False).cpu().numpy()   # retries
+    ref = omesh.paint(heavy, None, n, L, window)
+    np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * ref.max())
