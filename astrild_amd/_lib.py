@@ -69,7 +69,7 @@ SIGNATURES = {
     "ast_triple_product_sum": (_i, [_vp, _vp, _vp, _i, _sz, _vp, _vp]),
     "ast_slab_pack": (_i, [_vp, _vp, _i, _sz, _sz, _sz, _i, _vp]),
     "ast_slab_unpack": (_i, [_vp, _vp, _i, _sz, _sz, _sz, _i, _vp]),
-    "ast_kappa_stack": (_i, [_vp, _vp, _vp, _i, _sz, _i, _vp, _vp]),
+    "ast_kappa_stack": (_i, [_vp, _vp, _vp, _i, _sz, _i, _vp, _i, _vp]),
     "ast_lens_plan_create": (_i, [ct.POINTER(_vp), _i, _d]),
     "ast_lens_plan_destroy": (_i, [_vp]),
     "ast_kappa_to_alphas": (_i, [_vp, _vp, _vp, _vp, _vp]),

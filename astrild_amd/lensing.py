@@ -51,8 +51,9 @@ def kappa_stack(planes, wnum=None, wden=None, out=None):
         wn = as_device(np.asarray(wnum, dtype=np.float64))
         wd = as_device(np.asarray(wden, dtype=np.float64))
         assert wn.numel() == len(planes) == wd.numel()
+    aligned = all(t.data_ptr() % 16 == 0 for t in planes) and out.data_ptr() % 16 == 0
     check(_lib.lib().ast_kappa_stack(ptr(ptrs), ptr(wn), ptr(wd), len(planes), first.numel(), code, ptr(out),
-                                     stream()), "ast_kappa_stack")
+                                     int(aligned), stream()), "ast_kappa_stack")
     return out
 
 

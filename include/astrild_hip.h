@@ -346,9 +346,11 @@ int ast_slab_unpack(const void* in_d, void* out_d, int dtype, size_t n0, size_t 
  * re-weighting quantity * g(x_mid, x_s') / g(x_mid, x_s) of
  * rayramses.py:306-312 / simcoll.py:424-430.  planes_d: device array of
  * nplanes device pointers; wnum_d / wden_d: device doubles or NULL (no
- * re-weighting).  fp64 results are bit-identical to numpy. */
+ * re-weighting).  fp64 results are bit-identical to numpy.  aligned16 != 0: the caller
+ * promises that every plane pointer is 16-byte aligned (the pointers live on the device and are
+ * not inspected); the kernel then moves 16 bytes per lane when `count` divides evenly. */
 int ast_kappa_stack(const void* const* planes_d, const double* wnum_d, const double* wden_d,
-                    int nplanes, size_t count, int dtype, void* out_d, void* stream);
+                    int nplanes, size_t count, int dtype, void* out_d, int aligned16, void* stream);
 
 /* --------------------------------------- a-8 / a-9: per-map kappa pipeline */
 
