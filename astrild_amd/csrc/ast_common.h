@@ -46,6 +46,21 @@ __device__ inline int float64_edge_norm(int r, int mx, int my, int mz, double kf
 }
 }  // namespace ast
 
+namespace ast {
+// "has this process already raised the dynamic-LDS limit of this kernel on the CURRENT device?" - the attribute is
+// per device, so the flag is too (one process per GPU is the rule, but nothing forbids a second device).
+struct PerDeviceOnce {
+    bool done[64] = {};
+    bool need() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+        if (done[dev]) return false;
+        done[dev] = true;
+        return true;
+    }
+};
+}  // namespace ast
+
 #define AST_PROF(name, stream) ast::ProfScope ast_prof_scope_(name, stream)
 
 #define AST_CHECK_ARG(cond)                                              \

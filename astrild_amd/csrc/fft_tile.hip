@@ -104,13 +104,19 @@ __global__ void tile_isqrt_table_kernel(int* out, int count) {
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < count; v += gridDim.x * blockDim.x) out[v] = tile_isqrt(v);
 }
 
-template <int R1, int R2, int C, bool POWER>
+// INV: the inverse transform (sum_k X_k e^{+2 pi i k n / N}) as conj(FFT(conj(X))): conjugate on load and on store.
+// With INV the loads may come from a different array `src` of the same layout (data itself when null) and be
+// masked to a shell: rows are k_x, the batch index k_y, the column k_z, and only modes with lo2 <= |m|^2 < hi2 pass
+// (hi2 = 0: no mask) - the shell filter of the bispectrum estimator fused into its first inverse pass.
+struct ShellMask { const float2* src; long long lo2, hi2; };
+
+template <int R1, int R2, int C, bool POWER, bool INV = false>
 __global__ void __launch_bounds__(C * (R1 > R2 ? R1 : R2))
 // N = 1024 with binning: 128 VGPRs, so that two 8-wave workgroups fit a CU (see SPLIT below)
 __attribute__((amdgpu_waves_per_eu(POWER && R1 * R2 >= 1024 ? 4 : 1, POWER && R1 * R2 >= 1024 ? 4 : 8)))
 strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, size_t elem_stride,
                    size_t ncols, size_t batch_stride, unsigned tiles_per_batch, float scale,
-                   double* __restrict__ partial, const unsigned* __restrict__ edge_fall) {
+                   double* __restrict__ partial, const unsigned* __restrict__ edge_fall, ShellMask mask = ShellMask{nullptr, 0, 0}) {
     constexpr int N = R1 * R2;
     constexpr int NT = C * (R1 > R2 ? R1 : R2);
     constexpr int NB = N / 2 - 1;    // shells when POWER
@@ -144,10 +150,24 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
         float2 v[R1];
         // unconditional loads (columns past the end re-read the last valid one, idle sub-tasks the
         // last row block): predicated loads compile to a branch each
-        const float2* lbase = data + (size_t)b * batch_stride + min(c0 + c, ncols - 1);
+        const float2* lbase = (INV && mask.src ? mask.src : data) + (size_t)b * batch_stride + min(c0 + c, ncols - 1);
         const int lsub = task1 ? sub : R2 - 1;
 #pragma unroll
         for (int n1 = 0; n1 < R1; ++n1) v[n1] = lbase[(size_t)(n1 * R2 + lsub) * elem_stride];
+        if (INV) {
+            if (mask.hi2 > 0) {
+                const long long kz = (long long)min(c0 + c, ncols - 1), ky = (long long)((int)b > N / 2 ? (int)b - N : (int)b);
+                const long long m2yz = ky * ky + kz * kz;
+#pragma unroll
+                for (int n1 = 0; n1 < R1; ++n1) {
+                    const int row = n1 * R2 + lsub;
+                    const long long kx = row > N / 2 ? row - N : row, m2 = kx * kx + m2yz;
+                    if (m2 < mask.lo2 || m2 >= mask.hi2) v[n1] = make_float2(0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) v[n1].y = -v[n1].y;
+        }
         fft_reg<R1>(v);
         __syncthreads();                              // twiddle table is in LDS
         if (!SPLIT) {
@@ -193,7 +213,7 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
             for (int k2 = 0; k2 < R2; ++k2) {
                 float2 x = u[bitrev(k2, ilog2(R2))];
                 x.x *= scale;
-                x.y *= scale;
+                x.y *= INV ? -scale : scale;
                 base[(size_t)(sub + R1 * k2) * elem_stride] = x;
             }
         }
@@ -372,6 +392,76 @@ rows_r2c_kernel(const float* __restrict__ in, float2* __restrict__ out, const fl
         // X[k] = e - i t ;  X[M-k] = conj(e) - i * conj(w^k)... = conj(e + i t)
         orow[k] = make_float2((e.x + t.y) * scale, (e.y - t.x) * scale);
         orow[M - k] = make_float2((e.x - t.y) * scale, (-e.y - t.x) * scale);
+    }
+}
+
+// ------------------------------------------------------- contiguous-row C2R pass
+// in: nrows rows of M + 1 complex (pitch in_pitch complex, Hermitian half spectrum of a real row, X[0] and X[M] real
+// as far as they matter: their imaginary parts are ignored like in every C2R); out: rows of N = 2 M reals,
+// x[n] = sum_{k=0}^{N-1} X[k] e^{+2 pi i k n / N} (unnormalised).  The inverse of rows_r2c_kernel:
+//   Z[k] = (X[k] + conj X[M-k]) / 2  +  i w^{-k} (X[k] - conj X[M-k]) / 2,   w = e^{-2 pi i / N},  k < M
+//   z = IFFT_M(Z) (as conj(FFT(conj Z)), the two-stage register FFT of the forward pass),  x[2j] + i x[2j+1] = 2 z[j].
+template <int R1, int R2, int C>
+__global__ void __launch_bounds__(C * R2)
+rows_c2r_kernel(const float2* __restrict__ in, float* __restrict__ out, const float2* __restrict__ tw_g,
+                size_t nrows, size_t in_pitch, size_t out_pitch, float scale) {
+    constexpr int M = R1 * R2, N = 2 * M;
+    constexpr int NT = C * R2;
+    constexpr int R2P = R2 + 1;
+    constexpr int MP = M + 1;
+    extern __shared__ float2 lds[];
+    float2* Y = lds;                     // X rows [r][k <= M], then the stage buffer [r][k1][n2] (padded), then z[r][j]
+    float2* tw = lds + C * (R1 * R2P > MP ? R1 * R2P : MP);     // exp(-2 pi i m / N), m < N
+    for (int i = threadIdx.x; i < N; i += NT) tw[i] = tw_g[i];
+    const size_t row0 = (size_t)blockIdx.x * C;
+    for (int i = threadIdx.x; i < C * MP; i += NT) {
+        const int rr = i / MP, k = i % MP;
+        Y[rr * MP + k] = in[min(row0 + rr, nrows - 1) * in_pitch + k];
+    }
+    __syncthreads();
+    const int n2 = threadIdx.x % R2, r = threadIdx.x / R2;        // stage-1 task (r, n2)
+    float2 v[R1];
+#pragma unroll
+    for (int n1 = 0; n1 < R1; ++n1) {
+        const int k = n1 * R2 + n2;                               // < M
+        const float2 xk = Y[r * MP + k], xm = Y[r * MP + M - k];
+        const float2 e = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));      // (X[k] + conj X[M-k]) / 2
+        const float2 d = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y + xm.y));      // (X[k] - conj X[M-k]) / 2
+        const float2 w = tw[k];                                                        // w^k; conj = w^{-k}
+        const float2 t = make_float2(d.x * w.x + d.y * w.y, d.y * w.x - d.x * w.y);    // w^{-k} d
+        // Z = e + i t;  the FFT below runs on conj(Z)
+        v[n1] = make_float2(e.x - t.y, -(e.y + t.x));
+    }
+    __syncthreads();                                              // everyone has read the X rows: Y is reused
+    fft_reg<R1>(v);
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) {
+        float2 y = v[bitrev(k1, ilog2(R1))];
+        if (k1 != 0) y = cmul(y, tw[2 * n2 * k1]);                // W_M = W_N^2
+        Y[(r * R1 + k1) * R2P + n2] = y;
+    }
+    __syncthreads();
+    float2 u[R2];
+    const int k1 = threadIdx.x % R1, r2 = threadIdx.x / R1;       // stage-2 task (r2, k1)
+    const bool task2 = r2 < C;
+    if (task2) {
+#pragma unroll
+        for (int j = 0; j < R2; ++j) u[j] = Y[(r2 * R1 + k1) * R2P + j];
+        fft_reg<R2>(u);
+    }
+    __syncthreads();
+    if (task2) {
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) Y[r2 * MP + k1 + R1 * k2] = u[bitrev(k2, ilog2(R2))];
+    }
+    __syncthreads();
+    // z[j] = conj(result[j]); x[2j] = 2 Re z, x[2j+1] = 2 Im z
+    const float s2 = 2.0f * scale;
+    for (int i = threadIdx.x; i < C * M; i += NT) {
+        const int rr = i / M, j = i % M;
+        if (row0 + rr >= nrows) continue;
+        const float2 z = Y[rr * MP + j];
+        reinterpret_cast<float2*>(out + (row0 + rr) * out_pitch)[j] = make_float2(z.x * s2, -z.y * s2);
     }
 }
 
@@ -681,11 +771,10 @@ int launch_c2c(float2* data, const float2* tw, size_t elem_stride, size_t ncols,
     constexpr int N = R1 * R2, NT = C * (R1 > R2 ? R1 : R2);
     constexpr bool SPLIT = POWER && R1 == R2 && N * C * sizeof(float2) > 64 * 1024;       // as in the kernel
     const size_t lds = (size_t)((SPLIT ? N / 2 : N) * C + N) * sizeof(float2) + (POWER ? (N / 2) * sizeof(double) : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static ast::PerDeviceOnce attr_once;
+    if (attr_once.need()) {
         AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&strided_c2c_kernel<R1, R2, C, POWER>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     const size_t tiles = (ncols + C - 1) / C;
     AST_CHECK_ARG(tiles * batch < 0x7fffffffull);
@@ -694,6 +783,31 @@ int launch_c2c(float2* data, const float2* tw, size_t elem_stride, size_t ncols,
                                                                                    partial, edge_fall);
     AST_CHECK_LAUNCH();
     return AST_OK;
+}
+
+template <int R1, int R2, int C>
+int launch_c2c_inv(float2* data, const float2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride,
+                   float scale, ShellMask mask, hipStream_t s) {
+    constexpr int N = R1 * R2, NT = C * (R1 > R2 ? R1 : R2);
+    const size_t lds = (size_t)(N * C + N) * sizeof(float2);
+    static ast::PerDeviceOnce attr_once;
+    if (attr_once.need()) {
+        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&strided_c2c_kernel<R1, R2, C, false, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    const size_t tiles = (ncols + C - 1) / C;
+    AST_CHECK_ARG(tiles * batch < 0x7fffffffull);
+    strided_c2c_kernel<R1, R2, C, false, true><<<(unsigned)(tiles * batch), NT, lds, s>>>(data, tw, elem_stride, ncols, batch_stride,
+                                                                                        (unsigned)tiles, scale, nullptr, nullptr, mask);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+int dispatch_c2c_inv(size_t n, float2* d, const float2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride,
+                     float scale, ShellMask mask, hipStream_t s) {
+    if (n == 1024) return launch_c2c_inv<32, 32, 16>(d, tw, elem_stride, ncols, batch, batch_stride, scale, mask, s);
+    if (n == 512) return launch_c2c_inv<16, 32, 16>(d, tw, elem_stride, ncols, batch, batch_stride, scale, mask, s);
+    return launch_c2c_inv<16, 16, 16>(d, tw, elem_stride, ncols, batch, batch_stride, scale, mask, s);
 }
 
 template <bool POWER>
@@ -710,15 +824,32 @@ int launch_r2c(const float* in, float2* out, const float2* tw, size_t nrows, siz
     constexpr int M = R1 * R2, N = 2 * M, NT = C * R2;
     constexpr int BUF = C * (R1 * (R2 + 1) > M + 1 ? R1 * (R2 + 1) : M + 1);
     const size_t lds = (size_t)(BUF + N) * sizeof(float2);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static ast::PerDeviceOnce attr_once;
+    if (attr_once.need()) {
         AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rows_r2c_kernel<R1, R2, C, FOLDW>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     const size_t blocks = (nrows + C - 1) / C;
     AST_CHECK_ARG(blocks < 0x7fffffffull);
     rows_r2c_kernel<R1, R2, C, FOLDW><<<(unsigned)blocks, NT, lds, s>>>(in, out, tw, nrows, in_pitch, out_pitch, scale, mean, rec);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+template <int R1, int R2, int C>
+int launch_c2r(const float2* in, float* out, const float2* tw, size_t nrows, size_t in_pitch, size_t out_pitch, float scale,
+               hipStream_t s) {
+    constexpr int M = R1 * R2, N = 2 * M, NT = C * R2;
+    constexpr int BUF = C * (R1 * (R2 + 1) > M + 1 ? R1 * (R2 + 1) : M + 1);
+    const size_t lds = (size_t)(BUF + N) * sizeof(float2);
+    static ast::PerDeviceOnce attr_once;
+    if (attr_once.need()) {
+        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rows_c2r_kernel<R1, R2, C>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    const size_t blocks = (nrows + C - 1) / C;
+    AST_CHECK_ARG(blocks < 0x7fffffffull);
+    rows_c2r_kernel<R1, R2, C><<<(unsigned)blocks, NT, lds, s>>>(in, out, tw, nrows, in_pitch, out_pitch, scale);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
@@ -929,4 +1060,33 @@ extern "C" int ast_lowk_shell_sums(const void* modes, size_t n, double boxsize, 
                                                           binning == AST_BIN_FLOAT64 ? 2.0 * M_PI / boxsize : 0.0, sums);
     AST_CHECK_LAUNCH();
     return AST_OK;
+}
+
+// The unnormalised inverse of ast_fft_tile_r2c_3d's layout, real_out[x] = sum_k spec_k e^{+ikx}, for an (n, n, n/2+1)
+// half spectrum, in three tile passes (x, y, z).  spec_d is NOT modified; work_d (same size as spec_d) is.  With
+// m_hi > m_lo >= 0 only the modes with m_lo <= |m| < m_hi enter (the shell filter of the bispectrum estimator, fused
+// into the first pass's loads); m_hi = 0: all modes.
+extern "C" int ast_fft_tile_c2r_3d(const void* spec, void* work, void* out, int dtype, size_t n, int m_lo, int m_hi,
+                                   double scale, void* stream) {
+    AST_CHECK_ARG(spec != nullptr && work != nullptr && out != nullptr && spec != work && work != out);
+    AST_CHECK_ARG(ast_fft_tile_supported(dtype, n));
+    AST_CHECK_ARG(m_lo >= 0 && (m_hi == 0 || m_hi > m_lo));
+    const float2* tw = g_tw.get((int)n);
+    if (!tw) { ast::set_error("ast_fft_tile_c2r_3d: twiddle table allocation failed"); return AST_ERR_HIP; }
+    hipStream_t s = ast::as_stream(stream);
+    const size_t nz = n / 2 + 1;
+    ShellMask mask{(const float2*)spec, (long long)m_lo * m_lo, (long long)m_hi * m_hi};
+    {
+        AST_PROF("fft_tile.c2c_inv", s);
+        // x: rows k_x (element stride n * nz), batch k_y (stride nz), columns k_z; masked loads from spec, stores to work
+        int rc = dispatch_c2c_inv(n, (float2*)work, tw, n * nz, nz, n, nz, 1.0f, mask, s);
+        if (rc != AST_OK) return rc;
+        // y: per x plane, rows k_y (stride nz), in place
+        rc = dispatch_c2c_inv(n, (float2*)work, tw, nz, nz, n, n * nz, 1.0f, ShellMask{nullptr, 0, 0}, s);
+        if (rc != AST_OK) return rc;
+    }
+    AST_PROF("fft_tile.rows_c2r", s);
+    if (n == 1024) return launch_c2r<16, 32, 16>((const float2*)work, (float*)out, tw, n * n, nz, n, (float)scale, s);
+    if (n == 512) return launch_c2r<16, 16, 16>((const float2*)work, (float*)out, tw, n * n, nz, n, (float)scale, s);
+    return launch_c2r<8, 16, 16>((const float2*)work, (float*)out, tw, n * n, nz, n, (float)scale, s);
 }

@@ -1672,14 +1672,13 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
                 scatter_count_kernel<T, W, PX><<<nchunks, SC_THREADS, 0, s>>>(pos, np, g, w.tpb, w.bcount, w.col_flags, dropped);
                 scatter_scan_kernel<<<1, SC_BUCKETS, 0, s>>>(w.bcount, w.bstart, w.bcursor);
                 const size_t stage_lds = sc_round<T>() * (4 * sizeof(T) + sizeof(unsigned long long));
-                static bool attr_set = false;           // > 64 KB of dynamic LDS needs the attribute (per template instance)
-                if (!attr_set) {
+                static ast::PerDeviceOnce attr_once;
+                if (attr_once.need()) {
                     AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_level_a_kernel<T, W, PX>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds));
                     AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_level_b_kernel<T, W, PX>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds));
-                    attr_set = true;
-                }
+                            }
                 scatter_level_a_kernel<T, W, PX><<<nchunks, SC_THREADS, stage_lds, s>>>(pos, mass, np, g, w.tpb, w.bcursor, (T*)w.staging);
                 const unsigned long long late_cap = np / 4 * sizeof(uint32_t) / sizeof(T);       // the overflow list's room
                 scatter_level_b_kernel<T, W, PX><<<dim3(SC_BUCKETS, 32), SC_THREADS, stage_lds, s>>>(

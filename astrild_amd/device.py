@@ -128,7 +128,8 @@ def ngp_assign(x, y, z, values, npar, dtype=torch.float64):
                                     ptr(grid), ptr(owner), ptr(dropped), stream()), "ast_ngp_assign")
     nd = int(dropped.item())
     if nd:
-        raise IndexError(f"{nd} particles have coordinates outside [0, 1) (numpy would raise too)")
+        raise IndexError(f"{nd} particles have coordinates outside [0, 1) (numpy raises for >= 1 and wraps negative "
+                         f"indices, i.e. coordinates in [-1, 0), silently; both are rejected here)")
     return grid
 
 
@@ -192,7 +193,11 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
         ws_bytes = int(L.ast_paint_tiled_workspace_bytes(win, code, npart, n, nx, tflags))
     if method in ("tiled", "tiled2") and ws_bytes == 0:
         raise _lib.AstrildHipError("tiled paint needs a CIC/TSC window and nmesh a multiple of 32")
-    use_tiled = ws_bytes > 0 and (method in ("tiled", "tiled2") or npart >= 65536)
+    # "auto": the tiled paint walks every column of the grid and its workspace scales with the GRID, so it only pays
+    # when the tiles are reasonably full (>= 64 particles per 8 x 8 x 32 tile on average); sparse catalogues on big
+    # grids (SubFind haloes on nbins = 1024) take the direct atomic path
+    dense = npart >= 65536 and npart * 2048 >= 64 * nx * n * n
+    use_tiled = ws_bytes > 0 and (method in ("tiled", "tiled2") or dense)
     if defer_fold and not (use_tiled and not accumulate and x_start == 0 and nx == n):
         raise _lib.AstrildHipError("defer_fold needs the tiled overwrite paint of the whole periodic grid")
     if out is None:
@@ -424,7 +429,7 @@ def paint_power_1d(pos, mass, nmesh, boxsize, window="cic", scale=1.0, binning=N
     as one pipeline: where the fused fp32 path applies, the paint's halo fold rides on the FFT's z pass."""
     n = int(nmesh)
     fast = pos.dtype == torch.float32 and n % 32 == 0 and pos.shape[0] >= 65536 \
-        and bool(_lib.lib().ast_fft_tile_supported(F32, n))
+        and pos.shape[0] * 2048 >= 64 * n ** 3 and bool(_lib.lib().ast_fft_tile_supported(F32, n))     # tiles reasonably full
     if fast:
         # the grid holds rho - mean (subtracted before the fp32 rounding): only the discarded DC mode differs
         grid, halo = paint(pos, mass, n, boxsize, window, scale=scale, method="tiled", defer_fold=True,
