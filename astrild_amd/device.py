@@ -519,6 +519,19 @@ def c2r(spec, shape, out=None):
     return out
 
 
+def c2r_tile(spec, work=None, out=None, m_lo=0, m_hi=0, scale=1.0):
+    """Unnormalised inverse of :func:`r2c`'s layout through the hand-written tile passes (complex64 cubes of side
+    256/512/1024), optionally restricted to the shell m_lo <= |m| < m_hi (the bispectrum estimator's masked inverse
+    transform in one call).  ``spec`` is left intact; ``work`` (same shape) is scratch."""
+    n = spec.shape[0]
+    assert spec.is_cuda and spec.is_contiguous() and spec.dtype == torch.complex64 and tuple(spec.shape) == (n, n, n // 2 + 1)
+    work = torch.empty_like(spec) if work is None else work
+    out = torch.empty((n, n, n), dtype=torch.float32, device=spec.device) if out is None else out
+    check(_lib.lib().ast_fft_tile_c2r_3d(ptr(spec), ptr(work), ptr(out), F32, n, int(m_lo), int(m_hi), float(scale), stream()),
+          "ast_fft_tile_c2r_3d")
+    return out
+
+
 def shell_filter(spec, nmesh, m_lo, m_hi, out=None, i0=None, i1=None, dtype=None):
     """out = spec * 1[m_lo <= |m| < m_hi]; spec=None writes the bare indicator."""
     n = int(nmesh)
@@ -579,9 +592,13 @@ def bispectrum(field, boxsize, edges, triangles):
         _tri_cache[key] = ntri
         _tri_cache[key + ("residual",)] = worst
     dfields = {}
+    tile = spec.dtype == torch.complex64 and bool(_lib.lib().ast_fft_tile_supported(F32, n))
     for s in used:
-        shell_filter(spec, n, edges[s], edges[s + 1], out=scratch)
-        dfields[s] = c2r(scratch, (n, n, n))
+        if tile:                      # shell mask fused into the first of three tile passes
+            dfields[s] = c2r_tile(spec, work=scratch, m_lo=edges[s], m_hi=edges[s + 1])
+        else:
+            shell_filter(spec, n, edges[s], edges[s + 1], out=scratch)
+            dfields[s] = c2r(scratch, (n, n, n))
     nums = [triple_product_sum(dfields[i], dfields[j], dfields[l]) for (i, j, l) in triangles]
     num = torch.cat(nums).cpu().numpy()
     kf = 2.0 * np.pi / boxsize

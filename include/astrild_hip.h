@@ -240,6 +240,12 @@ int ast_fft_tile_c2c(void* data_d, int dtype, size_t n, size_t elem_stride, size
 int ast_fft_tile_rows_r2c(const void* in_d, void* out_d, int dtype, size_t n, size_t nrows, size_t in_pitch,
                           size_t out_pitch, double scale, void* stream);
 int ast_fft_tile_r2c_3d(const void* in_d, void* out_d, int dtype, size_t n, double scale, void* stream);
+/* The unnormalised inverse in three tile passes (x, y, z): out_d[x] = scale * sum_k spec_k e^{+ikx} for an (n, n, n/2+1)
+ * half spectrum (fp32, n in {256, 512, 1024}).  spec_d is not modified; work_d (as large as spec_d) is scratch.
+ * m_hi > m_lo >= 0: only the modes with m_lo <= |m| < m_hi enter - the shell filter of the bispectrum estimator
+ * (ast_shell_filter) fused into the first pass's loads; m_hi = 0: all modes. */
+int ast_fft_tile_c2r_3d(const void* spec_d, void* work_d, void* out_d, int dtype, size_t n, int m_lo, int m_hi,
+                        double scale, void* stream);
 /* a-4 + a-5 fused: FFTPower's shell sums of an (n, n, n) real grid.  z and y passes
  * go through scratch_d (line-aligned row pitch); the x pass adds w |delta_k|^2 of its
  * modes to per-workgroup shell tables instead of storing delta_k, and a fixed-order
