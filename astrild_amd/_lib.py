@@ -58,6 +58,8 @@ SIGNATURES = {
     "ast_fft_tile_power_3d": (_i, [_vp, _vp, _sz, _i, _sz, _d, _d, _i, _i, _vp, _vp]),
     "ast_fft_tile_isqrt_table": (_i, [_vp, _i, _vp]),
     "ast_fft_tile_power_3d_halo": (_i, [_vp, _vp, _i, _vp, _sz, _i, _sz, _d, _d, _i, _i, _vp, _vp]),
+    "ast_fft_tile_block_power_scratch_bytes": (_sz, [_sz, _sz]),
+    "ast_fft_tile_block_power": (_i, [_vp, _vp, _sz, _i, _sz, _sz, _sz, _sz, _d, _d, _i, _i, _vp, _vp]),
     "ast_lowk_work_bytes": (_sz, [_sz, _sz]),
     "ast_lowk_mode_count": (_i, []),
     "ast_lowk_shell_count": (_i, []),

@@ -108,7 +108,7 @@ __global__ void tile_isqrt_table_kernel(int* out, int count) {
 // With INV the loads may come from a different array `src` of the same layout (data itself when null) and be
 // masked to a shell: rows are k_x, the batch index k_y, the column k_z, and only modes with lo2 <= |m|^2 < hi2 pass
 // (hi2 = 0: no mask) - the shell filter of the bispectrum estimator fused into its first inverse pass.
-struct ShellMask { const float2* src; long long lo2, hi2; };
+struct ShellMask { const float2* src; long long lo2, hi2; int ky0 = 0; };     // ky0 (POWER): global k_y index of batch 0 (slab blocks)
 
 template <int R1, int R2, int C, bool POWER, bool INV = false>
 __global__ void __launch_bounds__(C * (R1 > R2 ? R1 : R2))
@@ -222,7 +222,8 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
         // one ds_add_f64 per mode; merging a wave's equal-shell lanes first (ballot + cross-lane
         // adds) measured slower: 16 kz x 4 kx lanes rarely share one shell
         const int kz = (int)(c0 + c);
-        const int ky = (int)b > N / 2 ? (int)b - N : (int)b;
+        const int kyi = (int)b + mask.ky0;
+        const int ky = kyi > N / 2 ? kyi - N : kyi;
         const int m2yz = ky * ky + kz * kz;
         const float w = (kz > 0 && kz < N / 2) ? 2.0f : 1.0f;
 #pragma unroll
@@ -767,7 +768,7 @@ struct TwiddleCache {
 
 template <int R1, int R2, int C, bool POWER>
 int launch_c2c(float2* data, const float2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride,
-               float scale, double* partial, hipStream_t s, const unsigned* edge_fall = nullptr) {
+               float scale, double* partial, hipStream_t s, const unsigned* edge_fall = nullptr, int ky0 = 0) {
     constexpr int N = R1 * R2, NT = C * (R1 > R2 ? R1 : R2);
     constexpr bool SPLIT = POWER && R1 == R2 && N * C * sizeof(float2) > 64 * 1024;       // as in the kernel
     const size_t lds = (size_t)((SPLIT ? N / 2 : N) * C + N) * sizeof(float2) + (POWER ? (N / 2) * sizeof(double) : 0);
@@ -780,7 +781,7 @@ int launch_c2c(float2* data, const float2* tw, size_t elem_stride, size_t ncols,
     AST_CHECK_ARG(tiles * batch < 0x7fffffffull);
     strided_c2c_kernel<R1, R2, C, POWER><<<(unsigned)(tiles * batch), NT, lds, s>>>(data, tw, elem_stride, ncols,
                                                                                    batch_stride, (unsigned)tiles, scale,
-                                                                                   partial, edge_fall);
+                                                                                   partial, edge_fall, ShellMask{nullptr, 0, 0, ky0});
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
@@ -812,10 +813,10 @@ int dispatch_c2c_inv(size_t n, float2* d, const float2* tw, size_t elem_stride, 
 
 template <bool POWER>
 int dispatch_c2c(size_t n, float2* d, const float2* tw, size_t elem_stride, size_t ncols, size_t batch,
-                 size_t batch_stride, float scale, double* partial, hipStream_t s, const unsigned* edge_fall = nullptr) {
-    if (n == 1024) return launch_c2c<32, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall);
-    if (n == 512) return launch_c2c<16, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall);
-    return launch_c2c<16, 16, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall);
+                 size_t batch_stride, float scale, double* partial, hipStream_t s, const unsigned* edge_fall = nullptr, int ky0 = 0) {
+    if (n == 1024) return launch_c2c<32, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0);
+    if (n == 512) return launch_c2c<16, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0);
+    return launch_c2c<16, 16, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0);
 }
 
 template <int R1, int R2, int C, int FOLDW = 0>
@@ -1089,4 +1090,48 @@ extern "C" int ast_fft_tile_c2r_3d(const void* spec, void* work, void* out, int 
     if (n == 1024) return launch_c2r<16, 32, 16>((const float2*)work, (float*)out, tw, n * n, nz, n, (float)scale, s);
     if (n == 512) return launch_c2r<16, 16, 16>((const float2*)work, (float*)out, tw, n * n, nz, n, (float)scale, s);
     return launch_c2r<8, 16, 16>((const float2*)work, (float*)out, tw, n * n, nz, n, (float)scale, s);
+}
+
+// The last pass of a slab-decomposed transform fused with the shell binning: `block_d` is a rank's (n, nloc, pitch)
+// block of the spectrum after the all-to-all (all k_x, k_y = ky0 .. ky0 + nloc - 1, half k_z; row pitch `pitch` >= n/2+1
+// complex); the axis-0 pass runs over it and, instead of storing delta_k, adds w |delta_k|^2 of its modes to
+// psum_d (+=, L^3 sum w |delta_k|^2 with delta_k scaled by `scale`; the block's contents afterwards are undefined).
+// scratch_d: ast_fft_tile_block_power_scratch_bytes(n, nloc) bytes.  first_bin: shells below it are skipped (they
+// come from the low-k channel).
+extern "C" size_t ast_fft_tile_block_power_scratch_bytes(size_t n, size_t nloc) {
+    const size_t tiles = (n / 2 + 1 + 15) / 16, nb = n / 2 - 1;
+    return (nloc * tiles + REDUCE_ROWS) * nb * sizeof(double);
+}
+
+extern "C" int ast_fft_tile_block_power(void* block, void* scratch, size_t scratch_bytes, int dtype, size_t n, size_t nloc,
+                                        size_t ky0, size_t pitch, double scale, double boxsize, int first_bin, int binning,
+                                        double* psum, void* stream) {
+    AST_CHECK_ARG(block != nullptr && scratch != nullptr && psum != nullptr && boxsize > 0.0);
+    AST_CHECK_ARG(ast_fft_tile_supported(dtype, n));
+    AST_CHECK_ARG(nloc >= 1 && ky0 + nloc <= n && pitch >= n / 2 + 1 && first_bin >= 0);
+    AST_CHECK_ARG(binning == AST_BIN_INTEGER || binning == AST_BIN_FLOAT64);
+    AST_CHECK_ARG(scratch_bytes >= ast_fft_tile_block_power_scratch_bytes(n, nloc));
+    const size_t nz = n / 2 + 1, tiles = (nz + 15) / 16;
+    const int nb = (int)(n / 2 - 1);
+    const float2* tw = g_tw.get((int)n);
+    if (!tw) { ast::set_error("ast_fft_tile_block_power: twiddle table allocation failed"); return AST_ERR_HIP; }
+    hipStream_t s = ast::as_stream(stream);
+    const unsigned* edge_fall = nullptr;
+    if (binning == AST_BIN_FLOAT64) {
+        edge_fall = g_edge.get(n, boxsize, s);
+        if (!edge_fall) { ast::set_error("ast_fft_tile_block_power: edge table allocation failed"); return AST_ERR_HIP; }
+        edge_fall += ky0 * tiles * (n == 256 ? 256 : 512);          // the table is [k_y][tile][thread]
+    }
+    double* partial = (double*)scratch;
+    double* partial2 = partial + nloc * tiles * nb;
+    {
+        AST_PROF("fft_tile.c2c_power", s);
+        int rc = dispatch_c2c<true>(n, (float2*)block, tw, nloc * pitch, nz, nloc, pitch, (float)scale, partial, s, edge_fall, (int)ky0);
+        if (rc != AST_OK) return rc;
+    }
+    AST_PROF("fft_tile.shell_reduce", s);
+    shell_partials_stage1_kernel<<<REDUCE_ROWS, 256, 0, s>>>(partial, nloc * tiles, nb, partial2);
+    shell_partials_stage2_kernel<<<(nb + 7) / 8, 256, 0, s>>>(partial2, nb, boxsize * boxsize * boxsize, first_bin, psum);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
 }

@@ -100,6 +100,26 @@ class HipSlabOps:
         plan.execute(block, None)
         return block
 
+    def axis0_power_supported(self, n):
+        return self.dtype == torch.float32 and self._tile_ok(0, n)
+
+    def fft1d_axis0_power(self, block, scale, n, boxsize, ky0, psum, first_bin):
+        """The axis-0 pass fused with the shell binning of the block (ast_fft_tile_block_power): delta_k never goes
+        back to HBM.  psum is overwritten with the block's shell sums (shells below first_bin left at zero)."""
+        from ._lib import check, lib
+        n0, nloc, pitch = block.shape
+        key = (n, nloc)
+        if getattr(self, "_bp_key", None) != key:
+            self._bp_key = key
+            self._bp_scratch = torch.empty(int(lib().ast_fft_tile_block_power_scratch_bytes(n, nloc)), dtype=torch.uint8,
+                                           device=self.device)
+        psum.zero_()
+        check(lib().ast_fft_tile_block_power(self.dev.ptr(block), self.dev.ptr(self._bp_scratch), self._bp_scratch.numel(), 0, n,
+                                             nloc, int(ky0), pitch, float(scale), float(boxsize), int(first_bin),
+                                             self.dev._bin_code(None), self.dev.ptr(psum), self.dev.stream()),
+              "ast_fft_tile_block_power")
+        return psum
+
     def shell_geometry(self, n, boxsize, i0, i1):
         return self.dev.shell_geometry(n, boxsize, i0, i1)
 
@@ -279,7 +299,7 @@ class SlabPowerPipeline:
             return self.buf
         return ghost_fold(self.buf, self.nloc, self.gl, self.gh, self.ops, self.group)
 
-    def forward_fft(self, owned):
+    def forward_fft(self, owned, last_pass=True):
         o = self.ops
         pending = []
         for c in range(self.chunks):
@@ -290,6 +310,8 @@ class SlabPowerPipeline:
             pending += exchange_chunk(self.packed[c], self.block, c, self.pc, self.nloc, self.group)
         for work in pending:
             work.wait()
+        if not last_pass:
+            return self.block
         return o.fft1d_axis0(self.block, 1.0 / float(self.n) ** 3)
 
     def step(self, check=False):
@@ -299,8 +321,15 @@ class SlabPowerPipeline:
             # the lowest shells from double-precision DFT sums of the rank's own planes (device.power_sums_fused's
             # low-k channel, split over the slabs): one more all-reduce, of 1183 complex numbers
             modes = self.ops.lowk_modes(owned, self.n, self.rank * self.nloc)
-        block = self.forward_fft(owned)
-        self.ops.power_bin(block, self.n, self.L, self.i0, self.i1, self.psum)
+        fused_fn = getattr(self.ops, "axis0_power_supported", None)
+        if fused_fn and fused_fn(self.n):
+            # axis-0 pass and shell binning in one kernel (the spectrum block is not written back)
+            block = self.forward_fft(owned, last_pass=False)
+            self.ops.fft1d_axis0_power(block, 1.0 / float(self.n) ** 3, self.n, self.L, self.rank * self.nloc, self.psum,
+                                       5 if modes is not None else 0)
+        else:
+            block = self.forward_fft(owned)
+            self.ops.power_bin(block, self.n, self.L, self.i0, self.i1, self.psum)
         comm_ready(self.group)
         dist.all_reduce(self.psum, group=self.group)
         if modes is not None:

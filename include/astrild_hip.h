@@ -271,6 +271,16 @@ int ast_fft_tile_power_3d_halo(const void* grid_d, const void* halo_rec_d, int w
                                size_t scratch_bytes, int dtype, size_t n, double boxsize, double mean,
                                int lowk, int binning, double* psum_d, void* stream);
 
+/* The axis-0 pass of a slab-decomposed transform fused with the shell binning (the multi-GPU counterpart of the fused x
+ * pass): block_d is the rank's (n, nloc, pitch) block of the spectrum after the all-to-all - all k_x, k_y = ky0 ..
+ * ky0 + nloc - 1, half k_z, `pitch` >= n/2+1 complex per row.  psum_d[shell] += L^3 sum w |scale * X|^2 over the block's
+ * modes; shells below first_bin are skipped (low-k channel); the block's contents afterwards are undefined.
+ * scratch_d: ast_fft_tile_block_power_scratch_bytes(n, nloc). */
+size_t ast_fft_tile_block_power_scratch_bytes(size_t n, size_t nloc);
+int ast_fft_tile_block_power(void* block_d, void* scratch_d, size_t scratch_bytes, int dtype, size_t n, size_t nloc,
+                             size_t ky0, size_t pitch, double scale, double boxsize, int first_bin, int binning,
+                             double* psum_d, void* stream);
+
 /* The low-k channel as separate calls, for slab-decomposed grids: every rank adds the contribution of its own
  * planes to the (2*6+1)^2 * 7 modes |m_i| <= 6, m_z >= 0 (complex128, [kx + 6][ky + 6][kz]); the modes are summed over
  * ranks; the sums of the ast_lowk_shell_count() lowest shells are then taken from them.
