@@ -51,6 +51,7 @@ SIGNATURES = {
     "ast_fft_plan_destroy": (_i, [_vp]),
     "ast_fft_tile_supported": (_i, [_i, _sz]),
     "ast_fft_tile_c2c": (_i, [_vp, _i, _sz, _sz, _sz, _sz, _sz, _d, _vp]),
+    "ast_fft_tile_c2c_packed": (_i, [_vp, _vp, _i, _sz, _sz, _sz, _i, _i, _vp, _d, _vp]),
     "ast_fft_tile_rows_r2c": (_i, [_vp, _vp, _i, _sz, _sz, _sz, _sz, _d, _vp]),
     "ast_fft_tile_r2c_3d": (_i, [_vp, _vp, _i, _sz, _d, _vp]),
     "ast_fft_tile_c2r_3d": (_i, [_vp, _vp, _vp, _i, _sz, _i, _i, _d, _vp]),
@@ -70,6 +71,8 @@ SIGNATURES = {
     "ast_interlace_compensate": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ast_shell_filter": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ast_triple_product_sum": (_i, [_vp, _vp, _vp, _i, _sz, _vp, _vp]),
+    "ast_triple_product_sums_scratch_bytes": (_sz, []),
+    "ast_triple_product_sums": (_i, [_vp, _i, _i, _sz, _vp, _i, _vp, _vp, _vp]),
     "ast_slab_pack": (_i, [_vp, _vp, _i, _sz, _sz, _sz, _i, _vp]),
     "ast_slab_unpack": (_i, [_vp, _vp, _i, _sz, _sz, _sz, _i, _vp]),
     "ast_kappa_stack": (_i, [_vp, _vp, _vp, _i, _sz, _i, _vp, _i, _vp]),

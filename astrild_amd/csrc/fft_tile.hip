@@ -108,15 +108,28 @@ __global__ void tile_isqrt_table_kernel(int* out, int count) {
 // With INV the loads may come from a different array `src` of the same layout (data itself when null) and be
 // masked to a shell: rows are k_x, the batch index k_y, the column k_z, and only modes with lo2 <= |m|^2 < hi2 pass
 // (hi2 = 0: no mask) - the shell filter of the bispectrum estimator fused into its first inverse pass.
-struct ShellMask { const float2* src; long long lo2, hi2; int ky0 = 0; };     // ky0 (POWER): global k_y index of batch 0 (slab blocks)
+// PRUNING (hi2 > 0): every mode outside the sphere |m| < m_hi is zero, so
+//   pass 0 (x; rows k_x, batch k_y, columns k_z) skips the tiles with k_y^2 + k_z0^2 >= hi2 entirely - no load, no
+//          store: nobody reads them again;
+//   pass 1 (y; rows k_y, batch x) skips the tiles with k_z0 >= m_hi and, inside the others, does not load the rows
+//          with k_y^2 + k_z0^2 >= hi2 (the very tiles pass 0 left unwritten: both passes cut k_z into the same tiles);
+//   the z pass (rows_c2r_kernel) reads k_z < m_hi only.
+// A shell of radius N/4 moves 40 % of the full transform's bytes.
+struct ShellMask { const float2* src; long long lo2, hi2; int ky0 = 0; int pass = 0; };     // ky0 (POWER): global k_y index of batch 0 (slab blocks)
 
-template <int R1, int R2, int C, bool POWER, bool INV = false>
+// PACK: the stores go to `pack.out` in the layout the slab transpose sends (what ast_slab_pack makes of the array): row
+// k_y of batch (plane) b lands in part k_y / c1 at ((part * nbatch + b) * c1 + k_y % c1) * ncols + column.
+// Part `self_part` (the rank's own piece, which never travels) goes to self_out instead, as (nbatch, c1, ncols).
+struct PackDst { float2* out = nullptr; unsigned c1_log2 = 0; unsigned nbatch = 0; float2* self_out = nullptr; unsigned self_part = ~0u; };
+
+template <int R1, int R2, int C, bool POWER, bool INV = false, bool PACK = false>
 __global__ void __launch_bounds__(C * (R1 > R2 ? R1 : R2))
 // N = 1024 with binning: 128 VGPRs, so that two 8-wave workgroups fit a CU (see SPLIT below)
 __attribute__((amdgpu_waves_per_eu(POWER && R1 * R2 >= 1024 ? 4 : 1, POWER && R1 * R2 >= 1024 ? 4 : 8)))
 strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, size_t elem_stride,
                    size_t ncols, size_t batch_stride, unsigned tiles_per_batch, float scale,
-                   double* __restrict__ partial, const unsigned* __restrict__ edge_fall, ShellMask mask = ShellMask{nullptr, 0, 0}) {
+                   double* __restrict__ partial, const unsigned* __restrict__ edge_fall, ShellMask mask = ShellMask{nullptr, 0, 0},
+                   PackDst pack = PackDst{}) {
     constexpr int N = R1 * R2;
     constexpr int NT = C * (R1 > R2 ? R1 : R2);
     constexpr int NB = N / 2 - 1;    // shells when POWER
@@ -130,12 +143,16 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
     float2* Y = lds;                 // [n2][k1][c]  (SPLIT: [n2 mod R2/2][k1][c])
     float2* tw = lds + YN * C;       // exp(-2 pi i m / N)
     double* shell = reinterpret_cast<double*>(lds + YN * C + N);    // [NB + 1] when POWER
+    const unsigned tile = blockIdx.x % tiles_per_batch, b = blockIdx.x / tiles_per_batch;
+    const size_t c0 = (size_t)tile * C;
+    if (INV && mask.hi2 > 0) {                        // pruning: block-uniform exits before any barrier
+        const long long kb = (long long)((int)b > N / 2 ? (int)b - N : (int)b);
+        const long long r2 = (long long)(c0 * c0) + (mask.pass == 0 ? kb * kb : 0);
+        if (r2 >= mask.hi2) return;
+    }
     for (int i = threadIdx.x; i < N; i += NT) tw[i] = tw_g[i];
     if (POWER)
         for (int i = threadIdx.x; i <= NB; i += NT) shell[i] = 0.0;
-
-    const unsigned tile = blockIdx.x % tiles_per_batch, b = blockIdx.x / tiles_per_batch;
-    const size_t c0 = (size_t)tile * C;
     const int c = threadIdx.x % C, sub = threadIdx.x / C;
     const bool col_ok = c0 + c < ncols;
     float2* base = data + (size_t)b * batch_stride + c0 + c;
@@ -152,10 +169,21 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
         // last row block): predicated loads compile to a branch each
         const float2* lbase = (INV && mask.src ? mask.src : data) + (size_t)b * batch_stride + min(c0 + c, ncols - 1);
         const int lsub = task1 ? sub : R2 - 1;
+        if (INV && mask.hi2 > 0 && mask.pass == 1) {
+            const long long c02 = (long long)(c0 * c0);
 #pragma unroll
-        for (int n1 = 0; n1 < R1; ++n1) v[n1] = lbase[(size_t)(n1 * R2 + lsub) * elem_stride];
+            for (int n1 = 0; n1 < R1; ++n1) {         // rows of tiles pass 0 skipped: zero, and not in memory
+                const int row = n1 * R2 + lsub;
+                const long long ky = row > N / 2 ? row - N : row;
+                v[n1] = make_float2(0.f, 0.f);
+                if (ky * ky + c02 < mask.hi2) v[n1] = lbase[(size_t)row * elem_stride];
+            }
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) v[n1] = lbase[(size_t)(n1 * R2 + lsub) * elem_stride];
+        }
         if (INV) {
-            if (mask.hi2 > 0) {
+            if (mask.hi2 > 0 && mask.pass == 0) {
                 const long long kz = (long long)min(c0 + c, ncols - 1), ky = (long long)((int)b > N / 2 ? (int)b - N : (int)b);
                 const long long m2yz = ky * ky + kz * kz;
 #pragma unroll
@@ -214,7 +242,13 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
                 float2 x = u[bitrev(k2, ilog2(R2))];
                 x.x *= scale;
                 x.y *= INV ? -scale : scale;
-                base[(size_t)(sub + R1 * k2) * elem_stride] = x;
+                if (PACK) {
+                    const unsigned row = sub + R1 * k2, part = row >> pack.c1_log2, jl = row & ((1u << pack.c1_log2) - 1u);
+                    if (part == pack.self_part) pack.self_out[((((size_t)b) << pack.c1_log2) + jl) * ncols + c0 + c] = x;
+                    else pack.out[((((size_t)part * pack.nbatch + b) << pack.c1_log2) + jl) * ncols + c0 + c] = x;
+                } else {
+                    base[(size_t)(sub + R1 * k2) * elem_stride] = x;
+                }
             }
         }
     }
@@ -405,7 +439,7 @@ rows_r2c_kernel(const float* __restrict__ in, float2* __restrict__ out, const fl
 template <int R1, int R2, int C>
 __global__ void __launch_bounds__(C * R2)
 rows_c2r_kernel(const float2* __restrict__ in, float* __restrict__ out, const float2* __restrict__ tw_g,
-                size_t nrows, size_t in_pitch, size_t out_pitch, float scale) {
+                size_t nrows, size_t in_pitch, size_t out_pitch, float scale, int kmax) {
     constexpr int M = R1 * R2, N = 2 * M;
     constexpr int NT = C * R2;
     constexpr int R2P = R2 + 1;
@@ -417,7 +451,9 @@ rows_c2r_kernel(const float2* __restrict__ in, float* __restrict__ out, const fl
     const size_t row0 = (size_t)blockIdx.x * C;
     for (int i = threadIdx.x; i < C * MP; i += NT) {
         const int rr = i / MP, k = i % MP;
-        Y[rr * MP + k] = in[min(row0 + rr, nrows - 1) * in_pitch + k];
+        float2 x = make_float2(0.f, 0.f);
+        if (k < kmax) x = in[min(row0 + rr, nrows - 1) * in_pitch + k];          // k >= kmax: zero by construction, not read
+        Y[rr * MP + k] = x;
     }
     __syncthreads();
     const int n2 = threadIdx.x % R2, r = threadIdx.x / R2;        // stage-1 task (r, n2)
@@ -804,6 +840,24 @@ int launch_c2c_inv(float2* data, const float2* tw, size_t elem_stride, size_t nc
     return AST_OK;
 }
 
+template <int R1, int R2, int C>
+int launch_c2c_pack(float2* data, const float2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride,
+                    float scale, PackDst pack, hipStream_t s) {
+    constexpr int N = R1 * R2, NT = C * (R1 > R2 ? R1 : R2);
+    const size_t lds = (size_t)(N * C + N) * sizeof(float2);
+    static ast::PerDeviceOnce attr_once;
+    if (attr_once.need()) {
+        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&strided_c2c_kernel<R1, R2, C, false, false, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    const size_t tiles = (ncols + C - 1) / C;
+    AST_CHECK_ARG(tiles * batch < 0x7fffffffull);
+    strided_c2c_kernel<R1, R2, C, false, false, true><<<(unsigned)(tiles * batch), NT, lds, s>>>(
+        data, tw, elem_stride, ncols, batch_stride, (unsigned)tiles, scale, nullptr, nullptr, ShellMask{nullptr, 0, 0}, pack);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
 int dispatch_c2c_inv(size_t n, float2* d, const float2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride,
                      float scale, ShellMask mask, hipStream_t s) {
     if (n == 1024) return launch_c2c_inv<32, 32, 16>(d, tw, elem_stride, ncols, batch, batch_stride, scale, mask, s);
@@ -839,7 +893,7 @@ int launch_r2c(const float* in, float2* out, const float2* tw, size_t nrows, siz
 
 template <int R1, int R2, int C>
 int launch_c2r(const float2* in, float* out, const float2* tw, size_t nrows, size_t in_pitch, size_t out_pitch, float scale,
-               hipStream_t s) {
+               int kmax, hipStream_t s) {
     constexpr int M = R1 * R2, N = 2 * M, NT = C * R2;
     constexpr int BUF = C * (R1 * (R2 + 1) > M + 1 ? R1 * (R2 + 1) : M + 1);
     const size_t lds = (size_t)(BUF + N) * sizeof(float2);
@@ -850,7 +904,7 @@ int launch_c2r(const float2* in, float* out, const float2* tw, size_t nrows, siz
     }
     const size_t blocks = (nrows + C - 1) / C;
     AST_CHECK_ARG(blocks < 0x7fffffffull);
-    rows_c2r_kernel<R1, R2, C><<<(unsigned)blocks, NT, lds, s>>>(in, out, tw, nrows, in_pitch, out_pitch, scale);
+    rows_c2r_kernel<R1, R2, C><<<(unsigned)blocks, NT, lds, s>>>(in, out, tw, nrows, in_pitch, out_pitch, scale, kmax);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
@@ -870,6 +924,34 @@ extern "C" int ast_fft_tile_c2c(void* data, int dtype, size_t n, size_t elem_str
     hipStream_t s = ast::as_stream(stream);
     AST_PROF("fft_tile.c2c", s);
     return dispatch_c2c<false>(n, (float2*)data, tw, elem_stride, ncols, batch, batch_stride, (float)scale, nullptr, s);
+}
+
+// The y pass of a rank's local planes with the slab pack fused into its stores: planes_d (nplanes, n, ncols) complex
+// (rows k_y, the z pass's output) is transformed along k_y and written to packed_d as `parts` blocks of
+// (nplanes, n / parts, ncols) - what ast_fft_tile_c2c followed by ast_slab_pack produce, without the extra read and
+// write of the spectrum.  planes_d is left untouched.  parts: a power of two dividing n.  With self_out_d, part
+// `self_part` (the rank's own piece) is written there as (nplanes, n / parts, ncols) - straight into the receive block -
+// and its slot in packed_d stays unwritten (packed_d may be NULL when parts == 1).
+extern "C" int ast_fft_tile_c2c_packed(const void* planes, void* packed, int dtype, size_t n, size_t ncols, size_t nplanes,
+                                       int parts, int self_part, void* self_out, double scale, void* stream) {
+    AST_CHECK_ARG(planes != nullptr && planes != packed && planes != self_out && ncols >= 1 && nplanes >= 1);
+    AST_CHECK_ARG((self_out == nullptr) || (self_part >= 0 && self_part < parts));
+    AST_CHECK_ARG(packed != nullptr || (self_out != nullptr && parts == 1));
+    AST_CHECK_ARG(ast_fft_tile_supported(dtype, n));
+    AST_CHECK_ARG(parts >= 1 && (parts & (parts - 1)) == 0 && n % (size_t)parts == 0);
+    const float2* tw = g_tw.get((int)n);
+    if (!tw) { ast::set_error("ast_fft_tile_c2c_packed: twiddle table allocation failed"); return AST_ERR_HIP; }
+    hipStream_t s = ast::as_stream(stream);
+    PackDst pack;
+    pack.out = (float2*)packed;
+    pack.nbatch = (unsigned)nplanes;
+    if (self_out) { pack.self_out = (float2*)self_out; pack.self_part = (unsigned)self_part; }
+    for (size_t c1 = n / (size_t)parts; c1 > 1; c1 >>= 1) ++pack.c1_log2;
+    AST_PROF("fft_tile.c2c", s);
+    float2* d = (float2*)const_cast<void*>(planes);
+    if (n == 1024) return launch_c2c_pack<32, 32, 16>(d, tw, ncols, ncols, nplanes, n * ncols, (float)scale, pack, s);
+    if (n == 512) return launch_c2c_pack<16, 32, 16>(d, tw, ncols, ncols, nplanes, n * ncols, (float)scale, pack, s);
+    return launch_c2c_pack<16, 16, 16>(d, tw, ncols, ncols, nplanes, n * ncols, (float)scale, pack, s);
 }
 
 static int rows_r2c_impl(const void* in, void* out, int dtype, size_t n, size_t nrows, size_t in_pitch,
@@ -1083,13 +1165,14 @@ extern "C" int ast_fft_tile_c2r_3d(const void* spec, void* work, void* out, int 
         int rc = dispatch_c2c_inv(n, (float2*)work, tw, n * nz, nz, n, nz, 1.0f, mask, s);
         if (rc != AST_OK) return rc;
         // y: per x plane, rows k_y (stride nz), in place
-        rc = dispatch_c2c_inv(n, (float2*)work, tw, nz, nz, n, n * nz, 1.0f, ShellMask{nullptr, 0, 0}, s);
+        rc = dispatch_c2c_inv(n, (float2*)work, tw, nz, nz, n, n * nz, 1.0f, ShellMask{nullptr, 0, mask.hi2, 0, 1}, s);
         if (rc != AST_OK) return rc;
     }
     AST_PROF("fft_tile.rows_c2r", s);
-    if (n == 1024) return launch_c2r<16, 32, 16>((const float2*)work, (float*)out, tw, n * n, nz, n, (float)scale, s);
-    if (n == 512) return launch_c2r<16, 16, 16>((const float2*)work, (float*)out, tw, n * n, nz, n, (float)scale, s);
-    return launch_c2r<8, 16, 16>((const float2*)work, (float*)out, tw, n * n, nz, n, (float)scale, s);
+    const int kmax = m_hi > 0 && (size_t)m_hi < nz ? m_hi : (int)nz;
+    if (n == 1024) return launch_c2r<16, 32, 16>((const float2*)work, (float*)out, tw, n * n, nz, n, (float)scale, kmax, s);
+    if (n == 512) return launch_c2r<16, 16, 16>((const float2*)work, (float*)out, tw, n * n, nz, n, (float)scale, kmax, s);
+    return launch_c2r<8, 16, 16>((const float2*)work, (float*)out, tw, n * n, nz, n, (float)scale, kmax, s);
 }
 
 // The last pass of a slab-decomposed transform fused with the shell binning: `block_d` is a rank's (n, nloc, pitch)

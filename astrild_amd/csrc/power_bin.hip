@@ -201,6 +201,72 @@ triple_sum_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __r
     if (threadIdx.x == 0) atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
 }
 
+// All triangle sums of a set of shell fields in ONE pass over the fields: a workgroup stages a chunk of TRI_CHUNK
+// cells of every field in LDS, then thread (t, part) adds the products of triangle t over its part of the chunk
+// (lanes of a wave = different triangles, same cell: the LDS row pitch is odd, distinct fields hit distinct banks,
+// equal fields broadcast).  Every field is read from HBM once instead of once per triangle it appears in (75
+// triangles over 31 shells at 512^3: 16.6 GB instead of 121 GB).  Products and sums in double, fixed order:
+// partial[block][thread], then triple_reduce_kernel adds blocks and parts in index order - deterministic.
+constexpr int TRI_CHUNK = 256;
+constexpr int TRI_THREADS = 256;
+constexpr int TRI_BLOCKS = 2048;          // persistent workgroups (8 per CU), grid-stride over the chunks
+template <typename T>
+__global__ void __launch_bounds__(TRI_THREADS)
+triple_sums_kernel(const T* const* __restrict__ fields, int nfields, const int* __restrict__ tri, int ntri, int parts,
+                   size_t n, double* __restrict__ partial) {
+    extern __shared__ unsigned char tri_lds[];
+    T* v = reinterpret_cast<T*>(tri_lds);                       // [nfields][TRI_CHUNK + 1]
+    constexpr int P = TRI_CHUNK + 1;
+    const int t = threadIdx.x % ntri, part = threadIdx.x / ntri;
+    const bool worker = part < parts;
+    int ia = 0, ib = 0, ic = 0;
+    if (worker) { ia = tri[3 * t] * P; ib = tri[3 * t + 1] * P; ic = tri[3 * t + 2] * P; }
+    const int per = (TRI_CHUNK + parts - 1) / parts;
+    const int c_lo = part * per, c_hi = min(c_lo + per, TRI_CHUNK);
+    double acc = 0.0;
+    const size_t nchunks = (n + TRI_CHUNK - 1) / TRI_CHUNK;
+    for (size_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        // unconditional loads in groups of 8 (a predicated load is a branch plus a full wait each: 31 serial memory
+        // latencies per chunk); cells past the end re-read the last one and are zeroed
+        const size_t cell = ch * TRI_CHUNK + threadIdx.x;
+        const size_t lc = cell < n ? cell : n - 1;
+        const T keep = cell < n ? (T)1 : (T)0;
+        for (int f0 = 0; f0 < nfields; f0 += 8) {
+            T tmp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)                 // the pointers come from memory: say that they are global, or the loads are flat
+                tmp[j] = ((const __attribute__((address_space(1))) T*)fields[min(f0 + j, nfields - 1)])[lc];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (f0 + j < nfields) v[(f0 + j) * P + threadIdx.x] = tmp[j] * keep;
+        }
+        __syncthreads();
+        if (worker) {                                 // two-level sum: a chunk's terms first (keeps the round-off of the
+            double sub = 0.0;                         // long running sum at sqrt(chunks), not sqrt(cells))
+#pragma unroll 4
+            for (int c = c_lo; c < c_hi; ++c) sub += (double)v[ia + c] * (double)v[ib + c] * (double)v[ic + c];
+            acc += sub;
+        }
+        __syncthreads();
+    }
+    partial[(size_t)blockIdx.x * TRI_THREADS + threadIdx.x] = worker ? acc : 0.0;
+}
+
+__global__ void __launch_bounds__(256)
+triple_reduce_kernel(const double* __restrict__ partial, int nblocks, int ntri, int parts, double* __restrict__ out) {
+    const int t = blockIdx.x;                                   // one workgroup per triangle
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblocks * parts; i += 256) {
+        const int blk = i / parts, part = i % parts;
+        acc += partial[(size_t)blk * TRI_THREADS + part * ntri + t];
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    __shared__ double w[4];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[t] = (w[0] + w[1]) + (w[2] + w[3]);
+}
+
 // (n0, n1, n2) -> parts x (n0, n1/parts, n2)
 template <typename C, bool UNPACK>
 __global__ void __launch_bounds__(256)
@@ -316,6 +382,45 @@ extern "C" int ast_triple_product_sum(const void* a, const void* b, const void* 
         triple_sum_kernel<float><<<g, 256, 0, s>>>((const float*)a, (const float*)b, (const float*)c, count, out);
     else
         triple_sum_kernel<double><<<g, 256, 0, s>>>((const double*)a, (const double*)b, (const double*)c, count, out);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+extern "C" size_t ast_triple_product_sums_scratch_bytes(void) { return (size_t)TRI_BLOCKS * TRI_THREADS * sizeof(double); }
+
+extern "C" int ast_triple_product_sums(const void* const* fields, int nfields, int dtype, size_t count, const int* tri,
+                                       int ntri, void* scratch, double* out, void* stream) {
+    AST_CHECK_ARG(fields && tri && scratch && out);
+    AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
+    AST_CHECK_ARG(nfields >= 1 && ntri >= 1 && ntri <= TRI_THREADS);
+    const size_t esz = dtype == AST_F32 ? 4 : 8;
+    const size_t lds = (size_t)nfields * (TRI_CHUNK + 1) * esz;
+    AST_CHECK_ARG(lds <= 160 * 1024);
+    hipStream_t s = ast::as_stream(stream);
+    const int parts = TRI_THREADS / ntri;
+    const size_t nchunks = (count + TRI_CHUNK - 1) / TRI_CHUNK;
+    // one resident wave of workgroups: 256 CUs x as many as the LDS lets a CU hold (no tail of a second round)
+    size_t resident = (160 * 1024) / (lds ? lds : 1);
+    resident = 256 * (resident < 1 ? 1 : resident > 8 ? 8 : resident);
+    const int blocks = (int)(nchunks < resident ? (nchunks ? nchunks : 1) : resident);
+    AST_PROF("triple_product_sums", s);
+    if (dtype == AST_F32) {
+        static ast::PerDeviceOnce attr_once;
+        if (attr_once.need())
+            AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&triple_sums_kernel<float>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        triple_sums_kernel<float><<<blocks, TRI_THREADS, lds, s>>>((const float* const*)fields, nfields, tri, ntri, parts, count,
+                                                                   (double*)scratch);
+    } else {
+        static ast::PerDeviceOnce attr_once;
+        if (attr_once.need())
+            AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&triple_sums_kernel<double>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        triple_sums_kernel<double><<<blocks, TRI_THREADS, lds, s>>>((const double* const*)fields, nfields, tri, ntri, parts, count,
+                                                                    (double*)scratch);
+    }
+    AST_CHECK_LAUNCH();
+    triple_reduce_kernel<<<ntri, 256, 0, s>>>((const double*)scratch, blocks, ntri, parts, out);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }

@@ -553,6 +553,32 @@ def triple_product_sum(a, b, c):
     return out
 
 
+def triple_product_sums(fields, triangles):
+    """sum over cells of f_i f_j f_l for every (i, j, l) in ``triangles`` (keys of the dict ``fields``), every field read
+    once per batch of <= 256 triangles (ast_triple_product_sums).  Returns a float64 tensor, one entry per triangle."""
+    L = _lib.lib()
+    triangles = [tuple(t) for t in triangles]
+    out = torch.zeros(len(triangles), dtype=torch.float64, device=device())
+    scratch = torch.empty(L.ast_triple_product_sums_scratch_bytes() // 8, dtype=torch.float64, device=device())
+    for b0 in range(0, len(triangles), 256):
+        batch = triangles[b0:b0 + 256]
+        used = sorted({s for t in batch for s in t})
+        first = fields[used[0]]
+        if len(used) * 257 * first.element_size() > 160 * 1024:          # more shells than one LDS chunk holds
+            for n, (i, j, l) in enumerate(batch):
+                out[b0 + n:b0 + n + 1] = triple_product_sum(fields[i], fields[j], fields[l])
+            continue
+        for s in used:
+            f = fields[s]
+            assert f.is_contiguous() and f.dtype == first.dtype and f.numel() == first.numel()
+        slot = {s: n for n, s in enumerate(used)}
+        ptrs = torch.tensor([fields[s].data_ptr() for s in used], dtype=torch.int64).to(device())
+        tri = torch.tensor([[slot[s] for s in t] for t in batch], dtype=torch.int32).to(device())
+        check(L.ast_triple_product_sums(ptr(ptrs), len(used), real_code(first), first.numel(), ptr(tri), len(batch),
+                                        ptr(scratch), ptr(out[b0:]), stream()), "ast_triple_product_sums")
+    return out
+
+
 _tri_cache = {}
 
 
@@ -582,7 +608,7 @@ def bispectrum(field, boxsize, edges, triangles):
         for s in used:
             shell_filter(None, n, edges[s], edges[s + 1], out=iscratch)
             ifields[s] = c2r(iscratch, (n, n, n))
-        dens = torch.cat([triple_product_sum(ifields[i], ifields[j], ifields[l]) for (i, j, l) in triangles]).cpu().numpy()
+        dens = triple_product_sums(ifields, triangles).cpu().numpy()
         del ifields, iscratch
         exact = dens / float(n) ** 3
         ntri = np.rint(exact).astype(np.int64)
@@ -599,8 +625,7 @@ def bispectrum(field, boxsize, edges, triangles):
         else:
             shell_filter(spec, n, edges[s], edges[s + 1], out=scratch)
             dfields[s] = c2r(scratch, (n, n, n))
-    nums = [triple_product_sum(dfields[i], dfields[j], dfields[l]) for (i, j, l) in triangles]
-    num = torch.cat(nums).cpu().numpy()
+    num = triple_product_sums(dfields, triangles).cpu().numpy()
     kf = 2.0 * np.pi / boxsize
     kmid = np.array([[kf * 0.5 * (edges[s] + edges[s + 1]) for s in t] for t in triangles])
     with np.errstate(invalid="ignore", divide="ignore"):

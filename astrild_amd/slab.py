@@ -81,6 +81,24 @@ class HipSlabOps:
         self.dev.fft_plan(0, code, (n1, n2), nloc, 1.0, False).execute(planes, out)      # AST_FFT_R2C
         return out
 
+    def packed_supported(self, planes, parts):
+        nloc, n1, n2 = planes.shape
+        return n1 == n2 and self._tile_ok(self.dev.real_code(planes), n1) and parts & (parts - 1) == 0
+
+    def fft2d_planes_packed(self, planes, spec, packed, parts, self_part, self_dst):
+        """fft2d_planes + pack in two kernels instead of three: the y pass stores straight into the send buffer
+        (piece s of `packed`) and the rank's own piece into ``self_dst`` (its place in the receive block)."""
+        from ._lib import check, lib
+        nloc, n1, n2 = planes.shape
+        code = self.dev.real_code(planes)
+        nz = n2 // 2 + 1
+        assert self_dst.is_contiguous() and packed.is_contiguous() and spec.is_contiguous()
+        check(lib().ast_fft_tile_rows_r2c(self.dev.ptr(planes), self.dev.ptr(spec), code, n2, nloc * n1, n2, nz,
+                                          1.0, self.dev.stream()), "ast_fft_tile_rows_r2c")
+        check(lib().ast_fft_tile_c2c_packed(self.dev.ptr(spec), self.dev.ptr(packed), code, n1, nz, nloc, parts,
+                                            self_part, self.dev.ptr(self_dst), 1.0, self.dev.stream()),
+              "ast_fft_tile_c2c_packed")
+
     def pack(self, spec, out, parts):
         from ._lib import check, lib
         n0, n1, n2 = spec.shape
@@ -184,18 +202,21 @@ def ghost_fold(buf, nloc, gl, gh, ops, group=None):
     return owned
 
 
-def exchange_chunk(packed_c, block, chunk, pc, nloc, group=None):
+def exchange_chunk(packed_c, block, chunk, pc, nloc, group=None, self_done=False):
     """Step 4 for one chunk of `pc` local planes.  packed_c: (P, pc, nly, nz) — piece s goes
     to rank s; it lands in block[s_src*nloc + chunk*pc : ... + pc] of the receiver.  Returns
-    the outstanding work handles (the local piece is copied right away)."""
+    the outstanding work handles (the local piece is copied right away, unless the producer has
+    already written it into the block: ``self_done``)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     ops_list = []
-    comm_ready(group)
+    if world > 1:
+        comm_ready(group)
     for s in range(world):
         dst = block[s * nloc + chunk * pc: s * nloc + (chunk + 1) * pc]
         if s == rank:
-            dst.copy_(packed_c[s])
+            if not self_done:
+                dst.copy_(packed_c[s])
             continue
         # complex payload moved as (re, im) pairs of the real dtype: every c10d backend takes that
         ops_list.append(dist.P2POp(dist.isend, torch.view_as_real(packed_c[s]), s, group))
@@ -305,6 +326,13 @@ class SlabPowerPipeline:
         for c in range(self.chunks):
             planes = owned[c * self.pc:(c + 1) * self.pc]
             spec = self.spec2d[c * self.pc:(c + 1) * self.pc]
+            packed_fn = getattr(o, "packed_supported", None)
+            if packed_fn and packed_fn(planes, self.world):
+                # y pass stores in send order; the rank's own piece goes straight into the receive block
+                mine = self.block[self.rank * self.nloc + c * self.pc: self.rank * self.nloc + (c + 1) * self.pc]
+                o.fft2d_planes_packed(planes, spec, self.packed[c], self.world, self.rank, mine)
+                pending += exchange_chunk(self.packed[c], self.block, c, self.pc, self.nloc, self.group, self_done=True)
+                continue
             o.fft2d_planes(planes, spec)
             o.pack(spec, self.packed[c], self.world)
             pending += exchange_chunk(self.packed[c], self.block, c, self.pc, self.nloc, self.group)

@@ -237,6 +237,15 @@ int ast_fft_plan_destroy(ast_fft_plan* plan);
 int ast_fft_tile_supported(int dtype, size_t n);
 int ast_fft_tile_c2c(void* data_d, int dtype, size_t n, size_t elem_stride, size_t ncols, size_t batch,
                      size_t batch_stride, double scale, void* stream);
+
+/* ast_fft_tile_c2c over the k_y axis of a rank's local planes (planes_d: (nplanes, n, ncols) complex, left intact)
+ * with ast_slab_pack fused into the stores: packed_d receives `parts` blocks of (nplanes, n / parts, ncols), the send
+ * buffer of the slab transpose (pmesh's r2c transposes inside the reference's FFTPower call,
+ * power_spectrum_3d.py:203-208).  parts: a power of two dividing n.  With self_out_d, part self_part (the rank's own
+ * piece, which never travels) is written there instead, as (nplanes, n / parts, ncols); packed_d may then be NULL when
+ * parts == 1. */
+int ast_fft_tile_c2c_packed(const void* planes_d, void* packed_d, int dtype, size_t n, size_t ncols, size_t nplanes,
+                            int parts, int self_part, void* self_out_d, double scale, void* stream);
 int ast_fft_tile_rows_r2c(const void* in_d, void* out_d, int dtype, size_t n, size_t nrows, size_t in_pitch,
                           size_t out_pitch, double scale, void* stream);
 int ast_fft_tile_r2c_3d(const void* in_d, void* out_d, int dtype, size_t n, double scale, void* stream);
@@ -340,6 +349,15 @@ int ast_shell_filter(const void* in_d, void* out_d, int dtype, int nmesh, int m_
 /* *out_d += sum_i a[i] * b[i] * c[i]  (double accumulator, device). */
 int ast_triple_product_sum(const void* a_d, const void* b_d, const void* c_d, int dtype,
                            size_t count, double* out_d, void* stream);
+
+/* out_d[t] = sum_i f[tri[3t]][i] * f[tri[3t+1]][i] * f[tri[3t+2]][i] for ntri <= 256 triangles over nfields device
+ * arrays of `count` reals (fields_d: device array of nfields device pointers; tri_d: device int32 [ntri][3] of field
+ * indices): every field is read ONCE (LDS-staged chunks), not once per triangle - the 75 cube sums of a 512^3
+ * bispectrum (bispectrum_3d.py:42-44's estimator) in one pass.  Double products and sums in a fixed order
+ * (deterministic).  scratch_d: ast_triple_product_sums_scratch_bytes() bytes.  nfields * 257 * sizeof(real) <= 160 KB. */
+size_t ast_triple_product_sums_scratch_bytes(void);
+int ast_triple_product_sums(const void* const* fields_d, int nfields, int dtype, size_t count, const int* tri_d,
+                            int ntri, void* scratch_d, double* out_d, void* stream);
 
 /* ------------------------------------------------- slab transpose helpers */
 

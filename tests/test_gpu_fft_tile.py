@@ -209,10 +209,38 @@ def test_tile_c2r_3d_and_fused_shell_mask(hip, n):
     assert torch.equal(spec, keep)                                 # the spectrum is left intact
     err = (back - t).abs().max().item()
     assert err < 5e-6 * np.abs(f).max(), err
-    for lo, hi in [(1, 9), (40, 48), (n // 2 - 8, n // 2)]:
+    # the masked transform is pruned (tiles and rows a shell leaves zero are neither written nor read): the work
+    # buffer starts as NaN, so a read of anything the earlier pass skipped would show
+    for lo, hi in [(0, 1), (1, 2), (1, 9), (15, 17), (40, 48), (n // 2 - 8, n // 2), (n // 2, n // 2 + 40), (1, n)]:
         masked = dev.shell_filter(spec, n, lo, hi)
         ref = dev.c2r(masked, (n, n, n))
-        got = dev.c2r_tile(spec, m_lo=lo, m_hi=hi)
+        work = torch.full_like(spec, float("nan"))
+        got = dev.c2r_tile(spec, work=work, m_lo=lo, m_hi=hi)
         scale = ref.abs().max().item()
-        assert (got - ref).abs().max().item() < 5e-6 * scale
+        assert torch.isfinite(got).all()
+        assert (got - ref).abs().max().item() < 5e-6 * scale, (lo, hi)
     assert hip.ast_fft_tile_c2r_3d(dev.ptr(spec), dev.ptr(spec), dev.ptr(back), 0, n, 0, 0, 1.0, dev.stream()) < 0   # work == spec
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_triple_product_sums_one_pass(hip, dtype):
+    """All triangle sums in one pass over the fields (ast_triple_product_sums) against float64 numpy; ragged cell
+    count (not a multiple of the chunk), repeated shells, more triangles than one batch, run-to-run identical."""
+    from astrild_amd import device as dev
+    torch.cuda.set_device(0)
+    rng = np.random.default_rng(5)
+    count, nf = 3 * 256 * 41 + 77, 7
+    host = {2 * s + 1: rng.standard_normal(count).astype(np.float32) for s in range(nf)}     # keys need not be 0..nf-1
+    fields = {k: dev.as_device(v).to(dtype) for k, v in host.items()}
+    keys = sorted(host)
+    tri = [(a, b, c) for a in keys for b in keys for c in keys if a <= b <= c]               # 84 triangles
+    tri = tri + [(keys[0], keys[1], keys[2])] * 200                                          # 284 > 256: two batches
+    got = dev.triple_product_sums(fields, tri)
+    again = dev.triple_product_sums(fields, tri)
+    assert torch.equal(got, again)
+    ref = np.array([np.sum(host[a].astype(np.float64) * host[b].astype(np.float64) * host[c].astype(np.float64))
+                    for a, b, c in tri])
+    scale = np.array([np.sum(np.abs(host[a].astype(np.float64) * host[b] * host[c])) for a, b, c in tri])
+    assert np.all(np.abs(got.cpu().numpy() - ref) <= 1e-13 * scale)
+    one = dev.triple_product_sum(fields[keys[0]], fields[keys[1]], fields[keys[2]]).item()
+    assert abs(one - ref[-1]) <= 1e-13 * scale[-1]

@@ -83,6 +83,41 @@ def test_slab_pack_unpack_round_trip(hip):
     assert hip.ast_slab_pack(dev.ptr(x), dev.ptr(packed), 0, n0, n1, n2, 5, dev.stream()) < 0     # 12 % 5 != 0
 
 
+@pytest.mark.parametrize("n,nplanes,parts", [(256, 3, 4), (512, 2, 8), (256, 2, 1)])
+def test_y_pass_with_fused_pack_equals_y_pass_then_pack(hip, n, nplanes, parts):
+    """ast_fft_tile_c2c_packed == ast_fft_tile_c2c followed by ast_slab_pack, bit for bit; the rank's own piece lands
+    in its separate destination and its slot of the send buffer stays untouched."""
+    from astrild_amd import device as dev, _lib
+    torch.cuda.set_device(0)
+    nz = n // 2 + 1
+    g = torch.Generator(device="cuda").manual_seed(n + parts)
+    x = torch.view_as_complex(torch.randn((nplanes, n, nz, 2), dtype=torch.float32, device="cuda", generator=g))
+    keep = x.clone()
+    ref = x.clone()
+    _lib.check(hip.ast_fft_tile_c2c(dev.ptr(ref), 0, n, nz, nz, nplanes, n * nz, 1.0, dev.stream()))
+    ref_packed = torch.empty((parts, nplanes, n // parts, nz), dtype=torch.complex64, device="cuda")
+    _lib.check(hip.ast_slab_pack(dev.ptr(ref), dev.ptr(ref_packed), 0, nplanes, n, nz, parts, dev.stream()))
+    packed = torch.empty_like(ref_packed)
+    _lib.check(hip.ast_fft_tile_c2c_packed(dev.ptr(x), dev.ptr(packed), 0, n, nz, nplanes, parts, -1, None, 1.0, dev.stream()))
+    assert torch.equal(x, keep)
+    assert torch.equal(packed, ref_packed)
+    me = parts - 1
+    packed2 = torch.full_like(ref_packed, 7.0)
+    mine = torch.empty((nplanes, n // parts, nz), dtype=torch.complex64, device="cuda")
+    _lib.check(hip.ast_fft_tile_c2c_packed(dev.ptr(x), dev.ptr(packed2), 0, n, nz, nplanes, parts, me, dev.ptr(mine), 1.0,
+                                           dev.stream()))
+    assert torch.equal(mine, ref_packed[me])
+    assert torch.all(packed2[me] == 7.0)
+    for s in range(parts):
+        if s != me:
+            assert torch.equal(packed2[s], ref_packed[s])
+    assert hip.ast_fft_tile_c2c_packed(dev.ptr(x), dev.ptr(packed), 0, n, nz, nplanes, 3, -1, None, 1.0, dev.stream()) < 0
+    if parts == 1:
+        only = torch.empty_like(mine)
+        _lib.check(hip.ast_fft_tile_c2c_packed(dev.ptr(x), None, 0, n, nz, nplanes, 1, 0, dev.ptr(only), 1.0, dev.stream()))
+        assert torch.equal(only, ref_packed[0])
+
+
 def test_slab_pipeline_object_on_one_gpu_over_nccl(hip):
     """The real SlabPowerPipeline (HipSlabOps, chunked exchange, all-reduces) with
     torch.distributed's nccl (= RCCL) backend at world_size 1, against the single-GPU path."""
