@@ -92,6 +92,7 @@ SIGNATURES = {
     "ast_peak_find": (_i, [_vp, _i, _i, _d, _d, _sz, _vp, _vp, _vp, _vp]),
     "ast_order_statistics": (_i, [_vp, _i, _sz, ct.POINTER(_sz), _i, ct.POINTER(_d), _vp, _vp]),
     "ast_histogram": (_i, [_vp, _i, _sz, _d, _d, _i, _vp, _vp]),
+    "ast_histogram_auto": (_i, [_vp, _i, _sz, _i, _vp, _vp, _vp]),
     "ast_add": (_i, [_vp, _vp, _vp, _i, _sz, _vp]),
     "ast_nfw_paint": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _d, _i, _i, _d, _i, _vp, _i, _vp]),
     "ast_add_patch": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),

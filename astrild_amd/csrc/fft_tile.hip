@@ -449,11 +449,23 @@ rows_c2r_kernel(const float2* __restrict__ in, float* __restrict__ out, const fl
     float2* tw = lds + C * (R1 * R2P > MP ? R1 * R2P : MP);     // exp(-2 pi i m / N), m < N
     for (int i = threadIdx.x; i < N; i += NT) tw[i] = tw_g[i];
     const size_t row0 = (size_t)blockIdx.x * C;
-    for (int i = threadIdx.x; i < C * MP; i += NT) {
-        const int rr = i / MP, k = i % MP;
-        float2 x = make_float2(0.f, 0.f);
-        if (k < kmax) x = in[min(row0 + rr, nrows - 1) * in_pitch + k];          // k >= kmax: zero by construction, not read
-        Y[rr * MP + k] = x;
+    {
+        // R2 threads per row, k = q + R2 i.  All loads of a thread are issued before the first LDS store (a load
+        // inside a per-lane condition is a branch and a full wait each); k >= kmax is zero by construction and not
+        // read - the cut is uniform over the workgroup, in steps of R2.
+        const int rr = threadIdx.x / R2, q = threadIdx.x % R2;
+        const float2* src = in + min(row0 + rr, nrows - 1) * in_pitch;
+        float2 tmp[R1 + 1];
+#pragma unroll
+        for (int i = 0; i <= R1; ++i) {
+            tmp[i] = make_float2(0.f, 0.f);
+            if (i * R2 < kmax) tmp[i] = src[min(q + R2 * i, M)];
+        }
+#pragma unroll
+        for (int i = 0; i <= R1; ++i) {
+            const int k = q + R2 * i;
+            if (k <= M) Y[rr * MP + k] = k < kmax ? tmp[i] : make_float2(0.f, 0.f);
+        }
     }
     __syncthreads();
     const int n2 = threadIdx.x % R2, r = threadIdx.x / R2;        // stage-1 task (r, n2)

@@ -52,16 +52,6 @@ kappa_stack_kernel(const T* const* __restrict__ planes, const double* __restrict
 }
 
 // ------------------------------------------------ kappa -> alpha / phi
-__global__ void __launch_bounds__(256)
-zero_pad_kernel(const double* __restrict__ in, int nc, double* __restrict__ out) {
-    const size_t n2 = 2 * (size_t)nc, total = n2 * n2;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-        const size_t i = idx / n2, j = idx % n2;
-        out[idx] = (i < (size_t)nc && j < (size_t)nc) ? in[i * nc + j] : 0.0;   // zero_padding, lensing_funcs.c:8-19
-    }
-}
-
 // kernel_alphas_iso / kernel_phi_iso (lensing_funcs.c:45-83, 117-148) in closed
 // form: the quarter plane i, j <= Ncc/2 is evaluated, the rest mirrored with
 // the reference's parities.  which: 0 = alpha1, 1 = alpha2, 2 = phi.
@@ -85,6 +75,35 @@ iso_kernel_build(int ncc, double dcell, int which, double* __restrict__ out) {
         if (which == 0 && i > h) v = -v;
         if (which == 1 && j > h) v = -v;
         out[idx] = v;
+    }
+}
+
+// zero_padding (lensing_funcs.c:8-19): kappa into the top-left nc x nc corner of the padded array; the rest of `out` is zero and stays zero (the plan
+// owns it, nothing else writes there): 2 x 134 MB moved per map instead of the 671 MB of a full zero_pad pass
+__global__ void __launch_bounds__(256)
+pad_corner_kernel(const double* __restrict__ in, int nc, double* __restrict__ out) {
+    const size_t n2 = 2 * (size_t)nc, total = (size_t)nc * nc;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const size_t i = idx / nc, j = idx % nc;
+        out[i * n2 + j] = in[idx];
+    }
+}
+
+// both products of kappa_to_alphas in one pass: the kappa spectrum is read once
+__global__ void __launch_bounds__(256)
+cmul2_kernel(const double2* __restrict__ a, const double2* __restrict__ b1, const double2* __restrict__ b2,
+             double2* __restrict__ out1, double2* __restrict__ out2, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double2 x = a[i], y1 = b1[i], y2 = b2[i];
+        double2 r1, r2;
+        r1.x = x.x * y1.x - x.y * y1.y;      // fft_convolve.c:75-78
+        r1.y = x.x * y1.y + x.y * y1.x;
+        r2.x = x.x * y2.x - x.y * y2.y;
+        r2.y = x.x * y2.y + x.y * y2.x;
+        out1[i] = r1;
+        out2[i] = r2;
     }
 }
 
@@ -178,7 +197,9 @@ struct ast_lens_plan {
     double bsz = 0.0;
     ast_fft_plan* r2c = nullptr;
     ast_fft_plan* c2r = nullptr;
-    double* pad = nullptr;        // (2nc)^2 real: padded kappa, then c2r output
+    double* pad = nullptr;        // (2nc)^2 real: kernel images (plan set-up), c2r output
+    double* pad_in = nullptr;     // (2nc)^2 real: padded kappa; zero outside the top-left corner, for the plan's lifetime
+    double2* prod2 = nullptr;     // second product spectrum (kappa_to_alphas forms both in one pass)
     double2* spec = nullptr;      // kappa spectrum
     double2* prod = nullptr;      // product spectrum (c2r input, overwritten by rocFFT)
     double2* kspec[3] = {nullptr, nullptr, nullptr};   // alpha1, alpha2, phi kernel spectra
@@ -224,6 +245,8 @@ extern "C" int ast_lens_plan_destroy(ast_lens_plan* p) {
     ast_fft_plan_destroy(p->r2c);
     ast_fft_plan_destroy(p->c2r);
     if (p->pad) (void)hipFree(p->pad);
+    if (p->pad_in) (void)hipFree(p->pad_in);
+    if (p->prod2) (void)hipFree(p->prod2);
     if (p->spec) (void)hipFree(p->spec);
     if (p->prod) (void)hipFree(p->prod);
     for (auto* k : p->kspec) if (k) (void)hipFree(k);
@@ -242,6 +265,8 @@ extern "C" int ast_lens_plan_create(ast_lens_plan** out, int nc, double bsz) {
     if (rc == AST_OK) rc = ast_fft_plan_create(&p->c2r, AST_FFT_C2R, AST_F64, 2, lens, 1, 1.0, 0);
     if (rc != AST_OK) { ast_lens_plan_destroy(p); return rc; }
     hipError_t e = hipMalloc(&p->pad, n2 * n2 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&p->pad_in, n2 * n2 * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(p->pad_in, 0, n2 * n2 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&p->spec, n2 * nh * sizeof(double2));
     if (e == hipSuccess) e = hipMalloc(&p->prod, n2 * nh * sizeof(double2));
     if (e != hipSuccess) {
@@ -266,6 +291,23 @@ static int lens_kernel_spectrum(ast_lens_plan* p, int which, hipStream_t s) {
     return AST_OK;
 }
 
+static int lens_forward(ast_lens_plan* p, const double* kappa, hipStream_t s) {
+    {
+        AST_PROF("lens.zero_pad", s);
+        pad_corner_kernel<<<ast::stream_grid((size_t)p->nc * p->nc, 256), 256, 0, s>>>(kappa, p->nc, p->pad_in);
+    }
+    AST_CHECK_LAUNCH();
+    return ast_fft_exec(p->r2c, p->pad_in, p->spec, s);       // out of place: the real-to-complex transform leaves its input alone
+}
+
+static int lens_crop(ast_lens_plan* p, double2* prod, double* out, hipStream_t s) {     // prod is overwritten (rocFFT C2R)
+    AST_FWD(ast_fft_exec(p->c2r, prod, p->pad, s));
+    AST_PROF("lens.crop_scale", s);
+    crop_scale_kernel<<<ast::stream_grid((size_t)p->nc * p->nc, 256), 256, 0, s>>>(p->pad, p->nc, p->bsz / (double)p->nc, out);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
 static int lens_convolve(ast_lens_plan* p, int which, double* out, hipStream_t s) {
     const size_t n2 = 2 * (size_t)p->nc, nh = n2 / 2 + 1;
     {
@@ -273,21 +315,7 @@ static int lens_convolve(ast_lens_plan* p, int which, double* out, hipStream_t s
         cmul_kernel<<<ast::stream_grid(n2 * nh, 256), 256, 0, s>>>(p->spec, p->kspec[which], p->prod, n2 * nh);
     }
     AST_CHECK_LAUNCH();
-    AST_FWD(ast_fft_exec(p->c2r, p->prod, p->pad, s));
-    AST_PROF("lens.crop_scale", s);
-    crop_scale_kernel<<<ast::stream_grid((size_t)p->nc * p->nc, 256), 256, 0, s>>>(p->pad, p->nc, p->bsz / (double)p->nc, out);
-    AST_CHECK_LAUNCH();
-    return AST_OK;
-}
-
-static int lens_forward(ast_lens_plan* p, const double* kappa, hipStream_t s) {
-    const size_t n2 = 2 * (size_t)p->nc;
-    {
-        AST_PROF("lens.zero_pad", s);
-        zero_pad_kernel<<<ast::stream_grid(n2 * n2, 256), 256, 0, s>>>(kappa, p->nc, p->pad);
-    }
-    AST_CHECK_LAUNCH();
-    return ast_fft_exec(p->r2c, p->pad, p->spec, s);
+    return lens_crop(p, p->prod, out, s);
 }
 
 extern "C" int ast_kappa_to_alphas(ast_lens_plan* p, const double* kappa, double* alpha1, double* alpha2, void* stream) {
@@ -296,8 +324,15 @@ extern "C" int ast_kappa_to_alphas(ast_lens_plan* p, const double* kappa, double
     AST_FWD(lens_kernel_spectrum(p, 0, s));
     AST_FWD(lens_kernel_spectrum(p, 1, s));
     AST_FWD(lens_forward(p, kappa, s));
-    AST_FWD(lens_convolve(p, 0, alpha1, s));
-    AST_FWD(lens_convolve(p, 1, alpha2, s));
+    const size_t n2 = 2 * (size_t)p->nc, nh = n2 / 2 + 1;
+    if (!p->prod2) AST_CHECK_HIP(hipMalloc(&p->prod2, n2 * nh * sizeof(double2)));
+    {
+        AST_PROF("lens.cmul", s);
+        cmul2_kernel<<<ast::stream_grid(n2 * nh, 256), 256, 0, s>>>(p->spec, p->kspec[0], p->kspec[1], p->prod, p->prod2, n2 * nh);
+    }
+    AST_CHECK_LAUNCH();
+    AST_FWD(lens_crop(p, p->prod, alpha1, s));
+    AST_FWD(lens_crop(p, p->prod2, alpha2, s));
     return AST_OK;
 }
 

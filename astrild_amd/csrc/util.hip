@@ -168,11 +168,18 @@ __global__ void sum_stage2_kernel(const double* __restrict__ part, int nparts, d
 //   f = (v - lo) * (nbins / (hi - lo));  idx = (int) f;  idx == nbins -> nbins-1;
 //   then numpy corrects against the float64 edges: v < edge[idx] -> idx-1,
 //   v >= edge[idx+1] && idx != nbins-1 -> idx+1.   edges = linspace(lo, hi, nbins+1).
+// range_d (or null): {lo, hi} on the device (ast_minmax's output) - the range=None case of np.histogram without a
+// host round trip; a degenerate range is widened by +-0.5 like numpy does.
 template <typename T, int MAXB>
 __global__ void hist_kernel(const T* buf, size_t n, double lo, double hi, int nbins,
-                            unsigned long long* counts) {
+                            unsigned long long* counts, const double* __restrict__ range_d = nullptr) {
     __shared__ unsigned int lh[MAXB];
     for (int i = threadIdx.x; i < nbins; i += blockDim.x) lh[i] = 0;
+    if (range_d) {
+        lo = range_d[0];
+        hi = range_d[1];
+        if (lo == hi) { lo -= 0.5; hi += 0.5; }
+    }
     __syncthreads();
     const double norm = (double)nbins / (hi - lo);
     const double step = (hi - lo) / (double)nbins;
@@ -322,6 +329,25 @@ extern "C" int ast_histogram(const void* buf, int dtype, size_t count, double lo
         hist_kernel<float, 4096><<<g, 256, 0, ast::as_stream(stream)>>>((const float*)buf, count, lo, hi, nbins, c);
     else
         hist_kernel<double, 4096><<<g, 256, 0, ast::as_stream(stream)>>>((const double*)buf, count, lo, hi, nbins, c);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+// np.histogram(buf, bins=nbins) with range=None in one stream-ordered call: min/max into range_d (2 doubles, as
+// ast_minmax), then the counts against that range read from the device.  The caller fetches counts and range together.
+extern "C" int ast_histogram_auto(const void* buf, int dtype, size_t count, int nbins, long long* counts, double* range_d,
+                                  void* stream) {
+    AST_CHECK_ARG(buf && counts && range_d && count > 0);
+    AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
+    AST_CHECK_ARG(nbins > 0 && nbins <= 4096);
+    const int rc = ast_minmax(buf, dtype, count, range_d, stream);
+    if (rc != AST_OK) return rc;
+    unsigned g = ast::stream_grid(count, 256);
+    auto* c = reinterpret_cast<unsigned long long*>(counts);
+    if (dtype == AST_F32)
+        hist_kernel<float, 4096><<<g, 256, 0, ast::as_stream(stream)>>>((const float*)buf, count, 0.0, 1.0, nbins, c, range_d);
+    else
+        hist_kernel<double, 4096><<<g, 256, 0, ast::as_stream(stream)>>>((const double*)buf, count, 0.0, 1.0, nbins, c, range_d);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }

@@ -159,13 +159,24 @@ def minmax(t):
 def histogram(t, nbins, range=None, density=False):
     """np.histogram(t, bins=nbins, range=, density=) -> (values, bin_edges) as numpy."""
     nbins = int(nbins)
-    lo, hi = minmax(t) if range is None else (float(range[0]), float(range[1]))
-    if lo == hi:                      # numpy widens a degenerate range by +-0.5
-        lo, hi = lo - 0.5, hi + 0.5
-    counts = torch.zeros(nbins, dtype=torch.int64, device=t.device)
-    check(_lib.lib().ast_histogram(ptr(t), real_code(t), t.numel(), lo, hi, nbins, ptr(counts), stream()),
-          "ast_histogram")
-    counts = counts.cpu().numpy()
+    if range is None:
+        # min/max and counts in one stream-ordered call; ONE transfer brings back both (counts, then the range's bits)
+        buf = torch.zeros(nbins + 2, dtype=torch.int64, device=t.device)
+        check(_lib.lib().ast_histogram_auto(ptr(t), real_code(t), t.numel(), nbins, ptr(buf), ptr(buf[nbins:]), stream()),
+              "ast_histogram_auto")
+        host = buf.cpu().numpy()
+        counts = host[:nbins]
+        lo, hi = (float(v) for v in host[nbins:].view(np.float64))
+        if lo == hi:                  # numpy widens a degenerate range by +-0.5
+            lo, hi = lo - 0.5, hi + 0.5
+    else:
+        lo, hi = float(range[0]), float(range[1])
+        if lo == hi:
+            lo, hi = lo - 0.5, hi + 0.5
+        counts = torch.zeros(nbins, dtype=torch.int64, device=t.device)
+        check(_lib.lib().ast_histogram(ptr(t), real_code(t), t.numel(), lo, hi, nbins, ptr(counts), stream()),
+              "ast_histogram")
+        counts = counts.cpu().numpy()
     edges = np.linspace(lo, hi, nbins + 1)
     if density:
         return counts / np.diff(edges) / counts.sum(), edges

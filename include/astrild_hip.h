@@ -459,6 +459,12 @@ int ast_minmax(const void* buf_d, int dtype, size_t count, double* out_d, void* 
 int ast_histogram(const void* buf_d, int dtype, size_t count, double lo, double hi, int nbins,
                   long long* counts_d, void* stream);
 
+/* np.histogram(buf, bins=nbins) with range=None (sky_array.py's PDF calls) without a host round trip between the
+ * min/max pass and the counting pass: range_d[0..1] receives {min, max} (a degenerate range counts against
+ * [min - 0.5, max + 0.5] like numpy), counts_d (zeroed by the caller) the bin counts. */
+int ast_histogram_auto(const void* buf_d, int dtype, size_t count, int nbins, long long* counts_d, double* range_d,
+                       void* stream);
+
 /* out[i] = a[i] + b[i]  (add_galaxy_shape_noise, sky_array.py:693-706). */
 int ast_add(const void* a_d, const void* b_d, void* out_d, int dtype, size_t count, void* stream);
 
