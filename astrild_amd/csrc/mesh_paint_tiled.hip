@@ -653,13 +653,15 @@ __device__ inline uint32_t block_exclusive_scan(const uint32_t* cnt, uint32_t* l
 // where[u] = table entry << 16 | rank of record u among the workgroup's records of that entry (0xffffffff: none);
 // lstart[]: the entries' first slots in the workgroup's destination order, base[]: their first index in `out`,
 // room[] (or null): how many records of an entry `out` still takes - the rest is not stored (the caller deposits them).
-template <typename T>
+// SW: words per record - 4 {x, y, z, m}, or 3 {x, y, z} when there are no masses (a quarter less staging traffic).
+template <typename T, int SW>
 __device__ inline void staged_store(const T (&rx)[SC_PER_THREAD], const T (&ry)[SC_PER_THREAD], const T (&rz)[SC_PER_THREAD],
                                     const T (&rm)[SC_PER_THREAD], const uint32_t (&where)[SC_PER_THREAD],
                                     const uint32_t* lstart, const unsigned long long* base, const uint32_t* room,
                                     uint32_t total, T* __restrict__ out, T* stage /* [SC_ROUND * 4] */,
                                     unsigned long long* sidx /* [SC_ROUND] */) {
     typedef T vec4_t __attribute__((ext_vector_type(4)));
+    struct Rec3 { T x, y, z; };
     constexpr uint32_t ROUND = sc_round<T>();
     for (uint32_t q0 = 0; q0 < total; q0 += ROUND) {
 #pragma unroll
@@ -668,7 +670,8 @@ __device__ inline void staged_store(const T (&rx)[SC_PER_THREAD], const T (&ry)[
             const uint32_t e = where[u] >> 16, r = where[u] & 0xffffu;
             const uint32_t sl = lstart[e] + r - q0;           // unsigned: slots of other rounds fail the test
             if (sl < ROUND) {
-                reinterpret_cast<vec4_t*>(stage)[sl] = vec4_t{rx[u], ry[u], rz[u], rm[u]};
+                if (SW == 4) reinterpret_cast<vec4_t*>(stage)[sl] = vec4_t{rx[u], ry[u], rz[u], rm[u]};
+                else reinterpret_cast<Rec3*>(stage)[sl] = Rec3{rx[u], ry[u], rz[u]};
                 sidx[sl] = (room == nullptr || r < room[e]) ? base[e] + r : ~0ull;
             }
         }
@@ -676,13 +679,15 @@ __device__ inline void staged_store(const T (&rx)[SC_PER_THREAD], const T (&ry)[
         const uint32_t here = min(ROUND, total - q0);
         for (uint32_t i = threadIdx.x; i < here; i += SC_THREADS) {
             const unsigned long long d = sidx[i];
-            if (d != ~0ull) *reinterpret_cast<vec4_t*>(out + 4 * (size_t)d) = reinterpret_cast<const vec4_t*>(stage)[i];
+            if (d == ~0ull) continue;
+            if (SW == 4) *reinterpret_cast<vec4_t*>(out + 4 * (size_t)d) = reinterpret_cast<const vec4_t*>(stage)[i];
+            else *reinterpret_cast<Rec3*>(out + 3 * (size_t)d) = reinterpret_cast<const Rec3*>(stage)[i];
         }
         __syncthreads();
     }
 }
 
-template <typename T, int W, bool PLAINX>
+template <typename T, int W, bool PLAINX, int SW>
 __global__ void __launch_bounds__(SC_THREADS)
 scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t np, TileGeom g, uint32_t tpb,
                        unsigned long long* __restrict__ cursor, T* __restrict__ staging) {
@@ -703,7 +708,7 @@ scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, si
         x[u] = pos[3 * p];
         y[u] = pos[3 * p + 1];
         z[u] = pos[3 * p + 2];
-        m[u] = mass ? mass[p] : (T)1;
+        m[u] = SW == 4 && mass ? mass[p] : (T)1;
     }
 #pragma unroll
     for (int u = 0; u < SC_PER_THREAD; ++u) {
@@ -720,7 +725,7 @@ scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, si
     __syncthreads();
     if (cnt[tid]) base[tid] = atomicAdd(&cursor[tid], (unsigned long long)cnt[tid]);
     const uint32_t total = block_exclusive_scan(cnt, lstart, SC_BUCKETS, wsum);
-    staged_store<T>(x, y, z, m, where, lstart, base, nullptr, total, staging, stage, sidx);
+    staged_store<T, SW>(x, y, z, m, where, lstart, base, nullptr, total, staging, stage, sidx);
 }
 
 // one record deposited with global atomics (a full tile segment): overflow_deposit_kernel's body
@@ -760,7 +765,7 @@ late_deposit_kernel(const T* __restrict__ late_list, const unsigned long long* _
                                     grid, dropped);
 }
 
-template <typename T, int W, bool PLAINX>
+template <typename T, int W, bool PLAINX, int SW>
 __global__ void __launch_bounds__(SC_THREADS)
 scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* __restrict__ bstart, TileGeom g, uint32_t tpb,
                        unsigned long long* __restrict__ fill64, T* __restrict__ strays, uint32_t scap,
@@ -775,7 +780,7 @@ scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* 
     const uint32_t bucket = blockIdx.x;
     const size_t b0 = (size_t)bstart[bucket], b1 = (size_t)bstart[bucket + 1];
     typedef T vec4_t __attribute__((ext_vector_type(4)));
-    const vec4_t* recs = reinterpret_cast<const vec4_t*>(staging);
+    struct Rec3 { T x, y, z; };
     for (size_t c0 = b0 + (size_t)blockIdx.y * SC_CHUNK; c0 < b1; c0 += (size_t)gridDim.y * SC_CHUNK) {
         for (uint32_t t = tid; t < tpb; t += SC_THREADS) cnt[t] = 0;
         __syncthreads();
@@ -783,8 +788,14 @@ scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* 
         uint32_t where[SC_PER_THREAD];               // tile in bucket << 16 | rank (< 16384)
 #pragma unroll
         for (int u = 0; u < SC_PER_THREAD; ++u) {
-            const vec4_t r = recs[min(c0 + (size_t)u * SC_THREADS + tid, b1 - 1)];
-            x[u] = r.x; y[u] = r.y; z[u] = r.z; m[u] = r.w;
+            const size_t ri = min(c0 + (size_t)u * SC_THREADS + tid, b1 - 1);
+            if (SW == 4) {
+                const vec4_t r = reinterpret_cast<const vec4_t*>(staging)[ri];
+                x[u] = r.x; y[u] = r.y; z[u] = r.z; m[u] = r.w;
+            } else {
+                const Rec3 r = reinterpret_cast<const Rec3*>(staging)[ri];
+                x[u] = r.x; y[u] = r.y; z[u] = r.z; m[u] = (T)1;
+            }
         }
 #pragma unroll
         for (int u = 0; u < SC_PER_THREAD; ++u) {
@@ -812,7 +823,7 @@ scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* 
                 else if (dropped) atomicAdd(dropped, 1ull);            // more than a quarter of all particles: reported, not lost silently
             }
         }
-        staged_store<T>(x, y, z, m, where, lstart, base, room, total, strays, stage, sidx);
+        staged_store<T, SW>(x, y, z, m, where, lstart, base, room, total, strays, stage, sidx);
     }
 }
 
@@ -1008,7 +1019,8 @@ tile_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileG
 // 1.3 TB/s global float-atomic flush (4 ms of the 13 ms tile kernel at 1024^3) is gone.
 // The few planes that wrap around the periodic z edge are added atomically at the end.
 // The particle lists a column walk reads.  FMT 0: 4-byte particle ids per tile (exact offsets of the two-pass
-// variant, tile_off / tile_count).  FMT 1: the compact lists of tile_group_kernel (group records + stray copies
+// variant, tile_off / tile_count).  FMT 2: as FMT 1 with 3-word stray copies {x, y, z} (the scatter path without masses;
+// there are no group records then).  FMT 1: the compact lists of tile_group_kernel (group records + stray copies
 // in fixed-capacity segments, counts in fill64: records in the high word, strays in the low).
 // (The list pointers are separate __restrict__ kernel arguments on purpose: read through a struct member the
 // per-tile counts become VECTOR loads followed by s_waitcnt vmcnt(0) - which also waits for every prefetched
@@ -1110,14 +1122,14 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     // per half wave - the tile's nrec group records followed by ceil(nst / 32) blocks of 32 consecutive stray
     // copies, so records and strays share batches (72 entries, i.e. 4.5 batches, per tile of the bench input).
     // off: FMT 0 first id of the tile's list; FMT 1 the tile id.  tz == g.ntz: past the end
-    using list_off_t = std::conditional_t<FMT == 1, uint32_t, size_t>;
+    using list_off_t = std::conditional_t<FMT != 0, uint32_t, size_t>;
     struct Batch { int tz; uint32_t i0, cnt; list_off_t off; uint32_t nrec, nst; };
     // The walk starts at a column-dependent tile and wraps around the periodic z edge (the ring
     // does not care), so concurrently running columns are at different z: in lockstep all of
     // them would store to / gather from addresses a large power of two apart.
     const int tz0 = ablate & 512 ? 0 : (int)(((unsigned)col * 2654435761u >> 16) % (unsigned)g.ntz);
     auto phys = [&](int step) { const int t = tz0 + step; return t >= g.ntz ? t - g.ntz : t; };   // step -> tile
-    constexpr uint32_t BATCH = FMT == 1 ? 8u * U : 256u * U;      // entries per batch
+    constexpr uint32_t BATCH = FMT != 0 ? 8u * U : 256u * U;      // entries per batch
     auto next_batch = [&](Batch bt) -> Batch {
         if (bt.tz >= 0 && bt.tz < g.ntz && bt.i0 + BATCH < bt.cnt) { bt.i0 += BATCH; return bt; }
         for (int nt = bt.tz + 1; nt < g.ntz; ++nt) {
@@ -1157,15 +1169,16 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
         act = 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (FMT == 1) {
+            if (FMT != 0) {
+                constexpr int SW = FMT == 2 ? 3 : 4;                            // stray copies: {x, y, z, m} or {x, y, z}
                 const uint32_t r = bt.i0 + u * 8 + (threadIdx.x >> 5), b = threadIdx.x & 31;
                 const bool st = r >= bt.nrec;                                   // uniform per half wave
                 const uint32_t sidx = (r - bt.nrec) * 32u + b;
                 const bool on = st ? (r < bt.cnt && sidx < bt.nst) : ((rec[u].mask >> b) & 1u) != 0;
                 act |= (uint32_t)on << u;
                 const uint32_t idx = st ? min(sidx, bt.nst - 1) : min(rec[u].first + b, (uint32_t)(wl.np - 1));    // np < 2^32 - 64: no wrap
-                const T* const sbase = wl_strays + 4 * ((size_t)bt.off * wl.scap);
-                const T* const src = st ? sbase + 4 * (size_t)idx : pos + 3 * (size_t)idx;
+                const T* const sbase = wl_strays + SW * ((size_t)bt.off * wl.scap);
+                const T* const src = st ? sbase + SW * (size_t)idx : pos + 3 * (size_t)idx;
                 p[3 * u + 0] = src[0];
                 p[3 * u + 1] = src[1];
                 p[3 * u + 2] = src[2];
@@ -1627,6 +1640,7 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
             {
                 AST_PROF("paint_tiled.deposit", s);
                 WalkCaps wl{w.rcap, w.scap, w.cap, np};
+                using I2 = std::integral_constant<int, 2>;
                 auto launch = [&](auto has_mass, auto fmt) {
                     column_deposit_kernel<T, W, decltype(has_mass)::value, decltype(fmt)::value><<<ncols, 256, 0, s>>>(
                         pos, mass, g, scale, w.index, tile_off, tile_count, w.fill64, w.recs, (const T*)w.strays, wl,
@@ -1635,7 +1649,9 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
                 using I0 = std::integral_constant<int, 0>;
                 using I1 = std::integral_constant<int, 1>;
                 if (two_pass) { if (mass) launch(std::true_type{}, I0{}); else launch(std::false_type{}, I0{}); }
-                else { if (mass) launch(std::true_type{}, I1{}); else launch(std::false_type{}, I1{}); }
+                else if (mass) launch(std::true_type{}, I1{});
+                else if (w.tpb) launch(std::false_type{}, I2{});          // scatter path without masses: 3-word stray copies
+                else launch(std::false_type{}, I1{});
             }
             if (!(flags & AST_PAINT_DEFER_FOLD)) {
                 AST_PROF("paint_tiled.fold", s);
@@ -1665,27 +1681,37 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
         deposit_pass(w.tile_off, w.tile_count, 0);
     } else if (overwrite && w.tpb) {
         {
-            AST_PROF("paint_tiled.fill", s);
             const unsigned nchunks = (unsigned)((np + SC_CHUNK - 1) / SC_CHUNK);
-            auto run = [&](auto px) -> int {
+            auto run = [&](auto px, auto sw) -> int {
                 constexpr bool PX = decltype(px)::value;
-                scatter_count_kernel<T, W, PX><<<nchunks, SC_THREADS, 0, s>>>(pos, np, g, w.tpb, w.bcount, w.col_flags, dropped);
-                scatter_scan_kernel<<<1, SC_BUCKETS, 0, s>>>(w.bcount, w.bstart, w.bcursor);
+                constexpr int SW = decltype(sw)::value;
+                {
+                    AST_PROF("paint_tiled.count", s);
+                    scatter_count_kernel<T, W, PX><<<nchunks, SC_THREADS, 0, s>>>(pos, np, g, w.tpb, w.bcount, w.col_flags, dropped);
+                    scatter_scan_kernel<<<1, SC_BUCKETS, 0, s>>>(w.bcount, w.bstart, w.bcursor);
+                }
                 const size_t stage_lds = sc_round<T>() * (4 * sizeof(T) + sizeof(unsigned long long));
                 static ast::PerDeviceOnce attr_once;
                 if (attr_once.need()) {
-                    AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_level_a_kernel<T, W, PX>),
+                    AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_level_a_kernel<T, W, PX, SW>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds));
-                    AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_level_b_kernel<T, W, PX>),
+                    AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_level_b_kernel<T, W, PX, SW>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds));
                             }
-                scatter_level_a_kernel<T, W, PX><<<nchunks, SC_THREADS, stage_lds, s>>>(pos, mass, np, g, w.tpb, w.bcursor, (T*)w.staging);
+                {
+                    AST_PROF("paint_tiled.level_a", s);
+                    scatter_level_a_kernel<T, W, PX, SW><<<nchunks, SC_THREADS, stage_lds, s>>>(pos, mass, np, g, w.tpb, w.bcursor, (T*)w.staging);
+                }
                 const unsigned long long late_cap = np / 4 * sizeof(uint32_t) / sizeof(T);       // the overflow list's room
-                scatter_level_b_kernel<T, W, PX><<<dim3(SC_BUCKETS, 32), SC_THREADS, stage_lds, s>>>(
+                AST_PROF("paint_tiled.level_b", s);
+                scatter_level_b_kernel<T, W, PX, SW><<<dim3(SC_BUCKETS, 32), SC_THREADS, stage_lds, s>>>(
                     (const T*)w.staging, w.bstart, g, w.tpb, w.fill64, (T*)w.strays, w.scap, (T*)w.ovf, late_cap, w.late, dropped);
                 return AST_OK;
             };
-            const int rc = plainx ? run(std::true_type{}) : run(std::false_type{});
+            using S3 = std::integral_constant<int, 3>;
+            using S4 = std::integral_constant<int, 4>;
+            const int rc = mass ? (plainx ? run(std::true_type{}, S4{}) : run(std::false_type{}, S4{}))
+                                : (plainx ? run(std::true_type{}, S3{}) : run(std::false_type{}, S3{}));
             if (rc != AST_OK) return rc;
         }
         deposit_pass(nullptr, nullptr, 0);
