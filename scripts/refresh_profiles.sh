@@ -13,9 +13,12 @@ lean="--cpu-sample 0 --kappa 0 --bispec 0 --legs 0"
 rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python3 $R/bench.py $lean > $out/${tag}_bench_under_rocprof.json 2> $out/rocprof_stats.stderr
 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch -o f --output-format csv -- python3 $R/bench.py $lean --steps 2 --warmup 1 > /dev/null 2> $out/pmc_fetch.stderr
 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write -o w --output-format csv -- python3 $R/bench.py $lean --steps 2 --warmup 1 > /dev/null 2> $out/pmc_write.stderr
+# the secondary legs (kappa pipeline with its rocFFT kernels, bispectrum, shuffled / TSC paints): kernel stats only
+rocprofv3 --kernel-trace --stats -d $out/stats_legs -o s --output-format csv -- python3 $R/bench.py --cpu-sample 0 --steps 3 --warmup 1 > $out/${tag}_legs_under_rocprof.json 2> $out/rocprof_legs.stderr
 cd $R
 python3 scripts/pmc_traffic_json.py $out/pmc_fetch $out/pmc_write $out/${tag}_pmc_traffic.json
 find $out/stats -name "*kernel_stats.csv" -exec cp {} $out/${tag}_bench_kernel_stats.csv \;
+find $out/stats_legs -name "*kernel_stats.csv" -exec cp {} $out/${tag}_legs_kernel_stats.csv \;
 # the raw traces are large: keep only the summaries
-rm -rf $out/stats $out/pmc_fetch $out/pmc_write
+rm -rf $out/stats $out/stats_legs $out/pmc_fetch $out/pmc_write
 ls -la $out
