@@ -117,12 +117,24 @@ __device__ inline double key2d(unsigned long long k) {
 template <typename T>
 __global__ void minmax_kernel(const T* buf, size_t n, unsigned long long* keys) {
     double lo = DBL_MAX, hi = -DBL_MAX;
-    size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        double v = (double)buf[i];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // four independent loads and running extrema per trip (one load in flight per thread read 134 MB at 0.6 TB/s)
+    double l[4] = {DBL_MAX, DBL_MAX, DBL_MAX, DBL_MAX}, h[4] = {-DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX};
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        T v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = buf[i + j * stride];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { l[j] = fmin(l[j], (double)v[j]); h[j] = fmax(h[j], (double)v[j]); }
+    }
+    for (; i < n; i += stride) {
+        const double v = (double)buf[i];
         lo = fmin(lo, v);
         hi = fmax(hi, v);
     }
+    lo = fmin(fmin(lo, l[0]), fmin(fmin(l[1], l[2]), l[3]));
+    hi = fmax(fmax(hi, h[0]), fmax(fmax(h[1], h[2]), h[3]));
     lo = wave_min(lo);
     hi = wave_max(hi);
     if ((threadIdx.x & 63) == 0) {
