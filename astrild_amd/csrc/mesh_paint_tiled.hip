@@ -580,6 +580,12 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
 // its tile's segment (strongly clustered input) is deposited on the spot with global atomics.
 constexpr int SC_THREADS = 1024, SC_PER_THREAD = 8, SC_CHUNK = SC_THREADS * SC_PER_THREAD;      // 16 per thread spills (128 VGPRs at 1024 threads)
 constexpr uint32_t SC_BUCKETS = 1024, SC_TPB_MAX = 2048;        // buckets; most tiles per bucket (LDS counters of level B)
+// Every bucket's range of the staging array is cut into SC_GROUPS sub-ranges, and chunk c writes into sub-range
+// c mod 8.  Blocks b and b + 8 share an XCD (observed placement; nothing here depends on it for correctness: the
+// sub-ranges are sized by the same label in the count pass), so the 96-byte runs that complete a 128-byte line come
+// from workgroups behind ONE L2 and the line leaves it whole.  With one cursor per bucket the pieces of a line sat in
+// different XCDs' L2s and went to HBM as partial writes: level A's stores ran at 2 TB/s.
+constexpr uint32_t SC_GROUPS = 8;
 
 template <typename T, int W, bool PLAINX>
 __global__ void __launch_bounds__(SC_THREADS)
@@ -600,17 +606,21 @@ scatter_count_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t 
         atomicAdd(&cnt[key / tpb], 1u);
     }
     __syncthreads();
-    if (cnt[tid]) atomicAdd(&bcount[tid], (unsigned long long)cnt[tid]);
+    if (cnt[tid]) atomicAdd(&bcount[(blockIdx.x % SC_GROUPS) * SC_BUCKETS + tid], (unsigned long long)cnt[tid]);
     if (dropped && ndrop) atomicAdd(dropped, ndrop);
 }
 
-// bstart[b] = exclusive prefix sum of bcount; cursor[b] = the same (level A advances it)
+// bstart[b * SC_GROUPS + g] = exclusive prefix sum of the counts in (bucket, group) order.  bcount and cursor (the
+// same values; level A advances them) are laid out [g][b]: a workgroup's 1024 atomics then touch 64 lines, not 1024.
+// Thread b owns its bucket's SC_GROUPS entries.
 __global__ void __launch_bounds__(SC_BUCKETS)
 scatter_scan_kernel(const unsigned long long* __restrict__ bcount, unsigned long long* __restrict__ bstart,
                     unsigned long long* __restrict__ cursor) {
     __shared__ unsigned long long s[SC_BUCKETS];
     const int tid = threadIdx.x;
-    s[tid] = bcount[tid];
+    unsigned long long c[SC_GROUPS], mine = 0;
+    for (uint32_t g = 0; g < SC_GROUPS; ++g) { c[g] = bcount[g * SC_BUCKETS + tid]; mine += c[g]; }
+    s[tid] = mine;
     __syncthreads();
     for (int o = 1; o < (int)SC_BUCKETS; o <<= 1) {
         const unsigned long long add = tid >= o ? s[tid - o] : 0ull;
@@ -618,10 +628,13 @@ scatter_scan_kernel(const unsigned long long* __restrict__ bcount, unsigned long
         s[tid] += add;
         __syncthreads();
     }
-    const unsigned long long ex = s[tid] - bcount[tid];
-    bstart[tid] = ex;
-    cursor[tid] = ex;
-    if (tid == (int)SC_BUCKETS - 1) bstart[SC_BUCKETS] = s[tid];
+    unsigned long long ex = s[tid] - mine;
+    for (uint32_t g = 0; g < SC_GROUPS; ++g) {
+        bstart[tid * SC_GROUPS + g] = ex;
+        cursor[g * SC_BUCKETS + tid] = ex;
+        ex += c[g];
+    }
+    if (tid == (int)SC_BUCKETS - 1) bstart[SC_BUCKETS * SC_GROUPS] = s[tid];
 }
 
 // records staged per round: 96 KB of LDS either way
@@ -723,7 +736,7 @@ scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, si
         }
     }
     __syncthreads();
-    if (cnt[tid]) base[tid] = atomicAdd(&cursor[tid], (unsigned long long)cnt[tid]);
+    if (cnt[tid]) base[tid] = atomicAdd(&cursor[(blockIdx.x % SC_GROUPS) * SC_BUCKETS + tid], (unsigned long long)cnt[tid]);
     const uint32_t total = block_exclusive_scan(cnt, lstart, SC_BUCKETS, wsum);
     staged_store<T, SW>(x, y, z, m, where, lstart, base, nullptr, total, staging, stage, sidx);
 }
@@ -778,7 +791,7 @@ scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* 
     unsigned long long* sidx = dyn + sc_round<T>() * 4 * sizeof(T) / sizeof(unsigned long long);
     const int tid = threadIdx.x;
     const uint32_t bucket = blockIdx.x;
-    const size_t b0 = (size_t)bstart[bucket], b1 = (size_t)bstart[bucket + 1];
+    const size_t b0 = (size_t)bstart[bucket * SC_GROUPS], b1 = (size_t)bstart[(bucket + 1) * SC_GROUPS];     // all its sub-ranges
     typedef T vec4_t __attribute__((ext_vector_type(4)));
     struct Rec3 { T x, y, z; };
     for (size_t c0 = b0 + (size_t)blockIdx.y * SC_CHUNK; c0 < b1; c0 += (size_t)gridDim.y * SC_CHUNK) {
@@ -1531,9 +1544,9 @@ struct Workspace {
     void* strays;                    // [tile][scap] x {x, y, z, m}
     uint32_t rcap, scap;
     // AST_PAINT_SCATTERED: two-level bucket scatter
-    unsigned long long* bcount;      // [SC_BUCKETS] records per coarse bucket
-    unsigned long long* bstart;      // [SC_BUCKETS + 1] their exclusive scan
-    unsigned long long* bcursor;     // [SC_BUCKETS] level A's write cursors
+    unsigned long long* bcount;      // [SC_BUCKETS * SC_GROUPS] records per (coarse bucket, chunk label)
+    unsigned long long* bstart;      // [SC_BUCKETS * SC_GROUPS + 1] their exclusive scan
+    unsigned long long* bcursor;     // [SC_BUCKETS * SC_GROUPS] level A write cursors
     unsigned long long* late;        // records that found their tile's segment full (deposited on the spot)
     void* staging;                   // [np] x {x, y, z, m}, bucket-major
     uint32_t tpb;                    // tiles per bucket (0: the scatter path does not apply)
@@ -1568,7 +1581,7 @@ Workspace carve(void* base, size_t np, uint32_t ntiles, uint32_t ncols, int flag
     const bool scattered = compact && (flags & AST_PAINT_SCATTERED);
     w.tpb = scattered ? (ntiles + SC_BUCKETS - 1) / SC_BUCKETS : 0;
     if (w.tpb > SC_TPB_MAX || np < (size_t)SC_CHUNK) w.tpb = 0;      // huge grids / tiny inputs: the grouping kernel does it
-    w.bcount = (unsigned long long*)take(w.tpb ? SC_BUCKETS * 8 : 0);
+    w.bcount = (unsigned long long*)take(w.tpb ? SC_BUCKETS * SC_GROUPS * 8 : 0);
     w.late = (unsigned long long*)take(w.tpb ? 8 : 0);
     w.tile_off = (uint32_t*)take((size_t)ntiles * 4);
     w.block_sums = (uint32_t*)take((size_t)((ntiles + 1023) / 1024 + 1) * 4);
@@ -1578,8 +1591,8 @@ Workspace carve(void* base, size_t np, uint32_t ntiles, uint32_t ncols, int flag
     w.index = (uint32_t*)take(two_pass ? np * 4 : compact ? 0 : (size_t)ntiles * w.cap * 4);
     w.recs = (GroupRec*)take((size_t)ntiles * w.rcap * sizeof(GroupRec));
     w.strays = take((size_t)ntiles * w.scap * 4 * esz);
-    w.bstart = (unsigned long long*)take(w.tpb ? (SC_BUCKETS + 1) * 8 : 0);
-    w.bcursor = (unsigned long long*)take(w.tpb ? SC_BUCKETS * 8 : 0);
+    w.bstart = (unsigned long long*)take(w.tpb ? (SC_BUCKETS * SC_GROUPS + 1) * 8 : 0);
+    w.bcursor = (unsigned long long*)take(w.tpb ? SC_BUCKETS * SC_GROUPS * 8 : 0);
     w.staging = take(w.tpb ? np * 4 * esz : 0);
     w.ovf = (uint32_t*)take(two_pass ? 0 : np * 4);
     w.rec = take(rec_bytes);

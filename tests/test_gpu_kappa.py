@@ -185,6 +185,21 @@ def test_histogram_counts_bit_exact_and_pdf(lens, dev, dtype):
     assert np.array_equal(c2, np.histogram(img.astype(np.float64), bins=10, range=(-0.01, 0.03))[0])
 
 
+def test_histogram_of_a_constant_map_and_ragged_minmax(lens, dev):
+    """range=None on a constant map: numpy widens the degenerate range by +-0.5 (done on the device here); min/max over
+    a length that is no multiple of the unrolled trip."""
+    img = np.full(1000, 0.25)
+    counts, edges = lens.histogram(dev.as_device(img), 8)
+    rc, re = np.histogram(img, bins=8)
+    assert np.array_equal(counts, rc)
+    npt.assert_allclose(edges, re, rtol=1e-15)
+    rng = np.random.default_rng(11)
+    for n in (1, 63, 4 * 2048 * 256 + 5, 5_000_003):
+        v = rng.standard_normal(n)
+        lo, hi = lens.minmax(dev.as_device(v))
+        assert lo == v.min() and hi == v.max()
+
+
 def test_histogram_values_on_bin_edges(lens, dev):
     # values exactly on edges: left-closed bins, right-most bin closed
     img = np.array([0.0, 0.1, 0.2, 0.3, 0.5, 0.7, 1.0, 1.0, 0.9999999999999999, 0.30000000000000004])
