@@ -1024,10 +1024,17 @@ extern "C" int ast_fft_tile_r2c_3d(const void* in, void* out, int dtype, size_t 
 
 // Row pitch (in complex elements) of the scratch spectrum used by ast_fft_tile_power_3d:
 // n/2+1 rounded up to a multiple of 16 so every 128-byte tile row is line-aligned.
-extern "C" size_t ast_fft_tile_power_scratch_bytes(size_t n) {
+extern "C" size_t ast_lowk_work_bytes(size_t n, size_t nx);
+static size_t power_core_bytes(size_t n) {
     const size_t nzp = ((n / 2 + 1) + 15) / 16 * 16;
     const size_t tiles = (n / 2 + 1 + 15) / 16;
     return n * n * nzp * sizeof(float2) + n * tiles * (n / 2 - 1) * sizeof(double) + 64 * sizeof(double);     // + low-k sums
+}
+static size_t lowk_area_bytes(size_t n);
+extern "C" size_t ast_fft_tile_power_scratch_bytes(size_t n) {
+    // spectrum, shell partials, low-k sums; then the low-k channel's own modes and work area (it runs on a second
+    // stream beside the FFT passes, so it cannot borrow the spectrum's space any more)
+    return (power_core_bytes(n) + 255) / 256 * 256 + lowk_area_bytes(n);
 }
 
 // FFTPower's shell sums of an (n, n, n) real grid without ever writing the spectrum:
@@ -1051,6 +1058,30 @@ extern "C" int ast_fft_tile_power_3d_halo(const void* grid, const void* halo_rec
 }
 
 constexpr size_t LOWK_MODES = (size_t)(2 * MBOX + 1) * (2 * MBOX + 1) * (MBOX + 1);
+static size_t lowk_area_bytes(size_t n) { return (LOWK_MODES * sizeof(double2) + 255) / 256 * 256 + ast_lowk_work_bytes(n, n); }
+
+// The low-k channel reads the grid only: it runs on a side stream while the main stream does the z and y passes (its z
+// kernel is half arithmetic, the FFT passes are memory bound; its four small kernels hide completely).  One side
+// stream and event pair per (device, main stream); the events are only ever recorded in that main stream's order.
+struct SideStream { int dev; hipStream_t main, side; hipEvent_t in, done; };
+struct SideStreamCache {
+    std::mutex m;
+    std::vector<SideStream> all;
+    const SideStream* get(hipStream_t main) {
+        std::lock_guard<std::mutex> lock(m);
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+        for (auto& e : all) if (e.dev == dev && e.main == main) return &e;
+        SideStream e{dev, main, nullptr, nullptr, nullptr};
+        if (hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&e.in, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&e.done, hipEventDisableTiming) != hipSuccess) return nullptr;
+        all.reserve(64);
+        if (all.size() >= 64) return nullptr;              // pointers into `all` stay valid: it never reallocates
+        all.push_back(e);
+        return &all.back();
+    }
+} g_side;
 
 // modes[kx + MBOX][ky + MBOX][kz] (+)= sum over the nx planes x0 .. x0 + nx - 1 (rows of n floats, n rows per plane) of
 // f(x, y, z) e^{-2 pi i (kx x + ky y + kz z) / n}.  work: nx * n * (MBOX + 1) + nx * 13 * 7 + 64 * 1183 double2.
@@ -1093,16 +1124,25 @@ static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, 
     const float2* tw = g_tw.get((int)n);
     if (!tw) { ast::set_error("ast_fft_tile_power_3d: twiddle table allocation failed"); return AST_ERR_HIP; }
     hipStream_t s = ast::as_stream(stream);
-    double* lowk_sums = (double*)((char*)scratch + ast_fft_tile_power_scratch_bytes(n)) - 64;
+    double* lowk_sums = (double*)((char*)scratch + power_core_bytes(n)) - 64;
+    const SideStream* side = nullptr;
     if (lowk) {
-        // the modes |m_i| <= MBOX as DFT sums in double, through the (still unused) spectrum scratch
-        AST_PROF("fft_tile.lowk", s);
-        double2* modes = (double2*)scratch;
-        int rc = lowk_modes((const float*)grid, (const float*)rec, window, (int)n, 0, (int)n, 0, modes, modes + LOWK_MODES, s);
-        if (rc != AST_OK) return rc;
-        const double ng = (double)n * (double)n * (double)n;
-        lowk_shell_kernel<<<1, 256, 0, s>>>(modes, boxsize * boxsize * boxsize / (ng * ng), kf_rule, lowk_sums);
-        AST_CHECK_LAUNCH();
+        // the modes |m_i| <= MBOX as DFT sums in double, on the side stream, in their own part of the scratch
+        side = g_side.get(s);
+        if (!side) { ast::set_error("ast_fft_tile_power_3d: side stream creation failed"); return AST_ERR_HIP; }
+        AST_CHECK_HIP(hipEventRecord(side->in, s));                  // the grid (and the previous call's use of the scratch) is done
+        AST_CHECK_HIP(hipStreamWaitEvent(side->side, side->in, 0));
+        {
+            AST_PROF("fft_tile.lowk", side->side);
+            double2* modes = (double2*)((char*)scratch + (power_core_bytes(n) + 255) / 256 * 256);
+            double2* work = (double2*)((char*)modes + (LOWK_MODES * sizeof(double2) + 255) / 256 * 256);
+            int rc = lowk_modes((const float*)grid, (const float*)rec, window, (int)n, 0, (int)n, 0, modes, work, side->side);
+            if (rc != AST_OK) return rc;
+            const double ng = (double)n * (double)n * (double)n;
+            lowk_shell_kernel<<<1, 256, 0, side->side>>>(modes, boxsize * boxsize * boxsize / (ng * ng), kf_rule, lowk_sums);
+            AST_CHECK_LAUNCH();
+        }
+        AST_CHECK_HIP(hipEventRecord(side->done, side->side));
     }
     int rc = rows_r2c_impl(grid, spec, dtype, n, n * n, n, nzp, 1.0, mean, stream, rec, window);      // z
     if (rc != AST_OK) return rc;
@@ -1124,7 +1164,10 @@ static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, 
     double* partial2 = (double*)scratch;                   // the spectrum scratch is dead after the x pass
     shell_partials_stage1_kernel<<<REDUCE_ROWS, 256, 0, s>>>(partial, n * tiles, nb, partial2);
     shell_partials_stage2_kernel<<<(nb + 7) / 8, 256, 0, s>>>(partial2, nb, boxsize * boxsize * boxsize, lowk ? MLOW : 0, psum);
-    if (lowk) lowk_patch_kernel<<<1, 64, 0, s>>>(lowk_sums, MLOW, psum);
+    if (lowk) {
+        AST_CHECK_HIP(hipStreamWaitEvent(s, side->done, 0));
+        lowk_patch_kernel<<<1, 64, 0, s>>>(lowk_sums, MLOW, psum);
+    }
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
