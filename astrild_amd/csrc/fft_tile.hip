@@ -319,16 +319,34 @@ shell_partials_stage2_kernel(const double* __restrict__ partial2, int nb, double
 
 // ------------------------------------------------------- contiguous-row R2C pass
 // in: nrows rows of N = 2*M reals (pitch in_pitch reals); out: rows of M+1 complex.
+// (constants of the low-k channel, described further down; the z pass below can produce its z sums on the side)
+constexpr int MLOW_FWD = 5, MBOX_FWD = MLOW_FWD + 1;
+__device__ constexpr double kC16f[16] = {1.0, 0.92387953251128674, 0.70710678118654752, 0.38268343236508977, 0.0,
+                                         -0.38268343236508977, -0.70710678118654752, -0.92387953251128674, -1.0,
+                                         -0.92387953251128674, -0.70710678118654752, -0.38268343236508977, 0.0,
+                                         0.38268343236508977, 0.70710678118654752, 0.92387953251128674};
+__device__ constexpr double kS16f[16] = {0.0, -0.38268343236508977, -0.70710678118654752, -0.92387953251128674, -1.0,
+                                         -0.92387953251128674, -0.70710678118654752, -0.38268343236508977, 0.0,
+                                         0.38268343236508977, 0.70710678118654752, 0.92387953251128674, 1.0,
+                                         0.92387953251128674, 0.70710678118654752, 0.38268343236508977};
+
+// LOWK (N = 1024 only): the thread's 32 samples x[64 n1 + 2 n2 + p] are in registers right after the load, so the
+// low-k channel's z sums S_kz = sum_z x[z] e^{-2 pi i kz z / N}, kz <= 6, are formed here in double instead of by a
+// second pass over the grid (lowk_z_kernel: 4.3 GB, 1.2 ms): per p the 16-term sum over n1 with the 16th roots of unity
+// as constants (e^{-2 pi i 64 / 1024}), then T_0 A + T_1 B with the lane's factors A = w^{2 kz n2}, B = w^{kz (2 n2 + 1)}
+// (table lowk_lane, double), then a transposed reduction over the row's 32 lanes.  Output as lowk_z_kernel's.
 // M = R1*R2.  One workgroup transforms C rows.
 // FOLDW = 2 / 3 (CIC / TSC): `in` is the grid a deferred-fold paint left (AST_PAINT_DEFER_FOLD) and `rec`
 // its halo records; the up to three record lines that end in a border row are added as the row is
 // loaded — sum of the records first, then onto the row, the order of column_fold_kernel, so the
 // result is bit-identical to folding first.  Rows are (x, y) lines of the periodic n^3 grid.
-template <int R1, int R2, int C, int FOLDW>
+template <int R1, int R2, int C, int FOLDW, bool LOWK = false>
 __global__ void __launch_bounds__(C * R2)
+__attribute__((amdgpu_waves_per_eu(LOWK ? 4 : 1, LOWK ? 4 : 8)))     // LOWK: keep two workgroups per CU (128 VGPRs)
 rows_r2c_kernel(const float* __restrict__ in, float2* __restrict__ out, const float2* __restrict__ tw_g,
                 size_t nrows, size_t in_pitch, size_t out_pitch, float scale, float mean,
-                const float* __restrict__ rec) {
+                const float* __restrict__ rec, const double2* __restrict__ lowk_lane = nullptr,
+                double* __restrict__ lowz = nullptr) {
     constexpr int M = R1 * R2, N = 2 * M;
     constexpr int NT = C * R2;
     constexpr int R2P = R2 + 1;
@@ -378,6 +396,55 @@ rows_r2c_kernel(const float* __restrict__ in, float2* __restrict__ out, const fl
                     v[n1].y += h[n1].y;
                 }
             }
+        }
+        if (LOWK) {
+            static_assert(!LOWK || (R1 == 16 && R2 == 32 && MBOX_FWD == 6), "laid out for N = 1024: 16 samples per p, 32 lanes per row");
+            double acc[14];
+#pragma unroll
+            for (int e = 0; e < 14; ++e) acc[e] = 0.0;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {                    // one parity at a time: 16 doubles live, not 32
+                double f[R1];
+#pragma unroll
+                for (int n1 = 0; n1 < R1; ++n1) f[n1] = (double)(p ? v[n1].y : v[n1].x);
+#pragma unroll
+                for (int kz = 0; kz <= MBOX_FWD; ++kz) {
+                    double tr = 0.0, ti = 0.0;
+#pragma unroll
+                    for (int n1 = 0; n1 < R1; ++n1) {
+                        const int rr = (kz * n1) % 16;           // e^{-2 pi i kz n1 / 16}: a compile-time constant
+                        if (rr == 0) tr += f[n1];
+                        else if (rr == 4) ti -= f[n1];
+                        else if (rr == 8) tr -= f[n1];
+                        else if (rr == 12) ti += f[n1];
+                        else { tr = fma(f[n1], kC16f[rr], tr); ti = fma(f[n1], kS16f[rr], ti); }
+                    }
+                    const double2 a = lowk_lane[(n2 * (MBOX_FWD + 1) + kz) * 2 + p];
+                    acc[2 * kz] = fma(a.x, tr, fma(-a.y, ti, acc[2 * kz]));
+                    acc[2 * kz + 1] = fma(a.x, ti, fma(a.y, tr, acc[2 * kz + 1]));
+                }
+            }
+            // 14 sums over the row's 32 lanes (a wave holds two rows): 14 -> 7 (+1 zero) -> 4 -> 2 -> 1, then the last pair
+            const int lane = threadIdx.x & 63;
+            auto level = [&](auto count_tag, int mask) {
+                constexpr int COUNT = decltype(count_tag)::value;
+                const bool upper = (lane & mask) != 0;
+#pragma unroll
+                for (int i = 0; i < COUNT / 2; ++i) {
+                    const double keep = upper ? acc[i + COUNT / 2] : acc[i];
+                    const double send = upper ? acc[i] : acc[i + COUNT / 2];
+                    acc[i] = keep + __shfl_xor(send, mask, 64);
+                }
+            };
+            level(std::integral_constant<int, 14>{}, 16);
+            acc[7] = 0.0;
+            level(std::integral_constant<int, 8>{}, 8);
+            level(std::integral_constant<int, 4>{}, 4);
+            level(std::integral_constant<int, 2>{}, 2);
+            acc[0] += __shfl_xor(acc[0], 1, 64);
+            const int sub = ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+            if ((lane & 1) == 0 && sub < 7 && row0 + r < nrows)
+                lowz[(row0 + r) * (size_t)(2 * (MBOX_FWD + 1)) + ((lane >> 4) & 1) * 7 + sub] = acc[0];
         }
 #pragma unroll
         for (int n1 = 0; n1 < R1; ++n1) {
@@ -885,20 +952,22 @@ int dispatch_c2c(size_t n, float2* d, const float2* tw, size_t elem_stride, size
     return launch_c2c<16, 16, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0);
 }
 
-template <int R1, int R2, int C, int FOLDW = 0>
+template <int R1, int R2, int C, int FOLDW = 0, bool LOWK = false>
 int launch_r2c(const float* in, float2* out, const float2* tw, size_t nrows, size_t in_pitch, size_t out_pitch,
-               float scale, float mean, hipStream_t s, const float* rec = nullptr) {
+               float scale, float mean, hipStream_t s, const float* rec = nullptr, const double2* lowk_lane = nullptr,
+               double* lowz = nullptr) {
     constexpr int M = R1 * R2, N = 2 * M, NT = C * R2;
     constexpr int BUF = C * (R1 * (R2 + 1) > M + 1 ? R1 * (R2 + 1) : M + 1);
     const size_t lds = (size_t)(BUF + N) * sizeof(float2);
     static ast::PerDeviceOnce attr_once;
     if (attr_once.need()) {
-        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rows_r2c_kernel<R1, R2, C, FOLDW>),
+        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rows_r2c_kernel<R1, R2, C, FOLDW, LOWK>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     const size_t blocks = (nrows + C - 1) / C;
     AST_CHECK_ARG(blocks < 0x7fffffffull);
-    rows_r2c_kernel<R1, R2, C, FOLDW><<<(unsigned)blocks, NT, lds, s>>>(in, out, tw, nrows, in_pitch, out_pitch, scale, mean, rec);
+    rows_r2c_kernel<R1, R2, C, FOLDW, LOWK><<<(unsigned)blocks, NT, lds, s>>>(in, out, tw, nrows, in_pitch, out_pitch, scale, mean, rec,
+                                                                             lowk_lane, lowz);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
@@ -966,9 +1035,36 @@ extern "C" int ast_fft_tile_c2c_packed(const void* planes, void* packed, int dty
     return launch_c2c_pack<16, 16, 16>(d, tw, ncols, ncols, nplanes, n * ncols, (float)scale, pack, s);
 }
 
+// lane factors of the fused low-k z sums (rows_r2c_kernel<.., LOWK>): [n2 < 32][kz <= 6][A, B],
+// A = e^{-2 pi i kz 2 n2 / 1024}, B = e^{-2 pi i kz (2 n2 + 1) / 1024}
+__global__ void lowk_lane_kernel(double2* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 32 * 7 * 2) return;
+    const int p = i & 1, kz = (i >> 1) % 7, n2 = (i >> 1) / 7;
+    double sn, cs;
+    sincospi(-2.0 * (double)((kz * (2 * n2 + p)) % 1024) / 1024.0, &sn, &cs);
+    out[i] = make_double2(cs, sn);
+}
+struct LowkLaneCache {
+    std::mutex m;
+    std::vector<std::pair<int, double2*>> tabs;
+    const double2* get(hipStream_t s) {
+        std::lock_guard<std::mutex> lock(m);
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+        for (auto& t : tabs) if (t.first == dev) return t.second;
+        double2* d = nullptr;
+        if (hipMalloc(&d, 32 * 7 * 2 * sizeof(double2)) != hipSuccess) return nullptr;
+        lowk_lane_kernel<<<2, 256, 0, s>>>(d);
+        if (hipGetLastError() != hipSuccess) return nullptr;
+        tabs.push_back({dev, d});
+        return d;
+    }
+} g_lowk_lane;
+
 static int rows_r2c_impl(const void* in, void* out, int dtype, size_t n, size_t nrows, size_t in_pitch,
                          size_t out_pitch, double scale, double mean, void* stream, const void* rec = nullptr,
-                         int window = 0) {
+                         int window = 0, double* lowz = nullptr) {
     AST_CHECK_ARG(in != nullptr && out != nullptr && in != out && nrows >= 1);
     AST_CHECK_ARG(ast_fft_tile_supported(dtype, n));
     AST_CHECK_ARG(in_pitch >= n && in_pitch % 2 == 0 && out_pitch >= n / 2 + 1);
@@ -978,6 +1074,17 @@ static int rows_r2c_impl(const void* in, void* out, int dtype, size_t n, size_t 
     AST_PROF("fft_tile.rows_r2c", s);
     const float* i = (const float*)in;
     float2* o = (float2*)out;
+    if (lowz != nullptr) {                   // with the low-k channel's z sums on the side (N = 1024)
+        AST_CHECK_ARG(n == 1024);
+        const double2* lane = g_lowk_lane.get(s);
+        if (!lane) { ast::set_error("ast_fft_tile_rows_r2c: low-k lane table allocation failed"); return AST_ERR_HIP; }
+        const float* h = (const float*)rec;
+        const float sc = (float)scale, mn = (float)mean;
+        if (rec == nullptr) return launch_r2c<16, 32, 16, 0, true>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, nullptr, lane, lowz);
+        AST_CHECK_ARG(nrows == n * n && in_pitch == n && (window == AST_WIN_CIC || window == AST_WIN_TSC));
+        if (window == AST_WIN_CIC) return launch_r2c<16, 32, 16, 2, true>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h, lane, lowz);
+        return launch_r2c<16, 32, 16, 3, true>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h, lane, lowz);
+    }
     if (rec != nullptr) {                    // fold the paint's halo records while loading (whole periodic grid)
         AST_CHECK_ARG(nrows == n * n && in_pitch == n && (window == AST_WIN_CIC || window == AST_WIN_TSC));
         const float* h = (const float*)rec;
@@ -1086,7 +1193,7 @@ struct SideStreamCache {
 // modes[kx + MBOX][ky + MBOX][kz] (+)= sum over the nx planes x0 .. x0 + nx - 1 (rows of n floats, n rows per plane) of
 // f(x, y, z) e^{-2 pi i (kx x + ky y + kz z) / n}.  work: nx * n * (MBOX + 1) + nx * 13 * 7 + 64 * 1183 double2.
 static int lowk_modes(const float* planes, const float* rec, int window, int n, int x0, int nx, int accumulate,
-                      double2* modes, double2* work, hipStream_t s) {
+                      double2* modes, double2* work, hipStream_t s, bool z_done = false) {
     double2* lowz = work;                                                  // [x][y][kz]
     double2* lowy = lowz + (size_t)nx * n * (MBOX + 1);                    // [x][ky][kz]
     double2* parts = lowy + (size_t)nx * (2 * MBOX + 1) * (MBOX + 1);      // [part][kx][ky][kz]
@@ -1098,7 +1205,8 @@ static int lowk_modes(const float* planes, const float* rec, int window, int n, 
         else if (window == AST_WIN_CIC) lowk_z_kernel<NJ, 2><<<blocks, 256, 0, s>>>(planes, rec, n, nrows, lowz);
         else lowk_z_kernel<NJ, 3><<<blocks, 256, 0, s>>>(planes, rec, n, nrows, lowz);
     };
-    if (n == 1024) z(std::integral_constant<int, 16>{});
+    if (z_done) {}                                       // the FFT's z pass has left the z sums in `work`
+    else if (n == 1024) z(std::integral_constant<int, 16>{});
     else if (n == 512) z(std::integral_constant<int, 8>{});
     else z(std::integral_constant<int, 4>{});
     const size_t lds = (size_t)n * sizeof(double2);
@@ -1126,26 +1234,34 @@ static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, 
     hipStream_t s = ast::as_stream(stream);
     double* lowk_sums = (double*)((char*)scratch + power_core_bytes(n)) - 64;
     const SideStream* side = nullptr;
-    if (lowk) {
+    double2* modes = (double2*)((char*)scratch + (power_core_bytes(n) + 255) / 256 * 256);
+    double2* work = (double2*)((char*)modes + (LOWK_MODES * sizeof(double2) + 255) / 256 * 256);
+    // N = 1024: the z pass forms the low-k z sums from the samples it holds anyway; other sizes: lowk_z_kernel
+    const bool z_fused = lowk && n == 1024 && !getenv("AST_LOWK_SEPARATE");
+    auto lowk_rest = [&]() -> int {
         // the modes |m_i| <= MBOX as DFT sums in double, on the side stream, in their own part of the scratch
-        side = g_side.get(s);
-        if (!side) { ast::set_error("ast_fft_tile_power_3d: side stream creation failed"); return AST_ERR_HIP; }
-        AST_CHECK_HIP(hipEventRecord(side->in, s));                  // the grid (and the previous call's use of the scratch) is done
+        AST_CHECK_HIP(hipEventRecord(side->in, s));                  // the grid (or the z sums) and the scratch are ready
         AST_CHECK_HIP(hipStreamWaitEvent(side->side, side->in, 0));
         {
             AST_PROF("fft_tile.lowk", side->side);
-            double2* modes = (double2*)((char*)scratch + (power_core_bytes(n) + 255) / 256 * 256);
-            double2* work = (double2*)((char*)modes + (LOWK_MODES * sizeof(double2) + 255) / 256 * 256);
-            int rc = lowk_modes((const float*)grid, (const float*)rec, window, (int)n, 0, (int)n, 0, modes, work, side->side);
+            int rc = lowk_modes((const float*)grid, (const float*)rec, window, (int)n, 0, (int)n, 0, modes, work, side->side, z_fused);
             if (rc != AST_OK) return rc;
             const double ng = (double)n * (double)n * (double)n;
             lowk_shell_kernel<<<1, 256, 0, side->side>>>(modes, boxsize * boxsize * boxsize / (ng * ng), kf_rule, lowk_sums);
             AST_CHECK_LAUNCH();
         }
         AST_CHECK_HIP(hipEventRecord(side->done, side->side));
+        return AST_OK;
+    };
+    if (lowk) {
+        side = g_side.get(s);
+        if (!side) { ast::set_error("ast_fft_tile_power_3d: side stream creation failed"); return AST_ERR_HIP; }
+        if (!z_fused) { const int rc = lowk_rest(); if (rc != AST_OK) return rc; }
     }
-    int rc = rows_r2c_impl(grid, spec, dtype, n, n * n, n, nzp, 1.0, mean, stream, rec, window);      // z
+    int rc = rows_r2c_impl(grid, spec, dtype, n, n * n, n, nzp, 1.0, mean, stream, rec, window,
+                           z_fused ? reinterpret_cast<double*>(work) : nullptr);                       // z
     if (rc != AST_OK) return rc;
+    if (z_fused) { rc = lowk_rest(); if (rc != AST_OK) return rc; }
     rc = ast_fft_tile_c2c(spec, dtype, n, nzp, nz, n, n * nzp, 1.0, stream);                          // y, per x-plane
     if (rc != AST_OK) return rc;
     const double inv_ng = 1.0 / ((double)n * (double)n * (double)n);

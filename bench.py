@@ -270,8 +270,9 @@ def _stage_table(prof, steps, npart_rank, ng_rank, esz, fused_bin, concurrent=()
                             "kernels": {s: round(prof[s][1] / steps, 4) for s in sites}}
             side = [s for s in sites if s in concurrent]
             if side:
-                stages[name]["concurrent"] = {"sites": side, "note": "on a second stream beside the z and y passes "
-                                              "(which it slows down: both read the grid); not added to `ms`"}
+                stages[name]["concurrent"] = {"sites": side, "note": "the low-k channel's y / x / shell kernels, on a second "
+                                              "stream beside the y pass (its z sums are formed inside rows_r2c at N = 1024); "
+                                              "not added to `ms`"}
     return stages, stage_sites, stage_bytes
 
 
