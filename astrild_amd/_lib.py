@@ -78,6 +78,9 @@ SIGNATURES = {
     "ast_kappa_stack": (_i, [_vp, _vp, _vp, _i, _sz, _i, _vp, _i, _vp]),
     "ast_lens_plan_create": (_i, [ct.POINTER(_vp), _i, _d]),
     "ast_lens_plan_destroy": (_i, [_vp]),
+    "ast_lens_cols_supported": (_i, [_sz]),
+    "ast_lens_cols_forward": (_i, [_vp, _sz, _sz, _sz, _sz, _vp]),
+    "ast_lens_cols_inverse": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "ast_kappa_to_alphas": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "ast_kappa_to_phi": (_i, [_vp, _vp, _vp, _vp]),
     "kappa0_to_alphas": (None, [_vp, _i, _d, _vp, _vp]),

@@ -156,27 +156,48 @@ def minmax(t):
     return float(lo), float(hi)
 
 
+class PendingHistogram:
+    """np.histogram(t, bins=nbins, range=None, density=) in flight: the min/max pass, the counting pass and the copy of
+    (counts, range) into pinned host memory are queued on the stream; ``result()`` waits for THAT copy only - kernels
+    queued after it keep running - and returns (values, bin_edges) as numpy."""
+
+    def __init__(self, t, nbins, density=False):
+        self.nbins, self.density = int(nbins), density
+        buf = torch.zeros(self.nbins + 2, dtype=torch.int64, device=t.device)
+        check(_lib.lib().ast_histogram_auto(ptr(t), real_code(t), t.numel(), self.nbins, ptr(buf), ptr(buf[self.nbins:]),
+                                            stream()), "ast_histogram_auto")
+        self.host = torch.empty(self.nbins + 2, dtype=torch.int64, pin_memory=True)
+        self.host.copy_(buf, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+        self._keep = buf
+
+    def result(self):
+        self.event.synchronize()
+        host = self.host.numpy()
+        counts = host[:self.nbins].copy()
+        lo, hi = (float(v) for v in host[self.nbins:].view(np.float64))
+        if lo == hi:                  # numpy widens a degenerate range by +-0.5
+            lo, hi = lo - 0.5, hi + 0.5
+        edges = np.linspace(lo, hi, self.nbins + 1)
+        if self.density:
+            return counts / np.diff(edges) / counts.sum(), edges
+        return counts, edges
+
+
 def histogram(t, nbins, range=None, density=False):
     """np.histogram(t, bins=nbins, range=, density=) -> (values, bin_edges) as numpy."""
     nbins = int(nbins)
     if range is None:
         # min/max and counts in one stream-ordered call; ONE transfer brings back both (counts, then the range's bits)
-        buf = torch.zeros(nbins + 2, dtype=torch.int64, device=t.device)
-        check(_lib.lib().ast_histogram_auto(ptr(t), real_code(t), t.numel(), nbins, ptr(buf), ptr(buf[nbins:]), stream()),
-              "ast_histogram_auto")
-        host = buf.cpu().numpy()
-        counts = host[:nbins]
-        lo, hi = (float(v) for v in host[nbins:].view(np.float64))
-        if lo == hi:                  # numpy widens a degenerate range by +-0.5
-            lo, hi = lo - 0.5, hi + 0.5
-    else:
-        lo, hi = float(range[0]), float(range[1])
-        if lo == hi:
-            lo, hi = lo - 0.5, hi + 0.5
-        counts = torch.zeros(nbins, dtype=torch.int64, device=t.device)
-        check(_lib.lib().ast_histogram(ptr(t), real_code(t), t.numel(), lo, hi, nbins, ptr(counts), stream()),
-              "ast_histogram")
-        counts = counts.cpu().numpy()
+        return PendingHistogram(t, nbins, density).result()
+    lo, hi = float(range[0]), float(range[1])
+    if lo == hi:
+        lo, hi = lo - 0.5, hi + 0.5
+    counts = torch.zeros(nbins, dtype=torch.int64, device=t.device)
+    check(_lib.lib().ast_histogram(ptr(t), real_code(t), t.numel(), lo, hi, nbins, ptr(counts), stream()),
+          "ast_histogram")
+    counts = counts.cpu().numpy()
     edges = np.linspace(lo, hi, nbins + 1)
     if density:
         return counts / np.diff(edges) / counts.sum(), edges
@@ -398,8 +419,9 @@ def bench_kappa_pipeline(nplanes=64, npix=4096, steps=3, warmup=1, theta_deg=20.
             kappa_stack(planes, wnum, wden, out=out)
         convert_code_to_phy_units("kappa_2", out)
         sp.gaussian(out, sigma_px, "gaussianFFT")
-        a1, a2 = lp.alphas(out)
-        return histogram(out, 100, density=True), a1, a2
+        pdf = PendingHistogram(out, 100, density=True)          # queued; fetched after kappa -> alpha has been launched,
+        a1, a2 = lp.alphas(out)                                  # so the host is never waiting on an idle GPU
+        return pdf.result(), a1, a2
 
     def barrier():
         if world > 1:

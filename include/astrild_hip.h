@@ -395,6 +395,18 @@ typedef struct ast_lens_plan ast_lens_plan;
  * spectra of the isotropic kernels of lensing_funcs.c:45-83,117-148. */
 int ast_lens_plan_create(ast_lens_plan** plan, int nc, double bsz);
 int ast_lens_plan_destroy(ast_lens_plan* plan);
+/* Column transforms of the zero-padded lens convolution (lensing_funcs.c:85-115 + fft_convolve.c:60-90), double,
+ * hand-written two-pass (four-step) passes over data_d[len][pitch] complex that skip the half known to be zero.
+ * len in {256 .. 8192}, powers of two (ast_lens_cols_supported).  The forward transform (in place) reads rows
+ * < nonzero_rows only (len or len / 2) and leaves frequency k = k1 + N1 k2 at row N2 k1 + k2 (a fixed permutation;
+ * spectra of one length are only ever multiplied with each other and transformed back).  The inverse
+ * (unnormalised) transforms spec_d * mul_d (mul_d NULL: spec_d alone) into out_d and writes the first keep_rows rows
+ * (len or len / 2), in natural order. */
+int ast_lens_cols_supported(size_t len);
+int ast_lens_cols_forward(void* data_d, size_t len, size_t pitch, size_t ncols, size_t nonzero_rows, void* stream);
+int ast_lens_cols_inverse(const void* spec_d, const void* mul_d, void* out_d, size_t len, size_t pitch, size_t ncols,
+                          size_t keep_rows, void* stream);
+
 /* Device-pointer variants (fp64, C-contiguous nc*nc). */
 int ast_kappa_to_alphas(ast_lens_plan* plan, const double* kappa_d, double* alpha1_d,
                         double* alpha2_d, void* stream);

@@ -301,3 +301,82 @@ def test_flat_sky_power_and_bispectrum_vs_oracle(lens, dev):
     lb, bb, nb = ok.flat_bispectrum_equilateral_brute(small, 2.0, e2)
     assert np.array_equal(bs.ntri, nb)
     npt.assert_allclose(bs.B, bb, rtol=1e-9, atol=1e-12 * np.abs(bb).max())
+
+
+_LENS_SPLIT = {8192: (64, 128), 4096: (64, 64), 2048: (32, 64), 1024: (32, 32), 512: (16, 32), 256: (16, 16)}
+
+
+@pytest.mark.parametrize("length", [256, 512, 1024, 2048, 8192])
+def test_lens_column_transforms_against_numpy(hip, dev, length):
+    """The two-pass column transforms of the padded lens convolution (lens_fft.hip): forward = np.fft.fft along axis 0
+    with frequency k1 + N1 k2 at row N2 k1 + k2; rows >= nonzero_rows are never read (NaN there); the inverse undoes it
+    (times `mul`, unnormalised) and writes only the rows that are kept."""
+    from astrild_amd import _lib
+    n1, n2 = _LENS_SPLIT[length]
+    pitch, ncols = 40, 37                                  # ragged: 37 of 40 columns, not a multiple of the 16-column tile
+    rng = np.random.default_rng(length)
+    x = rng.standard_normal((length, pitch)) + 1j * rng.standard_normal((length, pitch))
+    perm = np.array([(r // n2) + n1 * (r % n2) for r in range(length)])      # row r holds frequency perm[r]
+    ref = np.fft.fft(x[:, :ncols], axis=0)
+    d = dev.as_device(x.copy())
+    _lib.check(hip.ast_lens_cols_forward(dev.ptr(d), length, pitch, ncols, length, dev.stream()))
+    got = d.cpu().numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(got[:, :ncols] - ref[perm]).max() < 1e-13 * scale
+    assert np.array_equal(got[:, ncols:], x[:, ncols:])                      # columns past ncols untouched
+    # zero-padded input: the lower half holds NaN and is never read
+    xz = x.copy()
+    xz[length // 2:] = 0.0
+    refz = np.fft.fft(xz[:, :ncols], axis=0)
+    xn = x.copy()
+    xn[length // 2:] = np.nan
+    dz = dev.as_device(xn)
+    _lib.check(hip.ast_lens_cols_forward(dev.ptr(dz), length, pitch, ncols, length // 2, dev.stream()))
+    gotz = dz.cpu().numpy()
+    assert np.isfinite(gotz[:, :ncols]).all()
+    assert np.abs(gotz[:, :ncols] - refz[perm]).max() < 1e-13 * scale
+    # inverse of spec * mul, all rows
+    m = rng.standard_normal((length, pitch)) + 1j * rng.standard_normal((length, pitch))
+    spec_nat = ref * 1.0
+    mul_nat = m[:, :ncols]
+    want = np.fft.ifft(spec_nat * mul_nat, axis=0) * length
+    spec_perm = np.zeros((length, pitch), dtype=np.complex128)
+    mul_perm = np.zeros((length, pitch), dtype=np.complex128)
+    spec_perm[:, :ncols] = spec_nat[perm]
+    mul_perm[:, :ncols] = mul_nat[perm]
+    sd, md = dev.as_device(spec_perm), dev.as_device(mul_perm)
+    out = dev.as_device(np.full((length, pitch), np.nan + 0j))
+    _lib.check(hip.ast_lens_cols_inverse(dev.ptr(sd), dev.ptr(md), dev.ptr(out), length, pitch, ncols, length, dev.stream()))
+    o = out.cpu().numpy()
+    assert np.abs(o[:, :ncols] - want).max() < 1e-13 * np.abs(want).max()
+    assert np.array_equal(sd.cpu().numpy(), spec_perm)                       # inputs intact
+    # only the upper half kept
+    out2 = dev.as_device(np.full((length, pitch), np.nan + 0j))
+    _lib.check(hip.ast_lens_cols_inverse(dev.ptr(sd), dev.ptr(md), dev.ptr(out2), length, pitch, ncols, length // 2, dev.stream()))
+    o2 = out2.cpu().numpy()
+    assert np.abs(o2[:length // 2, :ncols] - want[:length // 2]).max() < 1e-13 * np.abs(want).max()
+    # in place without a multiplier: round trip
+    _lib.check(hip.ast_lens_cols_inverse(dev.ptr(d), None, dev.ptr(d), length, pitch, ncols, length, dev.stream()))
+    back = d.cpu().numpy()
+    assert np.abs(back[:, :ncols] / length - x[:, :ncols]).max() < 1e-13 * np.abs(x).max()
+    assert hip.ast_lens_cols_forward(dev.ptr(d), 3000, pitch, ncols, 3000, dev.stream()) < 0
+    assert hip.ast_lens_cols_supported(8192) == 1 and hip.ast_lens_cols_supported(100) == 0
+
+
+@pytest.mark.parametrize("npix,sigma_px", [(1000, 2.5), (777, 4.3), (2048, 7.5), (64, 3.0)])
+def test_gaussian_fft_smoothing_real_space_route_equals_fft_route(lens, dev, npix, sigma_px, monkeypatch):
+    """For 2.5 <= sigma_px <= 7.5 "gaussianFFT" runs as two periodic real-space passes; the FFT route (forced through
+    AST_SMOOTH_FFT) gives the same map to 1e-13 of its peak, on ragged sizes too."""
+    rng = np.random.default_rng(npix)
+    img = rng.standard_normal((npix, npix))
+    plan = lens.SmoothPlan(npix)
+    a = dev.as_device(img.copy())
+    plan.gaussian(a, sigma_px, "gaussianFFT")
+    monkeypatch.setenv("AST_SMOOTH_FFT", "1")
+    b = dev.as_device(img.copy())
+    plan.gaussian(b, sigma_px, "gaussianFFT")
+    monkeypatch.delenv("AST_SMOOTH_FFT")
+    a, b = a.cpu().numpy(), b.cpu().numpy()
+    assert not np.array_equal(a, b)                               # two different routes did run
+    npt.assert_allclose(a, b, rtol=0, atol=2e-13 * np.abs(b).max())
+    npt.assert_allclose(a.mean(), img.mean(), rtol=0, atol=1e-13)  # the periodic kernel sums to one
