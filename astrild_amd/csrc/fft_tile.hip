@@ -330,11 +330,12 @@ __device__ constexpr double kS16f[16] = {0.0, -0.38268343236508977, -0.707106781
                                          0.38268343236508977, 0.70710678118654752, 0.92387953251128674, 1.0,
                                          0.92387953251128674, 0.70710678118654752, 0.38268343236508977};
 
-// LOWK (N = 1024 only): the thread's 32 samples x[64 n1 + 2 n2 + p] are in registers right after the load, so the
-// low-k channel's z sums S_kz = sum_z x[z] e^{-2 pi i kz z / N}, kz <= 6, are formed here in double instead of by a
-// second pass over the grid (lowk_z_kernel: 4.3 GB, 1.2 ms): per p the 16-term sum over n1 with the 16th roots of unity
-// as constants (e^{-2 pi i 64 / 1024}), then T_0 A + T_1 B with the lane's factors A = w^{2 kz n2}, B = w^{kz (2 n2 + 1)}
-// (table lowk_lane, double), then a transposed reduction over the row's 32 lanes.  Output as lowk_z_kernel's.
+// LOWK: the thread's 2 R1 samples x[2 R2 n1 + 2 n2 + p] are in registers right after the load, so the low-k channel's
+// z sums S_kz = sum_z x[z] e^{-2 pi i kz z / N}, kz <= 6, are formed here in double instead of by a second pass over
+// the grid (lowk_z_kernel: 4.3 GB, 1.2 ms at 1024^3): per p the R1-term sum over n1 with the R1-th roots of unity as
+// constants (e^{-2 pi i 2 R2 / N} = e^{-2 pi i / R1}), then T_0 A + T_1 B with the lane's factors A = w^{2 kz n2},
+// B = w^{kz (2 n2 + 1)} (table lowk_lane, double), then a transposed reduction over the row's R2 lanes.  Output as
+// lowk_z_kernel's.
 // M = R1*R2.  One workgroup transforms C rows.
 // FOLDW = 2 / 3 (CIC / TSC): `in` is the grid a deferred-fold paint left (AST_PAINT_DEFER_FOLD) and `rec`
 // its halo records; the up to three record lines that end in a border row are added as the row is
@@ -398,7 +399,7 @@ rows_r2c_kernel(const float* __restrict__ in, float2* __restrict__ out, const fl
             }
         }
         if (LOWK) {
-            static_assert(!LOWK || (R1 == 16 && R2 == 32 && MBOX_FWD == 6), "laid out for N = 1024: 16 samples per p, 32 lanes per row");
+            static_assert(!LOWK || ((R1 == 16 || R1 == 8) && (R2 == 32 || R2 == 16) && MBOX_FWD == 6), "R1-th roots from the 16th-root table; 32 or 16 lanes per row");
             double acc[14];
 #pragma unroll
             for (int e = 0; e < 14; ++e) acc[e] = 0.0;
@@ -412,7 +413,7 @@ rows_r2c_kernel(const float* __restrict__ in, float2* __restrict__ out, const fl
                     double tr = 0.0, ti = 0.0;
 #pragma unroll
                     for (int n1 = 0; n1 < R1; ++n1) {
-                        const int rr = (kz * n1) % 16;           // e^{-2 pi i kz n1 / 16}: a compile-time constant
+                        const int rr = ((kz * n1) % R1) * (16 / R1);     // e^{-2 pi i kz n1 / R1}: a compile-time constant
                         if (rr == 0) tr += f[n1];
                         else if (rr == 4) ti -= f[n1];
                         else if (rr == 8) tr -= f[n1];
@@ -424,7 +425,8 @@ rows_r2c_kernel(const float* __restrict__ in, float2* __restrict__ out, const fl
                     acc[2 * kz + 1] = fma(a.x, ti, fma(a.y, tr, acc[2 * kz + 1]));
                 }
             }
-            // 14 sums over the row's 32 lanes (a wave holds two rows): 14 -> 7 (+1 zero) -> 4 -> 2 -> 1, then the last pair
+            // 14 sums over the row's R2 lanes (a wave holds 64 / R2 rows): 14 -> 7 (+1 zero) -> 4 -> 2 -> 1, with 32 lanes
+            // then the last pair
             const int lane = threadIdx.x & 63;
             auto level = [&](auto count_tag, int mask) {
                 constexpr int COUNT = decltype(count_tag)::value;
@@ -436,15 +438,18 @@ rows_r2c_kernel(const float* __restrict__ in, float2* __restrict__ out, const fl
                     acc[i] = keep + __shfl_xor(send, mask, 64);
                 }
             };
-            level(std::integral_constant<int, 14>{}, 16);
+            constexpr int TOP = R2 / 2;                      // 16 or 8
+            level(std::integral_constant<int, 14>{}, TOP);
             acc[7] = 0.0;
-            level(std::integral_constant<int, 8>{}, 8);
-            level(std::integral_constant<int, 4>{}, 4);
-            level(std::integral_constant<int, 2>{}, 2);
-            acc[0] += __shfl_xor(acc[0], 1, 64);
-            const int sub = ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
-            if ((lane & 1) == 0 && sub < 7 && row0 + r < nrows)
-                lowz[(row0 + r) * (size_t)(2 * (MBOX_FWD + 1)) + ((lane >> 4) & 1) * 7 + sub] = acc[0];
+            level(std::integral_constant<int, 8>{}, TOP / 2);
+            level(std::integral_constant<int, 4>{}, TOP / 4);
+            level(std::integral_constant<int, 2>{}, TOP / 8);
+            if (R2 == 32) acc[0] += __shfl_xor(acc[0], 1, 64);
+            constexpr int SH = R2 == 32 ? 1 : 0;             // the lane bits below the four that select the element
+            const int sel = lane >> SH;
+            const int sub = ((sel >> 2) & 1) * 4 + ((sel >> 1) & 1) * 2 + (sel & 1);
+            if ((R2 == 16 || (lane & 1) == 0) && sub < 7 && row0 + r < nrows)
+                lowz[(row0 + r) * (size_t)(2 * (MBOX_FWD + 1)) + ((sel >> 3) & 1) * 7 + sub] = acc[0];
         }
 #pragma unroll
         for (int n1 = 0; n1 < R1; ++n1) {
@@ -1035,29 +1040,31 @@ extern "C" int ast_fft_tile_c2c_packed(const void* planes, void* packed, int dty
     return launch_c2c_pack<16, 16, 16>(d, tw, ncols, ncols, nplanes, n * ncols, (float)scale, pack, s);
 }
 
-// lane factors of the fused low-k z sums (rows_r2c_kernel<.., LOWK>): [n2 < 32][kz <= 6][A, B],
-// A = e^{-2 pi i kz 2 n2 / 1024}, B = e^{-2 pi i kz (2 n2 + 1) / 1024}
-__global__ void lowk_lane_kernel(double2* __restrict__ out) {
+// lane factors of the fused low-k z sums (rows_r2c_kernel<.., LOWK>): [n2 < R2][kz <= 6][A, B],
+// A = e^{-2 pi i kz 2 n2 / N}, B = e^{-2 pi i kz (2 n2 + 1) / N}
+__global__ void lowk_lane_kernel(double2* __restrict__ out, int n, int lanes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 32 * 7 * 2) return;
+    if (i >= lanes * 7 * 2) return;
     const int p = i & 1, kz = (i >> 1) % 7, n2 = (i >> 1) / 7;
     double sn, cs;
-    sincospi(-2.0 * (double)((kz * (2 * n2 + p)) % 1024) / 1024.0, &sn, &cs);
+    sincospi(-2.0 * (double)((kz * (2 * n2 + p)) % n) / (double)n, &sn, &cs);
     out[i] = make_double2(cs, sn);
 }
 struct LowkLaneCache {
     std::mutex m;
-    std::vector<std::pair<int, double2*>> tabs;
-    const double2* get(hipStream_t s) {
+    struct E { int dev, n; double2* d; };
+    std::vector<E> tabs;
+    const double2* get(int n, hipStream_t s) {
         std::lock_guard<std::mutex> lock(m);
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-        for (auto& t : tabs) if (t.first == dev) return t.second;
+        for (auto& t : tabs) if (t.dev == dev && t.n == n) return t.d;
+        const int lanes = n == 1024 ? 32 : 16;
         double2* d = nullptr;
-        if (hipMalloc(&d, 32 * 7 * 2 * sizeof(double2)) != hipSuccess) return nullptr;
-        lowk_lane_kernel<<<2, 256, 0, s>>>(d);
+        if (hipMalloc(&d, (size_t)lanes * 7 * 2 * sizeof(double2)) != hipSuccess) return nullptr;
+        lowk_lane_kernel<<<2, 256, 0, s>>>(d, n, lanes);
         if (hipGetLastError() != hipSuccess) return nullptr;
-        tabs.push_back({dev, d});
+        tabs.push_back({dev, n, d});
         return d;
     }
 } g_lowk_lane;
@@ -1074,16 +1081,21 @@ static int rows_r2c_impl(const void* in, void* out, int dtype, size_t n, size_t 
     AST_PROF("fft_tile.rows_r2c", s);
     const float* i = (const float*)in;
     float2* o = (float2*)out;
-    if (lowz != nullptr) {                   // with the low-k channel's z sums on the side (N = 1024)
-        AST_CHECK_ARG(n == 1024);
-        const double2* lane = g_lowk_lane.get(s);
+    if (lowz != nullptr) {                   // with the low-k channel's z sums on the side
+        const double2* lane = g_lowk_lane.get((int)n, s);
         if (!lane) { ast::set_error("ast_fft_tile_rows_r2c: low-k lane table allocation failed"); return AST_ERR_HIP; }
         const float* h = (const float*)rec;
         const float sc = (float)scale, mn = (float)mean;
-        if (rec == nullptr) return launch_r2c<16, 32, 16, 0, true>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, nullptr, lane, lowz);
-        AST_CHECK_ARG(nrows == n * n && in_pitch == n && (window == AST_WIN_CIC || window == AST_WIN_TSC));
-        if (window == AST_WIN_CIC) return launch_r2c<16, 32, 16, 2, true>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h, lane, lowz);
-        return launch_r2c<16, 32, 16, 3, true>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h, lane, lowz);
+        AST_CHECK_ARG(rec == nullptr || (nrows == n * n && in_pitch == n && (window == AST_WIN_CIC || window == AST_WIN_TSC)));
+        auto go = [&](auto r1, auto r2) {
+            constexpr int R1 = decltype(r1)::value, R2 = decltype(r2)::value;
+            if (rec == nullptr) return launch_r2c<R1, R2, 16, 0, true>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, nullptr, lane, lowz);
+            if (window == AST_WIN_CIC) return launch_r2c<R1, R2, 16, 2, true>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h, lane, lowz);
+            return launch_r2c<R1, R2, 16, 3, true>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h, lane, lowz);
+        };
+        if (n == 1024) return go(std::integral_constant<int, 16>{}, std::integral_constant<int, 32>{});
+        if (n == 512) return go(std::integral_constant<int, 16>{}, std::integral_constant<int, 16>{});
+        return go(std::integral_constant<int, 8>{}, std::integral_constant<int, 16>{});
     }
     if (rec != nullptr) {                    // fold the paint's halo records while loading (whole periodic grid)
         AST_CHECK_ARG(nrows == n * n && in_pitch == n && (window == AST_WIN_CIC || window == AST_WIN_TSC));
@@ -1236,8 +1248,8 @@ static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, 
     const SideStream* side = nullptr;
     double2* modes = (double2*)((char*)scratch + (power_core_bytes(n) + 255) / 256 * 256);
     double2* work = (double2*)((char*)modes + (LOWK_MODES * sizeof(double2) + 255) / 256 * 256);
-    // N = 1024: the z pass forms the low-k z sums from the samples it holds anyway; other sizes: lowk_z_kernel
-    const bool z_fused = lowk && n == 1024 && !getenv("AST_LOWK_SEPARATE");
+    // the z pass forms the low-k z sums from the samples it holds anyway (AST_LOWK_SEPARATE: lowk_z_kernel instead)
+    const bool z_fused = lowk && !getenv("AST_LOWK_SEPARATE");
     auto lowk_rest = [&]() -> int {
         // the modes |m_i| <= MBOX as DFT sums in double, on the side stream, in their own part of the scratch
         AST_CHECK_HIP(hipEventRecord(side->in, s));                  // the grid (or the z sums) and the scratch are ready
