@@ -353,10 +353,13 @@ constexpr int GROUP_ITERS = 3;         // tiles that can get a record per 32-par
 constexpr uint32_t LREC_CAP = 512;     // records parked in LDS per interval (128 windows x up to 3; rest: slow path)
 struct GroupRec { uint32_t first, mask; };
 
+// a stray copy is {x, y, z, m}, or {x, y, z} when the paint has no masses (has_mass false: the walk reads it as FMT 2)
 template <typename T>
-__device__ inline void store_stray(T* __restrict__ strays, size_t slot, T x, T y, T z, T m) {
+__device__ inline void store_stray(T* __restrict__ strays, size_t slot, T x, T y, T z, T m, bool has_mass) {
     typedef T vec4_t __attribute__((ext_vector_type(4)));
-    *reinterpret_cast<vec4_t*>(strays + 4 * slot) = vec4_t{x, y, z, m};
+    struct Rec3 { T x, y, z; };
+    if (has_mass) *reinterpret_cast<vec4_t*>(strays + 4 * slot) = vec4_t{x, y, z, m};
+    else *reinterpret_cast<Rec3*>(strays + 3 * slot) = Rec3{x, y, z};
 }
 
 // One group or one stray placed by one thread (hash collision in the LDS table, or LDS lists full).
@@ -374,7 +377,7 @@ __device__ __noinline__ void place_group_slow(uint32_t key, uint32_t a, uint32_t
     } else {
         const uint32_t sidx = (uint32_t)atomicAdd(&fill64[key], 1ull);
         if (sidx < scap) store_stray(strays, (size_t)key * scap + sidx, pos[3 * (size_t)a], pos[3 * (size_t)a + 1],
-                                     pos[3 * (size_t)a + 2], mass ? mass[a] : (T)1);
+                                     pos[3 * (size_t)a + 2], mass ? mass[a] : (T)1, mass != nullptr);
         else ovf[atomicAdd(ovf_count, 1ull)] = a;
     }
 }
@@ -554,7 +557,7 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
             if (d == DST_NONE) continue;
             const uint32_t slot = d >> 16, at = d & 0xffffu;
             if (at < sroom_stray[slot]) store_stray(strays, (size_t)(sdst_stray[slot] + at), lst_x[k], lst_y[k], lst_z[k],
-                                                    mass ? mass[lst_p[k]] : (T)1);
+                                                    mass ? mass[lst_p[k]] : (T)1, mass != nullptr);
             else ovf[atomicAdd(ovf_count, 1ull)] = lst_p[k];
         }
         __syncthreads();                    // everyone is done with the lists and the table before they are re-armed
@@ -1032,8 +1035,8 @@ tile_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileG
 // 1.3 TB/s global float-atomic flush (4 ms of the 13 ms tile kernel at 1024^3) is gone.
 // The few planes that wrap around the periodic z edge are added atomically at the end.
 // The particle lists a column walk reads.  FMT 0: 4-byte particle ids per tile (exact offsets of the two-pass
-// variant, tile_off / tile_count).  FMT 2: as FMT 1 with 3-word stray copies {x, y, z} (the scatter path without masses;
-// there are no group records then).  FMT 1: the compact lists of tile_group_kernel (group records + stray copies
+// variant, tile_off / tile_count).  FMT 2: as FMT 1 with 3-word stray copies {x, y, z} (paints without masses).
+// FMT 1: the compact lists of tile_group_kernel (group records + stray copies
 // in fixed-capacity segments, counts in fill64: records in the high word, strays in the low).
 // (The list pointers are separate __restrict__ kernel arguments on purpose: read through a struct member the
 // per-tile counts become VECTOR loads followed by s_waitcnt vmcnt(0) - which also waits for every prefetched
@@ -1663,8 +1666,7 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
                 using I1 = std::integral_constant<int, 1>;
                 if (two_pass) { if (mass) launch(std::true_type{}, I0{}); else launch(std::false_type{}, I0{}); }
                 else if (mass) launch(std::true_type{}, I1{});
-                else if (w.tpb) launch(std::false_type{}, I2{});          // scatter path without masses: 3-word stray copies
-                else launch(std::false_type{}, I1{});
+                else launch(std::false_type{}, I2{});                     // no masses: 3-word stray copies
             }
             if (!(flags & AST_PAINT_DEFER_FOLD)) {
                 AST_PROF("paint_tiled.fold", s);
