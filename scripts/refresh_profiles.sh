@@ -7,7 +7,6 @@ tag=${1:-r02}
 R=$PWD
 out=$R/gpurun_out/profiles_$tag
 mkdir -p $out
-python3 bench.py > $out/${tag}_bench_1gpu.json 2> $out/bench.stderr
 cd /tmp && export TMPDIR=/tmp
 lean="--cpu-sample 0 --kappa 0 --bispec 0 --legs 0"
 rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python3 $R/bench.py $lean > $out/${tag}_bench_under_rocprof.json 2> $out/rocprof_stats.stderr
@@ -17,6 +16,9 @@ rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write -o w --output-format csv -- python3
 rocprofv3 --kernel-trace --stats -d $out/stats_legs -o s --output-format csv -- python3 $R/bench.py --cpu-sample 0 --steps 3 --warmup 1 > $out/${tag}_legs_under_rocprof.json 2> $out/rocprof_legs.stderr
 cd $R
 python3 scripts/pmc_traffic_json.py $out/pmc_fetch $out/pmc_write $out/${tag}_pmc_traffic.json
+# the plain bench line last: it quotes the PMC traffic just measured (same paint source, checked by hash)
+mkdir -p profiles && cp $out/${tag}_pmc_traffic.json profiles/${tag}_pmc_traffic.json
+python3 bench.py > $out/${tag}_bench_1gpu.json 2> $out/bench.stderr
 find $out/stats -name "*kernel_stats.csv" -exec cp {} $out/${tag}_bench_kernel_stats.csv \;
 find $out/stats_legs -name "*kernel_stats.csv" -exec cp {} $out/${tag}_legs_kernel_stats.csv \;
 # the raw traces are large: keep only the summaries
