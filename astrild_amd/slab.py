@@ -292,6 +292,7 @@ class SlabPowerPipeline:
         self.packed = o.empty((chunks, P, self.pc, self.nloc, self.nz), o.cdtype)
         self.block = o.empty((n, self.nloc, self.nz), o.cdtype)
         self.psum = o.zeros((n // 2 - 1,), torch.float64)
+        self._side = None
         # the rank's OWN planes hold rho - mean (subtracted before the fp32 rounding); its ghost planes, which are
         # added onto the neighbours' cells, stay plain sums
         lowk_fn = getattr(self.ops, "lowk_supported", None)
@@ -345,10 +346,20 @@ class SlabPowerPipeline:
     def step(self, check=False):
         owned = self.paint(check)
         modes = None
+        side = None
         if self.lowk:
             # the lowest shells from double-precision DFT sums of the rank's own planes (device.power_sums_fused's
-            # low-k channel, split over the slabs): one more all-reduce, of 1183 complex numbers
-            modes = self.ops.lowk_modes(owned, self.n, self.rank * self.nloc)
+            # low-k channel, split over the slabs): one more all-reduce, of 1183 complex numbers.  It only reads the
+            # planes: on the GPU it runs on a side stream beside the FFT chunks and their exchange.
+            if owned.is_cuda:
+                if self._side is None:
+                    self._side = torch.cuda.Stream()
+                side = self._side
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    modes = self.ops.lowk_modes(owned, self.n, self.rank * self.nloc)
+            else:
+                modes = self.ops.lowk_modes(owned, self.n, self.rank * self.nloc)
         fused_fn = getattr(self.ops, "axis0_power_supported", None)
         if fused_fn and fused_fn(self.n):
             # axis-0 pass and shell binning in one kernel (the spectrum block is not written back)
@@ -358,6 +369,9 @@ class SlabPowerPipeline:
         else:
             block = self.forward_fft(owned)
             self.ops.power_bin(block, self.n, self.L, self.i0, self.i1, self.psum)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            modes.record_stream(torch.cuda.current_stream())      # allocated under the side stream, used from here on
         comm_ready(self.group)
         dist.all_reduce(self.psum, group=self.group)
         if modes is not None:
