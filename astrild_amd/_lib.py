@@ -79,6 +79,9 @@ SIGNATURES = {
     "ast_lens_plan_create": (_i, [ct.POINTER(_vp), _i, _d]),
     "ast_lens_plan_destroy": (_i, [_vp]),
     "ast_lens_cols_supported": (_i, [_sz]),
+    "ast_lens_rows_supported": (_i, [_sz]),
+    "ast_lens_rows_forward": (_i, [_vp, _sz, _vp, _sz, _vp]),
+    "ast_lens_rows_inverse": (_i, [_vp, _sz, _sz, _d, _vp, _vp]),
     "ast_lens_cols_forward": (_i, [_vp, _sz, _sz, _sz, _sz, _vp]),
     "ast_lens_cols_inverse": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "ast_kappa_to_alphas": (_i, [_vp, _vp, _vp, _vp, _vp]),

@@ -285,6 +285,8 @@ struct ast_lens_plan {
     // two-pass column transforms of lens_fft.hip (which skip the zero half and leave the spectra in their permuted row
     // order - every spectrum of this plan goes the same way).  Otherwise: rocFFT's 2-D plans r2c / c2r.
     bool cols = false;
+    bool rows = false;                     // with cols: the nc non-zero rows by lens_fft.hip's row kernels too (nc = 512, 4096):
+                                           // kappa is read unpadded, the inverse stores the scaled corner
     ast_fft_plan* rows_fwd = nullptr;      // nc rows of 2nc reals -> nc rows of nc + 1 complex
     ast_fft_plan* rows_fwd_all = nullptr;  // all 2nc rows (kernel images)
     ast_fft_plan* rows_inv = nullptr;      // nc rows of nc + 1 complex -> nc rows of 2nc reals
@@ -350,6 +352,7 @@ extern "C" int ast_lens_plan_create(ast_lens_plan** out, int nc, double bsz) {
     const size_t lens[2] = {n2, n2};
     int rc = AST_OK;
     p->cols = ast_lens_cols_supported(n2) != 0 && !getenv("AST_LENS_ROCFFT_2D");
+    p->rows = p->cols && ast_lens_rows_supported((size_t)nc) != 0 && !getenv("AST_LENS_ROCFFT_ROWS");
     if (p->cols) {
         const size_t len1[1] = {n2}, one[1] = {1};
         rc = ast_fft_plan_create_general(&p->rows_fwd, AST_FFT_R2C, AST_F64, 1, len1, one, one, (size_t)nc, n2, nh, 1.0, 0);
@@ -393,6 +396,11 @@ static int lens_kernel_spectrum(ast_lens_plan* p, int which, hipStream_t s) {
 }
 
 static int lens_forward(ast_lens_plan* p, const double* kappa, hipStream_t s) {
+    if (p->rows) {
+        const size_t n2 = 2 * (size_t)p->nc, nh = n2 / 2 + 1;
+        AST_FWD(ast_lens_rows_forward(kappa, (size_t)p->nc, p->spec, nh, s));
+        return ast_lens_cols_forward(p->spec, n2, nh, nh, (size_t)p->nc, s);
+    }
     {
         AST_PROF("lens.zero_pad", s);
         pad_corner_kernel<<<ast::stream_grid((size_t)p->nc * p->nc, 256), 256, 0, s>>>(kappa, p->nc, p->pad_in);
@@ -410,6 +418,10 @@ static int lens_forward(ast_lens_plan* p, const double* kappa, hipStream_t s) {
 static int lens_convolve_cols(ast_lens_plan* p, int which, double* out, hipStream_t s) {
     const size_t n2 = 2 * (size_t)p->nc, nh = n2 / 2 + 1;
     AST_FWD(ast_lens_cols_inverse(p->spec, p->kspec[which], p->prod, n2, nh, nh, (size_t)p->nc, s));
+    if (p->rows) {                                                          // corner_matrix and out / (nx ny) * dx dy in the store
+        const double dsx = p->bsz / (double)p->nc;
+        return ast_lens_rows_inverse(p->prod, nh, (size_t)p->nc, dsx * dsx / (double)(n2 * n2), out, s);
+    }
     AST_FWD(ast_fft_exec(p->rows_inv, p->prod, p->pad, s));                 // nc rows of 2nc reals
     AST_PROF("lens.crop_scale", s);
     crop_scale_kernel<<<ast::stream_grid((size_t)p->nc * p->nc, 256), 256, 0, s>>>(p->pad, p->nc, p->bsz / (double)p->nc, out);

@@ -403,6 +403,14 @@ int ast_lens_plan_destroy(ast_lens_plan* plan);
  * (unnormalised) transforms spec_d * mul_d (mul_d NULL: spec_d alone) into out_d and writes the first keep_rows rows
  * (len or len / 2), in natural order. */
 int ast_lens_cols_supported(size_t len);
+/* The row transforms of the same convolution for nc = 512 / 4096 (ast_lens_rows_supported): forward - row r < nc of
+ * spec_d (pitch complex per row) = the length-2nc R2C of (kappa_d[r][0 .. nc), nc zeros), kappa read unpadded
+ * (zero_padding, lensing_funcs.c:8-19, never materialised); inverse - out_d[r][0 .. nc) = scale * the first nc reals of
+ * the unnormalised length-2nc C2R of spec_d[r][0 .. nc] (corner_matrix, lensing_funcs.c:33-43, and the
+ * 1 / (nx ny) dx dy of fft_convolve.c:88 in the store). */
+int ast_lens_rows_supported(size_t nc);
+int ast_lens_rows_forward(const double* kappa_d, size_t nc, void* spec_d, size_t pitch, void* stream);
+int ast_lens_rows_inverse(const void* spec_d, size_t pitch, size_t nc, double scale, double* out_d, void* stream);
 int ast_lens_cols_forward(void* data_d, size_t len, size_t pitch, size_t ncols, size_t nonzero_rows, void* stream);
 int ast_lens_cols_inverse(const void* spec_d, const void* mul_d, void* out_d, size_t len, size_t pitch, size_t ncols,
                           size_t keep_rows, void* stream);

@@ -380,3 +380,33 @@ def test_gaussian_fft_smoothing_real_space_route_equals_fft_route(lens, dev, npi
     assert not np.array_equal(a, b)                               # two different routes did run
     npt.assert_allclose(a, b, rtol=0, atol=2e-13 * np.abs(b).max())
     npt.assert_allclose(a.mean(), img.mean(), rtol=0, atol=1e-13)  # the periodic kernel sums to one
+
+
+@pytest.mark.parametrize("nc", [512, 4096])
+def test_lens_row_transforms_against_numpy(hip, dev, nc):
+    """Hand-written row transforms of the padded convolution: forward = np.fft.rfft of (row, nc zeros); inverse =
+    scale * first nc samples of the unnormalised irfft."""
+    from astrild_amd import _lib
+    rng = np.random.default_rng(nc)
+    rows = 6
+    nh = nc + 1
+    kap = rng.standard_normal((nc, nc))
+    spec = dev.as_device(np.full((nc, nh), np.nan + 0j))
+    kd = dev.as_device(kap)
+    _lib.check(hip.ast_lens_rows_forward(dev.ptr(kd), nc, dev.ptr(spec), nh, dev.stream()))
+    got = spec.cpu().numpy()
+    sel = [0, 1, 2, nc // 2, nc - 2, nc - 1][:rows]
+    ref = np.fft.rfft(np.concatenate([kap[sel], np.zeros((len(sel), nc))], axis=1), axis=1)
+    assert np.abs(got[sel] - ref).max() < 1e-12 * np.abs(ref).max()
+    assert np.isfinite(got).all()
+    # inverse on an arbitrary Hermitian-consistent spectrum: the spectrum of real rows of length 2 nc
+    full = rng.standard_normal((nc, 2 * nc))
+    sp = np.fft.rfft(full, axis=1)
+    sd = dev.as_device(sp)
+    out = dev.as_device(np.full((nc, nc), np.nan))
+    scale = 0.37
+    _lib.check(hip.ast_lens_rows_inverse(dev.ptr(sd), nh, nc, scale, dev.ptr(out), dev.stream()))
+    o = out.cpu().numpy()
+    want = scale * 2 * nc * full[:, :nc]                   # unnormalised C2R = length * irfft
+    assert np.abs(o - want).max() < 1e-12 * np.abs(want).max()
+    assert hip.ast_lens_rows_supported(4096) == 1 and hip.ast_lens_rows_supported(1024) == 0
