@@ -301,6 +301,8 @@ struct ast_smooth_plan {
     double* w_d = nullptr;
     int w_cap = 0;
     std::vector<double> w_h;
+    double w_sigma = -1.0;        // the weights in w_d belong to this sigma and kind (0: none yet): the upload - a pageable,
+    int w_kind = 0;               // stream-ordered copy that blocks the host behind everything queued - happens once per sigma
 };
 
 extern "C" int ast_kappa_stack(const void* const* planes, const double* wnum, const double* wden, int nplanes,
@@ -573,10 +575,14 @@ extern "C" int ast_gaussian_smooth(ast_smooth_plan* p, double* img, double sigma
         2 * (int)std::ceil(8.5 * sigma_px) + 1 <= p->w_cap && !getenv("AST_SMOOTH_FFT")) {
         // the same periodic convolution in real space (see gauss_periodic_x_kernel)
         const int radius = (int)std::ceil(8.5 * sigma_px);
-        p->w_h.assign(2 * radius + 1, 0.0);
-        const double norm = 1.0 / (sigma_px * std::sqrt(2.0 * M_PI));
-        for (int k = -radius; k <= radius; ++k) p->w_h[k + radius] = norm * std::exp(-0.5 * (double)(k * k) / (sigma_px * sigma_px));
-        AST_CHECK_HIP(hipMemcpyAsync(p->w_d, p->w_h.data(), p->w_h.size() * sizeof(double), hipMemcpyHostToDevice, s));
+        if (p->w_sigma != sigma_px || p->w_kind != 1) {
+            p->w_h.assign(2 * radius + 1, 0.0);
+            const double norm = 1.0 / (sigma_px * std::sqrt(2.0 * M_PI));
+            for (int k = -radius; k <= radius; ++k) p->w_h[k + radius] = norm * std::exp(-0.5 * (double)(k * k) / (sigma_px * sigma_px));
+            AST_CHECK_HIP(hipMemcpyAsync(p->w_d, p->w_h.data(), p->w_h.size() * sizeof(double), hipMemcpyHostToDevice, s));
+            p->w_sigma = sigma_px;
+            p->w_kind = 1;
+        }
         AST_PROF("smooth.periodic_passes", s);
         gauss_periodic_x_kernel<<<dim3((unsigned)((npix + 1023) / 1024), (unsigned)npix), 256, 0, s>>>(img, p->tmp, npix, p->w_d, radius);
         gauss_periodic_y_kernel<<<dim3((unsigned)((npix + 31) / 32), (unsigned)((npix + 63) / 64)), 256, 0, s>>>(p->tmp, img, npix, p->w_d, radius);
@@ -596,6 +602,7 @@ extern "C" int ast_gaussian_smooth(ast_smooth_plan* p, double* img, double sigma
     // scipy.ndimage._filters._gaussian_kernel1d: radius = int(truncate*sigma + 0.5), truncate = 4
     const int radius = (int)(4.0 * sigma_px + 0.5);
     AST_CHECK_ARG(2 * radius + 1 <= p->w_cap);
+    p->w_kind = 0;                // the real-space ("gaussian") weights below overwrite w_d
     p->w_h.assign(2 * radius + 1, 0.0);
     double sum = 0.0;
     const double sigma2 = sigma_px * sigma_px;

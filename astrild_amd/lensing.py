@@ -43,16 +43,23 @@ def kappa_stack(planes, wnum=None, wden=None, out=None):
     code = real_code(first)
     for t in planes:
         assert t.is_cuda and t.is_contiguous() and t.dtype == first.dtype and t.shape == first.shape
-    ptrs = torch.tensor([t.data_ptr() for t in planes], dtype=torch.int64, device=first.device)
     if out is None:
         out = torch.empty_like(first)
-    wn = wd = None
+    # pointer table and weights travel in ONE non-blocking copy from pinned memory: a pageable host-to-device copy is
+    # stream ordered AND blocks the host, i.e. the host would sit out everything still queued (the previous map)
+    P = len(planes)
+    host = torch.empty(3 * P, dtype=torch.int64, pin_memory=True)
+    host[:P] = torch.tensor([t.data_ptr() for t in planes], dtype=torch.int64)
     if wnum is not None:
-        wn = as_device(np.asarray(wnum, dtype=np.float64))
-        wd = as_device(np.asarray(wden, dtype=np.float64))
-        assert wn.numel() == len(planes) == wd.numel()
+        wn_h, wd_h = np.asarray(wnum, dtype=np.float64), np.asarray(wden, dtype=np.float64)
+        assert wn_h.size == P == wd_h.size
+        host[P:2 * P] = torch.from_numpy(np.ascontiguousarray(wn_h)).view(torch.int64)
+        host[2 * P:] = torch.from_numpy(np.ascontiguousarray(wd_h)).view(torch.int64)
+    table = host.to(first.device, non_blocking=True)
+    wn = table[P:2 * P].view(torch.float64) if wnum is not None else None
+    wd = table[2 * P:].view(torch.float64) if wnum is not None else None
     aligned = all(t.data_ptr() % 16 == 0 for t in planes) and out.data_ptr() % 16 == 0
-    check(_lib.lib().ast_kappa_stack(ptr(ptrs), ptr(wn), ptr(wd), len(planes), first.numel(), code, ptr(out),
+    check(_lib.lib().ast_kappa_stack(ptr(table), ptr(wn), ptr(wd), P, first.numel(), code, ptr(out),
                                      int(aligned), stream()), "ast_kappa_stack")
     return out
 
