@@ -188,9 +188,9 @@ gauss_real_pass_kernel(const double* __restrict__ in, double* __restrict__ out, 
 // Multiplying the spectrum by exp(-(2 pi sigma l)^2 / 2) is the periodic convolution with the sampled Gaussian
 // g[d] = exp(-d^2 / 2 sigma^2) / (sigma sqrt(2 pi)) up to the aliases of either: exp(-(pi sigma)^2 / 2 ... ) < 4e-14 of the
 // peak for sigma >= 2.5 px in Fourier space, exp(-R^2 / 2 sigma^2) < 2e-16 for the taps beyond R = 8.5 sigma in real
-// space.  For 2.5 <= sigma_px <= 7.5 (R <= 64) the smoothing therefore runs as two separable periodic passes through
+// space.  For 2.5 <= sigma_px <= 18.8 (R <= 160) the smoothing therefore runs as two separable periodic passes through
 // LDS tiles - 0.54 GB moved instead of two 4096^2 double transforms - and agrees with the FFT route to 1e-13.
-constexpr int GP_RMAX = 64;
+constexpr int GP_RMAX = 160;
 // along the rows (contiguous axis): a workgroup produces 1024 consecutive pixels of one row, 4 per thread with a
 // rolling register window (one LDS read per tap for 4 outputs)
 __global__ void __launch_bounds__(256)
@@ -199,9 +199,8 @@ gauss_periodic_x_kernel(const double* __restrict__ in, double* __restrict__ out,
     const int row = blockIdx.y, x0 = blockIdx.x * 1024;
     const double* src = in + (size_t)row * npix;
     for (int i = threadIdx.x; i < 1024 + 2 * radius; i += 256) {
-        int x = x0 - radius + i;
-        x = x < 0 ? x + npix : (x >= npix ? x - npix : x);
-        x = x < 0 ? x + npix : (x >= npix ? x - npix : x);        // npix >= radius is checked by the caller; twice covers tiny maps
+        int x = (x0 - radius + i) % npix;                 // periodic; the line may reach past a map narrower than 1024 pixels
+        if (x < 0) x += npix;
         line[i] = src[x];
     }
     __syncthreads();
@@ -230,14 +229,13 @@ gauss_periodic_x_kernel(const double* __restrict__ in, double* __restrict__ out,
 // along the columns: a workgroup produces a tile of 64 rows x 32 columns, thread = (column, group of 8 rows)
 __global__ void __launch_bounds__(256)
 gauss_periodic_y_kernel(const double* __restrict__ in, double* __restrict__ out, int npix, const double* __restrict__ w, int radius) {
-    __shared__ double tile[(64 + 2 * GP_RMAX) * 32];
+    extern __shared__ double tile[];                      // (64 + 2 radius) rows x 32 columns
     const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int x = blockIdx.x * 32 + c, y0 = blockIdx.y * 64;
     const int xs = x < npix ? x : npix - 1;
     for (int i = rg; i < 64 + 2 * radius; i += 8) {
-        int y = y0 - radius + i;
-        y = y < 0 ? y + npix : (y >= npix ? y - npix : y);
-        y = y < 0 ? y + npix : (y >= npix ? y - npix : y);
+        int y = (y0 - radius + i) % npix;
+        if (y < 0) y += npix;
         tile[i * 32 + c] = in[(size_t)y * npix + xs];
     }
     __syncthreads();
@@ -571,7 +569,7 @@ extern "C" int ast_gaussian_smooth(ast_smooth_plan* p, double* img, double sigma
     AST_CHECK_ARG(p && img && sigma_px > 0.0 && (mode == 0 || mode == 1));
     hipStream_t s = ast::as_stream(stream);
     const int npix = p->npix;
-    if (mode == 0 && sigma_px >= 2.5 && (int)std::ceil(8.5 * sigma_px) <= GP_RMAX && npix >= GP_RMAX &&
+    if (mode == 0 && sigma_px >= 2.5 && (int)std::ceil(8.5 * sigma_px) <= GP_RMAX && npix >= 2 &&
         2 * (int)std::ceil(8.5 * sigma_px) + 1 <= p->w_cap && !getenv("AST_SMOOTH_FFT")) {
         // the same periodic convolution in real space (see gauss_periodic_x_kernel)
         const int radius = (int)std::ceil(8.5 * sigma_px);
@@ -585,7 +583,12 @@ extern "C" int ast_gaussian_smooth(ast_smooth_plan* p, double* img, double sigma
         }
         AST_PROF("smooth.periodic_passes", s);
         gauss_periodic_x_kernel<<<dim3((unsigned)((npix + 1023) / 1024), (unsigned)npix), 256, 0, s>>>(img, p->tmp, npix, p->w_d, radius);
-        gauss_periodic_y_kernel<<<dim3((unsigned)((npix + 31) / 32), (unsigned)((npix + 63) / 64)), 256, 0, s>>>(p->tmp, img, npix, p->w_d, radius);
+        const size_t ylds = (size_t)(64 + 2 * radius) * 32 * sizeof(double);
+        static ast::PerDeviceOnce y_once;
+        if (y_once.need())
+            AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gauss_periodic_y_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)((64 + 2 * GP_RMAX) * 32 * sizeof(double))));
+        gauss_periodic_y_kernel<<<dim3((unsigned)((npix + 31) / 32), (unsigned)((npix + 63) / 64)), 256, ylds, s>>>(p->tmp, img, npix, p->w_d, radius);
         AST_CHECK_LAUNCH();
         return AST_OK;
     }

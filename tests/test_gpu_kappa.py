@@ -363,9 +363,9 @@ def test_lens_column_transforms_against_numpy(hip, dev, length):
     assert hip.ast_lens_cols_supported(8192) == 1 and hip.ast_lens_cols_supported(100) == 0
 
 
-@pytest.mark.parametrize("npix,sigma_px", [(1000, 2.5), (777, 4.3), (2048, 7.5), (64, 3.0)])
+@pytest.mark.parametrize("npix,sigma_px", [(1000, 2.5), (777, 4.3), (2048, 7.5), (64, 3.0), (1500, 18.8), (256, 12.0)])
 def test_gaussian_fft_smoothing_real_space_route_equals_fft_route(lens, dev, npix, sigma_px, monkeypatch):
-    """For 2.5 <= sigma_px <= 7.5 "gaussianFFT" runs as two periodic real-space passes; the FFT route (forced through
+    """For 2.5 <= sigma_px <= 18.8 "gaussianFFT" runs as two periodic real-space passes; the FFT route (forced through
     AST_SMOOTH_FFT) gives the same map to 1e-13 of its peak, on ragged sizes too."""
     rng = np.random.default_rng(npix)
     img = rng.standard_normal((npix, npix))
