@@ -283,7 +283,7 @@ struct ast_lens_plan {
     // two-pass column transforms of lens_fft.hip (which skip the zero half and leave the spectra in their permuted row
     // order - every spectrum of this plan goes the same way).  Otherwise: rocFFT's 2-D plans r2c / c2r.
     bool cols = false;
-    bool rows = false;                     // with cols: the nc non-zero rows by lens_fft.hip's row kernels too (nc = 512, 4096):
+    bool rows = false;                     // with cols: the nc non-zero rows by lens_fft.hip's row kernels too (nc = 128 .. 4096):
                                            // kappa is read unpadded, the inverse stores the scaled corner
     ast_fft_plan* rows_fwd = nullptr;      // nc rows of 2nc reals -> nc rows of nc + 1 complex
     ast_fft_plan* rows_fwd_all = nullptr;  // all 2nc rows (kernel images)

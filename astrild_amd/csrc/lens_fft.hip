@@ -163,74 +163,93 @@ struct TwCache {
 // ------------------------------------------------------------------ row transforms of the padded convolution
 // Row r < nc of the padded (2nc)^2 array holds nc reals followed by nc zeros.  Its real-to-complex transform of length
 // L = 2nc is the M = nc point complex transform of z[j] = x[2j] + i x[2j+1] (z[j] = 0 for j >= M / 2) followed by the
-// even/odd split; M = R^3 points (R = 16: nc = 4096; R = 8: nc = 512) go through three R-point register FFTs with two
-// exchanges through one LDS line (M + M / R double2: 68 KB at R = 16, two workgroups per CU), one row per workgroup
-// of R^2 threads:
-//   j = R^2 a + R b + c,  k = alpha + R beta + R^2 gamma
-//   stage 1 (thread j' = R b + c):   y[alpha][j'] = W_M^{j' alpha} sum_a z[R^2 a + j'] W_R^{a alpha}     (a < R / 2 only: the rest is zero)
-//   stage 2 (thread (alpha, c)):     y'[alpha][beta][c] = W_{R^2}^{c beta} sum_b y[alpha][R b + c] W_R^{b beta}
-//   stage 3 (thread (alpha, beta)):  Z[alpha + R beta + R^2 gamma] = sum_c y'[alpha][beta][c] W_R^{c gamma}
+// even/odd split; M = RA RB RC points (4096 = 16 16 16, 2048 = 16 16 8, 1024 = 16 8 8, 512 = 8 8 8, 256 = 8 8 4,
+// 128 = 8 4 4) go through three register FFTs with two exchanges through one LDS line (M + M / 8 double2: 74 KB at
+// M = 4096, two workgroups per CU), one row per workgroup:
+//   j = RB RC a + RC b + c,  k = alpha + RA beta + RA RB gamma
+//   stage 1 (thread j' = RC b + c):  y[alpha][j'] = W_M^{j' alpha} sum_a z[RB RC a + j'] W_RA^{a alpha}   (a < RA / 2 only: the rest is zero)
+//   stage 2 (thread (alpha, c)):     y'[alpha][beta][c] = W_{RB RC}^{c beta} sum_b y[alpha][RC b + c] W_RB^{b beta}
+//   stage 3 (thread (alpha, beta)):  Z[alpha + RA beta + RA RB gamma] = sum_c y'[alpha][beta][c] W_RC^{c gamma}
 // rocFFT's batched 1-D plans did these rows at 2.2 TB/s and needed the zero half in memory, a pad kernel before and a
 // crop kernel after; here kappa is read as it is (134 MB per map) and the inverse stores the kept, scaled corner.
-__device__ inline int lds_pad(int i, int r) { return i + i / r; }
+__device__ inline int lds_pad(int i) { return i + (i >> 3); }
 
-template <int R>
-__device__ inline void three_stage(double2 (&v)[R], double2* Y, const double2* __restrict__ twM, int t) {
-    // on entry: v[a] = input[R^2 a + t]; on exit: v[gamma'] (bit reversed) = output[alpha + R beta + R^2 gamma], t = alpha * R + beta
-    constexpr int R2 = R * R;
-    fft_reg<R>(v);
+template <int RA, int RB, int RC>
+struct RowGeo {
+    static constexpr int M = RA * RB * RC;
+    static constexpr int T1 = RB * RC, T2 = RA * RC, T3 = RA * RB;
+    static constexpr int NT = T1 > T2 ? (T1 > T3 ? T1 : T3) : (T2 > T3 ? T2 : T3);
+    static constexpr int RMAX = RA > RB ? (RA > RC ? RA : RC) : (RB > RC ? RB : RC);
+};
+
+// On entry (threads t < T1): va[a] = input[RB RC a + t].  On exit (threads t < T3, t = alpha * RB + beta): vc[bitrev(gamma)] =
+// output[alpha + RA beta + RA RB gamma].
+template <int RA, int RB, int RC>
+__device__ inline void three_stage(double2 (&va)[RA], double2 (&vc)[RC], double2* Y, const double2* __restrict__ twM, int t) {
+    using G = RowGeo<RA, RB, RC>;
+    if (t < G::T1) {
+        fft_reg<RA>(va);
 #pragma unroll
-    for (int al = 0; al < R; ++al) {
-        double2 y = v[bitrev(al, ilog2(R))];
-        if (al != 0) y = cmul(y, twM[t * al]);
-        Y[lds_pad(al * R2 + t, R)] = y;
-    }
-    __syncthreads();
-    {
-        const int al = t / R, c = t % R;
-#pragma unroll
-        for (int b = 0; b < R; ++b) v[b] = Y[lds_pad(al * R2 + R * b + c, R)];
-        fft_reg<R>(v);
-        // the slots this thread read are the slots it writes: no barrier in between
-#pragma unroll
-        for (int be = 0; be < R; ++be) {
-            double2 y = v[bitrev(be, ilog2(R))];
-            if (be != 0 && c != 0) y = cmul(y, twM[R * c * be]);
-            Y[lds_pad(al * R2 + R * be + c, R)] = y;
+        for (int al = 0; al < RA; ++al) {
+            double2 y = va[bitrev(al, ilog2(RA))];
+            if (al != 0) y = cmul(y, twM[t * al]);
+            Y[lds_pad(al * G::T1 + t)] = y;
         }
     }
     __syncthreads();
+    if (t < G::T2) {
+        const int al = t / RC, c = t % RC;
+        double2 vb[RB];
 #pragma unroll
-    for (int c = 0; c < R; ++c) v[c] = Y[lds_pad(t * R + c, R)];          // t = alpha * R + beta: R consecutive (padded) slots
-    fft_reg<R>(v);
+        for (int b = 0; b < RB; ++b) vb[b] = Y[lds_pad(al * G::T1 + RC * b + c)];
+        fft_reg<RB>(vb);
+        // the slots this thread read are the slots it writes: no barrier in between
+#pragma unroll
+        for (int be = 0; be < RB; ++be) {
+            double2 y = vb[bitrev(be, ilog2(RB))];
+            if (be != 0 && c != 0) y = cmul(y, twM[RA * c * be]);
+            Y[lds_pad(al * G::T1 + RC * be + c)] = y;
+        }
+    }
+    __syncthreads();
+    if (t < G::T3) {
+#pragma unroll
+        for (int c = 0; c < RC; ++c) vc[c] = Y[lds_pad(t * RC + c)];      // t = alpha * RB + beta: RC consecutive (padded) slots
+        fft_reg<RC>(vc);
+    }
 }
 
-template <int R>
-__global__ void __launch_bounds__(R * R)
+template <int RA, int RB, int RC>
+__global__ void __launch_bounds__((RowGeo<RA, RB, RC>::NT))
 lens_rows_forward_kernel(const double* __restrict__ kappa, int nc, double2* __restrict__ spec, size_t pitch,
                          const double2* __restrict__ twM, const double2* __restrict__ twL) {
-    constexpr int R2 = R * R, M = R2 * R;
+    using G = RowGeo<RA, RB, RC>;
+    constexpr int M = G::M;
     extern __shared__ double2 Y[];
     const int t = threadIdx.x;
     const size_t row = blockIdx.x;
     const double2* z = reinterpret_cast<const double2*>(kappa + row * (size_t)nc);      // M / 2 packed pairs
-    double2 v[R];
+    double2 va[RA], vc[RC];
+    if (t < G::T1) {
 #pragma unroll
-    for (int a = 0; a < R; ++a) v[a] = a < R / 2 ? z[R2 * a + t] : make_double2(0.0, 0.0);
-    three_stage<R>(v, Y, twM, t);
+        for (int a = 0; a < RA; ++a) va[a] = a < RA / 2 ? z[G::T1 * a + t] : make_double2(0.0, 0.0);
+    }
+    three_stage<RA, RB, RC>(va, vc, Y, twM, t);
     __syncthreads();                                      // everyone has read its stage-3 inputs: Y becomes Z[k]
+    if (t < G::T3) {
 #pragma unroll
-    for (int ga = 0; ga < R; ++ga) Y[lds_pad((t / R) + R * (t % R) + R2 * ga, R)] = v[bitrev(ga, ilog2(R))];
+        for (int ga = 0; ga < RC; ++ga) Y[lds_pad((t / RB) + RA * (t % RB) + RA * RB * ga)] = vc[bitrev(ga, ilog2(RC))];
+    }
     __syncthreads();
     double2* orow = spec + row * pitch;
-    for (int k = t; k <= M / 2; k += R2) {
-        const double2 zk = Y[lds_pad(k, R)];
+    for (int k = t; k <= M / 2; k += G::NT) {
+        const double2 zk = Y[lds_pad(k)];
         if (k == 0) {
             orow[0] = make_double2(zk.x + zk.y, 0.0);
             orow[M] = make_double2(zk.x - zk.y, 0.0);
             continue;
         }
-        const double2 zm = Y[lds_pad(M - k, R)];
+        const double2 zm = Y[lds_pad(M - k)];
         const double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));      // (Zk + conj Zm) / 2
         const double2 o = make_double2(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));      // (Zk - conj Zm) / 2
         const double2 tt = cmul(o, twL[k]);                                             // w^k o, w = e^{-2 pi i / L}
@@ -240,42 +259,47 @@ lens_rows_forward_kernel(const double* __restrict__ kappa, int nc, double2* __re
 }
 
 // rows of the product spectrum -> the kept corner: out[row][0 .. nc) = scale * (first nc reals of the length-2nc C2R)
-template <int R>
-__global__ void __launch_bounds__(R * R)
+template <int RA, int RB, int RC>
+__global__ void __launch_bounds__((RowGeo<RA, RB, RC>::NT))
 lens_rows_inverse_kernel(const double2* __restrict__ spec, size_t pitch, int nc, double scale, double* __restrict__ out,
                          const double2* __restrict__ twM, const double2* __restrict__ twL) {
-    constexpr int R2 = R * R, M = R2 * R;
+    using G = RowGeo<RA, RB, RC>;
+    constexpr int M = G::M;
     extern __shared__ double2 Y[];
     const int t = threadIdx.x;
     const size_t row = blockIdx.x;
     const double2* xrow = spec + row * pitch;
     // Z[k] = (X[k] + conj X[M-k]) / 2 + i w^{-k} (X[k] - conj X[M-k]) / 2, conjugated for the conj-FFT-conj inverse
-    for (int k = t; k <= M / 2; k += R2) {
+    for (int k = t; k <= M / 2; k += G::NT) {
         const double2 xk = xrow[k], xm = xrow[M - k];
         const double2 e = make_double2(0.5 * (xk.x + xm.x), 0.5 * (xk.y - xm.y));
         const double2 d = make_double2(0.5 * (xk.x - xm.x), 0.5 * (xk.y + xm.y));
         const double2 w = twL[k];
         const double2 tt = make_double2(fma(d.x, w.x, d.y * w.y), fma(d.y, w.x, -d.x * w.y));       // conj(w^k) d
-        // Z[k] = e + i t;  Z[M-k] = conj(e) + i conj(...) follows from the same formula with k -> M - k:
+        // Z[k] = e + i t;  Z[M-k] follows from the same formula with k -> M - k:
         //   e' = conj e, d' = -conj d, w^{-(M-k)} = -conj(w^{-k})  ->  t' = conj t,  Z[M-k] = conj(e) + i conj(t)
-        if (k < M) Y[lds_pad(k, R)] = make_double2(e.x - tt.y, -(e.y + tt.x));                      // conj(Z[k])
-        if (k != 0 && k != M / 2) Y[lds_pad(M - k, R)] = make_double2(e.x + tt.y, -(tt.x - e.y));   // conj(Z[M-k]) = e - i t
+        if (k < M) Y[lds_pad(k)] = make_double2(e.x - tt.y, -(e.y + tt.x));                         // conj(Z[k])
+        if (k != 0 && k != M / 2) Y[lds_pad(M - k)] = make_double2(e.x + tt.y, -(tt.x - e.y));      // conj(Z[M-k]) = e - i t
     }
     __syncthreads();
-    double2 v[R];
+    double2 va[RA], vc[RC];
+    if (t < G::T1) {
 #pragma unroll
-    for (int a = 0; a < R; ++a) v[a] = Y[lds_pad(R2 * a + t, R)];
+        for (int a = 0; a < RA; ++a) va[a] = Y[lds_pad(G::T1 * a + t)];
+    }
     __syncthreads();                                      // the line is overwritten by the stages
-    three_stage<R>(v, Y, twM, t);
+    three_stage<RA, RB, RC>(va, vc, Y, twM, t);
     __syncthreads();
-    // z[j], j = alpha + R beta + R^2 gamma < M / 2, i.e. gamma < R / 2: the kept half
+    // z[j], j = alpha + RA beta + RA RB gamma < M / 2, i.e. gamma < RC / 2: the kept half
+    if (t < G::T3) {
 #pragma unroll
-    for (int ga = 0; ga < R / 2; ++ga) Y[lds_pad((t / R) + R * (t % R) + R2 * ga, R)] = v[bitrev(ga, ilog2(R))];
+        for (int ga = 0; ga < RC / 2; ++ga) Y[lds_pad((t / RB) + RA * (t % RB) + RA * RB * ga)] = vc[bitrev(ga, ilog2(RC))];
+    }
     __syncthreads();
     double2* orow = reinterpret_cast<double2*>(out + row * (size_t)nc);
     const double s2 = 2.0 * scale;
-    for (int j = t; j < M / 2; j += R2) {
-        const double2 zz = Y[lds_pad(j, R)];              // conj of z[j]
+    for (int j = t; j < M / 2; j += G::NT) {
+        const double2 zz = Y[lds_pad(j)];                 // conj of z[j]
         orow[j] = make_double2(zz.x * s2, -zz.y * s2);    // x[2j] = 2 Re z, x[2j+1] = 2 Im z
     }
 }
@@ -368,7 +392,37 @@ extern "C" int ast_lens_cols_inverse(const void* spec, const void* mul, void* ou
                          keep_rows == len ? sp.n1 : sp.n1 / 2, 0, tw, (int)len, s);
 }
 
-extern "C" int ast_lens_rows_supported(size_t nc) { return nc == 4096 || nc == 512; }
+extern "C" int ast_lens_rows_supported(size_t nc) {
+    return nc == 4096 || nc == 2048 || nc == 1024 || nc == 512 || nc == 256 || nc == 128;
+}
+
+namespace {
+template <int RA, int RB, int RC>
+int rows_forward_launch(const double* kappa, size_t nc, double2* spec, size_t pitch, const double2* twM, const double2* twL, hipStream_t s) {
+    using G = RowGeo<RA, RB, RC>;
+    const size_t lds = (size_t)(G::M + G::M / 8) * sizeof(double2);
+    static ast::PerDeviceOnce once;
+    if (once.need() && lds > 48 * 1024)
+        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lens_rows_forward_kernel<RA, RB, RC>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lens_rows_forward_kernel<RA, RB, RC><<<(unsigned)nc, G::NT, lds, s>>>(kappa, (int)nc, spec, pitch, twM, twL);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+template <int RA, int RB, int RC>
+int rows_inverse_launch(const double2* spec, size_t pitch, size_t nc, double scale, double* out, const double2* twM, const double2* twL,
+                        hipStream_t s) {
+    using G = RowGeo<RA, RB, RC>;
+    const size_t lds = (size_t)(G::M + G::M / 8) * sizeof(double2);
+    static ast::PerDeviceOnce once;
+    if (once.need() && lds > 48 * 1024)
+        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lens_rows_inverse_kernel<RA, RB, RC>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lens_rows_inverse_kernel<RA, RB, RC><<<(unsigned)nc, G::NT, lds, s>>>(spec, pitch, (int)nc, scale, out, twM, twL);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+}  // namespace
 
 // spec_d[r][0 .. nc] (row pitch `pitch` complex) = R2C of length 2 nc of (kappa_d[r][0 .. nc), nc zeros), r < nc.
 extern "C" int ast_lens_rows_forward(const double* kappa, size_t nc, void* spec, size_t pitch, void* stream) {
@@ -379,18 +433,15 @@ extern "C" int ast_lens_rows_forward(const double* kappa, size_t nc, void* spec,
     const double2* twL = g_tw.get((int)(2 * nc), s);
     if (!twM || !twL) { ast::set_error("ast_lens_rows_forward: twiddle table allocation failed"); return AST_ERR_HIP; }
     AST_PROF("lens.rows_fwd", s);
-    if (nc == 4096) {
-        const size_t lds = (size_t)(4096 + 256) * sizeof(double2);
-        static ast::PerDeviceOnce once;
-        if (once.need()) AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lens_rows_forward_kernel<16>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lens_rows_forward_kernel<16><<<(unsigned)nc, 256, lds, s>>>(kappa, (int)nc, (double2*)spec, pitch, twM, twL);
-    } else {
-        const size_t lds = (size_t)(512 + 64) * sizeof(double2);
-        lens_rows_forward_kernel<8><<<(unsigned)nc, 64, lds, s>>>(kappa, (int)nc, (double2*)spec, pitch, twM, twL);
+    double2* o = (double2*)spec;
+    switch (nc) {
+        case 4096: return rows_forward_launch<16, 16, 16>(kappa, nc, o, pitch, twM, twL, s);
+        case 2048: return rows_forward_launch<16, 16, 8>(kappa, nc, o, pitch, twM, twL, s);
+        case 1024: return rows_forward_launch<16, 8, 8>(kappa, nc, o, pitch, twM, twL, s);
+        case 512: return rows_forward_launch<8, 8, 8>(kappa, nc, o, pitch, twM, twL, s);
+        case 256: return rows_forward_launch<8, 8, 4>(kappa, nc, o, pitch, twM, twL, s);
+        default: return rows_forward_launch<8, 4, 4>(kappa, nc, o, pitch, twM, twL, s);
     }
-    AST_CHECK_LAUNCH();
-    return AST_OK;
 }
 
 // out_d[r][0 .. nc) = scale * (the first nc reals of the length-2nc C2R of spec_d[r][0 .. nc]), r < nc (unnormalised C2R).
@@ -402,16 +453,13 @@ extern "C" int ast_lens_rows_inverse(const void* spec, size_t pitch, size_t nc, 
     const double2* twL = g_tw.get((int)(2 * nc), s);
     if (!twM || !twL) { ast::set_error("ast_lens_rows_inverse: twiddle table allocation failed"); return AST_ERR_HIP; }
     AST_PROF("lens.rows_inv", s);
-    if (nc == 4096) {
-        const size_t lds = (size_t)(4096 + 256) * sizeof(double2);
-        static ast::PerDeviceOnce once;
-        if (once.need()) AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lens_rows_inverse_kernel<16>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lens_rows_inverse_kernel<16><<<(unsigned)nc, 256, lds, s>>>((const double2*)spec, pitch, (int)nc, scale, out, twM, twL);
-    } else {
-        const size_t lds = (size_t)(512 + 64) * sizeof(double2);
-        lens_rows_inverse_kernel<8><<<(unsigned)nc, 64, lds, s>>>((const double2*)spec, pitch, (int)nc, scale, out, twM, twL);
+    const double2* x = (const double2*)spec;
+    switch (nc) {
+        case 4096: return rows_inverse_launch<16, 16, 16>(x, pitch, nc, scale, out, twM, twL, s);
+        case 2048: return rows_inverse_launch<16, 16, 8>(x, pitch, nc, scale, out, twM, twL, s);
+        case 1024: return rows_inverse_launch<16, 8, 8>(x, pitch, nc, scale, out, twM, twL, s);
+        case 512: return rows_inverse_launch<8, 8, 8>(x, pitch, nc, scale, out, twM, twL, s);
+        case 256: return rows_inverse_launch<8, 8, 4>(x, pitch, nc, scale, out, twM, twL, s);
+        default: return rows_inverse_launch<8, 4, 4>(x, pitch, nc, scale, out, twM, twL, s);
     }
-    AST_CHECK_LAUNCH();
-    return AST_OK;
 }

@@ -403,7 +403,7 @@ int ast_lens_plan_destroy(ast_lens_plan* plan);
  * (unnormalised) transforms spec_d * mul_d (mul_d NULL: spec_d alone) into out_d and writes the first keep_rows rows
  * (len or len / 2), in natural order. */
 int ast_lens_cols_supported(size_t len);
-/* The row transforms of the same convolution for nc = 512 / 4096 (ast_lens_rows_supported): forward - row r < nc of
+/* The row transforms of the same convolution for nc = 128 .. 4096, powers of two (ast_lens_rows_supported): forward - row r < nc of
  * spec_d (pitch complex per row) = the length-2nc R2C of (kappa_d[r][0 .. nc), nc zeros), kappa read unpadded
  * (zero_padding, lensing_funcs.c:8-19, never materialised); inverse - out_d[r][0 .. nc) = scale * the first nc reals of
  * the unnormalised length-2nc C2R of spec_d[r][0 .. nc] (corner_matrix, lensing_funcs.c:33-43, and the

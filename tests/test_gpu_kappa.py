@@ -382,7 +382,7 @@ def test_gaussian_fft_smoothing_real_space_route_equals_fft_route(lens, dev, npi
     npt.assert_allclose(a.mean(), img.mean(), rtol=0, atol=1e-13)  # the periodic kernel sums to one
 
 
-@pytest.mark.parametrize("nc", [512, 4096])
+@pytest.mark.parametrize("nc", [128, 256, 512, 1024, 2048, 4096])
 def test_lens_row_transforms_against_numpy(hip, dev, nc):
     """Hand-written row transforms of the padded convolution: forward = np.fft.rfft of (row, nc zeros); inverse =
     scale * first nc samples of the unnormalised irfft."""
@@ -409,4 +409,4 @@ def test_lens_row_transforms_against_numpy(hip, dev, nc):
     o = out.cpu().numpy()
     want = scale * 2 * nc * full[:, :nc]                   # unnormalised C2R = length * irfft
     assert np.abs(o - want).max() < 1e-12 * np.abs(want).max()
-    assert hip.ast_lens_rows_supported(4096) == 1 and hip.ast_lens_rows_supported(1024) == 0
+    assert hip.ast_lens_rows_supported(4096) == 1 and hip.ast_lens_rows_supported(8192) == 0 and hip.ast_lens_rows_supported(100) == 0
