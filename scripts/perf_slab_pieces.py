@@ -1,4 +1,5 @@
-"""Time the per-rank HIP pieces of the slab pipeline at the P=8, 1024^3 shape on one GPU."""
+"""Time the per-rank HIP pieces of the slab pipeline at the P-rank, 1024^3 shape on one GPU (default P = 8):
+what one rank computes per step, without the exchanges."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,19 +15,30 @@ def timeit(fn, reps=5):
         a.record(); fn(); b.record()
     torch.cuda.synchronize()
     return sorted(a.elapsed_time(b) for a, b in ev)[reps // 2]
+total = 0.0
+def line(name, ms):
+    global total
+    total += ms
+    print(f"{name:55s} {ms:7.3f} ms", flush=True)
 ppr = n ** 3 // P
 pos = ops.synth(n, n, L, 1, False, 0, ppr)
 gl = 5
 buf = ops.empty((nloc + 2 * gl, n, n))
-print(f"P={P}: slab paint {ppr} particles:", timeit(lambda: ops.paint(pos, None, n, L, 'cic', buf, (0 - gl) % n, nloc + 2 * gl)), "ms")
+mean = float(ppr) * P / float(n) ** 3
+line(f"slab paint, {ppr} particles (rho - mean on owned planes)",
+     timeit(lambda: ops.paint(pos, None, n, L, 'cic', buf, (0 - gl) % n, nloc + 2 * gl, offset=mean, owned=(gl, nloc))))
 owned = buf[gl:gl + nloc]
+line("ghost add (2 x %d planes)" % gl, timeit(lambda: (ops.add_into(buf[gl:2 * gl], buf[:gl]), ops.add_into(buf[nloc:nloc + gl], buf[nloc + gl:]))))
+line("low-k modes of the owned planes (side stream in the pipeline)", timeit(lambda: ops.lowk_modes(owned, n, 0)))
 spec2d = ops.empty((nloc, n, nz), ops.cdtype)
-print("2D R2C batch:", timeit(lambda: ops.fft2d_planes(owned, spec2d)), "ms")
-packed = ops.empty((P, nloc, nloc, nz), ops.cdtype)
-print("pack:", timeit(lambda: ops.pack(spec2d, packed, P)), "ms")
+chunks = 4
+pc = nloc // chunks
+packed = ops.empty((chunks, P, pc, nloc, nz), ops.cdtype)
 block = ops.empty((n, nloc, nz), ops.cdtype)
-block.copy_(packed.reshape(n, nloc, nz))
-print("axis-0 strided C2C:", timeit(lambda: ops.fft1d_axis0(block, 1.0)), "ms")
+def ffts():
+    for c in range(chunks):
+        ops.fft2d_planes_packed(owned[c * pc:(c + 1) * pc], spec2d[c * pc:(c + 1) * pc], packed[c], P, 0, block[c * pc:(c + 1) * pc])
+line(f"z rows + y pass storing in send order, {chunks} chunks", timeit(ffts))
 psum = ops.zeros((n // 2 - 1,), torch.float64)
-ops.shell_geometry(n, L, (0, n), (0, nloc))
-print("block power_bin:", timeit(lambda: ops.power_bin(block, n, L, (0, n), (0, nloc), psum)), "ms")
+line("axis-0 pass fused with the block's shell binning", timeit(lambda: ops.fft1d_axis0_power(block, 1.0 / n ** 3, n, L, 0, psum, 5)))
+print(f"{'sum (the low-k line overlaps the FFT chunks)':55s} {total:7.3f} ms")
