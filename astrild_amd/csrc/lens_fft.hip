@@ -219,20 +219,23 @@ __device__ inline void three_stage(double2 (&va)[RA], double2 (&vc)[RC], double2
     }
 }
 
-template <int RA, int RB, int RC>
+// ZPAD: the row holds M reals followed by M zeros that are not in memory (the lens plan); otherwise 2 M reals (the rows
+// of a 3-D grid: the z pass of the double-precision power spectrum).  in_pitch: reals between rows; the spectrum is
+// multiplied by `scale`.
+template <int RA, int RB, int RC, bool ZPAD>
 __global__ void __launch_bounds__((RowGeo<RA, RB, RC>::NT))
-lens_rows_forward_kernel(const double* __restrict__ kappa, int nc, double2* __restrict__ spec, size_t pitch,
-                         const double2* __restrict__ twM, const double2* __restrict__ twL) {
+lens_rows_forward_kernel(const double* __restrict__ kappa, size_t in_pitch, double2* __restrict__ spec, size_t pitch,
+                         const double2* __restrict__ twM, const double2* __restrict__ twL, double scale) {
     using G = RowGeo<RA, RB, RC>;
     constexpr int M = G::M;
     extern __shared__ double2 Y[];
     const int t = threadIdx.x;
     const size_t row = blockIdx.x;
-    const double2* z = reinterpret_cast<const double2*>(kappa + row * (size_t)nc);      // M / 2 packed pairs
+    const double2* z = reinterpret_cast<const double2*>(kappa + row * in_pitch);        // packed pairs: M / 2 (ZPAD) or M
     double2 va[RA], vc[RC];
     if (t < G::T1) {
 #pragma unroll
-        for (int a = 0; a < RA; ++a) va[a] = a < RA / 2 ? z[G::T1 * a + t] : make_double2(0.0, 0.0);
+        for (int a = 0; a < RA; ++a) va[a] = (!ZPAD || a < RA / 2) ? z[G::T1 * a + t] : make_double2(0.0, 0.0);
     }
     three_stage<RA, RB, RC>(va, vc, Y, twM, t);
     __syncthreads();                                      // everyone has read its stage-3 inputs: Y becomes Z[k]
@@ -245,16 +248,16 @@ lens_rows_forward_kernel(const double* __restrict__ kappa, int nc, double2* __re
     for (int k = t; k <= M / 2; k += G::NT) {
         const double2 zk = Y[lds_pad(k)];
         if (k == 0) {
-            orow[0] = make_double2(zk.x + zk.y, 0.0);
-            orow[M] = make_double2(zk.x - zk.y, 0.0);
+            orow[0] = make_double2((zk.x + zk.y) * scale, 0.0);
+            orow[M] = make_double2((zk.x - zk.y) * scale, 0.0);
             continue;
         }
         const double2 zm = Y[lds_pad(M - k)];
         const double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));      // (Zk + conj Zm) / 2
         const double2 o = make_double2(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));      // (Zk - conj Zm) / 2
         const double2 tt = cmul(o, twL[k]);                                             // w^k o, w = e^{-2 pi i / L}
-        orow[k] = make_double2(e.x + tt.y, e.y - tt.x);                                 // e - i t
-        orow[M - k] = make_double2(e.x - tt.y, -e.y - tt.x);                            // conj(e + i t)
+        orow[k] = make_double2((e.x + tt.y) * scale, (e.y - tt.x) * scale);             // e - i t
+        orow[M - k] = make_double2((e.x - tt.y) * scale, (-e.y - tt.x) * scale);        // conj(e + i t)
     }
 }
 
@@ -397,15 +400,18 @@ extern "C" int ast_lens_rows_supported(size_t nc) {
 }
 
 namespace {
-template <int RA, int RB, int RC>
-int rows_forward_launch(const double* kappa, size_t nc, double2* spec, size_t pitch, const double2* twM, const double2* twL, hipStream_t s) {
+template <int RA, int RB, int RC, bool ZPAD = true>
+int rows_forward_launch(const double* kappa, size_t nrows, double2* spec, size_t pitch, const double2* twM, const double2* twL, hipStream_t s,
+                        size_t in_pitch = 0, double scale = 1.0) {
     using G = RowGeo<RA, RB, RC>;
     const size_t lds = (size_t)(G::M + G::M / 8) * sizeof(double2);
     static ast::PerDeviceOnce once;
     if (once.need() && lds > 48 * 1024)
-        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lens_rows_forward_kernel<RA, RB, RC>),
+        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lens_rows_forward_kernel<RA, RB, RC, ZPAD>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lens_rows_forward_kernel<RA, RB, RC><<<(unsigned)nc, G::NT, lds, s>>>(kappa, (int)nc, spec, pitch, twM, twL);
+    AST_CHECK_ARG(nrows < 0x7fffffffull);
+    lens_rows_forward_kernel<RA, RB, RC, ZPAD><<<(unsigned)nrows, G::NT, lds, s>>>(kappa, in_pitch ? in_pitch : (size_t)G::M, spec, pitch, twM, twL,
+                                                                                 scale);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
@@ -462,4 +468,170 @@ extern "C" int ast_lens_rows_inverse(const void* spec, size_t pitch, size_t nc, 
         case 256: return rows_inverse_launch<8, 8, 4>(x, pitch, nc, scale, out, twM, twL, s);
         default: return rows_inverse_launch<8, 4, 4>(x, pitch, nc, scale, out, twM, twL, s);
     }
+}
+
+// ------------------------------------------------------------------ 3-D power spectrum of a double-precision grid
+// FFTPower of an in-memory grid in the reference's own dtype (power_spectrum_3d.py:183-224 on float64 arrays): z rows by
+// the row kernel above (no zero padding), y and x passes by col3_kernel - the three-stage scheme with the transform axis
+// strided: a workgroup takes 8 adjacent k_z columns (128-byte row pieces) of all N = RA RB RC rows, one LDS line per
+// column (147 KB at N = 1024: one workgroup per CU), ONE pass per axis where rocFFT's 3-D plan moves 2.1x the bytes.
+// The x pass does not store: it adds w |delta_k|^2 of its modes to the workgroup's LDS shell table (integer rule or
+// nbodykit's float64 edge rule, ast_common.h), written out as a row of `partial` and reduced in a fixed order.
+template <int RA, int RB, int RC, int C, bool POWER>
+__global__ void __launch_bounds__((C * RowGeo<RA, RB, RC>::NT))
+col3_kernel(double2* __restrict__ data, const double2* __restrict__ twM, size_t elem_stride, size_t ncols, size_t batch_stride,
+            unsigned tiles_per_batch, double scale, double* __restrict__ partial, double kf_rule) {
+    using G = RowGeo<RA, RB, RC>;
+    constexpr int N = G::M, NB = N / 2 - 1, LINE = N + N / 8;
+    extern __shared__ double2 lds64[];
+    double* shell = reinterpret_cast<double*>(lds64 + C * LINE);          // [NB + 1] when POWER
+    const int c = threadIdx.x % C, t = threadIdx.x / C;
+    const unsigned tile = blockIdx.x % tiles_per_batch, b = blockIdx.x / tiles_per_batch;
+    const size_t c0 = (size_t)tile * C;
+    const bool col_ok = c0 + c < ncols;
+    double2* base = data + (size_t)b * batch_stride + min(c0 + c, ncols - 1);
+    double2* Y = lds64 + c * LINE;
+    if (POWER)
+        for (int i = threadIdx.x; i <= NB; i += C * G::NT) shell[i] = 0.0;
+    double2 va[RA], vc[RC];
+    if (t < G::T1) {
+#pragma unroll
+        for (int a = 0; a < RA; ++a) va[a] = base[(size_t)(G::T1 * a + t) * elem_stride];
+    }
+    three_stage<RA, RB, RC>(va, vc, Y, twM, t);
+    if (t < G::T3 && col_ok) {
+        const int al = t / RB, be = t % RB;
+        if (!POWER) {
+#pragma unroll
+            for (int ga = 0; ga < RC; ++ga) {
+                double2 x = vc[bitrev(ga, ilog2(RC))];
+                x.x *= scale;
+                x.y *= scale;
+                base[(size_t)(al + RA * be + RA * RB * ga) * elem_stride] = x;
+            }
+        } else {
+            const int kz = (int)(c0 + c);
+            const int ky = (int)b > N / 2 ? (int)b - N : (int)b;
+            const int m2yz = ky * ky + kz * kz;
+            const double w = (kz > 0 && kz < N / 2) ? 2.0 : 1.0;
+#pragma unroll
+            for (int ga = 0; ga < RC; ++ga) {
+                const double2 x = vc[bitrev(ga, ilog2(RC))];
+                const int row = al + RA * be + RA * RB * ga;
+                const int kx = row > N / 2 ? row - N : row;
+                const int m2 = kx * kx + m2yz;
+                int r = (int)sqrt((double)m2);
+                while (r * r > m2) --r;
+                while ((r + 1) * (r + 1) <= m2) ++r;
+                if (kf_rule != 0.0 && r > 0 && r * r == m2) r = ast::float64_edge_norm(r, kx, ky, kz, kf_rule);
+                if (r >= 1 && r <= NB) atomicAdd(&shell[r], (x.x * x.x + x.y * x.y) * w);      // shell = r - 1
+            }
+        }
+    }
+    if (POWER) {
+        __syncthreads();
+        const double s2 = scale * scale;
+        for (int i = threadIdx.x; i < NB; i += C * G::NT) partial[(size_t)blockIdx.x * NB + i] = shell[i + 1] * s2;
+    }
+}
+
+// psum[bin] += pnorm * sum over workgroups of partial[wg][bin], fixed order: REDUCE64 blocks each add a contiguous range
+// of workgroup rows (lanes = consecutive bins), then one block adds those.
+constexpr int REDUCE64 = 1024;
+__global__ void __launch_bounds__(256)
+power64_stage1_kernel(const double* __restrict__ partial, size_t nwg, int nb, double* __restrict__ out) {
+    const size_t per = (nwg + REDUCE64 - 1) / REDUCE64;
+    const size_t w0 = (size_t)blockIdx.x * per, w1 = w0 + per < nwg ? w0 + per : nwg;
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        double acc = 0.0;
+        for (size_t wg = w0; wg < w1; ++wg) acc += partial[wg * nb + i];
+        out[(size_t)blockIdx.x * nb + i] = acc;
+    }
+}
+__global__ void __launch_bounds__(256)
+power64_stage2_kernel(const double* __restrict__ part, int nb, double pnorm, double* __restrict__ psum) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nb) return;
+    double acc = 0.0;
+    for (int r = 0; r < REDUCE64; ++r) acc += part[(size_t)r * nb + i];
+    psum[i] += pnorm * acc;
+}
+
+namespace {
+template <int RA, int RB, int RC, bool POWER>
+int col3_launch(double2* data, const double2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride, double scale,
+                double* partial, double kf_rule, hipStream_t s) {
+    using G = RowGeo<RA, RB, RC>;
+    constexpr int C = 8, LINE = G::M + G::M / 8;
+    const size_t lds = (size_t)C * LINE * sizeof(double2) + (POWER ? (G::M / 2) * sizeof(double) : 0);
+    static ast::PerDeviceOnce once;
+    if (once.need())
+        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&col3_kernel<RA, RB, RC, C, POWER>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t tiles = (ncols + C - 1) / C;
+    AST_CHECK_ARG(tiles * batch < 0x7fffffffull);
+    col3_kernel<RA, RB, RC, C, POWER><<<(unsigned)(tiles * batch), C * G::NT, lds, s>>>(data, tw, elem_stride, ncols, batch_stride,
+                                                                                        (unsigned)tiles, scale, partial, kf_rule);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+template <bool POWER>
+int col3_dispatch(size_t n, double2* data, const double2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride,
+                  double scale, double* partial, double kf_rule, hipStream_t s) {
+    if (n == 1024) return col3_launch<16, 8, 8, POWER>(data, tw, elem_stride, ncols, batch, batch_stride, scale, partial, kf_rule, s);
+    if (n == 512) return col3_launch<8, 8, 8, POWER>(data, tw, elem_stride, ncols, batch, batch_stride, scale, partial, kf_rule, s);
+    return col3_launch<8, 8, 4, POWER>(data, tw, elem_stride, ncols, batch, batch_stride, scale, partial, kf_rule, s);
+}
+}  // namespace
+
+extern "C" int ast_fft64_supported(size_t n) { return n == 256 || n == 512 || n == 1024; }
+
+// row pitch of the scratch spectrum (complex): n / 2 + 1 rounded up to 8 (128-byte pieces stay line aligned)
+static size_t fft64_pitch(size_t n) { return (n / 2 + 1 + 7) / 8 * 8; }
+extern "C" size_t ast_fft64_power_scratch_bytes(size_t n) {
+    const size_t nzp = fft64_pitch(n), tiles = (n / 2 + 1 + 7) / 8, nb = n / 2 - 1;
+    return n * n * nzp * sizeof(double2) + n * tiles * nb * sizeof(double) + (size_t)REDUCE64 * nb * sizeof(double);
+}
+
+// psum_d[shell] += L^3 sum over the shell's modes of w |delta_k|^2, delta_k = rfftn(grid) / n^3, for an (n, n, n) double
+// grid: FFTPower(ArrayMesh(grid), mode="1d", kmin = k_F)'s shell sums (power_spectrum_3d.py:183-224) without the
+// spectrum's last pass ever reaching HBM.  grid_d is not modified.
+extern "C" int ast_fft64_power_3d(const double* grid, void* scratch, size_t scratch_bytes, size_t n, double boxsize, int binning,
+                                  double* psum, void* stream) {
+    AST_CHECK_ARG(grid != nullptr && scratch != nullptr && psum != nullptr && boxsize > 0.0);
+    AST_CHECK_ARG(ast_fft64_supported(n) && scratch_bytes >= ast_fft64_power_scratch_bytes(n));
+    AST_CHECK_ARG(binning == AST_BIN_INTEGER || binning == AST_BIN_FLOAT64);
+    AST_CHECK_ARG(((uintptr_t)grid & 15) == 0);
+    hipStream_t s = ast::as_stream(stream);
+    const size_t nz = n / 2 + 1, nzp = fft64_pitch(n), tiles = (nz + 7) / 8, nb = n / 2 - 1;
+    double2* spec = (double2*)scratch;
+    double* partial = (double*)((char*)scratch + n * n * nzp * sizeof(double2));
+    double* part2 = partial + n * tiles * nb;
+    const double2* twH = g_tw.get((int)(n / 2), s);       // the rows' half-length transform
+    const double2* twN = g_tw.get((int)n, s);
+    if (!twH || !twN) { ast::set_error("ast_fft64_power_3d: twiddle table allocation failed"); return AST_ERR_HIP; }
+    int rc;
+    {
+        AST_PROF("fft64.rows_r2c", s);
+        if (n == 1024) rc = rows_forward_launch<8, 8, 8, false>(grid, n * n, spec, nzp, twH, twN, s, n, 1.0);
+        else if (n == 512) rc = rows_forward_launch<8, 8, 4, false>(grid, n * n, spec, nzp, twH, twN, s, n, 1.0);
+        else rc = rows_forward_launch<8, 4, 4, false>(grid, n * n, spec, nzp, twH, twN, s, n, 1.0);
+        if (rc != AST_OK) return rc;
+    }
+    {
+        AST_PROF("fft64.cols", s);
+        rc = col3_dispatch<false>(n, spec, twN, nzp, nz, n, n * nzp, 1.0, nullptr, 0.0, s);               // y, per x plane
+        if (rc != AST_OK) return rc;
+    }
+    const double kf_rule = binning == AST_BIN_FLOAT64 ? 2.0 * M_PI / boxsize : 0.0;
+    {
+        AST_PROF("fft64.cols_power", s);
+        rc = col3_dispatch<true>(n, spec, twN, n * nzp, nz, n, nzp, 1.0 / ((double)n * (double)n * (double)n), partial, kf_rule, s);
+        if (rc != AST_OK) return rc;
+    }
+    AST_PROF("fft64.shell_reduce", s);
+    power64_stage1_kernel<<<REDUCE64, 256, 0, s>>>(partial, n * tiles, (int)nb, part2);
+    power64_stage2_kernel<<<(unsigned)((nb + 255) / 256), 256, 0, s>>>(part2, (int)nb, boxsize * boxsize * boxsize, psum);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
 }

@@ -418,6 +418,30 @@ def lowk_shell_sums(modes, nmesh, boxsize, binning=None):
     return sums
 
 
+def fused_power64_supported(field):
+    n = field.shape[0]
+    return field.dim() == 3 and tuple(field.shape) == (n, n, n) and field.dtype == torch.float64 and field.is_contiguous() \
+        and bool(_lib.lib().ast_fft64_supported(n))
+
+
+def power_sums_fused64(field, boxsize, psum=None, binning=None):
+    """(ksum, psum, nmodes) of the auto power of a float64 cube of side 256/512/1024 through the hand-written
+    double-precision passes (ast_fft64_power_3d): one pass per axis, the last one fused with the shell binning."""
+    n = field.shape[0]
+    L = _lib.lib()
+    key = (torch.cuda.current_device(), n, "f64")
+    scratch = _power_scratch.get(key)
+    if scratch is None:
+        _power_scratch.clear()
+        scratch = _power_scratch[key] = torch.empty(int(L.ast_fft64_power_scratch_bytes(n)), dtype=torch.uint8, device=field.device)
+    if psum is None:
+        psum = torch.zeros(n // 2 - 1, dtype=torch.float64, device=field.device)
+    ksum, nmodes = shell_geometry(n, boxsize, binning=binning)
+    check(L.ast_fft64_power_3d(ptr(field), ptr(scratch), scratch.numel(), n, float(boxsize), _bin_code(binning), ptr(psum), stream()),
+          "ast_fft64_power_3d")
+    return ksum, psum, nmodes
+
+
 def fused_power_supported(field):
     n = field.shape[0]
     return field.dim() == 3 and tuple(field.shape) == (n, n, n) and field.dtype == torch.float32 \
@@ -448,6 +472,8 @@ def fftpower_1d(field1, boxsize, field2=None, fused=True, binning=None):
         # transform of an O(1) mean would leave its round-off on every shell
         mean = total_mass(field1.reshape(-1), 0) / float(field1.numel())
         return finish_power(*power_sums_fused(field1, boxsize, mean=mean, binning=binning))
+    if fused and field2 is None and fused_power64_supported(field1):
+        return finish_power(*power_sums_fused64(field1, boxsize, binning=binning))
     if field1.dtype == torch.float32 and not bool(_lib.lib().ast_fft_tile_supported(F32, n)):
         # an fp32 grid of a size the tile FFT does not cover: the rocFFT fp32 transform would carry the O(1) mean's
         # round-off into the low shells (2e-6 and worse); the transform runs in double instead

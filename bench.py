@@ -249,7 +249,7 @@ def _stage_table(prof, steps, npart_rank, ng_rank, esz, fused_bin, concurrent=()
     on a second stream beside the stage's other kernels - listed, but their time is not added to the stage's."""
     stage_sites = {
         "paint": [k for k in prof if k.startswith("paint")],
-        "fft": [k for k in prof if k.startswith("rocfft") or k.startswith("fft_tile") or k.startswith("slab.")],
+        "fft": [k for k in prof if k.startswith("rocfft") or k.startswith("fft_tile") or k.startswith("fft64") or k.startswith("slab.")],
         "power_bin": [k for k in prof if k == "power_bin"],        # absent when fused into the last FFT pass
     }
     stage_bytes = {
@@ -307,8 +307,9 @@ def power_leg(dev, n, npside, L, window, order, dtype, method, steps, warmup):
     psum = torch.zeros(n // 2 - 1, dtype=torch.float64, device="cuda")
     dev.shell_geometry(n, L)          # data independent, cached like the FFT plan
     fused = dev.fused_power_supported(grid)
+    fused64 = dev.fused_power64_supported(grid) and not os.environ.get("ASTRILD_BENCH_ROCFFT64")
     spec = None
-    if not fused:
+    if not fused and not fused64:
         spec = torch.empty((n, n, n // 2 + 1), dtype=torch.complex64 if dtype == "f32" else torch.complex128, device="cuda")
     mean = npart_total / float(n) ** 3
     hint = "scattered" if order == "shuffled" else None
@@ -326,6 +327,8 @@ def power_leg(dev, n, npside, L, window, order, dtype, method, steps, warmup):
         psum.zero_()
         if fused:                         # tile FFT with the shell binning fused into the last pass
             return dev.power_sums_fused(grid, L, psum=psum, mean=mean)
+        if fused64:                       # float64: hand-written double passes, binning fused into the x pass
+            return dev.power_sums_fused64(grid, L, psum=psum)
         dev.r2c(grid, out=spec)
         return dev.power_bin_1d(spec, None, n, L, psum=psum)
 

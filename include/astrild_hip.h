@@ -395,6 +395,15 @@ typedef struct ast_lens_plan ast_lens_plan;
  * spectra of the isotropic kernels of lensing_funcs.c:45-83,117-148. */
 int ast_lens_plan_create(ast_lens_plan** plan, int nc, double bsz);
 int ast_lens_plan_destroy(ast_lens_plan* plan);
+/* FFTPower of an in-memory float64 grid (the reference's dtype: power_spectrum_3d.py:183-224 on float64 arrays) for
+ * n = 256 / 512 / 1024 through hand-written double-precision passes (z rows, then ONE strided pass per axis, the last
+ * one fused with the shell binning): psum_d[shell] += L^3 sum_modes w |delta_k|^2, delta_k = rfftn(grid) / n^3.
+ * grid_d is not modified; scratch_d: ast_fft64_power_scratch_bytes(n) bytes. */
+int ast_fft64_supported(size_t n);
+size_t ast_fft64_power_scratch_bytes(size_t n);
+int ast_fft64_power_3d(const double* grid_d, void* scratch_d, size_t scratch_bytes, size_t n, double boxsize, int binning,
+                       double* psum_d, void* stream);
+
 /* Column transforms of the zero-padded lens convolution (lensing_funcs.c:85-115 + fft_convolve.c:60-90), double,
  * hand-written two-pass (four-step) passes over data_d[len][pitch] complex that skip the half known to be zero.
  * len in {256 .. 8192}, powers of two (ast_lens_cols_supported).  The forward transform (in place) reads rows

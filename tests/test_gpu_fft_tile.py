@@ -244,3 +244,28 @@ def test_triple_product_sums_one_pass(hip, dtype):
     assert np.all(np.abs(got.cpu().numpy() - ref) <= 1e-13 * scale)
     one = dev.triple_product_sum(fields[keys[0]], fields[keys[1]], fields[keys[2]]).item()
     assert abs(one - ref[-1]) <= 1e-13 * scale[-1]
+
+
+@pytest.mark.parametrize("n", [256, 512])
+def test_double_precision_fused_power_against_rocfft_route(hip, n):
+    """ast_fft64_power_3d (hand-written double passes, binning fused into the x pass) against rocFFT R2C + ast_power_bin_1d
+    on the same float64 grid, both shell rules; and against the numpy oracle at 256^3."""
+    from astrild_amd import device as dev
+    from oracle import fftpower as offt
+    torch.cuda.set_device(0)
+    rng = np.random.default_rng(n)
+    f = rng.standard_normal((n, n, n)) + 3.0
+    t = dev.as_device(f)
+    keep = t.clone()
+    for rule in ("float64", "integer"):
+        ks, ps, nm = dev.power_sums_fused64(t, 1000.0, binning=rule)
+        spec = dev.r2c(t)
+        ks2, ps2, nm2 = dev.power_bin_1d(spec, None, n, 1000.0, binning=rule)
+        assert torch.equal(nm, nm2)
+        np.testing.assert_allclose(ps.cpu().numpy(), ps2.cpu().numpy(), rtol=1e-11)
+    assert torch.equal(t, keep)                                     # the grid is left intact
+    res = dev.fftpower_1d(t, 1000.0)                                # default route for float64 cubes of this size
+    if n == 256:
+        ref = offt.fftpower_1d(f, 1000.0)
+        assert np.array_equal(res["modes"], ref["modes"])
+        np.testing.assert_allclose(res["power"], ref["power"].real, rtol=1e-9)
