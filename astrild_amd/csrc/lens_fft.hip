@@ -473,8 +473,8 @@ extern "C" int ast_lens_rows_inverse(const void* spec, size_t pitch, size_t nc, 
 // ------------------------------------------------------------------ 3-D power spectrum of a double-precision grid
 // FFTPower of an in-memory grid in the reference's own dtype (power_spectrum_3d.py:183-224 on float64 arrays): z rows by
 // the row kernel above (no zero padding), y and x passes by col3_kernel - the three-stage scheme with the transform axis
-// strided: a workgroup takes 8 adjacent k_z columns (128-byte row pieces) of all N = RA RB RC rows, one LDS line per
-// column (147 KB at N = 1024: one workgroup per CU), ONE pass per axis where rocFFT's 3-D plan moves 2.1x the bytes.
+// strided: a workgroup takes 4 or 8 adjacent k_z columns (64- or 128-byte row pieces) of all N = RA RB RC rows, one LDS
+// line per column, ONE pass per axis where rocFFT's 3-D plan moves 2.1x the bytes.
 // The x pass does not store: it adds w |delta_k|^2 of its modes to the workgroup's LDS shell table (integer rule or
 // nbodykit's float64 edge rule, ast_common.h), written out as a row of `partial` and reduced in a fixed order.
 template <int RA, int RB, int RC, int C, bool POWER>
@@ -558,11 +558,14 @@ power64_stage2_kernel(const double* __restrict__ part, int nb, double pnorm, dou
 }
 
 namespace {
+// columns per workgroup: 4 at N = 1024 (74 KB of LDS: two workgroups per CU; measured 4.5 + 4.0 ms for the y and x passes
+// against 5.4 + 4.5 with 8 columns and one workgroup per CU, 7.3 + 5.8 with 2), 8 below
+constexpr int col3_columns(size_t n) { return n == 1024 ? 4 : 8; }
 template <int RA, int RB, int RC, bool POWER>
 int col3_launch(double2* data, const double2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride, double scale,
                 double* partial, double kf_rule, hipStream_t s) {
     using G = RowGeo<RA, RB, RC>;
-    constexpr int C = 8, LINE = G::M + G::M / 8;
+    constexpr int C = col3_columns(G::M), LINE = G::M + G::M / 8;
     const size_t lds = (size_t)C * LINE * sizeof(double2) + (POWER ? (G::M / 2) * sizeof(double) : 0);
     static ast::PerDeviceOnce once;
     if (once.need())
@@ -589,7 +592,7 @@ extern "C" int ast_fft64_supported(size_t n) { return n == 256 || n == 512 || n 
 // row pitch of the scratch spectrum (complex): n / 2 + 1 rounded up to 8 (128-byte pieces stay line aligned)
 static size_t fft64_pitch(size_t n) { return (n / 2 + 1 + 7) / 8 * 8; }
 extern "C" size_t ast_fft64_power_scratch_bytes(size_t n) {
-    const size_t nzp = fft64_pitch(n), tiles = (n / 2 + 1 + 7) / 8, nb = n / 2 - 1;
+    const size_t nzp = fft64_pitch(n), cw = (size_t)col3_columns(n), tiles = (n / 2 + 1 + cw - 1) / cw, nb = n / 2 - 1;
     return n * n * nzp * sizeof(double2) + n * tiles * nb * sizeof(double) + (size_t)REDUCE64 * nb * sizeof(double);
 }
 
@@ -603,7 +606,7 @@ extern "C" int ast_fft64_power_3d(const double* grid, void* scratch, size_t scra
     AST_CHECK_ARG(binning == AST_BIN_INTEGER || binning == AST_BIN_FLOAT64);
     AST_CHECK_ARG(((uintptr_t)grid & 15) == 0);
     hipStream_t s = ast::as_stream(stream);
-    const size_t nz = n / 2 + 1, nzp = fft64_pitch(n), tiles = (nz + 7) / 8, nb = n / 2 - 1;
+    const size_t nz = n / 2 + 1, nzp = fft64_pitch(n), cw = (size_t)col3_columns(n), tiles = (nz + cw - 1) / cw, nb = n / 2 - 1;
     double2* spec = (double2*)scratch;
     double* partial = (double*)((char*)scratch + n * n * nzp * sizeof(double2));
     double* part2 = partial + n * tiles * nb;
