@@ -17,6 +17,7 @@
 // the scheme of fft_tile.hip's strided pass in double.
 #include "../../include/astrild_hip.h"
 #include "ast_common.h"
+#include "paint_tile_geom.h"
 #include <cmath>
 #include <mutex>
 #include <vector>
@@ -222,10 +223,14 @@ __device__ inline void three_stage(double2 (&va)[RA], double2 (&vc)[RC], double2
 // ZPAD: the row holds M reals followed by M zeros that are not in memory (the lens plan); otherwise 2 M reals (the rows
 // of a 3-D grid: the z pass of the double-precision power spectrum).  in_pitch: reals between rows; the spectrum is
 // multiplied by `scale`.
-template <int RA, int RB, int RC, bool ZPAD>
+// FOLDW = 2 / 3 (CIC / TSC, grids only): the grid is what a deferred-fold paint left and `rec` its halo records; the up to
+// three record lines that end in a border row are added as the row is loaded - records first, then onto the row, the
+// order of the paint's own fold kernel (as in fft_tile.hip's float row pass).
+template <int RA, int RB, int RC, bool ZPAD, int FOLDW = 0>
 __global__ void __launch_bounds__((RowGeo<RA, RB, RC>::NT))
 lens_rows_forward_kernel(const double* __restrict__ kappa, size_t in_pitch, double2* __restrict__ spec, size_t pitch,
-                         const double2* __restrict__ twM, const double2* __restrict__ twL, double scale) {
+                         const double2* __restrict__ twM, const double2* __restrict__ twL, double scale,
+                         const double* __restrict__ rec = nullptr) {
     using G = RowGeo<RA, RB, RC>;
     constexpr int M = G::M;
     extern __shared__ double2 Y[];
@@ -236,6 +241,27 @@ lens_rows_forward_kernel(const double* __restrict__ kappa, size_t in_pitch, doub
     if (t < G::T1) {
 #pragma unroll
         for (int a = 0; a < RA; ++a) va[a] = (!ZPAD || a < RA / 2) ? z[G::T1 * a + t] : make_double2(0.0, 0.0);
+        if (FOLDW != 0) {
+            constexpr int W = FOLDW != 0 ? FOLDW : 2;
+            const int ng = 2 * M;
+            const double* src[3];
+            const int ns = ast::halo_sources<double, W>(rec, (int)(row / ng), (int)(row % ng), ng, ng / ast::TX, ng / ast::TY, src);
+            if (ns > 0) {
+                double2 h[RA];
+#pragma unroll
+                for (int a = 0; a < RA; ++a) h[a] = reinterpret_cast<const double2*>(src[0])[G::T1 * a + t];
+                for (int k = 1; k < ns; ++k) {
+#pragma unroll
+                    for (int a = 0; a < RA; ++a) {
+                        const double2 q = reinterpret_cast<const double2*>(src[k])[G::T1 * a + t];
+                        h[a].x += q.x;
+                        h[a].y += q.y;
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < RA; ++a) { va[a].x += h[a].x; va[a].y += h[a].y; }
+            }
+        }
     }
     three_stage<RA, RB, RC>(va, vc, Y, twM, t);
     __syncthreads();                                      // everyone has read its stage-3 inputs: Y becomes Z[k]
@@ -400,18 +426,18 @@ extern "C" int ast_lens_rows_supported(size_t nc) {
 }
 
 namespace {
-template <int RA, int RB, int RC, bool ZPAD = true>
+template <int RA, int RB, int RC, bool ZPAD = true, int FOLDW = 0>
 int rows_forward_launch(const double* kappa, size_t nrows, double2* spec, size_t pitch, const double2* twM, const double2* twL, hipStream_t s,
-                        size_t in_pitch = 0, double scale = 1.0) {
+                        size_t in_pitch = 0, double scale = 1.0, const double* rec = nullptr) {
     using G = RowGeo<RA, RB, RC>;
     const size_t lds = (size_t)(G::M + G::M / 8) * sizeof(double2);
     static ast::PerDeviceOnce once;
     if (once.need() && lds > 48 * 1024)
-        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lens_rows_forward_kernel<RA, RB, RC, ZPAD>),
+        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lens_rows_forward_kernel<RA, RB, RC, ZPAD, FOLDW>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     AST_CHECK_ARG(nrows < 0x7fffffffull);
-    lens_rows_forward_kernel<RA, RB, RC, ZPAD><<<(unsigned)nrows, G::NT, lds, s>>>(kappa, in_pitch ? in_pitch : (size_t)G::M, spec, pitch, twM, twL,
-                                                                                 scale);
+    lens_rows_forward_kernel<RA, RB, RC, ZPAD, FOLDW><<<(unsigned)nrows, G::NT, lds, s>>>(kappa, in_pitch ? in_pitch : (size_t)G::M, spec, pitch,
+                                                                                        twM, twL, scale, rec);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
@@ -599,8 +625,21 @@ extern "C" size_t ast_fft64_power_scratch_bytes(size_t n) {
 // psum_d[shell] += L^3 sum over the shell's modes of w |delta_k|^2, delta_k = rfftn(grid) / n^3, for an (n, n, n) double
 // grid: FFTPower(ArrayMesh(grid), mode="1d", kmin = k_F)'s shell sums (power_spectrum_3d.py:183-224) without the
 // spectrum's last pass ever reaching HBM.  grid_d is not modified.
+static int fft64_power_impl(const double* grid, const double* rec, int window, void* scratch, size_t scratch_bytes, size_t n,
+                            double boxsize, int binning, double* psum, void* stream);
 extern "C" int ast_fft64_power_3d(const double* grid, void* scratch, size_t scratch_bytes, size_t n, double boxsize, int binning,
                                   double* psum, void* stream) {
+    return fft64_power_impl(grid, nullptr, 0, scratch, scratch_bytes, n, boxsize, binning, psum, stream);
+}
+// The same for a grid painted with AST_PAINT_OVERWRITE | AST_PAINT_DEFER_FOLD: halo_rec_d (ast_paint_tiled_halo) is folded
+// into the border rows as the z pass loads them.
+extern "C" int ast_fft64_power_3d_halo(const double* grid, const double* halo_rec, int window, void* scratch, size_t scratch_bytes,
+                                       size_t n, double boxsize, int binning, double* psum, void* stream) {
+    AST_CHECK_ARG(halo_rec != nullptr && (window == AST_WIN_CIC || window == AST_WIN_TSC));
+    return fft64_power_impl(grid, halo_rec, window, scratch, scratch_bytes, n, boxsize, binning, psum, stream);
+}
+static int fft64_power_impl(const double* grid, const double* rec, int window, void* scratch, size_t scratch_bytes, size_t n,
+                            double boxsize, int binning, double* psum, void* stream) {
     AST_CHECK_ARG(grid != nullptr && scratch != nullptr && psum != nullptr && boxsize > 0.0);
     AST_CHECK_ARG(ast_fft64_supported(n) && scratch_bytes >= ast_fft64_power_scratch_bytes(n));
     AST_CHECK_ARG(binning == AST_BIN_INTEGER || binning == AST_BIN_FLOAT64);
@@ -616,9 +655,17 @@ extern "C" int ast_fft64_power_3d(const double* grid, void* scratch, size_t scra
     int rc;
     {
         AST_PROF("fft64.rows_r2c", s);
-        if (n == 1024) rc = rows_forward_launch<8, 8, 8, false>(grid, n * n, spec, nzp, twH, twN, s, n, 1.0);
-        else if (n == 512) rc = rows_forward_launch<8, 8, 4, false>(grid, n * n, spec, nzp, twH, twN, s, n, 1.0);
-        else rc = rows_forward_launch<8, 4, 4, false>(grid, n * n, spec, nzp, twH, twN, s, n, 1.0);
+        auto rows = [&](auto ra, auto rb, auto rcc) {
+            constexpr int A = decltype(ra)::value, B = decltype(rb)::value, Cc = decltype(rcc)::value;
+            if (rec == nullptr) return rows_forward_launch<A, B, Cc, false, 0>(grid, n * n, spec, nzp, twH, twN, s, n, 1.0);
+            if (window == AST_WIN_CIC) return rows_forward_launch<A, B, Cc, false, 2>(grid, n * n, spec, nzp, twH, twN, s, n, 1.0, rec);
+            return rows_forward_launch<A, B, Cc, false, 3>(grid, n * n, spec, nzp, twH, twN, s, n, 1.0, rec);
+        };
+        using I4 = std::integral_constant<int, 4>;
+        using I8 = std::integral_constant<int, 8>;
+        if (n == 1024) rc = rows(I8{}, I8{}, I8{});
+        else if (n == 512) rc = rows(I8{}, I8{}, I4{});
+        else rc = rows(I8{}, I4{}, I4{});
         if (rc != AST_OK) return rc;
     }
     {

@@ -424,7 +424,7 @@ def fused_power64_supported(field):
         and bool(_lib.lib().ast_fft64_supported(n))
 
 
-def power_sums_fused64(field, boxsize, psum=None, binning=None):
+def power_sums_fused64(field, boxsize, psum=None, binning=None, halo=None):
     """(ksum, psum, nmodes) of the auto power of a float64 cube of side 256/512/1024 through the hand-written
     double-precision passes (ast_fft64_power_3d): one pass per axis, the last one fused with the shell binning."""
     n = field.shape[0]
@@ -437,6 +437,10 @@ def power_sums_fused64(field, boxsize, psum=None, binning=None):
     if psum is None:
         psum = torch.zeros(n // 2 - 1, dtype=torch.float64, device=field.device)
     ksum, nmodes = shell_geometry(n, boxsize, binning=binning)
+    if halo is not None:                      # grid from paint(..., defer_fold=True)
+        check(L.ast_fft64_power_3d_halo(ptr(field), halo.rec_ptr, halo.window_code, ptr(scratch), scratch.numel(), n,
+                                        float(boxsize), _bin_code(binning), ptr(psum), stream()), "ast_fft64_power_3d_halo")
+        return ksum, psum, nmodes
     check(L.ast_fft64_power_3d(ptr(field), ptr(scratch), scratch.numel(), n, float(boxsize), _bin_code(binning), ptr(psum), stream()),
           "ast_fft64_power_3d")
     return ksum, psum, nmodes
@@ -448,7 +452,7 @@ def fused_power_supported(field):
         and bool(_lib.lib().ast_fft_tile_supported(F32, n))
 
 
-def paint_power_1d(pos, mass, nmesh, boxsize, window="cic", scale=1.0, binning=None):
+def paint_power_1d(pos, mass, nmesh, boxsize, window="cic", scale=1.0, binning=None, defer_fold64=False):
     """``pm.paint(...)`` followed by ``FFTPower(ArrayMesh(grid), mode="1d")`` (stats_subfind.py:130-150)
     as one pipeline: where the fused fp32 path applies, the paint's halo fold rides on the FFT's z pass."""
     n = int(nmesh)
@@ -459,6 +463,11 @@ def paint_power_1d(pos, mass, nmesh, boxsize, window="cic", scale=1.0, binning=N
         grid, halo = paint(pos, mass, n, boxsize, window, scale=scale, method="tiled", defer_fold=True,
                            offset="mean")
         return finish_power(*power_sums_fused(grid, boxsize, halo=halo, binning=binning))
+    fast64 = pos.dtype == torch.float64 and n % 32 == 0 and pos.shape[0] >= 65536 \
+        and pos.shape[0] * 2048 >= 64 * n ** 3 and bool(_lib.lib().ast_fft64_supported(n))
+    if fast64 and defer_fold64:               # float64 with the halo fold inside the z pass: measured slower at 1024^3
+        grid, halo = paint(pos, mass, n, boxsize, window, scale=scale, method="tiled", defer_fold=True)      # (27.0 vs 26.4 ms:
+        return finish_power(*power_sums_fused64(grid, boxsize, halo=halo, binning=binning))                 # one row per workgroup)
     return fftpower_1d(paint(pos, mass, n, boxsize, window, scale=scale), boxsize, binning=binning)
 
 

@@ -403,6 +403,10 @@ int ast_fft64_supported(size_t n);
 size_t ast_fft64_power_scratch_bytes(size_t n);
 int ast_fft64_power_3d(const double* grid_d, void* scratch_d, size_t scratch_bytes, size_t n, double boxsize, int binning,
                        double* psum_d, void* stream);
+/* the same for a grid left by ast_paint_tiled(AST_PAINT_OVERWRITE | AST_PAINT_DEFER_FOLD): halo_rec_d
+ * (ast_paint_tiled_halo) is folded into the border rows as the z pass loads them */
+int ast_fft64_power_3d_halo(const double* grid_d, const double* halo_rec_d, int window, void* scratch_d, size_t scratch_bytes,
+                            size_t n, double boxsize, int binning, double* psum_d, void* stream);
 
 /* Column transforms of the zero-padded lens convolution (lensing_funcs.c:85-115 + fft_convolve.c:60-90), double,
  * hand-written two-pass (four-step) passes over data_d[len][pitch] complex that skip the half known to be zero.

@@ -274,3 +274,20 @@ def test_double_precision_fused_power_against_rocfft_route(hip, n):
         ref = offt.fftpower_1d(f, 1000.0)
         assert np.array_equal(res["modes"], ref["modes"])
         np.testing.assert_allclose(res["power"], ref["power"].real, rtol=1e-9)
+
+
+@pytest.mark.parametrize("window", ["cic", "tsc"])
+def test_double_precision_pipeline_with_deferred_fold(hip, window):
+    """paint(defer_fold) + ast_fft64_power_3d_halo (the halo records folded by the z pass) == paint + FFTPower on the
+    folded grid, for float64 particles (the reference's dtype)."""
+    from astrild_amd import device as dev
+    torch.cuda.set_device(0)
+    n, L = 256, 1000.0
+    pos = dev.synth_lattice_particles(n, n, L, seed=3, dtype=torch.float64)
+    got = dev.paint_power_1d(pos, None, n, L, window, defer_fold64=True)
+    plain = dev.paint_power_1d(pos, None, n, L, window)            # the default float64 route: folded grid, fused passes
+    np.testing.assert_allclose(plain["power"], got["power"], rtol=1e-12)
+    grid = dev.paint(pos, None, n, L, window)
+    ref = dev.fftpower_1d(grid, L, fused=False)
+    assert np.array_equal(got["modes"], ref["modes"])
+    np.testing.assert_allclose(got["power"], ref["power"], rtol=1e-10)
