@@ -546,9 +546,10 @@ col3_kernel(double2* __restrict__ data, const double2* __restrict__ twM, size_t 
                 const int row = al + RA * be + RA * RB * ga;
                 const int kx = row > N / 2 ? row - N : row;
                 const int m2 = kx * kx + m2yz;
-                int r = (int)sqrt((double)m2);
-                while (r * r > m2) --r;
-                while ((r + 1) * (r + 1) <= m2) ++r;
+                // floor(sqrt(m2)) for 0 <= m2 <= 3 * 512^2 from one raw v_sqrt_f32 of m2 + 1/2 (exact: fft_tile.hip's
+                // tile_isqrt, checked exhaustively by test_gpu_fft_tile) - a double square root plus two repair loops per
+                // mode were a third of this pass
+                int r = (int)__builtin_amdgcn_sqrtf((float)m2 + 0.5f);
                 if (kf_rule != 0.0 && r > 0 && r * r == m2) r = ast::float64_edge_norm(r, kx, ky, kz, kf_rule);
                 if (r >= 1 && r <= NB) atomicAdd(&shell[r], (x.x * x.x + x.y * x.y) * w);      // shell = r - 1
             }
