@@ -202,7 +202,7 @@ def main():
                                f"{args.window.upper()} paint on {n}^3 grid -> 3D R2C -> FFTPower 1d shells",
                    "ngrid": n, "nparticles": npart_total, "boxsize": L,
                    "order_note": "natural = lattice order, the spatially coherent best case for the scatter; the "
-                                 "shuffled (worst case) and TSC figures are in `legs`",
+                                 "shuffled (worst case), TSC and float64 figures are in `legs`",
                    "outside_timed_step": "FFT twiddles, per-shell geometry sums (sum w|k|, mode counts: data independent, "
                                          "cached per (N, L) like an FFT plan), workspace allocation",
                    "parallelism": "single GPU" if not use_slab else f"axis-0 slabs x{world}, RCCL all-to-all transpose"},
@@ -220,6 +220,13 @@ def main():
                 legs[name] = {"ms_per_step": round(lg["ms_per_step"], 3), "particles_per_s": npart_total / (lg["ms_per_step"] * 1e-3),
                               "end_to_end_frac": lg["roofline"]["end_to_end"]["frac"],
                               "stages": {k: {"ms": v["ms"], "frac": v["frac"]} for k, v in lg["roofline"]["stages"].items()}}
+            if args.dtype == "f32":
+                # the reference's own dtype: float64 particles and grid through the double-precision passes
+                lg = power_leg(dev, n, npside, L, "cic", "natural", "f64", args.method, steps=3, warmup=1)
+                legs["natural_cic_f64"] = {"ms_per_step": round(lg["ms_per_step"], 3),
+                                           "particles_per_s": npart_total / (lg["ms_per_step"] * 1e-3),
+                                           "end_to_end_frac": lg["roofline"]["end_to_end"]["frac"], "dtype": "f64",
+                                           "stages": {k: {"ms": v["ms"], "frac": v["frac"]} for k, v in lg["roofline"]["stages"].items()}}
             out["legs"] = legs
         if args.cpu_sample:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.window, L)
