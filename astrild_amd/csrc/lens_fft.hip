@@ -238,28 +238,38 @@ lens_rows_forward_kernel(const double* __restrict__ kappa, size_t in_pitch, doub
     const size_t row = blockIdx.x;
     const double2* z = reinterpret_cast<const double2*>(kappa + row * in_pitch);        // packed pairs: M / 2 (ZPAD) or M
     double2 va[RA], vc[RC];
+    // the halo sources of this row first (integer work, the same for the whole workgroup: one row per workgroup), so
+    // that the row's loads and the records' loads are all in flight together
+    const double* src[3] = {nullptr, nullptr, nullptr};
+    int ns = 0;
+    if (FOLDW != 0) {
+        constexpr int W = FOLDW != 0 ? FOLDW : 2;
+        const int ng = 2 * M;
+        ns = ast::halo_sources<double, W>(rec, (int)(row / ng), (int)(row % ng), ng, ng / ast::TX, ng / ast::TY, src);
+    }
     if (t < G::T1) {
 #pragma unroll
         for (int a = 0; a < RA; ++a) va[a] = (!ZPAD || a < RA / 2) ? z[G::T1 * a + t] : make_double2(0.0, 0.0);
-        if (FOLDW != 0) {
-            constexpr int W = FOLDW != 0 ? FOLDW : 2;
-            const int ng = 2 * M;
-            const double* src[3];
-            const int ns = ast::halo_sources<double, W>(rec, (int)(row / ng), (int)(row % ng), ng, ng / ast::TX, ng / ast::TY, src);
-            if (ns > 0) {
-                double2 h[RA];
+        if (FOLDW != 0 && ns > 0) {
+            double2 h0[RA], h1[RA], h2[RA];
 #pragma unroll
-                for (int a = 0; a < RA; ++a) h[a] = reinterpret_cast<const double2*>(src[0])[G::T1 * a + t];
-                for (int k = 1; k < ns; ++k) {
+            for (int a = 0; a < RA; ++a) h0[a] = reinterpret_cast<const double2*>(src[0])[G::T1 * a + t];
+            if (ns > 1) {
 #pragma unroll
-                    for (int a = 0; a < RA; ++a) {
-                        const double2 q = reinterpret_cast<const double2*>(src[k])[G::T1 * a + t];
-                        h[a].x += q.x;
-                        h[a].y += q.y;
-                    }
-                }
+                for (int a = 0; a < RA; ++a) h1[a] = reinterpret_cast<const double2*>(src[1])[G::T1 * a + t];
+            }
+            if (ns > 2) {
 #pragma unroll
-                for (int a = 0; a < RA; ++a) { va[a].x += h[a].x; va[a].y += h[a].y; }
+                for (int a = 0; a < RA; ++a) h2[a] = reinterpret_cast<const double2*>(src[2])[G::T1 * a + t];
+            }
+            // records first, then onto the row: the fold kernel's order
+#pragma unroll
+            for (int a = 0; a < RA; ++a) {
+                double2 h = h0[a];
+                if (ns > 1) { h.x += h1[a].x; h.y += h1[a].y; }
+                if (ns > 2) { h.x += h2[a].x; h.y += h2[a].y; }
+                va[a].x += h.x;
+                va[a].y += h.y;
             }
         }
     }

@@ -452,7 +452,7 @@ def fused_power_supported(field):
         and bool(_lib.lib().ast_fft_tile_supported(F32, n))
 
 
-def paint_power_1d(pos, mass, nmesh, boxsize, window="cic", scale=1.0, binning=None, defer_fold64=False):
+def paint_power_1d(pos, mass, nmesh, boxsize, window="cic", scale=1.0, binning=None, defer_fold64=True):
     """``pm.paint(...)`` followed by ``FFTPower(ArrayMesh(grid), mode="1d")`` (stats_subfind.py:130-150)
     as one pipeline: where the fused fp32 path applies, the paint's halo fold rides on the FFT's z pass."""
     n = int(nmesh)
@@ -465,9 +465,9 @@ def paint_power_1d(pos, mass, nmesh, boxsize, window="cic", scale=1.0, binning=N
         return finish_power(*power_sums_fused(grid, boxsize, halo=halo, binning=binning))
     fast64 = pos.dtype == torch.float64 and n % 32 == 0 and pos.shape[0] >= 65536 \
         and pos.shape[0] * 2048 >= 64 * n ** 3 and bool(_lib.lib().ast_fft64_supported(n))
-    if fast64 and defer_fold64:               # float64 with the halo fold inside the z pass: measured slower at 1024^3
-        grid, halo = paint(pos, mass, n, boxsize, window, scale=scale, method="tiled", defer_fold=True)      # (27.0 vs 26.4 ms:
-        return finish_power(*power_sums_fused64(grid, boxsize, halo=halo, binning=binning))                 # one row per workgroup)
+    if fast64 and defer_fold64:               # float64: the halo fold inside the double z pass (26.2 vs 26.5 ms at 1024^3)
+        grid, halo = paint(pos, mass, n, boxsize, window, scale=scale, method="tiled", defer_fold=True)
+        return finish_power(*power_sums_fused64(grid, boxsize, halo=halo, binning=binning))
     return fftpower_1d(paint(pos, mass, n, boxsize, window, scale=scale), boxsize, binning=binning)
 
 

@@ -329,6 +329,11 @@ def power_leg(dev, n, npside, L, window, order, dtype, method, steps, warmup):
                                 accumulate=False, defer_fold=True, offset=mean, hint=hint)
             psum.zero_()
             return dev.power_sums_fused(grid, L, psum=psum, halo=halo)
+        if fused64 and method in ("auto", "tiled"):     # float64: the halo fold rides on the double z pass too
+            _, halo = dev.paint(pos, None, n, L, window, out=grid, method="tiled", check_dropped=False,
+                                accumulate=False, defer_fold=True, hint=hint)
+            psum.zero_()
+            return dev.power_sums_fused64(grid, L, psum=psum, halo=halo)
         dev.paint(pos, None, n, L, window, out=grid, method=method, check_dropped=False,
                   accumulate=False, hint=hint)       # overwrite mode: no zero-fill pass
         psum.zero_()

@@ -284,8 +284,8 @@ def test_double_precision_pipeline_with_deferred_fold(hip, window):
     torch.cuda.set_device(0)
     n, L = 256, 1000.0
     pos = dev.synth_lattice_particles(n, n, L, seed=3, dtype=torch.float64)
-    got = dev.paint_power_1d(pos, None, n, L, window, defer_fold64=True)
-    plain = dev.paint_power_1d(pos, None, n, L, window)            # the default float64 route: folded grid, fused passes
+    got = dev.paint_power_1d(pos, None, n, L, window)             # default: the halo fold inside the z pass
+    plain = dev.paint_power_1d(pos, None, n, L, window, defer_fold64=False)     # folded grid, then the fused passes
     np.testing.assert_allclose(plain["power"], got["power"], rtol=1e-12)
     grid = dev.paint(pos, None, n, L, window)
     ref = dev.fftpower_1d(grid, L, fused=False)
