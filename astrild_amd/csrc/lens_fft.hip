@@ -1,3 +1,7 @@
+// Double-precision transforms written by hand.  Part 1: column and row transforms of the zero-padded lens convolution;
+// part 2 (end of the file): the 3-D power spectrum of a float64 grid (ast_fft64_power_3d), which reuses part 1's row
+// kernel and three-stage scheme.
+//
 // Column transforms of the zero-padded lens convolution (kappa -> alpha / phi, lensing_funcs.c:85-115 with
 // fft_convolve.c:60-90) in double precision, hand-written because the half that is zero can be skipped and rocFFT's
 // strided 8192-point double transform moves its data at 1.1 TB/s (0.98 ms per pass over the 537 MB half spectrum).
