@@ -700,3 +700,28 @@ static int fft64_power_impl(const double* grid, const double* rec, int window, v
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
+
+// rfftn(grid) * scale of an (n, n, n) float64 grid into spec_d (n, n, n / 2 + 1) complex, contiguous (pmesh's r2c with
+// scale = 1 / n^3, power_spectrum_3d.py:189-195): the z rows and two strided passes above, in place on spec_d.
+extern "C" int ast_fft64_r2c_3d(const double* grid, void* spec_out, size_t n, double scale, void* stream) {
+    AST_CHECK_ARG(grid != nullptr && spec_out != nullptr && (const void*)grid != spec_out && ast_fft64_supported(n));
+    AST_CHECK_ARG(((uintptr_t)grid & 15) == 0 && ((uintptr_t)spec_out & 15) == 0);
+    hipStream_t s = ast::as_stream(stream);
+    const size_t nz = n / 2 + 1;
+    double2* spec = (double2*)spec_out;
+    const double2* twH = g_tw.get((int)(n / 2), s);
+    const double2* twN = g_tw.get((int)n, s);
+    if (!twH || !twN) { ast::set_error("ast_fft64_r2c_3d: twiddle table allocation failed"); return AST_ERR_HIP; }
+    int rc;
+    {
+        AST_PROF("fft64.rows_r2c", s);
+        if (n == 1024) rc = rows_forward_launch<8, 8, 8, false, 0>(grid, n * n, spec, nz, twH, twN, s, n, 1.0);
+        else if (n == 512) rc = rows_forward_launch<8, 8, 4, false, 0>(grid, n * n, spec, nz, twH, twN, s, n, 1.0);
+        else rc = rows_forward_launch<8, 4, 4, false, 0>(grid, n * n, spec, nz, twH, twN, s, n, 1.0);
+        if (rc != AST_OK) return rc;
+    }
+    AST_PROF("fft64.cols", s);
+    rc = col3_dispatch<false>(n, spec, twN, nz, nz, n, n * nz, 1.0, nullptr, 0.0, s);                      // y, per x plane
+    if (rc != AST_OK) return rc;
+    return col3_dispatch<false>(n, spec, twN, n * nz, nz, n, nz, scale, nullptr, 0.0, s);                 // x
+}

@@ -286,7 +286,7 @@ def synth_lattice_particles(npside, nmesh, boxsize, seed=20240601, sigma_cells=0
 def r2c(field, out=None, engine="auto"):
     """pmesh-normalised forward transform: ``rfftn(field) / Ng``.
 
-    engine "tile": the hand-written three-pass LDS FFT (fp32 cubes of side 256/512/1024);
+    engine "tile": the hand-written three-pass LDS FFT (fp32 and fp64 cubes of side 256/512/1024);
     "rocfft": the rocFFT 3D R2C plan; "auto": tile when supported."""
     assert field.is_cuda and field.dim() == 3 and field.is_contiguous()
     n0, n1, n2 = field.shape
@@ -295,8 +295,12 @@ def r2c(field, out=None, engine="auto"):
         out = torch.empty((n0, n1, n2 // 2 + 1), dtype=_TO_CPLX[field.dtype], device=field.device)
     L = _lib.lib()
     tile_ok = n0 == n1 == n2 and bool(L.ast_fft_tile_supported(code, n0))
+    tile64 = n0 == n1 == n2 and field.dtype == torch.float64 and bool(L.ast_fft64_supported(n0)) and out.is_contiguous()
+    if tile64 and engine in ("auto", "tile"):
+        check(L.ast_fft64_r2c_3d(ptr(field), ptr(out), n0, 1.0 / float(n0) ** 3, stream()), "ast_fft64_r2c_3d")
+        return out
     if engine == "tile" and not tile_ok:
-        raise _lib.AstrildHipError("tile FFT supports fp32 cubes of side 256, 512 or 1024")
+        raise _lib.AstrildHipError("tile FFT supports cubes of side 256, 512 or 1024")
     if tile_ok and engine in ("auto", "tile"):
         check(L.ast_fft_tile_r2c_3d(ptr(field), ptr(out), code, n0, 1.0 / float(n0) ** 3, stream()),
               "ast_fft_tile_r2c_3d")

@@ -403,6 +403,9 @@ int ast_fft64_supported(size_t n);
 size_t ast_fft64_power_scratch_bytes(size_t n);
 int ast_fft64_power_3d(const double* grid_d, void* scratch_d, size_t scratch_bytes, size_t n, double boxsize, int binning,
                        double* psum_d, void* stream);
+/* spec_d (n, n, n / 2 + 1) complex double, contiguous = rfftn(grid_d) * scale (pmesh's r2c with scale = 1 / n^3) through
+ * the same passes; grid_d is not modified */
+int ast_fft64_r2c_3d(const double* grid_d, void* spec_d, size_t n, double scale, void* stream);
 /* the same for a grid left by ast_paint_tiled(AST_PAINT_OVERWRITE | AST_PAINT_DEFER_FOLD): halo_rec_d
  * (ast_paint_tiled_halo) is folded into the border rows as the z pass loads them */
 int ast_fft64_power_3d_halo(const double* grid_d, const double* halo_rec_d, int window, void* scratch_d, size_t scratch_bytes,
