@@ -1,6 +1,7 @@
 // Shared plumbing for libastrild_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdint>
@@ -50,13 +51,17 @@ namespace ast {
 // "has this process already raised the dynamic-LDS limit of this kernel on the CURRENT device?" - the attribute is
 // per device, so the flag is too (one process per GPU is the rule, but nothing forbids a second device).
 struct PerDeviceOnce {
-    bool done[64] = {};
-    bool need() {
+    std::atomic<bool> done[64] = {};
+    // need(): the attribute calls have to be made (again: they are idempotent, so two racing first callers both
+    // making them is harmless); mark() after they have SUCCEEDED.
+    bool need() const {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
-        if (done[dev]) return false;
-        done[dev] = true;
-        return true;
+        return !done[dev].load(std::memory_order_acquire);
+    }
+    void mark() {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) done[dev].store(true, std::memory_order_release);
     }
 };
 }  // namespace ast

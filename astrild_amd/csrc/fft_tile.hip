@@ -896,6 +896,7 @@ int launch_c2c(float2* data, const float2* tw, size_t elem_stride, size_t ncols,
     if (attr_once.need()) {
         AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&strided_c2c_kernel<R1, R2, C, POWER>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_once.mark();
     }
     const size_t tiles = (ncols + C - 1) / C;
     AST_CHECK_ARG(tiles * batch < 0x7fffffffull);
@@ -915,6 +916,7 @@ int launch_c2c_inv(float2* data, const float2* tw, size_t elem_stride, size_t nc
     if (attr_once.need()) {
         AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&strided_c2c_kernel<R1, R2, C, false, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_once.mark();
     }
     const size_t tiles = (ncols + C - 1) / C;
     AST_CHECK_ARG(tiles * batch < 0x7fffffffull);
@@ -933,6 +935,7 @@ int launch_c2c_pack(float2* data, const float2* tw, size_t elem_stride, size_t n
     if (attr_once.need()) {
         AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&strided_c2c_kernel<R1, R2, C, false, false, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_once.mark();
     }
     const size_t tiles = (ncols + C - 1) / C;
     AST_CHECK_ARG(tiles * batch < 0x7fffffffull);
@@ -968,6 +971,7 @@ int launch_r2c(const float* in, float2* out, const float2* tw, size_t nrows, siz
     if (attr_once.need()) {
         AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rows_r2c_kernel<R1, R2, C, FOLDW, LOWK>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_once.mark();
     }
     const size_t blocks = (nrows + C - 1) / C;
     AST_CHECK_ARG(blocks < 0x7fffffffull);
@@ -987,6 +991,7 @@ int launch_c2r(const float2* in, float* out, const float2* tw, size_t nrows, siz
     if (attr_once.need()) {
         AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rows_c2r_kernel<R1, R2, C>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_once.mark();
     }
     const size_t blocks = (nrows + C - 1) / C;
     AST_CHECK_ARG(blocks < 0x7fffffffull);

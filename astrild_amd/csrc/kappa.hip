@@ -585,9 +585,11 @@ extern "C" int ast_gaussian_smooth(ast_smooth_plan* p, double* img, double sigma
         gauss_periodic_x_kernel<<<dim3((unsigned)((npix + 1023) / 1024), (unsigned)npix), 256, 0, s>>>(img, p->tmp, npix, p->w_d, radius);
         const size_t ylds = (size_t)(64 + 2 * radius) * 32 * sizeof(double);
         static ast::PerDeviceOnce y_once;
-        if (y_once.need())
+        if (y_once.need()) {
             AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gauss_periodic_y_kernel),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)((64 + 2 * GP_RMAX) * 32 * sizeof(double))));
+            y_once.mark();
+        }
         gauss_periodic_y_kernel<<<dim3((unsigned)((npix + 31) / 32), (unsigned)((npix + 63) / 64)), 256, ylds, s>>>(p->tmp, img, npix, p->w_d, radius);
         AST_CHECK_LAUNCH();
         return AST_OK;

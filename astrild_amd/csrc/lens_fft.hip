@@ -159,7 +159,9 @@ struct TwCache {
         double2* d = nullptr;
         if (hipMalloc(&d, (size_t)len * sizeof(double2)) != hipSuccess) return nullptr;
         tw_table_kernel<<<(len + 255) / 256, 256, 0, s>>>(d, len);
-        if (hipGetLastError() != hipSuccess) return nullptr;
+        // once per (device, length): the table must be complete before ANY stream reads it (the pointer is handed
+        // to later callers without an event)
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipFree(d); return nullptr; }
         tabs.push_back({dev, len, d});
         return d;
     }
@@ -446,9 +448,11 @@ int rows_forward_launch(const double* kappa, size_t nrows, double2* spec, size_t
     using G = RowGeo<RA, RB, RC>;
     const size_t lds = (size_t)(G::M + G::M / 8) * sizeof(double2);
     static ast::PerDeviceOnce once;
-    if (once.need() && lds > 48 * 1024)
+    if (once.need() && lds > 48 * 1024) {
         AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lens_rows_forward_kernel<RA, RB, RC, ZPAD, FOLDW>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        once.mark();
+    }
     AST_CHECK_ARG(nrows < 0x7fffffffull);
     lens_rows_forward_kernel<RA, RB, RC, ZPAD, FOLDW><<<(unsigned)nrows, G::NT, lds, s>>>(kappa, in_pitch ? in_pitch : (size_t)G::M, spec, pitch,
                                                                                         twM, twL, scale, rec);
@@ -461,9 +465,11 @@ int rows_inverse_launch(const double2* spec, size_t pitch, size_t nc, double sca
     using G = RowGeo<RA, RB, RC>;
     const size_t lds = (size_t)(G::M + G::M / 8) * sizeof(double2);
     static ast::PerDeviceOnce once;
-    if (once.need() && lds > 48 * 1024)
+    if (once.need() && lds > 48 * 1024) {
         AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lens_rows_inverse_kernel<RA, RB, RC>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        once.mark();
+    }
     lens_rows_inverse_kernel<RA, RB, RC><<<(unsigned)nc, G::NT, lds, s>>>(spec, pitch, (int)nc, scale, out, twM, twL);
     AST_CHECK_LAUNCH();
     return AST_OK;
@@ -609,9 +615,11 @@ int col3_launch(double2* data, const double2* tw, size_t elem_stride, size_t nco
     constexpr int C = col3_columns(G::M), LINE = G::M + G::M / 8;
     const size_t lds = (size_t)C * LINE * sizeof(double2) + (POWER ? (G::M / 2) * sizeof(double) : 0);
     static ast::PerDeviceOnce once;
-    if (once.need())
+    if (once.need()) {
         AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&col3_kernel<RA, RB, RC, C, POWER>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        once.mark();
+    }
     const size_t tiles = (ncols + C - 1) / C;
     AST_CHECK_ARG(tiles * batch < 0x7fffffffull);
     col3_kernel<RA, RB, RC, C, POWER><<<(unsigned)(tiles * batch), C * G::NT, lds, s>>>(data, tw, elem_stride, ncols, batch_stride,

@@ -29,8 +29,11 @@
 // (AST_PAINT_TWO_PASS) is kept for strongly clustered data.
 #include "ast_common.h"
 #include "paint_tile_geom.h"
+#include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 namespace {
 
@@ -392,13 +395,21 @@ __device__ __noinline__ void place_group_slow(uint32_t key, uint32_t a, uint32_t
 // (its global atomics are issued by independent threads, all in flight together).
 constexpr uint32_t LST_CAP = 768;      // strays parked in LDS per interval (the bench input has ~330)
 
+// One late particle (AST_PAINT_XSORTED: its tile row has been handed to the column walk already) goes to the overflow
+// list.  NOT inlined, for the reason given at place_run_slow.
+__device__ __noinline__ void place_late_slow(uint32_t p, uint32_t* __restrict__ ovf, unsigned long long* __restrict__ ovf_count) {
+    ovf[atomicAdd(ovf_count, 1ull)] = p;
+}
+
+// The kernel handles the particles [p_begin, p_end) (p_begin a multiple of 32: the records' windows are aligned in
+// GLOBAL particle ids).  Tiles closed_lo <= id < closed_lo + closed_n are closed: their particles go to the overflow list.
 template <typename T, int W, bool PLAINX>
 __global__ void __launch_bounds__(256)
-tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t np, TileGeom g,
+tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t p_begin, size_t np, TileGeom g,
                   unsigned long long* __restrict__ fill64, GroupRec* __restrict__ recs, uint32_t rcap,
                   T* __restrict__ strays, uint32_t scap, uint32_t* __restrict__ ovf,
                   unsigned long long* __restrict__ ovf_count, uint32_t* __restrict__ col_flags,
-                  unsigned long long* dropped) {
+                  unsigned long long* dropped, uint32_t closed_lo, uint32_t closed_n) {
     __shared__ uint32_t skey[AGG_SLOTS], srun[AGG_SLOTS], sstray[AGG_SLOTS], sroom_run[AGG_SLOTS], sroom_stray[AGG_SLOTS];
     __shared__ unsigned long long sdst_run[AGG_SLOTS], sdst_stray[AGG_SLOTS];
     // group records: first, mask, tile key (phase 2 turns the key into slot << 16 | offset, DST_NONE = placed already)
@@ -417,7 +428,7 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
     __syncthreads();
     const size_t per_trip = 256 * IDX_UNROLL;
     const size_t per_interval = per_trip * AGG_TRIPS;
-    const size_t nintervals = (np + per_interval - 1) / per_interval;
+    const size_t nintervals = (np - p_begin + per_interval - 1) / per_interval;      // np: END of the range
     unsigned long long ndrop = 0;
     auto fetch = [&](size_t pbase, T (&x)[IDX_UNROLL], T (&y)[IDX_UNROLL], T (&z)[IDX_UNROLL]) {
 #pragma unroll
@@ -439,9 +450,9 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
     };
     static_assert(AGG_TRIPS % 2 == 0, "two register sets");
     T xa[IDX_UNROLL], ya[IDX_UNROLL], za[IDX_UNROLL], xb[IDX_UNROLL], yb[IDX_UNROLL], zb[IDX_UNROLL];
-    if ((size_t)blockIdx.x < nintervals) fetch((size_t)blockIdx.x * per_interval, xa, ya, za);
+    if ((size_t)blockIdx.x < nintervals) fetch(p_begin + (size_t)blockIdx.x * per_interval, xa, ya, za);
     for (size_t interval = blockIdx.x; interval < nintervals; interval += gridDim.x) {
-        const size_t p0 = interval * per_interval;
+        const size_t p0 = p_begin + interval * per_interval;
         const bool full = p0 + per_interval <= np;
         auto process = [&](int trip, const T (&x)[IDX_UNROLL], const T (&y)[IDX_UNROLL], const T (&z)[IDX_UNROLL]) {
 #pragma unroll
@@ -450,8 +461,12 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
                 const bool valid = full || p < np;
                 uint32_t key = tile_of<T, W, PLAINX>(x[u], y[u], z[u], g, col_flags);
                 if (!valid) key = 0xffffffffu;
+                if (!PLAINX && valid && key == 0xffffffffu) ++ndrop;
+                if (key - closed_lo < closed_n) {                   // (closed_n = 0: never; the dead key is far above any tile id)
+                    place_late_slow((uint32_t)p, ovf, ovf_count);
+                    key = 0xffffffffu;
+                }
                 const bool live = key != 0xffffffffu;
-                if (!PLAINX && valid && !live) ++ndrop;
                 // up to GROUP_ITERS tiles per 32-lane window get a group record.  The candidates are the tiles of
                 // three fixed lanes of the window (two v_readlane each, no cross-lane search): in a spatially
                 // coherent input nearly every window is one tile plus a few strays, and the first candidate
@@ -514,7 +529,7 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
         for (int trip = 0; trip < AGG_TRIPS; trip += 2) {
             fetch(p0 + (size_t)(trip + 1) * per_trip, xb, yb, zb);
             process(trip, xa, ya, za);
-            fetch(trip + 2 < AGG_TRIPS ? p0 + (size_t)(trip + 2) * per_trip : (interval + gridDim.x) * per_interval, xa, ya, za);
+            fetch(trip + 2 < AGG_TRIPS ? p0 + (size_t)(trip + 2) * per_trip : p_begin + (interval + gridDim.x) * per_interval, xa, ya, za);
             process(trip + 1, xb, yb, zb);
         }
         __syncthreads();
@@ -1041,6 +1056,42 @@ tile_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileG
 // (The list pointers are separate __restrict__ kernel arguments on purpose: read through a struct member the
 // per-tile counts become VECTOR loads followed by s_waitcnt vmcnt(0) - which also waits for every prefetched
 // position - instead of scalar loads.)
+// quantum of the fixed-point tiles (see column_deposit_kernel): 2 * cmax terms of at most mass_bound * |scale| each
+// stay below 2^SUM_BITS, every term below 2^50
+template <bool RAW>
+__device__ inline double paint_inv_quantum(uint32_t cmax, double mass_bound, double scale) {
+    constexpr int SUM_BITS = RAW ? 47 : 62;
+    const int bits = 33 - __clz((int)min(cmax, 0x3fffffffu));            // 2 * cmax < 2^bits
+    const double vmax = mass_bound * fabs(scale) > 0.0 ? mass_bound * fabs(scale) : 1.0;
+    return exp2((double)min(50, SUM_BITS - bits)) / vmax;
+}
+
+// where the z line of LDS column (a, b) of tile column `col` goes (see column_deposit_kernel)
+template <typename T, int W>
+__device__ inline unsigned long long column_line_dest(int a, int b, int col, int ox, int oy, const TileGeom& g, T* grid, T* rec) {
+    constexpr int LO = Window<W>::LO;
+    using RM = RingMap<W>;
+    const int px = ox + a - LO;
+    if (RM::owned(a, TX) && RM::owned(b, TY))
+        return px < g.nx_alloc ? ((unsigned long long)(grid + ((size_t)px * g.n + oy + b - LO) * g.n) |
+                                  (px >= g.off_lo && px < g.off_hi ? 2ull : 0ull)) : 0ull;
+    unsigned long long d = (unsigned long long)(rec + ((size_t)col * RM::COUNT + RM::cell(a, b)) * g.n);
+    if (g.nx_alloc != g.n && (px < 0 || px >= g.nx_alloc)) d |= 1ull;
+    return d;
+}
+
+// a fixed-point cell sum -> grid value: (sum * q - sub) rounded once.  RAW (fp32 grids): the low 48 bits hold the sum + BIAS
+template <typename T>
+__device__ inline T fixed_to_value(unsigned long long raw, double q, double sub, bool& any) {
+    if (sizeof(T) == 4) {
+        const unsigned long long low = raw & 0x0000ffffffffffffull;
+        any = low != (1ull << 47);
+        return (T)((__longlong_as_double((long long)(low | 0x4330000000000000ull)) - 4644337115725824.0) * q - sub);      // 2^52 + 2^47
+    }
+    any = raw != 0ull;
+    return (T)((double)(long long)raw * q - sub);
+}
+
 struct WalkCaps {
     uint32_t rcap, scap, cap;
     size_t np;
@@ -1053,10 +1104,9 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
                       const uint32_t* __restrict__ wl_tile_count, const unsigned long long* __restrict__ wl_fill64,
                       const GroupRec* __restrict__ wl_recs, const T* __restrict__ wl_strays, WalkCaps wl, double mass_bound,
                       const uint32_t* __restrict__ col_flags, T* __restrict__ grid, T* __restrict__ rec,
-                      double offset, unsigned long long* dropped) {
+                      double offset, unsigned long long* dropped, int col0, int nseg, unsigned long long* __restrict__ zrec) {
     constexpr int LX = TX + W - 1, LY = TY + W - 1, LZ = TZ + W - 1;
     constexpr int LO = Window<W>::LO, H = W - 1;
-    using RM = RingMap<W>;
     // The LDS tile accumulates in 64-bit FIXED POINT: ds_add_u64 retires ~1.9x the lanes per
     // clock of ds_add_f64 on scattered addresses (scripts/micro/lds_atomics.hip), integer sums
     // do not depend on arrival order (the whole paint is bit-reproducible), and the quantum
@@ -1069,13 +1119,21 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     //    48 bits non-negative, and the flush turns them into a double by or-ing them under the
     //    exponent of 2^52 (one v_and_or_b32) and subtracting 2^52 + 2^47.
     constexpr bool RAW = sizeof(T) == 4;
-    constexpr int SUM_BITS = RAW ? 47 : 62;
     constexpr unsigned long long BIAS = RAW ? (1ull << 47) : 0ull;
     // The z planes of the tile form a RING of LZ slots: local plane c of tile tz lives in slot
     // (c + tz * TZ) mod LZ, so the W-1 halo planes carried from one tile to the next stay where
     // they are and the flush only has to re-arm the TZ slots it stored.
     __shared__ unsigned long long tile[LX * LY * LZ];        // ((a * LY + b) * LZ + slot), slot fastest
-    const int col = blockIdx.x;
+    // the launch walks the columns col0 .. col0 + gridDim.x - 1 (mod the column count: the x-sorted pipeline's last
+    // launch wraps around to the tile rows it held back)
+    // nseg > 1: the column is cut into nseg z-segments of ntz / nseg tiles, one workgroup each (more, shorter
+    // workgroups: thin launches of the x-sorted pipeline and thin slab buffers still fill the chip).  Where two
+    // segments meet, the lower one's top halo planes and the upper one's first planes leave as EXACT sums
+    // (zrec) and z_seam_kernel writes their one correctly rounded total.
+    const int seg = nseg > 1 ? (int)(blockIdx.x % (unsigned)nseg) : 0;
+    int col = col0 + (int)(nseg > 1 ? blockIdx.x / (unsigned)nseg : blockIdx.x);
+    col = col >= g.ntx * g.nty ? col - g.ntx * g.nty : col;
+    const int nsteps = g.ntz / nseg;                            // tiles this workgroup walks
     DSTAMP_DECL;
     const int ty = col % g.nty, tx = col / g.nty;
     const int ox = tx * TX, oy = ty * TY;
@@ -1090,19 +1148,8 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     __shared__ unsigned long long dest[LX * LY];
     // exact sums of the first H planes the walk flushes: the periodic wrap at the end of the walk lands on them
     __shared__ unsigned long long first_planes[LX * LY * H];
-    for (int ab = threadIdx.x; ab < LX * LY; ab += 256) {
-        const int b = ab % LY, a = ab / LY;
-        const int px = ox + a - LO;
-        unsigned long long d;
-        if (RM::owned(a, TX) && RM::owned(b, TY)) {
-            d = px < g.nx_alloc ? ((unsigned long long)(grid + ((size_t)px * g.n + oy + b - LO) * g.n) |
-                                   (px >= g.off_lo && px < g.off_hi ? 2ull : 0ull)) : 0ull;
-        } else {
-            d = (unsigned long long)(rec + ((size_t)col * RM::COUNT + RM::cell(a, b)) * g.n);
-            if (!x_periodic && (px < 0 || px >= g.nx_alloc)) d |= 1ull;
-        }
-        dest[ab] = d;
-    }
+    for (int ab = threadIdx.x; ab < LX * LY; ab += 256)
+        dest[ab] = column_line_dest<T, W>(ab / LY, ab % LY, col, ox, oy, g, grid, rec);
     // quantum: a cell collects at most the particles of two consecutive tiles, each contribution
     // is <= mass_bound * |scale|; keep every sum below 2^SUM_BITS and every term below 2^50
     // (FMT 1: the bound is the segments' capacity, the same for every column and independent of how the
@@ -1113,9 +1160,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     } else {
         cmax = (uint32_t)min(5ull * wl.cap, 0x3fffffffull);      // 32 * rcap + the largest scap = 5 * cap
     }
-    const int bits = 33 - __clz((int)min(cmax, 0x3fffffffu));            // 2 * cmax < 2^bits
-    const double vmax = mass_bound * fabs(scale) > 0.0 ? mass_bound * fabs(scale) : 1.0;
-    const double invq = exp2((double)min(50, SUM_BITS - bits)) / vmax;
+    const double invq = paint_inv_quantum<RAW>(cmax, mass_bound, scale);
     const double q = 1.0 / invq;
     // tile-relative cell lookup (paint_window.h locate_rel); x also carries the slab offset
     int orx = g.x_start + ox;
@@ -1137,18 +1182,19 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     // A tile's work is a list of ENTRIES.  FMT 0: particle ids, one per thread slot.  FMT 1: 32-lane entries, one
     // per half wave - the tile's nrec group records followed by ceil(nst / 32) blocks of 32 consecutive stray
     // copies, so records and strays share batches (72 entries, i.e. 4.5 batches, per tile of the bench input).
-    // off: FMT 0 first id of the tile's list; FMT 1 the tile id.  tz == g.ntz: past the end
+    // off: FMT 0 first id of the tile's list; FMT 1 the tile id.  tz == nsteps: past the end
     using list_off_t = std::conditional_t<FMT != 0, uint32_t, size_t>;
     struct Batch { int tz; uint32_t i0, cnt; list_off_t off; uint32_t nrec, nst; };
     // The walk starts at a column-dependent tile and wraps around the periodic z edge (the ring
     // does not care), so concurrently running columns are at different z: in lockstep all of
     // them would store to / gather from addresses a large power of two apart.
-    const int tz0 = ablate & 512 ? 0 : (int)(((unsigned)col * 2654435761u >> 16) % (unsigned)g.ntz);
+    int tz0 = (ablate & 512 ? 0 : (int)(((unsigned)col * 2654435761u >> 16) % (unsigned)g.ntz)) + seg * nsteps;
+    tz0 = tz0 >= g.ntz ? tz0 - g.ntz : tz0;                     // first tile of this workgroup's walk
     auto phys = [&](int step) { const int t = tz0 + step; return t >= g.ntz ? t - g.ntz : t; };   // step -> tile
     constexpr uint32_t BATCH = FMT != 0 ? 8u * U : 256u * U;      // entries per batch
     auto next_batch = [&](Batch bt) -> Batch {
-        if (bt.tz >= 0 && bt.tz < g.ntz && bt.i0 + BATCH < bt.cnt) { bt.i0 += BATCH; return bt; }
-        for (int nt = bt.tz + 1; nt < g.ntz; ++nt) {
+        if (bt.tz >= 0 && bt.tz < nsteps && bt.i0 + BATCH < bt.cnt) { bt.i0 += BATCH; return bt; }
+        for (int nt = bt.tz + 1; nt < nsteps; ++nt) {
             const uint32_t t = (uint32_t)((tx * g.nty + ty) * g.ntz + phys(nt));
             if (FMT == 0) {
                 const uint32_t cnt = wl_tile_count[t];
@@ -1159,7 +1205,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
                 if (nrec + nst) return Batch{nt, 0u, nrec + (nst + 31u) / 32u, (list_off_t)t, nrec, nst};
             }
         }
-        return Batch{g.ntz, 0u, bt.cnt, bt.off, bt.nrec, bt.nst};           // keeps a loadable span
+        return Batch{nsteps, 0u, bt.cnt, bt.off, bt.nrec, bt.nst};           // keeps a loadable span
     };
     // stage 1 of a batch: LOAD ONLY - the id (FMT 0) or the group record (FMT 1) of each of this thread's U
     // slots.  Nothing may be computed from the loaded values here: that would wait for them on the spot, and with
@@ -1295,7 +1341,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     T pA[3 * U], mA[U], pB[3 * U], mB[U];
     GroupRec iX[U], iY[U];
     uint32_t aA = 0, aB = 0;                // occupied slots of the position sets
-    if (cur_tz < g.ntz) {                   // uniform: the column holds particles
+    if (cur_tz < nsteps) {                  // uniform: the column holds particles
         load_idx(nxt, iY);
         load_pos(nxt, iY, aA, pA, mA);
         nxt = next_batch(nxt);
@@ -1375,7 +1421,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     DSTAMP(0);
     for (;;) {
         flush_until(cur_tz);
-        if (cur_tz >= g.ntz) break;
+        if (cur_tz >= nsteps) break;
         oz = phys(cur_tz) * TZ;
         {
             DSTAMP(1);
@@ -1390,7 +1436,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
             nxt = nn;
         }
         flush_until(cur_tz);
-        if (cur_tz >= g.ntz) break;
+        if (cur_tz >= nsteps) break;
         oz = phys(cur_tz) * TZ;
         {
             DSTAMP(1);
@@ -1416,24 +1462,65 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     // and the barrier order the two.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
+    if (nseg > 1) {
+        // the seam is another workgroup's: both parts leave as exact sums, [column][segment][first | top][ab][k]
+        unsigned long long* const zf = zrec + ((size_t)col * nseg + seg) * 2 * (LX * LY * H);
+        for (int i = threadIdx.x; i < LX * LY * H; i += 256) {
+            const int k = i % H, ab = i / H;
+            int sl = k + sh;
+            sl = sl >= LZ ? sl - LZ : sl;
+            zf[i] = first_planes[i];
+            zf[LX * LY * H + i] = tile[ab * LZ + sl];
+        }
+        if (dropped && ndrop) atomicAdd(dropped, ndrop);
+        return;
+    }
     for (int i = threadIdx.x; i < LX * LY * H; i += 256) {
         const int k = i % H, ab = i / H;
         int sl = k + sh;
         sl = sl >= LZ ? sl - LZ : sl;
         const unsigned long long raw = first_planes[i] + tile[ab * LZ + sl] - BIAS;
         const unsigned long long d = dest[ab];
-        const double sub = (d & 2ull) ? offset : 0.0;
-        T v;
         bool any;
-        if (RAW) {
-            const unsigned long long low = raw & 0x0000ffffffffffffull;
-            any = low != BIAS;
-            v = (T)((__longlong_as_double((long long)(low | 0x4330000000000000ull)) - 4644337115725824.0) * q - sub);
-        } else {
-            any = raw != 0ull;
-            v = (T)((double)(long long)raw * q - sub);
-        }
+        const T v = fixed_to_value<T>(raw, q, (d & 2ull) ? offset : 0.0, any);
         if (d == 0ull) { ndrop += any; continue; }      // owned plane the buffer does not hold
+        typedef __attribute__((address_space(1))) T gT;
+        ((gT*)(d & ~3ull))[ast::wrap1(tz0 * TZ + k - LO, g.n)] = v;
+    }
+    if (dropped && ndrop) atomicAdd(dropped, ndrop);
+}
+
+// nseg > 1: the seams between the z-segments of a column.  Segment s starts at tile (t0(col) + s * ntz / nseg) mod ntz;
+// its first H planes are the sum of what it deposited there itself (first) and the top halo of the segment below
+// (top): both exact, so the cell gets the one correctly rounded total - the same value the unsegmented walk stores.
+template <typename T, int W>
+__global__ void __launch_bounds__(256)
+z_seam_kernel(const unsigned long long* __restrict__ zrec, TileGeom g, double scale, uint32_t cmax, double mass_bound,
+              T* __restrict__ grid, T* __restrict__ rec, double offset, unsigned long long* dropped, int col0, int nseg) {
+    constexpr int LX = TX + W - 1, LY = TY + W - 1;
+    constexpr int LO = Window<W>::LO, H = W - 1;
+    constexpr bool RAW = sizeof(T) == 4;
+    constexpr unsigned long long BIAS = RAW ? (1ull << 47) : 0ull;
+    int col = col0 + (int)blockIdx.x;
+    col = col >= g.ntx * g.nty ? col - g.ntx * g.nty : col;
+    const int ty = col % g.nty, tx = col / g.nty;
+    const int ox = tx * TX, oy = ty * TY;
+    const int nsteps = g.ntz / nseg;
+    const int t00 = (int)(((unsigned)col * 2654435761u >> 16) % (unsigned)g.ntz);
+    const double q = 1.0 / paint_inv_quantum<RAW>(cmax, mass_bound, scale);
+    unsigned long long ndrop = 0;
+    for (int i = threadIdx.x; i < nseg * LX * LY * H; i += 256) {
+        const int seg = i / (LX * LY * H), j = i % (LX * LY * H);
+        const int k = j % H, ab = j / H;
+        const int below = seg == 0 ? nseg - 1 : seg - 1;
+        const unsigned long long raw = zrec[((size_t)col * nseg + seg) * 2 * (LX * LY * H) + j] +
+                                       zrec[((size_t)col * nseg + below) * 2 * (LX * LY * H) + LX * LY * H + j] - BIAS;
+        const unsigned long long d = column_line_dest<T, W>(ab / LY, ab % LY, col, ox, oy, g, grid, rec);
+        bool any;
+        const T v = fixed_to_value<T>(raw, q, (d & 2ull) ? offset : 0.0, any);
+        if (d == 0ull) { ndrop += any; continue; }      // owned plane the buffer does not hold
+        int tz0 = t00 + seg * nsteps;
+        tz0 = tz0 >= g.ntz ? tz0 - g.ntz : tz0;
         typedef __attribute__((address_space(1))) T gT;
         ((gT*)(d & ~3ull))[ast::wrap1(tz0 * TZ + k - LO, g.n)] = v;
     }
@@ -1530,6 +1617,77 @@ column_fold_kernel(const T* __restrict__ rec, TileGeom g, T* __restrict__ grid) 
     }
 }
 
+// Second stream of the x-sorted pipeline and the events that order it against the caller's stream (per device, made once).
+struct SidePipe {
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ev;
+};
+SidePipe* side_pipe(int nevents) {
+    static std::mutex mu;
+    static SidePipe pipes[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    SidePipe& p = pipes[dev];
+    if (!p.side && hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking) != hipSuccess) { p.side = nullptr; return nullptr; }
+    while ((int)p.ev.size() < nevents) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        p.ev.push_back(e);
+    }
+    return &p;
+}
+
+// How the single-pass overwrite paint is cut up: z-segments per column (walk workgroups = columns x nseg) and, with
+// AST_PAINT_XSORTED, chunks of `chunk_planes` buffer planes' worth of particles.  A function of the geometry, np and
+// the flags only (the workspace is sized from it); AST_PAINT_ZSEG / AST_PAINT_XCHUNK_MB / AST_PAINT_XMARGIN /
+// AST_PAINT_XSTREAMS override it for experiments.
+struct WalkPlan {
+    int nseg;            // z-segments per column (divides ntz)
+    int chunks;          // 1: not chunked
+    int chunk_planes;    // planes of particles per chunk
+    int margin_planes;   // a tile row is walked once the chunks cover its planes plus this many
+    int streams;         // 2: the walks run on a second stream beside the grouping of the next chunks
+};
+inline int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+inline int seg_count(int want, int ntz) {            // largest divisor of ntz that is a power of two <= want
+    int n = 1;
+    while (n * 2 <= want && ntz % (n * 2) == 0) n *= 2;
+    return n;
+}
+inline WalkPlan walk_plan(const TileGeom& g, size_t np, int flags, size_t esz) {
+    WalkPlan p{1, 1, g.nx_alloc, 0, 1};
+    if ((flags & AST_PAINT_TWO_PASS) || !(flags & AST_PAINT_OVERWRITE)) return p;
+    const unsigned ncols = (unsigned)(g.ntx * g.nty);
+    int rows_per_launch = g.ntx;
+    if ((flags & AST_PAINT_XSORTED) && !(flags & AST_PAINT_SCATTERED)) {
+        // Default: FOUR chunks, walks on a second stream beside the grouping of the next chunk (8.0 against 8.24 ms
+        // at 1024^3: both kernels are bound by the bytes they move, overlapping them buys little).  Measured and not
+        // adopted: chunks of 24-96 MB of positions (AST_PAINT_XCHUNK_MB), so that a chunk would still sit in the
+        // 256 MB Infinity Cache when the walk gathers it - launches of ~1000 workgroups are bound by their tails:
+        // 13.5-20.7 ms, grouping 5.8-10.8 and walks 6.0 where the two big launches take 3.7 + 4.7.
+        const double plane_bytes = (double)np * 3.0 * (double)esz / (double)g.nx_alloc;
+        const int mb = env_int("AST_PAINT_XCHUNK_MB", 0);
+        int cp = mb > 0 ? (int)(1048576.0 * (double)mb / plane_bytes + 0.5) : (g.nx_alloc + 3) / 4;
+        cp = std::max(2, std::min(cp, g.nx_alloc));
+        const int K = (g.nx_alloc + cp - 1) / cp;
+        if (K >= 2 && g.ntx >= 4 * K / 2 && np >= (size_t)K * 16 * 4096) {
+            p.chunks = K;
+            p.chunk_planes = cp;
+            p.margin_planes = env_int("AST_PAINT_XMARGIN", g.nx_alloc == g.n ? 4 : 12);
+            p.streams = env_int("AST_PAINT_XSTREAMS", mb > 0 ? 1 : 2);
+            rows_per_launch = std::max(1, cp / TX);
+        }
+    }
+    // enough workgroups per walk launch to fill 256 CUs a few times over
+    const unsigned per_launch = (unsigned)rows_per_launch * (unsigned)g.nty;
+    int want = 1;
+    if (p.chunks > 1) { while (per_launch * (unsigned)want < 2048u && want < 16) want *= 2; }
+    else if (ncols < 4096u) { while (ncols * (unsigned)want < 8192u && want < 8) want *= 2; }
+    p.nseg = seg_count(env_int("AST_PAINT_ZSEG", want), g.ntz);
+    return p;
+}
+
 struct Workspace {
     unsigned long long* ovf_count;   // single pass: particles in the overflow list
     uint32_t* col_flags;             // per tile column: 1 = holds a particle outside the box (general cell lookup)
@@ -1540,6 +1698,7 @@ struct Workspace {
     uint32_t* index;                 // particle indices, tile-major
     uint32_t* ovf;                   // single pass: indices that did not fit their tile's segment
     void* rec;                       // OVERWRITE flush: per-column halo records [column][ring cell][z]
+    unsigned long long* zrec;        // z-segmented walk: exact seam sums [column][segment][first | top][LX * LY * H]
     uint32_t cap;                    // single pass: index slots per tile
     // single pass + OVERWRITE: the compact lists of tile_group_kernel instead of `index`
     unsigned long long* fill64;      // per tile: group records requested << 32 | strays requested
@@ -1570,7 +1729,7 @@ inline uint32_t tile_capacity(size_t np, uint32_t ntiles) {
 // (with AST_PAINT_OVERWRITE) the compact group / stray lists.  A tile's group segment holds cap / MINPOP records
 // (enough for `cap` particles however they are grouped), its stray segment cap / 4 copies - or `cap` with
 // AST_PAINT_SCATTERED, for input without spatial order where every particle is a stray.
-Workspace carve(void* base, size_t np, uint32_t ntiles, uint32_t ncols, int flags, size_t esz, size_t rec_bytes) {
+Workspace carve(void* base, size_t np, uint32_t ntiles, uint32_t ncols, int flags, size_t esz, size_t rec_bytes, size_t zrec_bytes = 0) {
     const bool two_pass = (flags & AST_PAINT_TWO_PASS) != 0;
     const bool compact = !two_pass && (flags & AST_PAINT_OVERWRITE);
     Workspace w;
@@ -1599,6 +1758,7 @@ Workspace carve(void* base, size_t np, uint32_t ntiles, uint32_t ncols, int flag
     w.staging = take(w.tpb ? np * 4 * esz : 0);
     w.ovf = (uint32_t*)take(two_pass ? 0 : np * 4);
     w.rec = take(rec_bytes);
+    w.zrec = (unsigned long long*)take(zrec_bytes);
     w.bytes = off;
     return w;
 }
@@ -1616,6 +1776,13 @@ bool tiled_geometry(int nmesh, int nx_alloc, TileGeom& g, uint32_t& ntiles) {
     return true;
 }
 
+inline size_t seam_bytes(int window, const TileGeom& g, size_t np, size_t esz, int flags) {
+    const WalkPlan p = walk_plan(g, np, flags, esz);
+    if (p.nseg <= 1) return 0;
+    const size_t cells = window == AST_WIN_TSC ? (size_t)(TX + 2) * (TY + 2) * 2 : (size_t)(TX + 1) * (TY + 1);
+    return (size_t)g.ntx * g.nty * p.nseg * 2 * cells * sizeof(unsigned long long);
+}
+
 inline size_t record_bytes(int window, const TileGeom& g, size_t esz, int flags) {
     if (!(flags & AST_PAINT_OVERWRITE)) return 0;
     const size_t ring = window == AST_WIN_TSC ? RingMap<3>::COUNT : RingMap<2>::COUNT;
@@ -1628,8 +1795,10 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
     const bool two_pass = (flags & AST_PAINT_TWO_PASS) != 0;
     const bool overwrite = (flags & AST_PAINT_OVERWRITE) != 0;
     const unsigned ncols = (unsigned)(g.ntx * g.nty);
+    const WalkPlan plan = walk_plan(g, np, flags, sizeof(T));
     Workspace w = carve(workspace, np, ntiles, ncols, flags, sizeof(T),
-                        record_bytes(W == 3 ? AST_WIN_TSC : AST_WIN_CIC, g, sizeof(T), flags));
+                        record_bytes(W == 3 ? AST_WIN_TSC : AST_WIN_CIC, g, sizeof(T), flags),
+                        seam_bytes(W == 3 ? AST_WIN_TSC : AST_WIN_CIC, g, np, sizeof(T), flags));
     // ovf_count, col_flags, tile_count, tile_fill and fill64 are contiguous at the front of the workspace
     AST_CHECK_HIP(hipMemsetAsync(w.ovf_count, 0, (size_t)((char*)w.tile_off - (char*)w.ovf_count), s));
     const size_t per_interval = (size_t)256 * IDX_UNROLL * AGG_TRIPS;
@@ -1651,27 +1820,39 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
             tile_index_kernel<T, W, MODE, false><<<ga, 256, 0, s>>>(pos, np, g, tile_count, tile_off, tile_fill, index, cap, ovf,
                                                                     ovf_count, w.col_flags, drop);
     };
+    // the column walk over the columns col0 .. col0 + ncol - 1 (mod ncols) on stream st
+    auto walk_pass = [&](const uint32_t* tile_off, const uint32_t* tile_count, int col0, unsigned ncol, hipStream_t st) {
+        AST_PROF("paint_tiled.deposit", st);
+        WalkCaps wl{w.rcap, w.scap, w.cap, np};
+        using I2 = std::integral_constant<int, 2>;
+        const int nseg = two_pass ? 1 : plan.nseg;
+        auto launch = [&](auto has_mass, auto fmt) {
+            column_deposit_kernel<T, W, decltype(has_mass)::value, decltype(fmt)::value><<<ncol * (unsigned)nseg, 256, 0, st>>>(
+                pos, mass, g, scale, w.index, tile_off, tile_count, w.fill64, w.recs, (const T*)w.strays, wl,
+                mass ? mass_bound : 1.0, w.col_flags, grid, (T*)w.rec, offset, dropped, col0, nseg, w.zrec);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        if (two_pass) { if (mass) launch(std::true_type{}, I0{}); else launch(std::false_type{}, I0{}); }
+        else if (mass) launch(std::true_type{}, I1{});
+        else launch(std::false_type{}, I2{});                     // no masses: 3-word stray copies
+    };
+    // the seams of a z-segmented walk (all columns, after their walks), then the x / y halo fold
+    auto fold_pass = [&]() {
+        if (!two_pass && plan.nseg > 1) {
+            AST_PROF("paint_tiled.seams", s);
+            z_seam_kernel<T, W><<<ncols, 256, 0, s>>>(w.zrec, g, scale, (uint32_t)std::min<unsigned long long>(5ull * w.cap, 0x3fffffffull),
+                                                       mass ? mass_bound : 1.0, grid, (T*)w.rec, offset, dropped, 0, plan.nseg);
+        }
+        if (!(flags & AST_PAINT_DEFER_FOLD)) {
+            AST_PROF("paint_tiled.fold", s);
+            column_fold_kernel<T, W><<<ncols, 256, 0, s>>>((const T*)w.rec, g, grid);
+        }
+    };
     auto deposit_pass = [&](const uint32_t* tile_off, const uint32_t* tile_count, uint32_t cap) {
         if (overwrite) {
-            {
-                AST_PROF("paint_tiled.deposit", s);
-                WalkCaps wl{w.rcap, w.scap, w.cap, np};
-                using I2 = std::integral_constant<int, 2>;
-                auto launch = [&](auto has_mass, auto fmt) {
-                    column_deposit_kernel<T, W, decltype(has_mass)::value, decltype(fmt)::value><<<ncols, 256, 0, s>>>(
-                        pos, mass, g, scale, w.index, tile_off, tile_count, w.fill64, w.recs, (const T*)w.strays, wl,
-                        mass ? mass_bound : 1.0, w.col_flags, grid, (T*)w.rec, offset, dropped);
-                };
-                using I0 = std::integral_constant<int, 0>;
-                using I1 = std::integral_constant<int, 1>;
-                if (two_pass) { if (mass) launch(std::true_type{}, I0{}); else launch(std::false_type{}, I0{}); }
-                else if (mass) launch(std::true_type{}, I1{});
-                else launch(std::false_type{}, I2{});                     // no masses: 3-word stray copies
-            }
-            if (!(flags & AST_PAINT_DEFER_FOLD)) {
-                AST_PROF("paint_tiled.fold", s);
-                column_fold_kernel<T, W><<<ncols, 256, 0, s>>>((const T*)w.rec, g, grid);
-            }
+            walk_pass(tile_off, tile_count, 0, ncols, s);
+            fold_pass();
         } else {
             AST_PROF("paint_tiled.deposit", s);
             tile_deposit_kernel<T, W><<<ntiles, 256, 0, s>>>(pos, mass, g, scale, w.index, tile_off, tile_count, cap, grid, dropped);
@@ -1712,7 +1893,8 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds));
                     AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_level_b_kernel<T, W, PX, SW>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds));
-                            }
+                    attr_once.mark();
+                }
                 {
                     AST_PROF("paint_tiled.level_a", s);
                     scatter_level_a_kernel<T, W, PX, SW><<<nchunks, SC_THREADS, stage_lds, s>>>(pos, mass, np, g, w.tpb, w.bcursor, (T*)w.staging);
@@ -1734,16 +1916,70 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
         late_deposit_kernel<T, W><<<1024, 256, 0, s>>>((const T*)w.ovf, w.late, np / 4 * sizeof(uint32_t) / sizeof(T), g, scale, grid,
                                                        dropped);
     } else if (overwrite) {
-        {
+        auto group_pass = [&](size_t pb, size_t pe, uint32_t closed_lo, uint32_t closed_n) {
             AST_PROF("paint_tiled.fill", s);
+            const size_t nint = (pe - pb + per_interval - 1) / per_interval;
+            const unsigned gg = (unsigned)(nint > want ? want : nint);
             if (plainx)
-                tile_group_kernel<T, W, true><<<ga, 256, 0, s>>>(pos, mass, np, g, w.fill64, w.recs, w.rcap, (T*)w.strays, w.scap,
-                                                                 w.ovf, w.ovf_count, w.col_flags, dropped);
+                tile_group_kernel<T, W, true><<<gg, 256, 0, s>>>(pos, mass, pb, pe, g, w.fill64, w.recs, w.rcap, (T*)w.strays, w.scap,
+                                                                 w.ovf, w.ovf_count, w.col_flags, dropped, closed_lo, closed_n);
             else
-                tile_group_kernel<T, W, false><<<ga, 256, 0, s>>>(pos, mass, np, g, w.fill64, w.recs, w.rcap, (T*)w.strays, w.scap,
-                                                                  w.ovf, w.ovf_count, w.col_flags, dropped);
+                tile_group_kernel<T, W, false><<<gg, 256, 0, s>>>(pos, mass, pb, pe, g, w.fill64, w.recs, w.rcap, (T*)w.strays, w.scap,
+                                                                  w.ovf, w.ovf_count, w.col_flags, dropped, closed_lo, closed_n);
+        };
+        // AST_PAINT_XSORTED: the particles come in ascending x (buffer planes).  They are grouped chunk by chunk
+        // (plan.chunk_planes planes' worth each); a tile row is walked as soon as the chunks cover its planes plus a
+        // margin - while the chunk's positions are still in the Infinity Cache, so the walk's gather does not go to
+        // HBM a second time.  A particle that arrives for a row already handed to the walk ("late": the input was not
+        // sorted after all) goes to the overflow list and is deposited with global atomics at the end - the result
+        // never depends on the assumption, only the speed.  A periodic grid's row 0 also takes the wrap of the LAST
+        // particles: it is walked last.  plan.streams == 2: the walks run on a second stream, each beside the grouping
+        // of the following chunks (which wait for the walk before the one they overlap: the grouping must not run
+        // ahead, or the positions are gone from the cache before they are gathered).
+        const int K = plan.chunks;
+        if (K == 1) {
+            group_pass(0, np, 0u, 0u);
+            deposit_pass(nullptr, nullptr, 0);
+        } else {
+            const bool two_streams = plan.streams > 1;
+            SidePipe* sp = two_streams ? side_pipe(2 * g.ntx + 4) : nullptr;
+            if (two_streams && !sp) { ast::set_error("ast_paint_tiled: no side stream"); return AST_ERR_HIP; }
+            AST_PROF("paint_tiled.pipeline", s);
+            const bool x_periodic = g.nx_alloc == g.n;
+            const int m0 = x_periodic ? 1 : 0;                         // rows [0, m0) are held back to the end
+            const uint32_t rs = (uint32_t)(g.nty * g.ntz);             // tiles per row
+            int prev = m0, nev = 0;
+            hipEvent_t walk_done[2] = {nullptr, nullptr};              // the last two walks on the side stream
+            for (int k = 0; k < K; ++k) {
+                const size_t pb = (size_t)((double)k / K * (double)np) / per_interval * per_interval;
+                const size_t pe = k + 1 == K ? np : (size_t)((double)(k + 1) / K * (double)np) / per_interval * per_interval;
+                if (two_streams && walk_done[1]) AST_CHECK_HIP(hipStreamWaitEvent(s, walk_done[1], 0));
+                if (pe > pb) group_pass(pb, pe, (uint32_t)m0 * rs, (uint32_t)(prev - m0) * rs);
+                // rows whose planes (plus the margin) the chunks 0..k cover
+                const int covered = (int)((long long)(k + 1) * g.nx_alloc / K) - plan.margin_planes;
+                const int r = k + 1 == K ? g.ntx : std::max(prev, std::min(g.ntx, covered / TX));
+                if (r > prev || k + 1 == K) {
+                    const int rows = r - prev + (k + 1 == K ? m0 : 0);      // the last launch wraps around to row 0
+                    hipStream_t ws = s;
+                    if (two_streams) {
+                        AST_CHECK_HIP(hipEventRecord(sp->ev[nev], s));
+                        AST_CHECK_HIP(hipStreamWaitEvent(sp->side, sp->ev[nev], 0));
+                        ++nev;
+                        ws = sp->side;
+                    }
+                    if (rows > 0) walk_pass(nullptr, nullptr, prev * g.nty, (unsigned)(rows * g.nty), ws);
+                    if (two_streams) {
+                        AST_CHECK_HIP(hipEventRecord(sp->ev[nev], sp->side));
+                        walk_done[1] = walk_done[0];
+                        walk_done[0] = sp->ev[nev];
+                        ++nev;
+                    }
+                    prev = r;
+                }
+            }
+            if (two_streams && walk_done[0]) AST_CHECK_HIP(hipStreamWaitEvent(s, walk_done[0], 0));
+            fold_pass();
         }
-        deposit_pass(nullptr, nullptr, 0);
         AST_PROF("paint_tiled.overflow", s);
         overflow_deposit_kernel<T, W><<<1024, 256, 0, s>>>(pos, mass, w.ovf, w.ovf_count, g, scale, grid, dropped);
     } else {
@@ -1783,7 +2019,8 @@ extern "C" size_t ast_paint_tiled_workspace_bytes(int window, int dtype, size_t 
     uint32_t ntiles = 0;
     if (nmesh <= 0 || nx_alloc <= 0 || !tiled_geometry(nmesh, nx_alloc, g, ntiles)) return 0;
     return carve(nullptr, np, ntiles, (uint32_t)(g.ntx * g.nty), flags, dtype == AST_F32 ? 4 : 8,
-                 record_bytes(window, g, dtype == AST_F32 ? 4 : 8, flags)).bytes;
+                 record_bytes(window, g, dtype == AST_F32 ? 4 : 8, flags),
+                 seam_bytes(window, g, np, dtype == AST_F32 ? 4 : 8, flags)).bytes;
 }
 
 // Where ast_paint_tiled(... AST_PAINT_OVERWRITE | AST_PAINT_DEFER_FOLD) left the halo records of a paint with
@@ -1867,7 +2104,8 @@ extern "C" int ast_paint_tiled(int window, int dtype, const void* pos, const voi
     g.off_lo = offset_start;
     g.off_hi = offset_start + (offset_count < 0 ? nx_alloc : offset_count);
     const size_t need = carve(nullptr, np, ntiles, (uint32_t)(g.ntx * g.nty), flags, dtype == AST_F32 ? 4 : 8,
-                              record_bytes(window, g, dtype == AST_F32 ? 4 : 8, flags)).bytes;
+                              record_bytes(window, g, dtype == AST_F32 ? 4 : 8, flags),
+                              seam_bytes(window, g, np, dtype == AST_F32 ? 4 : 8, flags)).bytes;
     if (workspace_bytes < need) {
         ast::set_error("ast_paint_tiled: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
         return AST_ERR_WORKSPACE;

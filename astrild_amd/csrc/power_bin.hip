@@ -406,16 +406,20 @@ extern "C" int ast_triple_product_sums(const void* const* fields, int nfields, i
     AST_PROF("triple_product_sums", s);
     if (dtype == AST_F32) {
         static ast::PerDeviceOnce attr_once;
-        if (attr_once.need())
+        if (attr_once.need()) {
             AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&triple_sums_kernel<float>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_once.mark();
+        }
         triple_sums_kernel<float><<<blocks, TRI_THREADS, lds, s>>>((const float* const*)fields, nfields, tri, ntri, parts, count,
                                                                    (double*)scratch);
     } else {
         static ast::PerDeviceOnce attr_once;
-        if (attr_once.need())
+        if (attr_once.need()) {
             AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&triple_sums_kernel<double>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_once.mark();
+        }
         triple_sums_kernel<double><<<blocks, TRI_THREADS, lds, s>>>((const double* const*)fields, nfields, tri, ntri, parts, count,
                                                                     (double*)scratch);
     }

@@ -168,7 +168,8 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     before the one rounding to the grid dtype; ``offset="mean"`` uses total mass * scale / nmesh^3,
     i.e. the grid holds rho - mean (only the DC mode changes, which FFTPower discards).
     hint: "scattered" sizes the tiled overwrite paint's workspace for particles without spatial order in memory
-    (AST_PAINT_SCATTERED).  stats: a dict that receives the list statistics of the tiled overwrite paint.
+    (AST_PAINT_SCATTERED); "xsorted" says they come in ascending x (lattice order, slab-ordered files): grouping and
+    column walk then overlap chunk by chunk (AST_PAINT_XSORTED; a wrong hint costs time, never correctness).  stats: a dict that receives the list statistics of the tiled overwrite paint.
     shift: added to every coordinate in grid units (0.5 paints the second mesh of an interlaced pair).
     offset_planes: (first, count) of the buffer planes the offset applies to (default: all) - a slab buffer's
     ghost planes are added onto other ranks' cells and must stay plain sums.
@@ -186,9 +187,12 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     npart = pos.shape[0]
     dropped = torch.zeros(1, dtype=torch.int64, device=pos.device)
     ws_bytes = 0
-    # TWO_PASS | OVERWRITE | DEFER_FOLD | SCATTERED
+    # TWO_PASS | OVERWRITE | DEFER_FOLD | SCATTERED | XSORTED
+    if hint not in (None, "scattered", "xsorted"):
+        raise ValueError(hint)
     tflags = (1 if method == "tiled2" else 0) | (0 if accumulate else 2) | (4 if defer_fold else 0) | \
-             (8 if hint == "scattered" and not accumulate and method != "tiled2" else 0)
+             (8 if hint == "scattered" and not accumulate and method != "tiled2" else 0) | \
+             (16 if hint == "xsorted" and not accumulate and method != "tiled2" else 0)
     if method in ("auto", "tiled", "tiled2") and win != 0 and npart < 2**32 - 65:
         ws_bytes = int(L.ast_paint_tiled_workspace_bytes(win, code, npart, n, nx, tflags))
     if method in ("tiled", "tiled2") and ws_bytes == 0:
@@ -241,7 +245,7 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
                 dropped.zero_()
                 del ws
                 if not tflags & 8:
-                    tflags |= 8
+                    tflags = (tflags | 8) & ~16
                 elif not tflags & 1:
                     tflags = (tflags & ~8) | 1
                     compact = False
@@ -487,9 +491,10 @@ def fftpower_1d(field1, boxsize, field2=None, fused=True, binning=None):
         return finish_power(*power_sums_fused(field1, boxsize, mean=mean, binning=binning))
     if fused and field2 is None and fused_power64_supported(field1):
         return finish_power(*power_sums_fused64(field1, boxsize, binning=binning))
-    if field1.dtype == torch.float32 and not bool(_lib.lib().ast_fft_tile_supported(F32, n)):
-        # an fp32 grid of a size the tile FFT does not cover: the rocFFT fp32 transform would carry the O(1) mean's
-        # round-off into the low shells (2e-6 and worse); the transform runs in double instead
+    if field1.dtype == torch.float32:
+        # fp32 grids that do not take the fused path above - cross spectra, sizes the tile FFT does not cover: an fp32
+        # transform would carry the O(1) mean's round-off into the low shells (2e-6 and worse: only the fused path
+        # removes the mean and patches the lowest shells); the transforms run in double instead
         field1 = field1.double()
         field2 = None if field2 is None else field2.double()
     s1 = r2c(field1)

@@ -84,8 +84,9 @@ def kappa_stack_sharded(planes, wnum=None, wden=None, group=None, root=0, all_ra
         full = ops.empty(world * chunk)
         dist.all_gather_into_tensor(full, mine, group=group)
         return full[:n]
+    # `root` is a rank of `group`; dist.gather's dst is a GLOBAL rank
     parts = [ops.empty(chunk) for _ in range(world)] if rank == root else None
-    dist.gather(mine, parts, dst=root, group=group)
+    dist.gather(mine, parts, dst=dist.get_global_rank(group, root) if group is not None else root, group=group)
     if rank != root:
         return None
     return torch.cat(parts)[:n]

@@ -29,6 +29,8 @@ import torch.distributed as dist
 class HipSlabOps:
     """Local arithmetic on the GPU through the C-ABI."""
 
+    paint_hints = True          # paint() takes hint= (the numpy double of the CPU tests does not)
+
     def __init__(self, dtype=torch.float32):
         from . import device as dev
         self.dev = dev
@@ -42,9 +44,9 @@ class HipSlabOps:
     def empty(self, shape, dtype=None):
         return torch.empty(shape, dtype=dtype or self.dtype, device=self.device)
 
-    def paint(self, pos, mass, n, boxsize, window, out, x_start, nx_alloc, check=False, offset=0.0, owned=None):
+    def paint(self, pos, mass, n, boxsize, window, out, x_start, nx_alloc, check=False, offset=0.0, owned=None, hint=None):
         return self.dev.paint(pos, mass, n, boxsize, window, out=out, x_start=x_start, nx_alloc=nx_alloc,
-                              check_dropped=check, accumulate=False, offset=offset, offset_planes=owned)
+                              check_dropped=check, accumulate=False, offset=offset, offset_planes=owned, hint=hint)
 
     def lowk_supported(self, n):
         return self.dtype == torch.float32 and self._tile_ok(0, n)
@@ -176,30 +178,48 @@ def comm_ready(group=None):
         torch.cuda.synchronize()
 
 
+class GhostExchange:
+    """Step 2 in two halves.  buf: (gl + nloc + gh, N, N) with the owned planes in the middle.  Lower ghosts belong
+    to rank r-1 (its top gl planes), upper ghosts to rank r+1 (its bottom gh planes).  ``start`` posts the sends and
+    receives (both ghost blocks are contiguous plane ranges of buf: nothing is copied), ``finish`` waits for them
+    and adds the incoming planes - only the first gh and the last gl owned planes change, so everything that reads
+    the planes in between may run while the ghosts travel."""
+
+    def __init__(self, buf, nloc, gl, gh, ops, group=None):
+        self.buf, self.nloc, self.gl, self.gh, self.ops, self.group = buf, nloc, gl, gh, ops, group
+        self.from_right = torch.empty_like(buf[:gl])       # right neighbour's lower ghosts -> my top planes
+        self.from_left = torch.empty_like(buf[gl + nloc:])  # left neighbour's upper ghosts -> my bottom planes
+        self.reqs = None
+
+    def start(self):
+        world = dist.get_world_size(self.group)
+        rank = dist.get_rank(self.group)
+        left, right = (rank - 1) % world, (rank + 1) % world
+        comm_ready(self.group)
+        self.reqs = dist.batch_isend_irecv([
+            dist.P2POp(dist.isend, self.buf[:self.gl], left, self.group),
+            dist.P2POp(dist.isend, self.buf[self.gl + self.nloc:], right, self.group),
+            dist.P2POp(dist.irecv, self.from_right, right, self.group),
+            dist.P2POp(dist.irecv, self.from_left, left, self.group),
+        ])
+
+    def finish(self):
+        if self.reqs is None:
+            return
+        for q in self.reqs:
+            q.wait()
+        self.reqs = None
+        owned = self.buf[self.gl: self.gl + self.nloc]
+        self.ops.add_into(owned[self.nloc - self.gl:], self.from_right)
+        self.ops.add_into(owned[:self.gh], self.from_left)
+
+
 def ghost_fold(buf, nloc, gl, gh, ops, group=None):
-    """Step 2.  buf: (gl + nloc + gh, N, N) with the owned planes in the middle.
-    Lower ghosts belong to rank r-1 (its top gl planes), upper ghosts to rank r+1
-    (its bottom gh planes); both are sent and the incoming ones are added."""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    left, right = (rank - 1) % world, (rank + 1) % world
-    lower = buf[:gl].contiguous()
-    upper = buf[gl + nloc:].contiguous()
-    from_right = torch.empty_like(lower)       # right neighbour's lower ghosts -> my top planes
-    from_left = torch.empty_like(upper)        # left neighbour's upper ghosts -> my bottom planes
-    comm_ready(group)
-    reqs = dist.batch_isend_irecv([
-        dist.P2POp(dist.isend, lower, left, group),
-        dist.P2POp(dist.isend, upper, right, group),
-        dist.P2POp(dist.irecv, from_right, right, group),
-        dist.P2POp(dist.irecv, from_left, left, group),
-    ])
-    for q in reqs:
-        q.wait()
-    owned = buf[gl: gl + nloc]
-    ops.add_into(owned[nloc - gl:], from_right)
-    ops.add_into(owned[:gh], from_left)
-    return owned
+    """Step 2 as one blocking call (see GhostExchange)."""
+    ex = GhostExchange(buf, nloc, gl, gh, ops, group)
+    ex.start()
+    ex.finish()
+    return buf[gl: gl + nloc]
 
 
 def exchange_chunk(packed_c, block, chunk, pc, nloc, group=None, self_done=False):
@@ -293,6 +313,13 @@ class SlabPowerPipeline:
         self.block = o.empty((n, self.nloc, self.nz), o.cdtype)
         self.psum = o.zeros((n // 2 - 1,), torch.float64)
         self._side = None
+        self._stage_s = {}
+        self.hint = None if (shuffle or route or pos is not None) else "xsorted"     # the synthetic set comes in lattice order
+        self.ghosts = GhostExchange(self.buf, self.nloc, self.gl, self.gh, o, group) if P > 1 else None
+        # chunks whose planes the incoming ghosts do not touch are transformed (and sent) first, while the ghosts travel
+        edge = {c for c in range(chunks) if c * self.pc < self.gh or (c + 1) * self.pc > self.nloc - self.gl}
+        self.chunk_order = [c for c in range(chunks) if c not in edge] + sorted(edge)
+        self.first_edge = len(self.chunk_order) - len(edge)
         # the rank's OWN planes hold rho - mean (subtracted before the fp32 rounding); its ghost planes, which are
         # added onto the neighbours' cells, stay plain sums
         lowk_fn = getattr(self.ops, "lowk_supported", None)
@@ -308,23 +335,55 @@ class SlabPowerPipeline:
         dist.all_reduce(self.ksum, group=group)
         dist.all_reduce(self.nmodes, group=group)
 
-    def paint(self, check=False):
+    def wire_bytes(self):
+        """What one step of this rank puts on the links: ghost planes to the two ring neighbours, its pieces of the
+        half spectrum to the P - 1 peers, and the all-reduced sums."""
+        if self.world == 1:
+            return {"ghost": 0, "transpose": 0, "allreduce": 0}
+        esz = torch.empty((), dtype=self.ops.dtype).element_size() if hasattr(self.ops, "dtype") else 4
+        return {"ghost": (self.gl + self.gh) * self.n * self.n * esz,
+                "transpose": (self.world - 1) * self.nloc * self.nloc * self.nz * 2 * esz,
+                "allreduce": (self.n // 2 - 1) * 8 + (1183 * 16 if self.lowk else 0)}
+
+    def stage_ms(self, steps):
+        """Host-side wall time per step spent in each stage's calls since the last reset (enqueue time with RCCL,
+        real time with the synchronising gloo rehearsal): where a step's host thread goes."""
+        out = {k: v / max(1, steps) for k, v in self._stage_s.items()}
+        self._stage_s = {}
+        return {k: v * 1e3 for k, v in out.items()}
+
+    def _tick(self, name, t0):
+        import time
+        self._stage_s[name] = self._stage_s.get(name, 0.0) + (time.perf_counter() - t0)
+
+    def paint(self, check=False, fold=True):
         """check=True synchronises and raises if a deposit fell outside the ghost zone.  The owned cells hold
         rho - mean (the mean is subtracted in double before the rounding to the grid dtype; ghost planes and halo
-        records stay additive, so the fold still adds up): only the DC mode differs."""
+        records stay additive, so the fold still adds up): only the DC mode differs.  fold=False: the ghost exchange
+        is only STARTED (self.ghosts.finish() completes the first and last owned planes)."""
+        kw = {"hint": self.hint} if self.hint and getattr(self.ops, "paint_hints", False) else {}
         if self.mean_offset:
             self.ops.paint(self.pos, None, self.n, self.L, self.window, self.buf, self.x_start, self.nx_alloc, check,
-                           offset=self.mean_offset, owned=(self.gl, self.nloc))
+                           offset=self.mean_offset, owned=(self.gl, self.nloc), **kw)
         else:
-            self.ops.paint(self.pos, None, self.n, self.L, self.window, self.buf, self.x_start, self.nx_alloc, check)
+            self.ops.paint(self.pos, None, self.n, self.L, self.window, self.buf, self.x_start, self.nx_alloc, check, **kw)
         if self.world == 1:
             return self.buf
-        return ghost_fold(self.buf, self.nloc, self.gl, self.gh, self.ops, self.group)
+        self.ghosts.start()
+        if fold:
+            self.ghosts.finish()
+        return self.buf[self.gl: self.gl + self.nloc]
 
-    def forward_fft(self, owned, last_pass=True):
+    def forward_fft(self, owned, last_pass=True, before_edge=None):
+        """Steps 3-5.  before_edge(): called once, before the first chunk that holds planes the ghost exchange
+        changes (interior chunks are transformed and sent while the ghosts are still travelling)."""
+        import time
         o = self.ops
         pending = []
-        for c in range(self.chunks):
+        t0 = time.perf_counter()
+        for i, c in enumerate(self.chunk_order):
+            if i == self.first_edge and before_edge is not None:
+                before_edge()
             planes = owned[c * self.pc:(c + 1) * self.pc]
             spec = self.spec2d[c * self.pc:(c + 1) * self.pc]
             packed_fn = getattr(o, "packed_supported", None)
@@ -337,45 +396,63 @@ class SlabPowerPipeline:
             o.fft2d_planes(planes, spec)
             o.pack(spec, self.packed[c], self.world)
             pending += exchange_chunk(self.packed[c], self.block, c, self.pc, self.nloc, self.group)
+        if self.first_edge >= len(self.chunk_order) and before_edge is not None:
+            before_edge()                     # (one rank: no chunk waits for ghosts)
+        self._tick("fft2d+exchange.enqueue", t0)
+        t0 = time.perf_counter()
         for work in pending:
             work.wait()
+        self._tick("exchange.wait", t0)
         if not last_pass:
             return self.block
         return o.fft1d_axis0(self.block, 1.0 / float(self.n) ** 3)
 
     def step(self, check=False):
-        owned = self.paint(check)
-        modes = None
-        side = None
-        if self.lowk:
-            # the lowest shells from double-precision DFT sums of the rank's own planes (device.power_sums_fused's
-            # low-k channel, split over the slabs): one more all-reduce, of 1183 complex numbers.  It only reads the
-            # planes: on the GPU it runs on a side stream beside the FFT chunks and their exchange.
-            if owned.is_cuda:
-                if self._side is None:
-                    self._side = torch.cuda.Stream()
-                side = self._side
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    modes = self.ops.lowk_modes(owned, self.n, self.rank * self.nloc)
-            else:
-                modes = self.ops.lowk_modes(owned, self.n, self.rank * self.nloc)
+        import time
+        t0 = time.perf_counter()
+        owned = self.paint(check, fold=False)
+        self._tick("paint.enqueue", t0)
+        state = {"modes": None, "side": None}
+
+        def finish_ghosts():
+            t1 = time.perf_counter()
+            if self.ghosts is not None:
+                self.ghosts.finish()
+            self._tick("ghost.wait+add", t1)
+            if self.lowk:
+                # the lowest shells from double-precision DFT sums of the rank's own (complete) planes
+                # (device.power_sums_fused's low-k channel, split over the slabs): one more all-reduce, of 1183
+                # complex numbers.  It only reads the planes: on the GPU it runs on a side stream beside the FFT
+                # chunks and their exchange.
+                if owned.is_cuda:
+                    if self._side is None:
+                        self._side = torch.cuda.Stream()
+                    state["side"] = self._side
+                    self._side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(self._side):
+                        state["modes"] = self.ops.lowk_modes(owned, self.n, self.rank * self.nloc)
+                else:
+                    state["modes"] = self.ops.lowk_modes(owned, self.n, self.rank * self.nloc)
+
         fused_fn = getattr(self.ops, "axis0_power_supported", None)
         if fused_fn and fused_fn(self.n):
             # axis-0 pass and shell binning in one kernel (the spectrum block is not written back)
-            block = self.forward_fft(owned, last_pass=False)
+            block = self.forward_fft(owned, last_pass=False, before_edge=finish_ghosts)
             self.ops.fft1d_axis0_power(block, 1.0 / float(self.n) ** 3, self.n, self.L, self.rank * self.nloc, self.psum,
-                                       5 if modes is not None else 0)
+                                       5 if self.lowk else 0)
         else:
-            block = self.forward_fft(owned)
+            block = self.forward_fft(owned, before_edge=finish_ghosts)
             self.ops.power_bin(block, self.n, self.L, self.i0, self.i1, self.psum)
+        modes, side = state["modes"], state["side"]
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             modes.record_stream(torch.cuda.current_stream())      # allocated under the side stream, used from here on
+        t0 = time.perf_counter()
         comm_ready(self.group)
         dist.all_reduce(self.psum, group=self.group)
         if modes is not None:
             modes_r = torch.view_as_real(modes)
             dist.all_reduce(modes_r, group=self.group)
             self.ops.lowk_patch(modes, self.n, self.L, self.psum)
+        self._tick("allreduce.enqueue", t0)
         return self.ksum, self.psum, self.nmodes

@@ -140,8 +140,42 @@ def kappa_leg(dev, steps, warmup, group=None):
                                         group=group)
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(ngpus):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes ourselves (one per GPU, through
+    torch.distributed.run) as CHILDREN of this process, which has not touched the GPU and never will; relay rank 0's
+    JSON line and exit with the launcher's status."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for ln in proc.stdout.decode(errors="replace").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    if line is not None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    if proc.returncode != 0 or line is None:
+        raise SystemExit(proc.returncode or 1)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)
+        return
     # stdout carries exactly ONE JSON line: everything else a library may print there
     # (RCCL's version banner at communicator creation, for one) is sent to stderr
     sys.stdout.flush()
@@ -151,8 +185,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     # rehearsal of the N > 1 code path on a one-GPU box (timings are meaningless there):
     # ASTRILD_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo instead of RCCL
@@ -208,6 +240,8 @@ def main():
                    "parallelism": "single GPU" if not use_slab else f"axis-0 slabs x{world}, RCCL all-to-all transpose"},
         "roofline": roofline,
     }
+    if "diag" in leg:
+        out["multi_gpu"] = leg["diag"]
     if rank == 0 and not use_slab:
         if args.legs:
             # the other orderings / windows of the same workload, a few steps each (same kernels, same accounting)
@@ -277,9 +311,11 @@ def _stage_table(prof, steps, npart_rank, ng_rank, esz, fused_bin, concurrent=()
                             "kernels": {s: round(prof[s][1] / steps, 4) for s in sites}}
             side = [s for s in sites if s in concurrent]
             if side:
-                stages[name]["concurrent"] = {"sites": side, "note": "the low-k channel's y / x / shell kernels, on a second "
-                                              "stream beside the y pass (its z sums are formed inside rows_r2c at N = 1024); "
-                                              "not added to `ms`"}
+                stages[name]["concurrent"] = {"sites": side, "note": "not added to `ms`: fft_tile.lowk = the low-k channel's "
+                                              "y / x / shell kernels on a second stream beside the y pass (its z sums are "
+                                              "formed inside rows_r2c at N = 1024); paint_tiled.fill / .deposit = the "
+                                              "grouping and column-walk launches of the x-sorted pipeline, which overlap on "
+                                              "two streams - paint_tiled.pipeline is their wall time on the launch stream"}
     return stages, stage_sites, stage_bytes
 
 
@@ -319,7 +355,7 @@ def power_leg(dev, n, npside, L, window, order, dtype, method, steps, warmup):
     if not fused and not fused64:
         spec = torch.empty((n, n, n // 2 + 1), dtype=torch.complex64 if dtype == "f32" else torch.complex128, device="cuda")
     mean = npart_total / float(n) ** 3
-    hint = "scattered" if order == "shuffled" else None
+    hint = "scattered" if order == "shuffled" else "xsorted"        # natural = lattice order: ascending x
 
     def step():
         if fused and method in ("auto", "tiled"):
@@ -359,8 +395,9 @@ def power_leg(dev, n, npside, L, window, order, dtype, method, steps, warmup):
     # sanity: the spectrum that was timed is a real one (finite, positive at Nyquist-ish k)
     res = dev.finish_power(*sums)
     assert np.isfinite(res["power"]).all() and res["power"][-1] > 0
+    overlapped = ("paint_tiled.fill", "paint_tiled.deposit") if "paint_tiled.pipeline" in prof else ()
     stages, stage_sites, stage_bytes = _stage_table(prof, steps, npart_total, n ** 3, esz, fused_bin=True,
-                                                    concurrent=("fft_tile.lowk",))
+                                                    concurrent=("fft_tile.lowk",) + overlapped)
     dom = max(stages, key=lambda k: stages[k]["ms"])
     traffic, source = (None, None)
     if dom == "paint" and n == 1024 and npside == 1024 and window == "cic" and dtype == "f32" and order == "natural":
@@ -385,7 +422,8 @@ def slab_leg(dev, dist, n, npside, L, args, world, barrier):
     esz = 4 if args.dtype == "f32" else 8
     # shuffled order: a rank's particles lie anywhere in the box, so they are routed to their slabs first (all-to-all-v)
     pipe = slab.SlabPowerPipeline(n, L, npside, window=args.window, dtype=tdt, seed=20240601,
-                                  shuffle=(args.order == "shuffled"), route=(args.order == "shuffled"))
+                                  shuffle=(args.order == "shuffled"), route=(args.order == "shuffled"),
+                                  ghost=3)     # base cells up to 3 planes (6 sigma of the jitter) outside the slab; checked below
     pipe.step(check=True)             # once, untimed: no deposit may fall outside the ghost zone
     for _ in range(args.warmup):
         pipe.step()
@@ -398,13 +436,22 @@ def slab_leg(dev, dist, n, npside, L, args, world, barrier):
     elapsed = time.perf_counter() - t0
     prof = dev.profile_report()
     dev.profile_enable(False)
+    # diagnostics of the N > 1 line: every rank's own wall time and per-site kernel times, and what a step puts on
+    # the links (so that the first run on real xGMI says where the time went)
+    mine = {"rank": dist.get_rank(), "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "kernels_ms": {k: round(v[1] / args.steps, 4) for k, v in prof.items()},
+            "stage_ms": {k: round(v, 4) for k, v in pipe.stage_ms(args.steps).items()}}
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, mine)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     ms_per_step = elapsed / args.steps * 1e3
     res = dev.finish_power(*sums)
     assert np.isfinite(res["power"]).all() and res["power"][-1] > 0
-    stages, stage_sites, stage_bytes = _stage_table(prof, args.steps, npside ** 3 / world, n ** 3 / world, esz, fused_bin=False)
+    overlapped = ("paint_tiled.fill", "paint_tiled.deposit") if "paint_tiled.pipeline" in prof else ()
+    stages, stage_sites, stage_bytes = _stage_table(prof, args.steps, npside ** 3 / world, n ** 3 / world, esz, fused_bin=False,
+                                                    concurrent=overlapped)
     dom = max(stages, key=lambda k: stages[k]["ms"])
     total = sum(stage_bytes.values())
     roofline = {
@@ -415,7 +462,10 @@ def slab_leg(dev, dist, n, npside, L, args, world, barrier):
                        "frac": round(total / (ms_per_step * 1e6) / HBM_PEAK_GBS, 4)},
         "stages": stages, "ranks": world, "backend": dist.get_backend(),
     }
-    return {"ms_per_step": ms_per_step, "roofline": roofline}
+    return {"ms_per_step": ms_per_step, "roofline": roofline,
+            "diag": {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                     "wire_bytes_per_step_per_rank": pipe.wire_bytes(), "chunks": pipe.chunks,
+                     "nx_alloc": pipe.nx_alloc, "per_rank": per_rank}}
 
 
 if __name__ == "__main__":

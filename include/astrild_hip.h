@@ -146,6 +146,13 @@ int ast_paint(int window, int dtype, const void* pos_d, const void* mass_d, size
  * all of it (3.4x the workspace).  Without the hint unordered input still paints correctly - what does not
  * fit goes through the (slow) overflow list. */
 #define AST_PAINT_SCATTERED 8
+/* AST_PAINT_XSORTED (single pass + AST_PAINT_OVERWRITE, not with AST_PAINT_SCATTERED): a hint that the particles
+ * come in ascending x (buffer planes) - lattice order, slab-ordered snapshot files.  The paint then runs as a
+ * pipeline over chunks of particles: while chunk k + 1 is grouped, the column walk of the tile rows that chunk
+ * k completed runs beside it on a second stream (event-ordered against `stream`).  A particle that arrives for a
+ * row already walked goes through the overflow list (global atomics): input that is not sorted after all still
+ * paints correctly, only slower. */
+#define AST_PAINT_XSORTED 16
 /* offset (AST_PAINT_OVERWRITE only, else 0): every OWNED cell is stored as (sum - offset), the
  * subtraction done in double on the exact fixed-point sum before the single rounding to `dtype`
  * (halo records stay additive).  With offset = total mass * scale / nmesh^3 the grid holds the

@@ -463,3 +463,63 @@ def test_repeated_fused_pipeline_calls_are_bit_identical(hip):
         if ref is None:
             ref = p.copy()
         assert np.array_equal(ref, p)
+
+
+# ------------------------------------------------------------------ z-segmented walk and the x-sorted chunk pipeline
+def _env(monkeypatch, **kv):
+    for k, v in kv.items():
+        if v is None:
+            monkeypatch.delenv(k, raising=False)
+        else:
+            monkeypatch.setenv(k, str(v))
+
+
+@pytest.mark.parametrize("window", ["cic", "tsc"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_z_segmented_walk_is_bit_identical(dev, monkeypatch, window, dtype):
+    """A column cut into z-segments (more, shorter workgroups; the seams written from exact sums by z_seam_kernel) gives
+    the grid of the unsegmented walk bit for bit - also with masses, an offset, and a slab buffer with a partial tile."""
+    n, L = 128, 1000.0
+    rng = np.random.default_rng(5)
+    pos = dev.as_device(omesh.lattice_particles(n, n, L, seed=3, dtype=dtype))
+    mass = dev.as_device(rng.uniform(0.5, 2.0, size=n ** 3).astype(dtype))
+    cases = [dict(), dict(x_start=120, nx_alloc=20, check_dropped=False)]
+    for kw in cases:
+        _env(monkeypatch, AST_PAINT_ZSEG=1)
+        ref = dev.paint(pos, mass, n, L, window, method="tiled", accumulate=False, offset=0.25, **kw)
+        for nseg in (2, 4):
+            _env(monkeypatch, AST_PAINT_ZSEG=nseg)
+            got = dev.paint(pos, mass, n, L, window, method="tiled", accumulate=False, offset=0.25, **kw)
+            assert torch.equal(got, ref), (window, dtype, kw, nseg)
+    _env(monkeypatch, AST_PAINT_ZSEG=None)
+
+
+@pytest.mark.parametrize("window", ["cic", "tsc"])
+@pytest.mark.parametrize("streams", [1, 2])
+def test_xsorted_pipeline_matches_plain_paint(dev, monkeypatch, window, streams):
+    """AST_PAINT_XSORTED on lattice-ordered particles: chunked grouping + row-by-row walks give the plain paint's grid bit
+    for bit (nothing arrives late: overflow 0); on SHUFFLED particles the hint is wrong, the late arrivals go through the
+    overflow list and the grid still matches the oracle."""
+    n, L = 256, 1000.0
+    _env(monkeypatch, AST_PAINT_XCHUNK_MB=4, AST_PAINT_XSTREAMS=streams)
+    pos = dev.synth_lattice_particles(n, n, L, dtype=torch.float32)
+    ref = dev.paint(pos, None, n, L, window, method="tiled", accumulate=False, offset="mean")
+    st = {}
+    got = dev.paint(pos, None, n, L, window, method="tiled", accumulate=False, offset="mean", hint="xsorted", stats=st)
+    assert st["overflow"] == 0
+    assert torch.equal(got, ref)
+    # a slab buffer (not periodic in x): rows are walked in order, row 0 is not held back
+    kw = dict(x_start=64, nx_alloc=72, check_dropped=False)
+    sel = pos[(pos[:, 0] >= 66 * L / n) & (pos[:, 0] < 134 * L / n)].contiguous()
+    ref = dev.paint(sel, None, n, L, window, method="tiled", accumulate=False, **kw)
+    got = dev.paint(sel, None, n, L, window, method="tiled", accumulate=False, hint="xsorted", **kw)
+    assert torch.equal(got, ref)
+    if streams == 1:
+        n2 = 128
+        shuf = omesh.lattice_particles(n2, n2, L, seed=9, shuffle=True, dtype=np.float32)
+        st = {}
+        got = dev.paint(dev.as_device(shuf), None, n2, L, window, method="tiled", accumulate=False, hint="xsorted",
+                        stats=st, check_dropped=False).cpu().numpy()
+        assert st["overflow"] > 0
+        np.testing.assert_allclose(got, omesh.paint(shuf, None, n2, L, window), rtol=2e-6, atol=2e-6)
+    _env(monkeypatch, AST_PAINT_XCHUNK_MB=None, AST_PAINT_XSTREAMS=None)
