@@ -154,21 +154,22 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
     if (POWER)
         for (int i = threadIdx.x; i <= NB; i += NT) shell[i] = 0.0;
     const int c = threadIdx.x % C, sub = threadIdx.x / C;
-    const bool col_ok = c0 + c < ncols;
+    const bool col_ok = (unsigned)c0 + (unsigned)c < (unsigned)ncols;       // 32-bit: the host checks ncols < 2^31
     float2* base = data + (size_t)b * batch_stride + c0 + c;
     // AST_BIN_FLOAT64: bit k2 of this thread's word says that its epilogue mode (row sub + R1 * k2, column c) has an
     // integer norm AND nbodykit's float64 comparison puts it one shell lower.  The words are data independent and
     // come precomputed (edge_fall_kernel): one register, no double-precision code in this register-tight kernel.
-    unsigned fallmask = 0;
-    if (POWER && edge_fall) fallmask = edge_fall[(size_t)blockIdx.x * NT + threadIdx.x];
     float2 u[R2];
     {                                                 // stage 1: task (c, n2 = sub)
         const bool task1 = sub < R2;
         float2 v[R1];
         // unconditional loads (columns past the end re-read the last valid one, idle sub-tasks the
         // last row block): predicated loads compile to a branch each
-        const float2* lbase = (INV && mask.src ? mask.src : data) + (size_t)b * batch_stride + min(c0 + c, ncols - 1);
+        // address = UNIFORM base (batch and row block: scalar registers) + one 32-bit per-lane offset shared by all
+        // R1 loads (global_load ... v_off, s[base]): per-load 64-bit lane addresses cost two VGPRs each while in flight
+        const float2* ubase = (INV && mask.src ? mask.src : data) + (size_t)b * batch_stride;
         const int lsub = task1 ? sub : R2 - 1;
+        const uint32_t voff = (uint32_t)lsub * (uint32_t)elem_stride + min((uint32_t)c0 + (uint32_t)c, (uint32_t)ncols - 1u);     // host checks: < 2^29
         if (INV && mask.hi2 > 0 && mask.pass == 1) {
             const long long c02 = (long long)(c0 * c0);
 #pragma unroll
@@ -176,11 +177,11 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
                 const int row = n1 * R2 + lsub;
                 const long long ky = row > N / 2 ? row - N : row;
                 v[n1] = make_float2(0.f, 0.f);
-                if (ky * ky + c02 < mask.hi2) v[n1] = lbase[(size_t)row * elem_stride];
+                if (ky * ky + c02 < mask.hi2) v[n1] = (ubase + (size_t)(n1 * R2) * elem_stride)[voff];
             }
         } else {
 #pragma unroll
-            for (int n1 = 0; n1 < R1; ++n1) v[n1] = lbase[(size_t)(n1 * R2 + lsub) * elem_stride];
+            for (int n1 = 0; n1 < R1; ++n1) v[n1] = (ubase + (size_t)(n1 * R2) * elem_stride)[voff];
         }
         if (INV) {
             if (mask.hi2 > 0 && mask.pass == 0) {
@@ -252,10 +253,16 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
             }
         }
     }
-    if (POWER && col_ok && sub < R1) {
+    int tid_e = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid_e));                 // the epilogue's column comes from the thread id again: not carried (spilled) from the top
+    if (POWER && (unsigned)c0 + (unsigned)(tid_e % C) < (unsigned)ncols && sub < R1) {
         // one ds_add_f64 per mode; merging a wave's equal-shell lanes first (ballot + cross-lane
         // adds) measured slower: 16 kz x 4 kx lanes rarely share one shell
-        const int kz = (int)(c0 + c);
+        // (the word is fetched HERE, not at the top: nothing of this epilogue may stay live across the two register
+        // FFTs - the kernel is held to 128 VGPRs and every long-lived value there turned into scratch traffic)
+        unsigned fallmask = 0;
+        if (edge_fall) fallmask = edge_fall[(size_t)blockIdx.x * NT + threadIdx.x];
+        const int kz = (int)c0 + tid_e % C;
         const int kyi = (int)b + mask.ky0;
         const int ky = kyi > N / 2 ? kyi - N : kyi;
         const int m2yz = ky * ky + kz * kz;
@@ -900,6 +907,7 @@ int launch_c2c(float2* data, const float2* tw, size_t elem_stride, size_t ncols,
     }
     const size_t tiles = (ncols + C - 1) / C;
     AST_CHECK_ARG(tiles * batch < 0x7fffffffull);
+    AST_CHECK_ARG((size_t)(R2 - 1) * elem_stride + ncols < (1ull << 29));      // the kernel's 32-bit lane offsets
     strided_c2c_kernel<R1, R2, C, POWER><<<(unsigned)(tiles * batch), NT, lds, s>>>(data, tw, elem_stride, ncols,
                                                                                    batch_stride, (unsigned)tiles, scale,
                                                                                    partial, edge_fall, ShellMask{nullptr, 0, 0, ky0});
@@ -920,6 +928,7 @@ int launch_c2c_inv(float2* data, const float2* tw, size_t elem_stride, size_t nc
     }
     const size_t tiles = (ncols + C - 1) / C;
     AST_CHECK_ARG(tiles * batch < 0x7fffffffull);
+    AST_CHECK_ARG((size_t)(R2 - 1) * elem_stride + ncols < (1ull << 29));      // the kernel's 32-bit lane offsets
     strided_c2c_kernel<R1, R2, C, false, true><<<(unsigned)(tiles * batch), NT, lds, s>>>(data, tw, elem_stride, ncols, batch_stride,
                                                                                         (unsigned)tiles, scale, nullptr, nullptr, mask);
     AST_CHECK_LAUNCH();
@@ -939,6 +948,7 @@ int launch_c2c_pack(float2* data, const float2* tw, size_t elem_stride, size_t n
     }
     const size_t tiles = (ncols + C - 1) / C;
     AST_CHECK_ARG(tiles * batch < 0x7fffffffull);
+    AST_CHECK_ARG((size_t)(R2 - 1) * elem_stride + ncols < (1ull << 29));      // the kernel's 32-bit lane offsets
     strided_c2c_kernel<R1, R2, C, false, false, true><<<(unsigned)(tiles * batch), NT, lds, s>>>(
         data, tw, elem_stride, ncols, batch_stride, (unsigned)tiles, scale, nullptr, nullptr, ShellMask{nullptr, 0, 0}, pack);
     AST_CHECK_LAUNCH();

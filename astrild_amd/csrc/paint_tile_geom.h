@@ -34,7 +34,9 @@ __device__ inline int halo_sources(const T* rec, int x, int y, int n, int ntx, i
     using RM = RingMap<W>;
     const int tx = x / TX, ao = x % TX, ty = y / TY, bo = y % TY;
     int ns = 0;
-    src[0] = src[1] = src[2] = nullptr;
+    // three scalars filled by selects: a `src[ns++] = ...` with a run-time ns puts the array into scratch memory
+    // (32 bytes per lane written and read back by every thread of the z pass)
+    const T *s0 = nullptr, *s1 = nullptr, *s2 = nullptr;
 #pragma unroll
     for (int dx = -1; dx <= 1; ++dx) {
 #pragma unroll
@@ -43,9 +45,17 @@ __device__ inline int halo_sources(const T* rec, int x, int y, int n, int ntx, i
             const int a = ao + LO - dx * TX, b = bo + LO - dy * TY;   // this cell in the neighbour's LDS frame
             if (a < 0 || a >= RM::LX || b < 0 || b >= RM::LY) continue;
             const int ntx_ = wrap1(tx + dx, ntx), nty_ = wrap1(ty + dy, nty);
-            if (ns < 3) src[ns++] = rec + ((size_t)(ntx_ * nty + nty_) * RM::COUNT + RM::cell(a, b)) * (size_t)n;
+            const T* p = rec + ((size_t)(ntx_ * nty + nty_) * RM::COUNT + RM::cell(a, b)) * (size_t)n;
+            s0 = ns == 0 ? p : s0;
+            s1 = ns == 1 ? p : s1;
+            s2 = ns == 2 ? p : s2;
+            ++ns;
         }
     }
+    src[0] = s0;
+    src[1] = s1;
+    src[2] = s2;
+    ns = ns > 3 ? 3 : ns;
     return ns;
 }
 

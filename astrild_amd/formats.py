@@ -1,7 +1,7 @@
 """On-disk formats either side of the hot path: files go straight into / come straight
 out of device memory, without the reference's intermediate numpy / pandas copies.
 
-* DTFE density-grid binaries -> device grid.  Layout, from the reference's reader
+* DTFE density-grid binaries -> device grid (file -> page-locked staging buffer -> HBM, dtype conversion on the device).  Layout, from the reference's reader
   (particles/hutils/density.py:100-233 ``DensityHeader``, :345-442 ``readDensityData``; the same file
   format is read at rays/voids/tunnels/density.py): every block is framed by two uint64 byte counts;
   block 1 is the 1024-byte header, block 2 the payload of ``totalGrid * components`` values (f4, or i4
@@ -75,42 +75,55 @@ def data_layout(header: Dict) -> Tuple[str, int]:
 
 def read_density_grid(path: str, to_device: bool = True, dtype=None):
     """``readDensityData`` + the reshape of dtfe.py:70-74 / powmes.py:21-23: returns ``(header, grid)`` with the
-    grid ``(gx, gy, gz)`` (or ``(gx, gy, gz, components)``), x slowest, as a CUDA tensor (``to_device``) in the
-    file's own dtype or ``dtype``.  Pieces of a multi-file result are read one after the other into one array."""
+    grid ``(gx, gy, gz)`` (or ``(gx, gy, gz, components)``), x slowest.  ``to_device``: the payload is read from
+    the file straight into page-locked host memory, copied to the GPU from there and converted to ``dtype`` ON the
+    device (no pageable numpy intermediate, no host-side astype); the result is a CUDA tensor.  Otherwise a numpy
+    array.
+
+    Results split over several files (``noDensityFiles > 1``) are refused: the reference's own reader places every
+    piece at offset 0 of its array (density.py:437, ``startPosition + dataSize`` discards the sum), so there is no
+    behaviour of a consumer to be compatible with, and the header does not say along which axis the pieces join."""
     header, nbytes = read_density_header(path)
     kind, comps = data_layout(header)
-    total = int(header["totalGrid"]) * comps
-    nfiles = max(1, int(header["noDensityFiles"]))
-    data = np.empty(total, dtype=kind)
-    if nfiles == 1 and nbytes != data.nbytes:
-        raise DensityFileError(f"payload of {nbytes} bytes, the header announces {data.nbytes}")
-    start = 0
-    for i in range(nfiles):
-        name = path if nfiles == 1 and os.path.isfile(path) else f"{path}.{i}"
-        if not os.path.isfile(name):
-            raise DensityFileError(f"Cannot find the density file number {i + 1} with expected name '{name}'.")
-        with open(name, "rb") as f:
-            _framed(f, HEADER_BYTES, "header")
-            piece = np.fromfile(f, DENSITY_HEADER_DTYPE, 1)[0]
-            _framed(f, HEADER_BYTES, "header trailer")
-            count = int(piece["totalGrid"]) * comps
-            lead = _framed(f, None, "data block")
-            if lead != count * data.itemsize or start + count > total:
-                raise DensityFileError(f"'{name}': data block of {lead} bytes does not match its header")
-            got = np.fromfile(f, kind, count)
-            if got.size != count:
-                raise DensityFileError(f"'{name}': truncated data block")
-            data[start:start + count] = got
-            trail = np.fromfile(f, np.uint64, 1)
-            if trail.size != 1 or int(trail[0]) != lead:
-                raise DensityFileError(f"'{name}': the byte counts before and after the data differ")
-        start += count
+    if int(header["noDensityFiles"]) > 1:
+        raise DensityFileError(f"'{path}': a result split over {int(header['noDensityFiles'])} files is not supported "
+                               f"(the reference's reader overwrites offset 0 with every piece, density.py:437)")
+    count = int(header["totalGrid"]) * comps
+    np_kind = np.dtype(kind)
+    if nbytes != count * np_kind.itemsize:
+        raise DensityFileError(f"payload of {nbytes} bytes, the header announces {count * np_kind.itemsize}")
+    name = path if os.path.isfile(path) else path + ".0"
+    host = None
+    if to_device:
+        import torch
+        host = torch.empty(count, dtype=torch.float32 if kind == "f4" else torch.int32, pin_memory=True)
+        buf = host.numpy()
+    else:
+        buf = np.empty(count, dtype=np_kind)
+    with open(name, "rb") as f:
+        _framed(f, HEADER_BYTES, "header")
+        f.seek(HEADER_BYTES, os.SEEK_CUR)
+        _framed(f, HEADER_BYTES, "header trailer")
+        lead = _framed(f, None, "data block")
+        if lead != buf.nbytes:
+            raise DensityFileError(f"'{name}': data block of {lead} bytes does not match its header")
+        got = f.readinto(memoryview(buf).cast("B"))
+        if got != buf.nbytes:
+            raise DensityFileError(f"'{name}': truncated data block")
+        trail = np.fromfile(f, np.uint64, 1)
+        if trail.size != 1 or int(trail[0]) != lead:
+            raise DensityFileError(f"'{name}': the byte counts before and after the data differ")
     shape = tuple(int(v) for v in header["gridSize"]) + ((comps,) if comps > 1 else ())
-    grid = data.reshape(shape)
     if not to_device:
+        grid = buf.reshape(shape)
         return header, (grid if dtype is None else grid.astype(dtype))
     from . import device as dev
-    return header, dev.as_device(grid, dtype)
+    grid = host.to(dev.device(), non_blocking=True).reshape(shape)
+    if dtype is not None and grid.dtype != dtype:
+        grid = grid.to(dtype)                      # on the device
+    import torch
+    torch.cuda.current_stream().synchronize()      # the pinned staging buffer is released on return
+    return header, grid
 
 
 def write_density_grid(path: str, grid, box_size: float, file_type: int = 1, redshift: float = 0.0, **extra) -> None:

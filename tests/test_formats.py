@@ -43,22 +43,16 @@ def test_density_grid_round_trip_and_errors(tmp_path):
         formats.read_density_header(str(tmp_path / "missing"))
 
 
-def test_density_grid_split_over_several_files(tmp_path):
+def test_density_grid_split_over_several_files_is_refused(tmp_path):
+    """The reference's reader puts every piece of a multi-file result at offset 0 (density.py:437): there is no
+    behaviour to mirror, so such files are refused with a message that says so."""
     grid = np.arange(4 * 3 * 2, dtype=np.float32).reshape(4, 3, 2)
     root = str(tmp_path / "split.den")
     for i, part in enumerate((grid[:2], grid[2:])):
-        formats.write_density_grid(f"{root}.{i}", part, 10.0)
-        raw = np.fromfile(f"{root}.{i}", np.uint8)
-        rec = np.frombuffer(raw[8:8 + 1024].tobytes(), formats.DENSITY_HEADER_DTYPE).copy()
-        rec["noDensityFiles"], rec["indexDensityFile"] = 2, i
-        if i == 0:                                      # the first file's header describes the whole grid
-            rec["gridSize"], rec["totalGrid"] = grid.shape, grid.size
-        body = raw.copy()
-        body[8:8 + 1024] = np.frombuffer(rec.tobytes(), np.uint8)
-        open(f"{root}.{i}", "wb").write(body.tobytes())
-    # piece 0 carries the total grid size in its header but only its own payload: patch its piece count
-    raw = np.fromfile(f"{root}.0", np.uint8)
-    with pytest.raises(formats.DensityFileError):       # header says 24 values, the block holds 12
+        formats.write_density_grid(f"{root}.{i}", part, 10.0, noDensityFiles=2, indexDensityFile=i)
+    header, _ = formats.read_density_header(root)
+    assert int(header["noDensityFiles"]) == 2
+    with pytest.raises(formats.DensityFileError, match="split over 2 files"):
         formats.read_density_grid(root, to_device=False)
 
 

@@ -300,3 +300,53 @@ def test_sharded_bispectrum_ranks_share_one_gpu(tmp_path):
     assert np.array_equal(got["ntri"], ref["ntri"])
     ok_ = ref["ntri"] > 0
     npt.assert_allclose(got["B"][ok_], ref["B"][ok_], rtol=1e-12)
+
+
+def test_density_file_to_device_grid_to_power_spectrum(tmp_path):
+    """§8f-4 on the GPU: a DTFE density binary (.a_den; float payload, header variants) goes through
+    PowerSpectrum3D._read_data (file -> pinned staging -> device, conversion to the class dtype on the device) and
+    through the P(k) path; compared with the oracle on the same array.  Reference: particles/hutils/density.py:345-442
+    (reader), power_spectrum_3d.py:140-153 (_read_data), dtfe.py:70-80 (the .npy detour this replaces)."""
+    from astrild_amd import formats
+    from astrild_amd.power_spectra import PowerSpectrum3D
+    rng = np.random.default_rng(21)
+    n, L = 64, 500.0
+    grid = (rng.standard_normal((n, n, n)) + 3.0).astype(np.float32)
+    variants = {"snap_005.a_den": dict(file_type=1), "snap_005.a_velDiv": dict(file_type=13, redshift=0.5, Omega0=0.3),
+                "snap_005.den": dict(file_type=50, HubbleParam=0.7, method=np.uint64(3))}
+    for name, kw in variants.items():
+        path = str(tmp_path / name)
+        formats.write_density_grid(path, grid, L, **kw)
+        sim = FakeSimulation(tmp_path, n, L, {5: path})
+        for dtype in (torch.float64, torch.float32):
+            ps = PowerSpectrum3D("particles", sim)
+            ps.dtype = dtype
+            dgrid = ps._read_data(path)
+            assert dgrid.is_cuda and dgrid.dtype == dtype and tuple(dgrid.shape) == (n, n, n)
+            npt.assert_array_equal(dgrid.cpu().numpy(), grid.astype(np.float64 if dtype == torch.float64 else np.float32))
+            k, p = ps._power_spectrum_3d(dgrid)
+            kr, pr = offt.power_spectrum_3d(grid.astype(np.float64), L)
+            npt.assert_allclose(k, kr, rtol=1e-12)
+            npt.assert_allclose(p, pr, rtol=1e-9 if dtype == torch.float64 else 1e-6)
+    # a vector file (three components per grid point) is a 4-D array: refused like in the reference (:68)
+    vec = str(tmp_path / "snap_005.a_vel")
+    formats.write_density_grid(vec, np.stack([grid] * 3, axis=3), L, file_type=11)
+    sim = FakeSimulation(tmp_path, n, L, {5: vec})
+    ps = PowerSpectrum3D("particles", sim)
+    assert tuple(ps._read_data(vec).shape) == (n, n, n, 3)
+    with pytest.raises(BaseException):
+        ps.compute(["vel"], [{"path": "x", "root": "snap", "extension": "a_vel"}], save=False)
+
+
+def test_fp32_cross_spectrum_meets_the_accuracy_of_the_auto_path():
+    """fp32 cross spectra at a tile-FFT size used to go through the fp32 transform with the O(1) mean left
+    in; they are transformed in double now.  N = 256, against the float64 pipeline."""
+    from astrild_amd import device as dev
+    n, L = 256, 1000.0
+    rng = np.random.default_rng(4)
+    a = (rng.standard_normal((n, n, n)) * 0.1 + 1.0).astype(np.float32)
+    b = (a + rng.standard_normal((n, n, n)).astype(np.float32) * 0.05).astype(np.float32)
+    r32 = dev.fftpower_1d(dev.as_device(a), L, dev.as_device(b))
+    r64 = dev.fftpower_1d(dev.as_device(a.astype(np.float64)), L, dev.as_device(b.astype(np.float64)))
+    assert np.array_equal(r32["modes"], r64["modes"])
+    npt.assert_allclose(r32["power"], r64["power"], rtol=1e-6)

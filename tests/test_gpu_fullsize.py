@@ -164,3 +164,54 @@ def test_config_e_bispectrum_512(dev):
     np.testing.assert_allclose(r32["B"][ok], r64["B"][ok], rtol=2e-4, atol=1e-5 * scale)
     dev._tri_cache.clear()
     dev.clear_plan_cache()
+
+
+def test_bench_path_at_1024_against_the_float64_pipeline(dev):
+    """What bench.py times, at the size it times it: fp32 paint(defer_fold, offset=mean, x-sorted pipeline) +
+    power_sums_fused(halo=) (rows_r2c with the halo fold and the low-k z sums, the x pass fused with the shell
+    binning) against the float64 pipeline on the SAME fp32 positions: mode counts equal, every shell within 1e-6
+    (north_star), and the shell sums of the fused path equal to those of its own folded grid transformed separately."""
+    n, L = 1024, 1000.0
+    pos = dev.synth_lattice_particles(n, n, L, seed=20240601, dtype=torch.float32)
+    mean = pos.shape[0] / float(n) ** 3
+    grid, halo = dev.paint(pos, None, n, L, "cic", method="tiled", accumulate=False, defer_fold=True, offset=mean,
+                           hint="xsorted", check_dropped=False)
+    r32 = dev.finish_power(*dev.power_sums_fused(grid, L, halo=halo))
+    del grid, halo
+    r64 = dev.paint_power_1d(pos.double(), None, n, L, "cic")
+    assert np.array_equal(r32["modes"], r64["modes"])
+    np.testing.assert_allclose(r32["k"], r64["k"], rtol=1e-12)
+    np.testing.assert_allclose(r32["power"], r64["power"], rtol=1e-6)
+    # Parseval on the same grid with the fold done by the paint: sum over ALL modes of w |delta_k|^2 == <delta^2>,
+    # and the shells of the fused path add up to the part of it inside the Nyquist sphere
+    g2 = dev.paint(pos, None, n, L, "cic", method="tiled", accumulate=False, offset=mean)
+    del pos
+    rhs = float((g2.double() ** 2).mean())
+    spec = dev.r2c(g2)
+    del g2
+    w = torch.full((n // 2 + 1,), 2.0, dtype=torch.float64, device="cuda")
+    w[0] = w[-1] = 1.0
+    p3 = spec.real.double() ** 2
+    p3 += spec.imag.double() ** 2
+    lhs = float((p3 * w).sum())
+    del p3
+    assert lhs == pytest.approx(rhs, rel=2e-6)
+    ks, ps, nm = dev.power_bin_1d(spec, None, n, L)
+    inside = float(ps.sum()) / L ** 3
+    fused = float(np.nansum(r32["power"] * r32["modes"])) / L ** 3
+    assert fused == pytest.approx(inside, rel=2e-6) and inside < lhs
+
+
+def test_shuffled_tsc_at_512_against_the_float64_pipeline(dev):
+    """Unordered particles + TSC (what stats_subfind.py:125-131 feeds the paint): the scattered fp32 path with the
+    fused transform against the float64 pipeline on the same positions."""
+    n, L = 512, 1000.0
+    pos = dev.synth_lattice_particles(n, n, L, seed=7, dtype=torch.float32, shuffle=True)
+    mean = pos.shape[0] / float(n) ** 3
+    grid, halo = dev.paint(pos, None, n, L, "tsc", method="tiled", accumulate=False, defer_fold=True, offset=mean,
+                           hint="scattered", check_dropped=False)
+    r32 = dev.finish_power(*dev.power_sums_fused(grid, L, halo=halo))
+    del grid, halo
+    r64 = dev.paint_power_1d(pos.double(), None, n, L, "tsc")
+    assert np.array_equal(r32["modes"], r64["modes"])
+    np.testing.assert_allclose(r32["power"], r64["power"], rtol=1e-6)
