@@ -70,6 +70,8 @@ SIGNATURES = {
     "ast_power_bin_1d": (_i, [_vp, _vp, _i, _i, _d, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "ast_interlace_compensate": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ast_shell_filter": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ast_shell_mask_real": (_i, [_vp, _i, _i, _i, _vp]),
+    "ast_half_real_to_full": (_i, [_vp, _vp, _i, _vp]),
     "ast_triple_product_sum": (_i, [_vp, _vp, _vp, _i, _sz, _vp, _vp]),
     "ast_triple_product_sums_scratch_bytes": (_sz, []),
     "ast_triple_product_sums": (_i, [_vp, _i, _i, _sz, _vp, _i, _vp, _vp, _vp]),
@@ -86,6 +88,7 @@ SIGNATURES = {
     "ast_lens_cols_supported": (_i, [_sz]),
     "ast_lens_rows_supported": (_i, [_sz]),
     "ast_lens_rows_forward": (_i, [_vp, _sz, _vp, _sz, _vp]),
+    "ast_lens_rows_forward_full": (_i, [_vp, _sz, _sz, _vp, _sz, _vp]),
     "ast_lens_rows_inverse": (_i, [_vp, _sz, _sz, _d, _vp, _vp]),
     "ast_lens_cols_forward": (_i, [_vp, _sz, _sz, _sz, _sz, _vp]),
     "ast_lens_cols_inverse": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),

@@ -18,13 +18,25 @@ namespace {
 // ----------------------------------------------------------- kappa stack
 // V pixels per thread (16-byte loads), planes four at a time: the four loads are issued before the first add, the
 // adds stay in plane order (first = copy, then running +=: numpy's sequence, bit for bit)
+#ifndef KSTACK_NT
+#define KSTACK_NT 1                // 1: nontemporal loads (every plane is read exactly once)
+#endif
+#ifndef KSTACK_DEPTH
+#define KSTACK_DEPTH 4             // planes whose loads are issued before the first add
+#endif
 template <typename T, int V>
 __global__ void __launch_bounds__(256)
 kappa_stack_kernel(const T* const* __restrict__ planes, const double* __restrict__ wnum,
                    const double* __restrict__ wden, int nplanes, size_t count, T* __restrict__ out) {
     typedef T vec_t __attribute__((ext_vector_type(V)));
+    constexpr int D = KSTACK_DEPTH;
     const size_t nvec = count / V;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    auto load = [&](int p, size_t i) -> vec_t {
+        const vec_t* src = reinterpret_cast<const vec_t*>(planes[p]) + i;
+        if (KSTACK_NT) return __builtin_nontemporal_load(src);
+        return *src;
+    };
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
         vec_t acc;
         auto term = [&](vec_t v, int p) {
@@ -35,16 +47,15 @@ kappa_stack_kernel(const T* const* __restrict__ planes, const double* __restrict
             return v;
         };
         int p = 0;
-        for (; p + 4 <= nplanes; p += 4) {
-            const vec_t v0 = reinterpret_cast<const vec_t*>(planes[p])[i], v1 = reinterpret_cast<const vec_t*>(planes[p + 1])[i],
-                        v2 = reinterpret_cast<const vec_t*>(planes[p + 2])[i], v3 = reinterpret_cast<const vec_t*>(planes[p + 3])[i];
-            acc = p == 0 ? term(v0, p) : acc + term(v0, p);
-            acc = acc + term(v1, p + 1);
-            acc = acc + term(v2, p + 2);
-            acc = acc + term(v3, p + 3);
+        for (; p + D <= nplanes; p += D) {
+            vec_t v[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) v[d] = load(p + d, i);
+#pragma unroll
+            for (int d = 0; d < D; ++d) acc = (p == 0 && d == 0) ? term(v[d], p + d) : acc + term(v[d], p + d);
         }
         for (; p < nplanes; ++p) {
-            const vec_t v = reinterpret_cast<const vec_t*>(planes[p])[i];
+            const vec_t v = load(p, i);
             acc = p == 0 ? term(v, p) : acc + term(v, p);
         }
         reinterpret_cast<vec_t*>(out)[i] = acc;
@@ -353,7 +364,9 @@ extern "C" int ast_lens_plan_create(ast_lens_plan** out, int nc, double bsz) {
     int rc = AST_OK;
     p->cols = ast_lens_cols_supported(n2) != 0 && !getenv("AST_LENS_ROCFFT_2D");
     p->rows = p->cols && ast_lens_rows_supported((size_t)nc) != 0 && !getenv("AST_LENS_ROCFFT_ROWS");
-    if (p->cols) {
+    if (p->rows) {
+        // hand-written rows and columns: no rocFFT plan at all
+    } else if (p->cols) {
         const size_t len1[1] = {n2}, one[1] = {1};
         rc = ast_fft_plan_create_general(&p->rows_fwd, AST_FFT_R2C, AST_F64, 1, len1, one, one, (size_t)nc, n2, nh, 1.0, 0);
         if (rc == AST_OK) rc = ast_fft_plan_create_general(&p->rows_fwd_all, AST_FFT_R2C, AST_F64, 1, len1, one, one, n2, n2, nh, 1.0, 0);
@@ -364,8 +377,8 @@ extern "C" int ast_lens_plan_create(ast_lens_plan** out, int nc, double bsz) {
     }
     if (rc != AST_OK) { ast_lens_plan_destroy(p); return rc; }
     hipError_t e = hipMalloc(&p->pad, n2 * n2 * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&p->pad_in, n2 * n2 * sizeof(double));
-    if (e == hipSuccess) e = hipMemset(p->pad_in, 0, n2 * n2 * sizeof(double));
+    if (e == hipSuccess && !p->rows) e = hipMalloc(&p->pad_in, n2 * n2 * sizeof(double));      // (the row kernels read kappa unpadded)
+    if (e == hipSuccess && !p->rows) e = hipMemset(p->pad_in, 0, n2 * n2 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&p->spec, n2 * nh * sizeof(double2));
     if (e == hipSuccess) e = hipMalloc(&p->prod, n2 * nh * sizeof(double2));
     if (e != hipSuccess) {
@@ -385,7 +398,10 @@ static int lens_kernel_spectrum(ast_lens_plan* p, int which, hipStream_t s) {
     const double dsx = p->bsz / (double)p->nc;
     iso_kernel_build<<<ast::stream_grid(n2 * n2, 256), 256, 0, s>>>((int)n2, dsx, which, p->pad);
     AST_CHECK_LAUNCH();
-    if (p->cols) {
+    if (p->rows) {
+        AST_FWD(ast_lens_rows_forward_full(p->pad, (size_t)p->nc, n2, p->kspec[which], nh, s));
+        AST_FWD(ast_lens_cols_forward(p->kspec[which], n2, nh, nh, n2, s));
+    } else if (p->cols) {
         AST_FWD(ast_fft_exec(p->rows_fwd_all, p->pad, p->kspec[which], s));
         AST_FWD(ast_lens_cols_forward(p->kspec[which], n2, nh, nh, n2, s));
     } else {

@@ -49,7 +49,13 @@ __device__ inline double2 cmul(double2 a, double2 w) {
     return make_double2(fma(a.x, w.x, -a.y * w.y), fma(a.x, w.y, a.y * w.x));
 }
 
-// forward FFT of R <= 16 points in registers, decimation in frequency: X[k] ends up in v[bitrev(k)]
+// e^{-2 pi i r / 32} for odd r (the even ones are the 16th roots above): cos and sin of pi r / 16
+__device__ constexpr double kC32odd[8] = {0.98078528040323044, 0.83146961230254524, 0.55557023301960222, 0.19509032201612827,
+                                          -0.19509032201612827, -0.55557023301960222, -0.83146961230254524, -0.98078528040323044};
+__device__ constexpr double kS32odd[8] = {-0.19509032201612827, -0.55557023301960222, -0.83146961230254524, -0.98078528040323044,
+                                          -0.98078528040323044, -0.83146961230254524, -0.55557023301960222, -0.19509032201612827};
+
+// forward FFT of R <= 32 points in registers, decimation in frequency: X[k] ends up in v[bitrev(k)]
 template <int R>
 __device__ inline void fft_reg(double2 (&v)[R]) {
 #pragma unroll
@@ -61,10 +67,11 @@ __device__ inline void fft_reg(double2 (&v)[R]) {
                 const double2 a = v[blk + j], b = v[blk + j + h];
                 v[blk + j] = make_double2(a.x + b.x, a.y + b.y);
                 const double2 d = make_double2(a.x - b.x, a.y - b.y);
-                const int t = j * (8 / h);                   // W_{2h}^j = W_16^{j * 16 / (2h)}
+                const int t = j * (16 / h);                  // W_{2h}^j = W_32^{j * 32 / (2h)}, t < 16
                 if (t == 0) v[blk + j + h] = d;
-                else if (t == 4) v[blk + j + h] = make_double2(d.y, -d.x);          // * (-i)
-                else v[blk + j + h] = cmul(d, make_double2(kC16[t], kS16[t]));
+                else if (t == 8) v[blk + j + h] = make_double2(d.y, -d.x);          // * (-i)
+                else if (t % 2 == 0) v[blk + j + h] = cmul(d, make_double2(kC16[t / 2], kS16[t / 2]));
+                else v[blk + j + h] = cmul(d, make_double2(kC32odd[t / 2], kS32odd[t / 2]));
             }
         }
     }
@@ -364,6 +371,7 @@ int launch_pass(const double2* in, const double2* mul, double2* out, size_t pitc
 struct Split { int n1, n2; };
 bool split_of(size_t len, Split& sp) {
     switch (len) {
+        case 16384: sp = {128, 128}; return true;
         case 8192: sp = {64, 128}; return true;
         case 4096: sp = {64, 64}; return true;
         case 2048: sp = {32, 64}; return true;
@@ -438,7 +446,7 @@ extern "C" int ast_lens_cols_inverse(const void* spec, const void* mul, void* ou
 }
 
 extern "C" int ast_lens_rows_supported(size_t nc) {
-    return nc == 4096 || nc == 2048 || nc == 1024 || nc == 512 || nc == 256 || nc == 128;
+    return nc == 8192 || nc == 4096 || nc == 2048 || nc == 1024 || nc == 512 || nc == 256 || nc == 128;
 }
 
 namespace {
@@ -487,12 +495,35 @@ extern "C" int ast_lens_rows_forward(const double* kappa, size_t nc, void* spec,
     AST_PROF("lens.rows_fwd", s);
     double2* o = (double2*)spec;
     switch (nc) {
+        case 8192: return rows_forward_launch<32, 16, 16>(kappa, nc, o, pitch, twM, twL, s);      // the reference's npix default (sky_array.py:266)
         case 4096: return rows_forward_launch<16, 16, 16>(kappa, nc, o, pitch, twM, twL, s);
         case 2048: return rows_forward_launch<16, 16, 8>(kappa, nc, o, pitch, twM, twL, s);
         case 1024: return rows_forward_launch<16, 8, 8>(kappa, nc, o, pitch, twM, twL, s);
         case 512: return rows_forward_launch<8, 8, 8>(kappa, nc, o, pitch, twM, twL, s);
         case 256: return rows_forward_launch<8, 8, 4>(kappa, nc, o, pitch, twM, twL, s);
         default: return rows_forward_launch<8, 4, 4>(kappa, nc, o, pitch, twM, twL, s);
+    }
+}
+
+// spec_d[r][0 .. nc] = R2C of length 2 nc of the FULL row in_d[r][0 .. 2 nc) (no zero padding), r < nrows: the rows of the
+// convolution kernels (lensing_funcs.c:45-83 fills all of the padded array), so that a plan needs no rocFFT at all.
+extern "C" int ast_lens_rows_forward_full(const double* in, size_t nc, size_t nrows, void* spec, size_t pitch, void* stream) {
+    AST_CHECK_ARG(in != nullptr && spec != nullptr && ast_lens_rows_supported(nc) && pitch >= nc + 1 && nrows >= 1);
+    AST_CHECK_ARG(((uintptr_t)in & 15) == 0);
+    hipStream_t s = ast::as_stream(stream);
+    const double2* twM = g_tw.get((int)nc, s);
+    const double2* twL = g_tw.get((int)(2 * nc), s);
+    if (!twM || !twL) { ast::set_error("ast_lens_rows_forward_full: twiddle table allocation failed"); return AST_ERR_HIP; }
+    AST_PROF("lens.rows_fwd", s);
+    double2* o = (double2*)spec;
+    switch (nc) {
+        case 8192: return rows_forward_launch<32, 16, 16, false>(in, nrows, o, pitch, twM, twL, s, 2 * nc);
+        case 4096: return rows_forward_launch<16, 16, 16, false>(in, nrows, o, pitch, twM, twL, s, 2 * nc);
+        case 2048: return rows_forward_launch<16, 16, 8, false>(in, nrows, o, pitch, twM, twL, s, 2 * nc);
+        case 1024: return rows_forward_launch<16, 8, 8, false>(in, nrows, o, pitch, twM, twL, s, 2 * nc);
+        case 512: return rows_forward_launch<8, 8, 8, false>(in, nrows, o, pitch, twM, twL, s, 2 * nc);
+        case 256: return rows_forward_launch<8, 8, 4, false>(in, nrows, o, pitch, twM, twL, s, 2 * nc);
+        default: return rows_forward_launch<8, 4, 4, false>(in, nrows, o, pitch, twM, twL, s, 2 * nc);
     }
 }
 
@@ -507,6 +538,7 @@ extern "C" int ast_lens_rows_inverse(const void* spec, size_t pitch, size_t nc, 
     AST_PROF("lens.rows_inv", s);
     const double2* x = (const double2*)spec;
     switch (nc) {
+        case 8192: return rows_inverse_launch<32, 16, 16>(x, pitch, nc, scale, out, twM, twL, s);
         case 4096: return rows_inverse_launch<16, 16, 16>(x, pitch, nc, scale, out, twM, twL, s);
         case 2048: return rows_inverse_launch<16, 16, 8>(x, pitch, nc, scale, out, twM, twL, s);
         case 1024: return rows_inverse_launch<16, 8, 8>(x, pitch, nc, scale, out, twM, twL, s);

@@ -132,6 +132,32 @@ shell_filter_kernel(const C* __restrict__ in, C* __restrict__ out, int n, long l
 }
 
 
+// The shell indicator on the FULL lattice as a real array, and the real part of a half spectrum unfolded onto the full
+// lattice: together with a forward float64 transform they give the bispectrum estimator's I_s(x) = sum_{k in s} e^{ikx}
+// without an inverse transform - the indicator is real and even (k in s <=> -k in s), so its inverse transform equals
+// its forward one and is real and even itself: I_s(x) = Re FFT[1_s](x), and for x_z > N/2 the value at -x.
+__global__ void __launch_bounds__(256)
+shell_mask_real_kernel(double* __restrict__ out, int n, long long lo2, long long hi2) {
+    const size_t total = (size_t)n * n * n;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int m2i = freq((int)(i % n), n), m1 = freq((int)((i / n) % n), n), m0 = freq((int)(i / ((size_t)n * n)), n);
+        const long long m2 = (long long)m0 * m0 + (long long)m1 * m1 + (long long)m2i * m2i;
+        out[i] = (m2 >= lo2 && m2 < hi2) ? 1.0 : 0.0;
+    }
+}
+__global__ void __launch_bounds__(256)
+half_real_to_full_kernel(const double2* __restrict__ spec, double* __restrict__ out, int n) {
+    const int nz = n / 2 + 1;
+    const size_t total = (size_t)n * n * n;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int z = (int)(i % n), y = (int)((i / n) % n), x = (int)(i / ((size_t)n * n));
+        if (z >= nz) { z = n - z; y = y ? n - y : 0; x = x ? n - x : 0; }
+        out[i] = spec[((size_t)x * n + y) * nz + z].x;
+    }
+}
+
 // f-1: interlacing + window compensation of a catalogue-painted mesh (nbodykit CatalogMesh with interlaced=True /
 // compensated=True, the parameters astrild writes at power_spectrum_3d.py:197-212; nbodykit is un-vendored, its
 // published formulas restated).  c1 is the spectrum of the plain paint, c2 of the paint shifted by half a cell
@@ -343,6 +369,22 @@ extern "C" int ast_shell_filter(const void* in, void* out, int dtype, int nmesh,
         shell_filter_kernel<float2><<<g, 256, 0, s>>>((const float2*)in, (float2*)out, nmesh, lo2, hi2, i0_start, i0_count, i1_start, i1_count);
     else
         shell_filter_kernel<double2><<<g, 256, 0, s>>>((const double2*)in, (double2*)out, nmesh, lo2, hi2, i0_start, i0_count, i1_start, i1_count);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+extern "C" int ast_shell_mask_real(double* out, int nmesh, int m_lo, int m_hi, void* stream) {
+    AST_CHECK_ARG(out != nullptr && nmesh >= 4 && nmesh % 2 == 0 && m_lo >= 0 && m_hi > m_lo);
+    shell_mask_real_kernel<<<ast::stream_grid((size_t)nmesh * nmesh * nmesh, 256), 256, 0, ast::as_stream(stream)>>>(
+        out, nmesh, (long long)m_lo * m_lo, (long long)m_hi * m_hi);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+extern "C" int ast_half_real_to_full(const void* spec, double* out, int nmesh, void* stream) {
+    AST_CHECK_ARG(spec != nullptr && out != nullptr && (const void*)out != spec && nmesh >= 4 && nmesh % 2 == 0);
+    half_real_to_full_kernel<<<ast::stream_grid((size_t)nmesh * nmesh * nmesh, 256), 256, 0, ast::as_stream(stream)>>>(
+        (const double2*)spec, out, nmesh);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }

@@ -114,22 +114,36 @@ __device__ inline double key2d(unsigned long long k) {
     return __longlong_as_double((long long)u);
 }
 
-template <typename T>
-__global__ void minmax_kernel(const T* buf, size_t n, unsigned long long* keys) {
-    double lo = DBL_MAX, hi = -DBL_MAX;
+// V elements per load (16 bytes when the buffer is aligned), four loads in flight per thread, extrema reduced over the
+// wave and then over the workgroup: ONE pair of atomics per workgroup.  (One pair per WAVE - 8192 waves hammering two
+// addresses - took 0.2 ms for a 134 MB map that streams in 0.03: the same-address atomics serialise at the memory side.)
+template <typename T, int V>
+__global__ void __launch_bounds__(256) minmax_kernel(const T* __restrict__ buf, size_t n, unsigned long long* keys) {
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    __shared__ double slo[4], shi[4];
+    const size_t nvec = n / V;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // four independent loads and running extrema per trip (one load in flight per thread read 134 MB at 0.6 TB/s)
     double l[4] = {DBL_MAX, DBL_MAX, DBL_MAX, DBL_MAX}, h[4] = {-DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX};
-    for (; i + 3 * stride < n; i += 4 * stride) {
-        T v[4];
+    const vec_t* vb = reinterpret_cast<const vec_t*>(buf);
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+        vec_t v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = buf[i + j * stride];
+        for (int j = 0; j < 4; ++j) v[j] = vb[i + j * stride];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { l[j] = fmin(l[j], (double)v[j]); h[j] = fmax(h[j], (double)v[j]); }
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) { l[j] = fmin(l[j], (double)v[j][k]); h[j] = fmax(h[j], (double)v[j][k]); }
+        }
     }
-    for (; i < n; i += stride) {
-        const double v = (double)buf[i];
+    double lo = DBL_MAX, hi = -DBL_MAX;
+    for (; i < nvec; i += stride) {
+        const vec_t v = vb[i];
+#pragma unroll
+        for (int k = 0; k < V; ++k) { lo = fmin(lo, (double)v[k]); hi = fmax(hi, (double)v[k]); }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - nvec * V) {           // the elements past the last whole vector
+        const double v = (double)buf[nvec * V + threadIdx.x];
         lo = fmin(lo, v);
         hi = fmax(hi, v);
     }
@@ -137,9 +151,11 @@ __global__ void minmax_kernel(const T* buf, size_t n, unsigned long long* keys) 
     hi = fmax(fmax(hi, h[0]), fmax(fmax(h[1], h[2]), h[3]));
     lo = wave_min(lo);
     hi = wave_max(hi);
-    if ((threadIdx.x & 63) == 0) {
-        atomicMin(&keys[0], d2key(lo));
-        atomicMax(&keys[1], d2key(hi));
+    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMin(&keys[0], d2key(fmin(fmin(slo[0], slo[1]), fmin(slo[2], slo[3]))));
+        atomicMax(&keys[1], d2key(fmax(fmax(shi[0], shi[1]), fmax(shi[2], shi[3]))));
     }
 }
 
@@ -305,11 +321,16 @@ extern "C" int ast_minmax(const void* buf, int dtype, size_t count, double* out,
     hipStream_t s = ast::as_stream(stream);
     auto* keys = reinterpret_cast<unsigned long long*>(out);
     minmax_init<<<1, 1, 0, s>>>(keys);
-    unsigned g = ast::stream_grid(count, 256);
-    if (dtype == AST_F32)
-        minmax_kernel<float><<<g, 256, 0, s>>>((const float*)buf, count, keys);
-    else
-        minmax_kernel<double><<<g, 256, 0, s>>>((const double*)buf, count, keys);
+    const bool wide = ((uintptr_t)buf & 15) == 0;
+    const size_t per = wide ? 16 / (dtype == AST_F32 ? 4 : 8) : 1;
+    unsigned g = ast::stream_grid((count + per - 1) / per, 256);
+    if (dtype == AST_F32) {
+        if (wide) minmax_kernel<float, 4><<<g, 256, 0, s>>>((const float*)buf, count, keys);
+        else minmax_kernel<float, 1><<<g, 256, 0, s>>>((const float*)buf, count, keys);
+    } else {
+        if (wide) minmax_kernel<double, 2><<<g, 256, 0, s>>>((const double*)buf, count, keys);
+        else minmax_kernel<double, 1><<<g, 256, 0, s>>>((const double*)buf, count, keys);
+    }
     minmax_finish<<<1, 1, 0, s>>>(keys);
     AST_CHECK_LAUNCH();
     return AST_OK;

@@ -649,7 +649,18 @@ def bispectrum(field, boxsize, edges, triangles):
         # alone would move sum I_i I_j I_l / Ng by thousands.  In double the sum is within ~1e-3 of the integer.
         iscratch = torch.empty(spec.shape, dtype=torch.complex128, device=spec.device)
         ifields = {}
+        L = _lib.lib()
+        forward_only = bool(L.ast_fft64_supported(n))
         for s in used:
+            if forward_only:
+                # the indicator is real and even: its inverse transform is its forward one (hand-written double
+                # passes, no rocFFT), real up to round-off, unfolded from the half lattice onto the full one
+                mask = torch.empty((n, n, n), dtype=torch.float64, device=spec.device)
+                check(L.ast_shell_mask_real(ptr(mask), n, edges[s], edges[s + 1], stream()), "ast_shell_mask_real")
+                check(L.ast_fft64_r2c_3d(ptr(mask), ptr(iscratch), n, 1.0, stream()), "ast_fft64_r2c_3d")
+                check(L.ast_half_real_to_full(ptr(iscratch), ptr(mask), n, stream()), "ast_half_real_to_full")
+                ifields[s] = mask
+                continue
             shell_filter(None, n, edges[s], edges[s + 1], out=iscratch)
             ifields[s] = c2r(iscratch, (n, n, n))
         dens = triple_product_sums(ifields, triangles).cpu().numpy()

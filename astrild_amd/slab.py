@@ -314,7 +314,9 @@ class SlabPowerPipeline:
         self.psum = o.zeros((n // 2 - 1,), torch.float64)
         self._side = None
         self._stage_s = {}
-        self.hint = None if (shuffle or route or pos is not None) else "xsorted"     # the synthetic set comes in lattice order
+        # (hint="xsorted" - grouping and walks overlapped chunk by chunk - is available but buys nothing measurable:
+        # both paint kernels are bound by their index arithmetic)
+        self.hint = None
         self.ghosts = GhostExchange(self.buf, self.nloc, self.gl, self.gh, o, group) if P > 1 else None
         # chunks whose planes the incoming ghosts do not touch are transformed (and sent) first, while the ghosts travel
         edge = {c for c in range(chunks) if c * self.pc < self.gh or (c + 1) * self.pc > self.nloc - self.gl}

@@ -355,7 +355,7 @@ def power_leg(dev, n, npside, L, window, order, dtype, method, steps, warmup):
     if not fused and not fused64:
         spec = torch.empty((n, n, n // 2 + 1), dtype=torch.complex64 if dtype == "f32" else torch.complex128, device="cuda")
     mean = npart_total / float(n) ** 3
-    hint = "scattered" if order == "shuffled" else "xsorted"        # natural = lattice order: ascending x
+    hint = "scattered" if order == "shuffled" else None
 
     def step():
         if fused and method in ("auto", "tiled"):

@@ -352,6 +352,12 @@ int ast_power_bin_1d(const void* spec1_d, const void* spec2_d, int dtype, int nm
  * ast_power_bin_1d. */
 int ast_shell_filter(const void* in_d, void* out_d, int dtype, int nmesh, int m_lo, int m_hi,
                      int i0_start, int i0_count, int i1_start, int i1_count, void* stream);
+/* I_s(x) = sum_{k in shell} e^{ikx} WITHOUT an inverse transform (bispectra/bispectrum_3d.py:42-44, the estimator's
+ * triangle counts): the shell indicator m_lo <= |m| < m_hi on the full lattice as an (n, n, n) float64 array
+ * (ast_shell_mask_real) is real and even, so its forward transform (ast_fft64_r2c_3d, scale 1) IS I_s on the half
+ * lattice, real up to round-off; ast_half_real_to_full unfolds the real part onto the full (n, n, n) lattice. */
+int ast_shell_mask_real(double* out_d, int nmesh, int m_lo, int m_hi, void* stream);
+int ast_half_real_to_full(const void* spec_d, double* out_d, int nmesh, void* stream);
 
 /* *out_d += sum_i a[i] * b[i] * c[i]  (double accumulator, device). */
 int ast_triple_product_sum(const void* a_d, const void* b_d, const void* c_d, int dtype,
@@ -433,6 +439,9 @@ int ast_lens_cols_supported(size_t len);
  * 1 / (nx ny) dx dy of fft_convolve.c:88 in the store). */
 int ast_lens_rows_supported(size_t nc);
 int ast_lens_rows_forward(const double* kappa_d, size_t nc, void* spec_d, size_t pitch, void* stream);
+/* The same for FULL rows of 2 nc reals (no zero padding), nrows of them with pitch 2 nc: the rows of the convolution
+ * kernels (lensing_funcs.c:45-83), so that a lens plan of a supported size runs without rocFFT. */
+int ast_lens_rows_forward_full(const double* in_d, size_t nc, size_t nrows, void* spec_d, size_t pitch, void* stream);
 int ast_lens_rows_inverse(const void* spec_d, size_t pitch, size_t nc, double scale, double* out_d, void* stream);
 int ast_lens_cols_forward(void* data_d, size_t len, size_t pitch, size_t ncols, size_t nonzero_rows, void* stream);
 int ast_lens_cols_inverse(const void* spec_d, const void* mul_d, void* out_d, size_t len, size_t pitch, size_t ncols,

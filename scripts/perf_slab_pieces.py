@@ -22,11 +22,17 @@ def line(name, ms):
     print(f"{name:55s} {ms:7.3f} ms", flush=True)
 ppr = n ** 3 // P
 pos = ops.synth(n, n, L, 1, False, 0, ppr)
-gl = 5
+gl = int(sys.argv[2]) if len(sys.argv) > 2 else 4          # ghost + 1 planes on each side (bench.py: ghost = 3)
 buf = ops.empty((nloc + 2 * gl, n, n))
 mean = float(ppr) * P / float(n) ** 3
-line(f"slab paint, {ppr} particles (rho - mean on owned planes)",
+line(f"slab paint, {ppr} particles, {nloc + 2 * gl} planes (rho - mean on owned planes)",
      timeit(lambda: ops.paint(pos, None, n, L, 'cic', buf, (0 - gl) % n, nloc + 2 * gl, offset=mean, owned=(gl, nloc))))
+dev.profile_enable(True)
+for _ in range(5):
+    ops.paint(pos, None, n, L, 'cic', buf, (0 - gl) % n, nloc + 2 * gl, offset=mean, owned=(gl, nloc))
+torch.cuda.synchronize()
+print("    paint kernels:", {k: round(v[1] / 5, 3) for k, v in dev.profile_report().items()}, flush=True)
+dev.profile_enable(False)
 owned = buf[gl:gl + nloc]
 line("ghost add (2 x %d planes)" % gl, timeit(lambda: (ops.add_into(buf[gl:2 * gl], buf[:gl]), ops.add_into(buf[nloc:nloc + gl], buf[nloc + gl:]))))
 line("low-k modes of the owned planes (side stream in the pipeline)", timeit(lambda: ops.lowk_modes(owned, n, 0)))

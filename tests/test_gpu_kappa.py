@@ -303,10 +303,10 @@ def test_flat_sky_power_and_bispectrum_vs_oracle(lens, dev):
     npt.assert_allclose(bs.B, bb, rtol=1e-9, atol=1e-12 * np.abs(bb).max())
 
 
-_LENS_SPLIT = {8192: (64, 128), 4096: (64, 64), 2048: (32, 64), 1024: (32, 32), 512: (16, 32), 256: (16, 16)}
+_LENS_SPLIT = {16384: (128, 128), 8192: (64, 128), 4096: (64, 64), 2048: (32, 64), 1024: (32, 32), 512: (16, 32), 256: (16, 16)}
 
 
-@pytest.mark.parametrize("length", [256, 512, 1024, 2048, 8192])
+@pytest.mark.parametrize("length", [256, 512, 1024, 2048, 8192, 16384])
 def test_lens_column_transforms_against_numpy(hip, dev, length):
     """The two-pass column transforms of the padded lens convolution (lens_fft.hip): forward = np.fft.fft along axis 0
     with frequency k1 + N1 k2 at row N2 k1 + k2; rows >= nonzero_rows are never read (NaN there); the inverse undoes it
@@ -382,7 +382,7 @@ def test_gaussian_fft_smoothing_real_space_route_equals_fft_route(lens, dev, npi
     npt.assert_allclose(a.mean(), img.mean(), rtol=0, atol=1e-13)  # the periodic kernel sums to one
 
 
-@pytest.mark.parametrize("nc", [128, 256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize("nc", [128, 256, 512, 1024, 2048, 4096, 8192])
 def test_lens_row_transforms_against_numpy(hip, dev, nc):
     """Hand-written row transforms of the padded convolution: forward = np.fft.rfft of (row, nc zeros); inverse =
     scale * first nc samples of the unnormalised irfft."""
@@ -409,4 +409,47 @@ def test_lens_row_transforms_against_numpy(hip, dev, nc):
     o = out.cpu().numpy()
     want = scale * 2 * nc * full[:, :nc]                   # unnormalised C2R = length * irfft
     assert np.abs(o - want).max() < 1e-12 * np.abs(want).max()
-    assert hip.ast_lens_rows_supported(4096) == 1 and hip.ast_lens_rows_supported(8192) == 0 and hip.ast_lens_rows_supported(100) == 0
+    assert hip.ast_lens_rows_supported(4096) == 1 and hip.ast_lens_rows_supported(8192) == 1 and hip.ast_lens_rows_supported(100) == 0
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_minmax_wide_loads_tails_and_unaligned_views(dtype):
+    """ast_minmax (np.histogram's range=None pass; the paint's mass bound): 16-byte loads, one pair of atomics per
+    workgroup - against numpy for lengths that are not multiples of the vector, tiny inputs and a view that starts off a
+    16-byte boundary (scalar loads)."""
+    from astrild_amd import device as dev, lensing
+    rng = np.random.default_rng(12)
+    for n in (1, 3, 255, 4097, 1_000_003, 4096 * 4096):
+        a = rng.standard_normal(n).astype(dtype)
+        a[rng.integers(n)] = -77.5
+        a[rng.integers(n)] = 99.25 if n > 1 else a[0]
+        t = dev.as_device(a)
+        lo, hi = lensing.minmax(t)
+        assert (lo, hi) == (float(a.min()), float(a.max()))
+        if n > 4:
+            lo, hi = lensing.minmax(t[1:])
+            assert (lo, hi) == (float(a[1:].min()), float(a[1:].max()))
+
+
+def test_lens_plan_at_the_reference_default_npix_8192(lens, dev, monkeypatch):
+    """nc = 8192 is the reference's halo-map default (sky_array.py:266,348): the hand-written row (32 x 16 x 16 points) and
+    column (128 x 128) transforms carry the plan there too; against the rocFFT 2-D route on the same map, and no rocFFT
+    kernel runs in the hand-written one (the profile sites are the lens.* ones only)."""
+    nc, bsz = 8192, np.deg2rad(10.0)
+    g = torch.Generator(device="cuda").manual_seed(8192)
+    kd = torch.randn((nc, nc), generator=g, device="cuda", dtype=torch.float64) * 0.01
+    plan = lens.LensPlan(nc, bsz)
+    dev.profile_enable(True)
+    a1, a2 = plan.alphas(kd)
+    torch.cuda.synchronize()
+    sites = set(dev.profile_report())
+    dev.profile_enable(False)
+    assert sites and all(s.startswith("lens.") for s in sites), sites
+    del plan
+    monkeypatch.setenv("AST_LENS_ROCFFT_2D", "1")
+    ref = lens.LensPlan(nc, bsz)
+    r1, r2 = ref.alphas(kd)
+    monkeypatch.delenv("AST_LENS_ROCFFT_2D")
+    for a, r in ((a1, r1), (a2, r2)):
+        assert float((a - r).abs().max()) <= 1e-11 * float(r.abs().max())
+    assert float(a1.abs().max()) > 0.0

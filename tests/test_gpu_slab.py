@@ -203,3 +203,54 @@ def test_route_kernels_group_particles_by_destination_slab(hip, window, dtype):
         got = np.concatenate([spos[seg], smass[seg, None]], axis=1)
         exp = np.concatenate([pos[dest == p], mass[dest == p, None]], axis=1)
         assert np.array_equal(got[np.lexsort(got.T)], exp[np.lexsort(exp.T)])
+
+
+@pytest.mark.parametrize("ghost", [3, 4])
+def test_one_rank_of_eight_at_1024_local_pieces(hip, ghost):
+    """World 8 is what the driver's scaling run uses and cannot be rehearsed with 8 GPU processes on this box (6 at most):
+    the LOCAL pieces of rank 3 of 8 at the 1024^3 shape in one process - slab buffer of 136 planes (ghost 3: whole tiles)
+    or 138 (ghost 4: partial last tile), z-segmented walk, y pass storing in send order for 8 parts, axis-0 pass of the
+    (1024, 128, 513) block fused with its shell binning - each against the plain route."""
+    from astrild_amd import device as dev, slab
+    torch.cuda.set_device(0)
+    n, L, P, r = 1024, 1000.0, 8, 3
+    nloc, nz = n // P, n // 2 + 1
+    gl = ghost + 1
+    ops = slab.HipSlabOps(torch.float32)
+    ppr = n ** 3 // P
+    pos = ops.synth(n, n, L, 5, False, r * ppr, ppr)
+    x_start, nx_alloc = (r * nloc - gl) % n, nloc + 2 * gl
+    buf = ops.empty((nx_alloc, n, n))
+    mean = 1.0
+    ops.paint(pos, None, n, L, "cic", buf, x_start, nx_alloc, check=True, offset=mean, owned=(gl, nloc))
+    # the same particles into the whole periodic grid (8 x 8 x 32 tiles at another alignment, one segment per column,
+    # another fixed-point quantum - it follows the tile capacity - and rho - mean formed after the rounding instead of
+    # before it): the planes agree to an ulp of the largest cell
+    full = dev.paint(pos, None, n, L, "cic", method="tiled", accumulate=False)
+    ref = full[x_start:x_start + nx_alloc].clone()
+    ref[gl:gl + nloc] -= mean
+    assert float((buf - ref).abs().max()) <= 2.4e-7 * float(full.max())
+    assert float(buf[:gl].sum(dtype=torch.float64) + buf[gl + nloc:].sum(dtype=torch.float64)) > 0.0      # ghosts are used
+    del full, ref, pos
+    owned = buf[gl:gl + nloc]
+    # y pass in send order, 8 parts
+    spec = ops.empty((nloc, n, nz), ops.cdtype)
+    want = ops.empty((P, nloc, nloc, nz), ops.cdtype)
+    ops.fft2d_planes(owned, spec)
+    ops.pack(spec, want, P)
+    packed = torch.full_like(want, 3.0)
+    mine = ops.empty((nloc, nloc, nz), ops.cdtype)
+    ops.fft2d_planes_packed(owned, spec, packed, P, r, mine)
+    assert torch.equal(mine, want[r])
+    for s in range(P):
+        assert torch.equal(packed[s], want[s]) if s != r else bool(torch.all(packed[s] == 3.0))
+    del packed, want, spec, mine, buf
+    # axis-0 pass + binning of a block
+    g = torch.Generator(device="cuda").manual_seed(3)
+    block = torch.view_as_complex(torch.randn((n, nloc, nz, 2), generator=g, device="cuda", dtype=torch.float32))
+    psum = ops.zeros((n // 2 - 1,), torch.float64)
+    ops.fft1d_axis0_power(block.clone(), 1.0 / float(n) ** 3, n, L, r * nloc, psum, 0)
+    blk = ops.fft1d_axis0(block, 1.0 / float(n) ** 3)
+    psum2 = ops.zeros((n // 2 - 1,), torch.float64)
+    ops.power_bin(blk, n, L, (0, n), (r * nloc, nloc), psum2)
+    np.testing.assert_allclose(psum.cpu().numpy(), psum2.cpu().numpy(), rtol=2e-6)

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the slab pipeline's collective logic (ghost fold,
+"""CPU, world_size 2 and 8 over gloo: the slab pipeline's collective logic (ghost fold,
 pack + all-to-all transpose, strided axis-0 pass, per-rank shell binning,
 all-reduce) with a numpy double for the local arithmetic, against the
 single-process oracle."""
@@ -22,20 +22,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _particles():
-    return omesh.lattice_particles(NPS, N, L, seed=7, sigma_cells=0.5)
+def _particles(n=N, nps=NPS):
+    return omesh.lattice_particles(nps, n, L, seed=7, sigma_cells=0.5)
 
 
-def _worker(rank, world, port, window, out_dir, chunks=2):
+def _worker(rank, world, port, window, out_dir, chunks=2, n=N, nps=NPS, ghost=2):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from astrild_amd import slab
         from tests.slab_doubles import NumpySlabOps
-        pos = _particles()
+        pos = _particles(n, nps)
         ppr = len(pos) // world
         mine = torch.from_numpy(np.ascontiguousarray(pos[rank * ppr:(rank + 1) * ppr]))
-        pipe = slab.SlabPowerPipeline(N, L, NPS, window=window, dtype=torch.float64, ghost=2,
+        pipe = slab.SlabPowerPipeline(n, L, nps, window=window, dtype=torch.float64, ghost=ghost,
                                       ops=NumpySlabOps(), pos=mine, chunks=chunks)
         owned = pipe.paint(check=True).clone()
         ks, ps, nm = pipe.step(check=True)
@@ -45,25 +45,28 @@ def _worker(rank, world, port, window, out_dir, chunks=2):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("window,chunks", [("cic", 1), ("cic", 4), ("tsc", 2)])
-def test_slab_pipeline_two_ranks_matches_single_process_oracle(tmp_path, window, chunks):
-    world = 2
+# world 8 is the driver's scaling run: 8 planes per rank, ghost 3 + 1 on each side, the interior chunks transformed and
+# sent while the ghost planes travel, the edge chunks after them
+@pytest.mark.parametrize("window,chunks,world,n,nps,ghost", [("cic", 1, 2, N, NPS, 2), ("cic", 4, 2, N, NPS, 2),
+                                                             ("tsc", 2, 2, N, NPS, 2), ("cic", 4, 8, 64, 32, 3),
+                                                             ("tsc", 8, 8, 64, 32, 3)])
+def test_slab_pipeline_ranks_match_single_process_oracle(tmp_path, window, chunks, world, n, nps, ghost):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, window, str(tmp_path), chunks), nprocs=world, join=True)
-    pos = _particles()
-    full = omesh.paint(pos, None, N, L, window)
+    mp.spawn(_worker, args=(world, port, window, str(tmp_path), chunks, n, nps, ghost), nprocs=world, join=True)
+    pos = _particles(n, nps)
+    full = omesh.paint(pos, None, n, L, window)
     ref = offt.fftpower_1d(full, L)
     spec = offt.r2c(full)
     res = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
-    nloc = N // world
+    nloc = n // world
     for r in range(world):
         # ghost fold reproduces the owned planes of the global paint
         np.testing.assert_allclose(res[r]["owned"], full[r * nloc:(r + 1) * nloc], rtol=1e-13, atol=1e-13)
         # transpose: rank r holds delta_k[:, r*nloc:(r+1)*nloc, :] for all kx
         np.testing.assert_allclose(res[r]["block"], spec[:, r * nloc:(r + 1) * nloc, :], rtol=1e-11, atol=1e-14)
     # all-reduced shell sums are identical on both ranks and match the oracle
-    assert np.array_equal(res[0]["nm"], res[1]["nm"]) and np.array_equal(res[0]["nm"], ref["modes"])
-    np.testing.assert_allclose(res[0]["ps"], res[1]["ps"], rtol=0, atol=0)
+    assert np.array_equal(res[0]["nm"], res[-1]["nm"]) and np.array_equal(res[0]["nm"], ref["modes"])
+    np.testing.assert_allclose(res[0]["ps"], res[-1]["ps"], rtol=0, atol=0)
     np.testing.assert_allclose(res[0]["ks"] / res[0]["nm"], ref["k"], rtol=1e-13)
     np.testing.assert_allclose(res[0]["ps"] / res[0]["nm"], ref["power"].real, rtol=1e-10)
 
