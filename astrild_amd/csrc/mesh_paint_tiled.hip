@@ -122,9 +122,11 @@ __device__ inline uint32_t tile_of(T x, T y, T z, const TileGeom& g, uint32_t* _
         if (b >= g.nx_alloc) return 0xffffffffu;
         bx = (unsigned)b;
     }
-    const uint32_t col = (bx / TX) * (unsigned)g.nty + (unsigned)cy / TY;
+    // 24-bit multiplies (v_mad_u32_u24, full rate; a 32-bit multiply-add compiles to the quarter-rate v_mad_u64_u32):
+    // tile rows, columns and tiles per column are all below 2^24 (tiled_geometry checks)
+    const uint32_t col = __umul24(bx / TX, (unsigned)g.nty) + (unsigned)cy / TY;
     if (far && col_flags) atomicOr(&col_flags[col], 1u);
-    return col * (unsigned)g.ntz + (unsigned)cz / TZ;
+    return __umul24(col, (unsigned)g.ntz) + (unsigned)cz / TZ;
 }
 
 // Run structure of one wave's 64 consecutive particles.
@@ -405,6 +407,7 @@ __device__ __noinline__ void place_late_slow(uint32_t p, uint32_t* __restrict__ 
 // GLOBAL particle ids).  Tiles closed_lo <= id < closed_lo + closed_n are closed: their particles go to the overflow list.
 template <typename T, int W, bool PLAINX>
 __global__ void __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 && PLAINX ? 5 : 1, sizeof(T) == 4 && PLAINX ? 5 : 8)))      // fp32, whole grid: 96 VGPRs, five workgroups per CU (what the 31 KB of LDS allow)
 tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t p_begin, size_t np, TileGeom g,
                   unsigned long long* __restrict__ fill64, GroupRec* __restrict__ recs, uint32_t rcap,
                   T* __restrict__ strays, uint32_t scap, uint32_t* __restrict__ ovf,
@@ -430,13 +433,19 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
     const size_t per_interval = per_trip * AGG_TRIPS;
     const size_t nintervals = (np - p_begin + per_interval - 1) / per_interval;      // np: END of the range
     unsigned long long ndrop = 0;
+    // pbase is UNIFORM: the trip's base address stays in scalar registers and a lane adds a 32-bit offset (a 64-bit
+    // lane address cost two quarter-rate v_mad_u64_u32 and a 64-bit compare / select per load: ~9 of the kernel's ~93
+    // vector instructions per particle).  Unconditional loads: lanes past the end re-read the last particle.
     auto fetch = [&](size_t pbase, T (&x)[IDX_UNROLL], T (&y)[IDX_UNROLL], T (&z)[IDX_UNROLL]) {
+        const size_t pb = min(pbase, np - 1);
+        const T* __restrict__ bp = pos + 3 * pb;
+        const uint32_t last = (uint32_t)min((size_t)(256 * IDX_UNROLL - 1), np - 1 - pb);
 #pragma unroll
         for (int u = 0; u < IDX_UNROLL; ++u) {
-            const size_t p = min(pbase + (size_t)u * 256 + tid, np - 1);      // unconditional loads
-            x[u] = pos[3 * p + 0];
-            y[u] = pos[3 * p + 1];
-            z[u] = pos[3 * p + 2];
+            const uint32_t rel = 3u * min((uint32_t)(u * 256 + tid), last);
+            x[u] = bp[rel + 0];
+            y[u] = bp[rel + 1];
+            z[u] = bp[rel + 2];
         }
     };
     auto slow = [&](uint32_t key, uint32_t a, uint32_t mask) {
@@ -454,16 +463,18 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
     for (size_t interval = blockIdx.x; interval < nintervals; interval += gridDim.x) {
         const size_t p0 = p_begin + interval * per_interval;
         const bool full = p0 + per_interval <= np;
+        const uint32_t p0_32 = (uint32_t)p0, left = (uint32_t)min(np - p0, per_interval);      // particle ids fit 32 bits (checked by the host)
         auto process = [&](int trip, const T (&x)[IDX_UNROLL], const T (&y)[IDX_UNROLL], const T (&z)[IDX_UNROLL]) {
 #pragma unroll
             for (int u = 0; u < IDX_UNROLL; ++u) {
-                const size_t p = p0 + (size_t)trip * per_trip + (size_t)u * 256 + tid;
-                const bool valid = full || p < np;
+                const uint32_t prel = (uint32_t)(trip * (int)per_trip + u * 256 + tid);
+                const uint32_t p = p0_32 + prel;
+                const bool valid = full || prel < left;
                 uint32_t key = tile_of<T, W, PLAINX>(x[u], y[u], z[u], g, col_flags);
                 if (!valid) key = 0xffffffffu;
                 if (!PLAINX && valid && key == 0xffffffffu) ++ndrop;
                 if (key - closed_lo < closed_n) {                   // (closed_n = 0: never; the dead key is far above any tile id)
-                    place_late_slow((uint32_t)p, ovf, ovf_count);
+                    place_late_slow(p, ovf, ovf_count);
                     key = 0xffffffffu;
                 }
                 const bool live = key != 0xffffffffu;
@@ -615,11 +626,13 @@ scatter_count_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t 
     __syncthreads();
     unsigned long long ndrop = 0;
     const size_t p0 = (size_t)blockIdx.x * SC_CHUNK;
+    const T* __restrict__ bp = pos + 3 * p0;                       // uniform base, 32-bit lane offsets
+    const uint32_t left = (uint32_t)min(np - p0, (size_t)SC_CHUNK);
 #pragma unroll 4
     for (int u = 0; u < SC_PER_THREAD; ++u) {
-        const size_t p = p0 + (size_t)u * SC_THREADS + tid;
-        if (p >= np) break;
-        const uint32_t key = tile_of<T, W, PLAINX>(pos[3 * p], pos[3 * p + 1], pos[3 * p + 2], g, col_flags);
+        const uint32_t rel = (uint32_t)(u * SC_THREADS + tid);
+        if (rel >= left) break;
+        const uint32_t key = tile_of<T, W, PLAINX>(bp[3 * rel], bp[3 * rel + 1], bp[3 * rel + 2], g, col_flags);
         if (key == 0xffffffffu) { ++ndrop; continue; }
         atomicAdd(&cnt[key / tpb], 1u);
     }
@@ -733,13 +746,15 @@ scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, si
     const size_t p0 = (size_t)blockIdx.x * SC_CHUNK;
     T x[SC_PER_THREAD], y[SC_PER_THREAD], z[SC_PER_THREAD], m[SC_PER_THREAD];
     uint32_t where[SC_PER_THREAD];                   // bucket << 16 | rank inside the workgroup's run (< 16384)
+    const T* __restrict__ bp = pos + 3 * p0;                       // uniform base, 32-bit lane offsets
+    const uint32_t last = (uint32_t)min(np - 1 - p0, (size_t)(SC_CHUNK - 1));
 #pragma unroll
     for (int u = 0; u < SC_PER_THREAD; ++u) {
-        const size_t p = min(p0 + (size_t)u * SC_THREADS + tid, np - 1);       // unconditional loads
-        x[u] = pos[3 * p];
-        y[u] = pos[3 * p + 1];
-        z[u] = pos[3 * p + 2];
-        m[u] = SW == 4 && mass ? mass[p] : (T)1;
+        const uint32_t rel = min((uint32_t)(u * SC_THREADS + tid), last);      // unconditional loads
+        x[u] = bp[3 * rel];
+        y[u] = bp[3 * rel + 1];
+        z[u] = bp[3 * rel + 2];
+        m[u] = SW == 4 && mass ? mass[p0 + rel] : (T)1;
     }
 #pragma unroll
     for (int u = 0; u < SC_PER_THREAD; ++u) {
@@ -1771,7 +1786,7 @@ bool tiled_geometry(int nmesh, int nx_alloc, TileGeom& g, uint32_t& ntiles) {
     g.nty = nmesh / TY;
     g.ntz = nmesh / TZ;
     const unsigned long long nt = (unsigned long long)g.ntx * g.nty * g.ntz;
-    if (nt >= (1ull << 31)) return false;
+    if (nt >= (1ull << 31) || (unsigned long long)g.ntx * g.nty >= (1ull << 24)) return false;      // (24-bit multiplies in tile_of)
     ntiles = (uint32_t)nt;
     return true;
 }

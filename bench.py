@@ -88,6 +88,11 @@ def cpu_baseline(sample, window, boxsize):
                      "fft_s": round(t3 - t2, 3), "binning_s": round(t4 - t3, 3), "paint_s_single_thread": round(t1 - t0, 3),
                      "note": f"scipy.fft.rfftn(workers={ncpu}) + numpy shell binning; paint as in the single-thread leg"},
         "cpu_model": _cpu_model(), "logical_cores": ncpu,
+        # the same port on the benchmark's own configuration, by particle count (its paint, binning and FFT are all
+        # O(N) or O(N log N) in the 8x larger problem): a projection, not a measurement
+        "projected_1024_cubed": {"seconds_single_thread": round(1024 ** 3 / (n / (t2 - t0)), 1),
+                                 "seconds_threaded_fft": round(1024 ** 3 / (n / ((t1 - t0) + (t4 - t2))), 1),
+                                 "note": "particles of the 1024^3 workload / the sample's particles per second"},
     }
 
 
@@ -247,6 +252,7 @@ def main():
             # the other orderings / windows of the same workload, a few steps each (same kernels, same accounting)
             legs = {}
             for name, (win, order) in {"shuffled_cic": ("cic", "shuffled"), "natural_tsc": ("tsc", "natural"),
+                                       "shuffled_tsc": ("tsc", "shuffled"),      # what stats_subfind.py:125-131 feeds the paint
                                        "natural_cic": ("cic", "natural")}.items():
                 if (win, order) == (args.window, args.order):
                     continue
