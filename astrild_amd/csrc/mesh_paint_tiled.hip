@@ -1138,7 +1138,17 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     // The z planes of the tile form a RING of LZ slots: local plane c of tile tz lives in slot
     // (c + tz * TZ) mod LZ, so the W-1 halo planes carried from one tile to the next stay where
     // they are and the flush only has to re-arm the TZ slots it stored.
-    __shared__ unsigned long long tile[LX * LY * LZ];        // ((a * LY + b) * LZ + slot), slot fastest
+    // Row pitch PZ >= LZ cells (WALK_PZ, default LZ).  The walk is bound by its LDS atomics (rocprofv3: LDS 77 % busy, 59 %
+    // of its cycles bank conflicts: the 32 z-consecutive particles of a half wave fill all 64 banks, so every particle
+    // the jitter moved to a neighbouring (x, y) row collides with one that stayed).  Measured and NOT adopted: PZ = 48 -
+    // rows half of the banks apart - runs the bare atomics 1.29x faster (scripts/micro/lds_tile_atomics.hip: 335 -> 433 G
+    // particles/s; 32-bit cells 543, a 32-bit lo plane with returning adds + carry into a hi plane 377), but the 31 KB
+    // tile leaves 5 workgroups per CU instead of 7 and the walk gets slower: CIC 4.62 -> 4.71 ms (TSC 13.1 -> 12.3).
+#ifndef WALK_PZ
+#define WALK_PZ 0
+#endif
+    constexpr int PZ = WALK_PZ > LZ ? WALK_PZ : LZ;
+    __shared__ unsigned long long tile[LX * LY * PZ];        // ((a * LY + b) * PZ + slot), slot fastest
     // the launch walks the columns col0 .. col0 + gridDim.x - 1 (mod the column count: the x-sorted pipeline's last
     // launch wraps around to the tile rows it held back)
     // nseg > 1: the column is cut into nseg z-segments of ntz / nseg tiles, one workgroup each (more, shorter
@@ -1154,7 +1164,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     const int ox = tx * TX, oy = ty * TY;
     const bool x_periodic = g.nx_alloc == g.n;
     unsigned long long ndrop = 0;
-    for (int i = threadIdx.x; i < LX * LY * LZ; i += 256) tile[i] = BIAS;
+    for (int i = threadIdx.x; i < LX * LY * PZ; i += 256) tile[i] = BIAS;
     // where the z line of LDS column (a, b) goes: the owned cells' grid line (bit 1 set: `offset`
     // is subtracted there, in double, before the one rounding to T) or the halo ring's record line
     // (bit 0: a halo that points outside a slab buffer, counted as dropped when non-zero);
@@ -1327,7 +1337,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
             unsigned long long* slot[W];          // (lx, ly) row at the ring slots of planes lz + c
             int sl = lz + sh;
             sl = sl >= LZ ? sl - LZ : sl;
-            unsigned long long* const row0 = &tile[(lx * LY + ly) * LZ];
+            unsigned long long* const row0 = &tile[(lx * LY + ly) * PZ];
 #pragma unroll
             for (int c = 0; c < W; ++c) {
                 slot[c] = row0 + sl;
@@ -1343,7 +1353,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
                     for (int c = 0; c < W; ++c) {
                         long long v = __double_as_longlong(__fma_rn(mab, wz[c], 6755399441055744.0));   // |mab wz| < 2^50
                         if (!RAW) v -= 0x4338000000000000ll;
-                        unsigned long long* cell = slot[c] + (a * LY + b) * LZ;
+                        unsigned long long* cell = slot[c] + (a * LY + b) * PZ;
                         if (ablate & 2) asm volatile("" ::"v"(v), "v"(cell)); else atomicAdd(cell, (unsigned long long)v);
                     }
                 }
@@ -1398,8 +1408,8 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
                 bool any = false;
 #pragma unroll
                 for (int i = 0; i < VW; ++i) {
-                    const unsigned long long raw = tile[ab * LZ + sl[i]];
-                    tile[ab * LZ + sl[i]] = BIAS;
+                    const unsigned long long raw = tile[ab * PZ + sl[i]];
+                    tile[ab * PZ + sl[i]] = BIAS;
                     any |= raw != BIAS;
                     if (ftz == 0 && c0 + i < H) first_planes[ab * H + c0 + i] = raw;     // (stored below, rewritten at the end)
                     if (RAW) {
@@ -1485,7 +1495,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
             int sl = k + sh;
             sl = sl >= LZ ? sl - LZ : sl;
             zf[i] = first_planes[i];
-            zf[LX * LY * H + i] = tile[ab * LZ + sl];
+            zf[LX * LY * H + i] = tile[ab * PZ + sl];
         }
         if (dropped && ndrop) atomicAdd(dropped, ndrop);
         return;
@@ -1494,7 +1504,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
         const int k = i % H, ab = i / H;
         int sl = k + sh;
         sl = sl >= LZ ? sl - LZ : sl;
-        const unsigned long long raw = first_planes[i] + tile[ab * LZ + sl] - BIAS;
+        const unsigned long long raw = first_planes[i] + tile[ab * PZ + sl] - BIAS;
         const unsigned long long d = dest[ab];
         bool any;
         const T v = fixed_to_value<T>(raw, q, (d & 2ull) ? offset : 0.0, any);

@@ -121,6 +121,12 @@ def bispectrum_leg(dev, n=512, width=8):
     prof = dev.profile_report()
     dev.profile_enable(False)
     ng = n ** 3
+    traffic = None
+    import glob
+    tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bispectrum.json")))
+    if tf:                                    # PMC passes kept under profiles/ (scripts/refresh_profiles.sh): NOT measured by this run
+        traffic = {"GB_per_call": json.load(open(tf[-1])).get("numerator_corrected_GB_per_call"),
+                   "file": os.path.relpath(tf[-1], ROOT), "measured_in_this_run": False}
     # per shell: the three passes of an UNPRUNED inverse transform (read + write of the half spectrum twice, read of it
     # and write of the real cube once = 24 B per cell) + one read of the cube by the triangle sums.  The transform
     # skips the parts of the spectrum that a shell leaves zero, so the bytes really moved are fewer.
@@ -128,12 +134,16 @@ def bispectrum_leg(dev, n=512, width=8):
     return {"metric": f"bispectrum on {n}^3 grid: {nsh} shells of width {width} k_F, {len(tri)} triangle bins, fp32",
             "value": len(tri) / dt, "unit": "triangle bins/s", "ms_total": dt * 1e3,
             "alg_GB": round(alg / 1e9, 2), "GBps": round(alg / dt / 1e9, 1), "frac": round(alg / dt / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic": traffic,
+            "frac_of_peak_on_bytes_moved": (round(traffic["GB_per_call"] / dt / HBM_PEAK_GBS, 4)
+                                            if traffic and traffic["GB_per_call"] else None),
             "ntri_total": int(np.sum(res["ntri"])), "ntri_residual": res["ntri_residual"],
             "first_call_ms_with_triangle_counts": round(first_ms, 1),
             "note": "value / ms_total time the estimator's numerator (31 masked, pruned inverse FFTs + all 75 cube sums in one "
-                    "pass over the 31 fields); alg_GB prices unpruned three-pass transforms; the triangle counts (31 more "
-                    "inverse FFTs in fp64 + the sums) are geometry, computed on the first call and cached - first_call_ms "
-                    "includes them and the plan creation",
+                    "pass over the 31 fields); alg_GB / frac price UNPRUNED three-pass transforms (the kernels skip what a shell "
+                    "leaves zero), frac_of_peak_on_bytes_moved uses the bytes the PMC counters saw; the triangle counts (31 "
+                    "forward float64 transforms of the shell indicators + the sums) are geometry, computed on the first call "
+                    "and cached - first_call_ms includes them",
             "kernels_ms": {k: round(v[1], 3) for k, v in prof.items()}}
 
 
