@@ -142,7 +142,7 @@ struct PackDst { float2* out = nullptr; unsigned c1_log2 = 0; unsigned nbatch = 
 template <int R1, int R2, int C, bool POWER, bool INV = false, bool PACK = false>
 __global__ void __launch_bounds__(C * (R1 > R2 ? R1 : R2))
 // N = 1024 with binning: 128 VGPRs, so that two 8-wave workgroups fit a CU (see SPLIT below)
-__attribute__((amdgpu_waves_per_eu(POWER && R1 * R2 >= 1024 ? 4 : 1, POWER && R1 * R2 >= 1024 ? 4 : 8)))
+__attribute__((amdgpu_waves_per_eu((POWER || C > 16) && R1 * R2 >= 1024 ? 4 : 1, (POWER || C > 16) && R1 * R2 >= 1024 ? 4 : 8)))
 strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, size_t elem_stride,
                    size_t ncols, size_t batch_stride, unsigned tiles_per_batch, float scale,
                    double* __restrict__ partial, const unsigned* __restrict__ edge_fall, ShellMask mask = ShellMask{nullptr, 0, 0},
@@ -154,7 +154,7 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
     // buffer is 64 KB instead of 128 KB and TWO workgroups fit a CU: with one, the loads, the two register
     // FFTs and the binning of a tile run strictly one after the other (x pass 1.83 -> 1.54 ms).  The y pass
     // is bound by its 128-byte strided reads AND writes and loses a little with it (1.96 -> 2.03): not split.
-    constexpr bool SPLIT = POWER && R1 == R2 && N * C * sizeof(float2) > 64 * 1024;
+    constexpr bool SPLIT = (POWER || C > 16) && R1 == R2 && N * C * sizeof(float2) > 64 * 1024;
     constexpr int YN = SPLIT ? N / 2 : N;
     extern __shared__ float2 lds[];
     float2* Y = lds;                 // [n2][k1][c]  (SPLIT: [n2 mod R2/2][k1][c])
@@ -172,7 +172,6 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
         for (int i = threadIdx.x; i <= NB; i += NT) shell[i] = 0.0;
     const int c = threadIdx.x % C, sub = threadIdx.x / C;
     const bool col_ok = (unsigned)c0 + (unsigned)c < (unsigned)ncols;       // 32-bit: the host checks ncols < 2^31
-    float2* base = data + (size_t)b * batch_stride + c0 + c;
     // AST_BIN_FLOAT64: bit k2 of this thread's word says that its epilogue mode (row sub + R1 * k2, column c) has an
     // integer norm AND nbodykit's float64 comparison puts it one shell lower.  The words are data independent and
     // come precomputed (edge_fall_kernel): one register, no double-precision code in this register-tight kernel.
@@ -254,7 +253,14 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
     }
     if (sub < R1) {
         fft_reg<R2>(u);
-        if (col_ok && !POWER) {
+        // (store addresses and the column test rebuilt from the thread id here: the 32-column variant is held to 128 VGPRs
+        // and would otherwise carry - spill - them across the two register FFTs)
+        int tid_s = (int)threadIdx.x;
+        if (C > 16) asm volatile("" : "+v"(tid_s));
+        const int cs = C > 16 ? tid_s % C : c;
+        const bool ok_s = C > 16 ? (unsigned)c0 + (unsigned)cs < (unsigned)ncols : col_ok;
+        if (ok_s && !POWER) {
+            float2* const base = data + (size_t)b * batch_stride + c0 + cs;
 #pragma unroll
             for (int k2 = 0; k2 < R2; ++k2) {
                 float2 x = u[bitrev(k2, ilog2(R2))];
@@ -914,7 +920,7 @@ template <int R1, int R2, int C, bool POWER>
 int launch_c2c(float2* data, const float2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride,
                float scale, double* partial, hipStream_t s, const unsigned* edge_fall = nullptr, int ky0 = 0) {
     constexpr int N = R1 * R2, NT = C * (R1 > R2 ? R1 : R2);
-    constexpr bool SPLIT = POWER && R1 == R2 && N * C * sizeof(float2) > 64 * 1024;       // as in the kernel
+    constexpr bool SPLIT = (POWER || C > 16) && R1 == R2 && N * C * sizeof(float2) > 64 * 1024;       // as in the kernel
     const size_t lds = (size_t)((SPLIT ? N / 2 : N) * C + N) * sizeof(float2) + (POWER ? (N / 2) * sizeof(double) : 0);
     static ast::PerDeviceOnce attr_once;
     if (attr_once.need()) {
@@ -982,6 +988,11 @@ int dispatch_c2c_inv(size_t n, float2* d, const float2* tw, size_t elem_stride, 
 template <bool POWER>
 int dispatch_c2c(size_t n, float2* d, const float2* tw, size_t elem_stride, size_t ncols, size_t batch,
                  size_t batch_stride, float scale, double* partial, hipStream_t s, const unsigned* edge_fall = nullptr, int ky0 = 0) {
+#ifndef FWD_C
+#define FWD_C 32                    // columns per workgroup of the plain forward pass at N = 1024: 32 = 256-byte row pieces, one 1024-thread
+                                    // workgroup per CU with the split exchange (y pass 2.02 -> 1.91 ms); 16 = as in rounds 1-2
+#endif
+    if constexpr (!POWER) { if (n == 1024) return launch_c2c<32, 32, FWD_C, false>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0); }
     if (n == 1024) return launch_c2c<32, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0);
     if (n == 512) return launch_c2c<16, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0);
     return launch_c2c<16, 16, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0);

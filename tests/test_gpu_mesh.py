@@ -508,6 +508,14 @@ def test_xsorted_pipeline_matches_plain_paint(dev, monkeypatch, window, streams)
     got = dev.paint(pos, None, n, L, window, method="tiled", accumulate=False, offset="mean", hint="xsorted", stats=st)
     assert st["overflow"] == 0
     assert torch.equal(got, ref)
+    # float64 particles with masses (group records + 4-word stray copies)
+    rng = np.random.default_rng(3)
+    pos64 = pos.double()
+    mass64 = dev.as_device(rng.uniform(0.5, 2.0, size=pos.shape[0]))
+    ref = dev.paint(pos64, mass64, n, L, window, method="tiled", accumulate=False)
+    got = dev.paint(pos64, mass64, n, L, window, method="tiled", accumulate=False, hint="xsorted")
+    assert torch.equal(got, ref)
+    del pos64, mass64
     # a slab buffer (not periodic in x): rows are walked in order, row 0 is not held back
     kw = dict(x_start=64, nx_alloc=72, check_dropped=False)
     sel = pos[(pos[:, 0] >= 66 * L / n) & (pos[:, 0] < 134 * L / n)].contiguous()
