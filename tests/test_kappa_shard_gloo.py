@@ -142,3 +142,30 @@ def test_rayramses_sum_snapshots_shards_planes_over_ranks(tmp_path):
         for r in range(world):
             np.testing.assert_allclose(res[r][key], seq, rtol=0, atol=1e-14 * np.abs(seq).max() + 1e-15)
         assert np.array_equal(res[0][key], res[1][key])                       # every rank holds the same bits
+
+
+def _subgroup_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from astrild_amd import kappa_shard
+        from tests.kappa_doubles import NumpyStackOps
+        sub = dist.new_group([1, 2])                      # every rank creates it; ranks 1 and 2 use it
+        if rank == 0:
+            return
+        planes = _planes(5)
+        ids = kappa_shard.my_plane_ids(5, sub)            # group rank 0 = global rank 1
+        res = kappa_shard.kappa_stack_sharded([planes[i] for i in ids], group=sub, root=0, ops=NumpyStackOps())
+        assert (res is not None) == (rank == 1)            # the group's root is GLOBAL rank 1
+        if res is not None:
+            np.save(os.path.join(out_dir, "sub.npy"), res.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_stack_on_a_subgroup_that_does_not_start_at_global_rank_0(tmp_path):
+    mp.spawn(_subgroup_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    planes = _planes(5)
+    expect = (planes[0] + planes[2] + planes[4]) + (planes[1] + planes[3])
+    got = np.load(tmp_path / "sub.npy").reshape(NPIX, NPIX)
+    np.testing.assert_array_equal(got, expect)
