@@ -421,6 +421,7 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
     __shared__ T lst_x[LST_CAP], lst_y[LST_CAP], lst_z[LST_CAP];
     __shared__ uint32_t lst_p[LST_CAP], lst_key[LST_CAP], lst_n;
     constexpr uint32_t DST_NONE = 0xffffffffu;
+    FSTAMP_DECL;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int half = lane >> 5;
@@ -536,6 +537,7 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
                 }
             }
         };
+        FSTAMP(1);
 #pragma unroll
         for (int trip = 0; trip < AGG_TRIPS; trip += 2) {
             fetch(p0 + (size_t)(trip + 1) * per_trip, xb, yb, zb);
@@ -543,7 +545,9 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
             fetch(trip + 2 < AGG_TRIPS ? p0 + (size_t)(trip + 2) * per_trip : p_begin + (interval + gridDim.x) * per_interval, xa, ya, za);
             process(trip + 1, xb, yb, zb);
         }
+        FSTAMP(2);
         __syncthreads();
+        FSTAMP(3);
         // phase 2: slots
         const uint32_t nr = min(lrec_n, LREC_CAP), ns = min(lst_n, LST_CAP);
         for (uint32_t k = tid; k < nr; k += 256) {
@@ -558,7 +562,9 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
             if (slot < 0) { slow(key, lst_p[k], 0u); lst_key[k] = DST_NONE; }
             else lst_key[k] = ((uint32_t)slot << 16) | atomicAdd(&sstray[slot], 1u);
         }
+        FSTAMP(4);
         __syncthreads();
+        FSTAMP(5);
         // phase 3: reserve
         if (skey[tid] != SLOT_EMPTY) {
             const uint32_t t = skey[tid], cr = srun[tid], cs = sstray[tid];
@@ -569,7 +575,9 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
             sdst_stray[tid] = (unsigned long long)t * scap + bs;
             sroom_stray[tid] = scap - bs;
         }
+        FSTAMP(6);
         __syncthreads();
+        FSTAMP(7);
         // phase 4: scatter
         for (uint32_t k = tid; k < nr; k += 256) {
             const uint32_t d = lrec_key[k];
@@ -586,13 +594,16 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
                                                     mass ? mass[lst_p[k]] : (T)1, mass != nullptr);
             else ovf[atomicAdd(ovf_count, 1ull)] = lst_p[k];
         }
+        FSTAMP(8);
         __syncthreads();                    // everyone is done with the lists and the table before they are re-armed
         skey[tid] = SLOT_EMPTY;
         srun[tid] = 0;
         sstray[tid] = 0;
         if (tid == 0) { lst_n = 0; lrec_n = 0; }
         __syncthreads();
+        FSTAMP(9);
     }
+    FSTAMP_END;
     if (dropped && ndrop) atomicAdd(dropped, ndrop);
 }
 

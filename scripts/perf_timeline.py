@@ -13,11 +13,11 @@ lib = _lib.lib()
 st = np.zeros(64 * 4096, dtype=np.uint64); cn = np.zeros(64, dtype=np.uint32)
 f = lib.ast_debug_stamps; f.argtypes = [ct.c_void_p, ct.c_void_p]; f.restype = ct.c_int
 for rep in range(2):
-    dev.paint(pos, None, n, L, window, out=grid, method="tiled", check_dropped=False, accumulate=False)
+    dev.paint(pos, None, n, L, window, out=grid, method="tiled", check_dropped=False, accumulate=False, defer_fold=True)
     torch.cuda.synchronize()
     f(st.ctypes.data, cn.ctypes.data)          # read + reset; keep the second (warm) run
 if os.environ.get("FILL"):
-    names0 = {1: "(gap)", 2: "trip", 3: "barrier 1", 4: "table flush+misses", 5: "barrier 2", 6: "scatter", 7: "barrier 3"}
+    names0 = {1: "(start)", 2: "trips", 3: "barrier 1", 4: "slots", 5: "barrier 2", 6: "reserve", 7: "barrier 3", 8: "scatter", 9: "barriers 4+5"}
 names = {0: "start", 1: "iter", 2: "next_batch", 3: "issue loads", 4: "deposit", 5: "pre-flush", 6: "barrier A", 7: "flush", 8: "barrier B", 9: "end"}
 tot = collections.Counter(); cnt = collections.Counter(); span = []
 for w in range(64):
