@@ -612,8 +612,8 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
 // (every particle is a stray of a tile no neighbour shares: one returning global atomic and one 16-byte scattered
 // store per particle, 74 ms at 1024^3).  Two radix levels instead, every workgroup handling 16384 records so that a
 // bucket receives a run of records (16 at the first level, 32 at the second) for ONE reservation atomic:
-//   count     records per coarse bucket (SC_BUCKETS buckets of tpb consecutive tiles), exclusive scan -> bucket starts;
-//   level A   particle -> 16-byte record {x, y, z, m} in its bucket's range of a staging array;
+//   level A   particle -> 16-byte record {x, y, z, m} in its coarse bucket's (SC_BUCKETS buckets of tpb consecutive tiles)
+//             fixed-capacity segment of a staging array (no counting pass, see scatter_level_a_kernel);
 //   level B   bucket by bucket, record -> the stray segment of its tile (the format the column walk reads), slots
 //             reserved per (workgroup, tile) from the tile's fill64 counter.
 // The walk then finds only stray copies (no group records) and reads them contiguously.  A record that does not fit
@@ -622,62 +622,10 @@ constexpr int SC_THREADS = 1024, SC_PER_THREAD = 8, SC_CHUNK = SC_THREADS * SC_P
 constexpr uint32_t SC_BUCKETS = 1024, SC_TPB_MAX = 2048;        // buckets; most tiles per bucket (LDS counters of level B)
 // Every bucket's range of the staging array is cut into SC_GROUPS sub-ranges, and chunk c writes into sub-range
 // c mod 8.  Blocks b and b + 8 share an XCD (observed placement; nothing here depends on it for correctness: the
-// sub-ranges are sized by the same label in the count pass), so the 96-byte runs that complete a 128-byte line come
+// sub-ranges are fixed segments, one per (bucket, label)), so the 96-byte runs that complete a 128-byte line come
 // from workgroups behind ONE L2 and the line leaves it whole.  With one cursor per bucket the pieces of a line sat in
 // different XCDs' L2s and went to HBM as partial writes: level A's stores ran at 2 TB/s.
 constexpr uint32_t SC_GROUPS = 8;
-
-template <typename T, int W, bool PLAINX>
-__global__ void __launch_bounds__(SC_THREADS)
-scatter_count_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t tpb, unsigned long long* __restrict__ bcount,
-                     uint32_t* __restrict__ col_flags, unsigned long long* dropped) {
-    __shared__ uint32_t cnt[SC_BUCKETS];
-    const int tid = threadIdx.x;
-    cnt[tid] = 0;
-    __syncthreads();
-    unsigned long long ndrop = 0;
-    const size_t p0 = (size_t)blockIdx.x * SC_CHUNK;
-    const T* __restrict__ bp = pos + 3 * p0;                       // uniform base, 32-bit lane offsets
-    const uint32_t left = (uint32_t)min(np - p0, (size_t)SC_CHUNK);
-#pragma unroll 4
-    for (int u = 0; u < SC_PER_THREAD; ++u) {
-        const uint32_t rel = (uint32_t)(u * SC_THREADS + tid);
-        if (rel >= left) break;
-        const uint32_t key = tile_of<T, W, PLAINX>(bp[3 * rel], bp[3 * rel + 1], bp[3 * rel + 2], g, col_flags);
-        if (key == 0xffffffffu) { ++ndrop; continue; }
-        atomicAdd(&cnt[key / tpb], 1u);
-    }
-    __syncthreads();
-    if (cnt[tid]) atomicAdd(&bcount[(blockIdx.x % SC_GROUPS) * SC_BUCKETS + tid], (unsigned long long)cnt[tid]);
-    if (dropped && ndrop) atomicAdd(dropped, ndrop);
-}
-
-// bstart[b * SC_GROUPS + g] = exclusive prefix sum of the counts in (bucket, group) order.  bcount and cursor (the
-// same values; level A advances them) are laid out [g][b]: a workgroup's 1024 atomics then touch 64 lines, not 1024.
-// Thread b owns its bucket's SC_GROUPS entries.
-__global__ void __launch_bounds__(SC_BUCKETS)
-scatter_scan_kernel(const unsigned long long* __restrict__ bcount, unsigned long long* __restrict__ bstart,
-                    unsigned long long* __restrict__ cursor) {
-    __shared__ unsigned long long s[SC_BUCKETS];
-    const int tid = threadIdx.x;
-    unsigned long long c[SC_GROUPS], mine = 0;
-    for (uint32_t g = 0; g < SC_GROUPS; ++g) { c[g] = bcount[g * SC_BUCKETS + tid]; mine += c[g]; }
-    s[tid] = mine;
-    __syncthreads();
-    for (int o = 1; o < (int)SC_BUCKETS; o <<= 1) {
-        const unsigned long long add = tid >= o ? s[tid - o] : 0ull;
-        __syncthreads();
-        s[tid] += add;
-        __syncthreads();
-    }
-    unsigned long long ex = s[tid] - mine;
-    for (uint32_t g = 0; g < SC_GROUPS; ++g) {
-        bstart[tid * SC_GROUPS + g] = ex;
-        cursor[g * SC_BUCKETS + tid] = ex;
-        ex += c[g];
-    }
-    if (tid == (int)SC_BUCKETS - 1) bstart[SC_BUCKETS * SC_GROUPS] = s[tid];
-}
 
 // records staged per round: 96 KB of LDS either way
 template <typename T> constexpr uint32_t sc_round() { return sizeof(T) == 4 ? 4096u : 2048u; }
@@ -742,15 +690,22 @@ __device__ inline void staged_store(const T (&rx)[SC_PER_THREAD], const T (&ry)[
     }
 }
 
+// No counting pass: every (bucket, group) owns a FIXED segment of cap_bg records of the staging array (twice the mean: a
+// read of all positions - 2.5 ms at 1024^3 - just to size the segments exactly was a tenth of the unordered paint).  A record
+// that does not fit its segment (strongly clustered input) goes to the late list like one that does not fit its tile's
+// stray segment in level B, and is deposited with global atomics; device.paint sees the count and repaints two-pass.
 template <typename T, int W, bool PLAINX, int SW>
 __global__ void __launch_bounds__(SC_THREADS)
 scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t np, TileGeom g, uint32_t tpb,
-                       unsigned long long* __restrict__ cursor, T* __restrict__ staging) {
-    __shared__ uint32_t cnt[SC_BUCKETS], lstart[SC_BUCKETS], wsum[16];
+                       unsigned long long* __restrict__ cursor, T* __restrict__ staging, uint32_t cap_bg,
+                       uint32_t* __restrict__ col_flags, T* __restrict__ late_list, unsigned long long late_cap,
+                       unsigned long long* __restrict__ late, unsigned long long* dropped) {
+    __shared__ uint32_t cnt[SC_BUCKETS], lstart[SC_BUCKETS], room[SC_BUCKETS], wsum[16];
     __shared__ unsigned long long base[SC_BUCKETS];
     extern __shared__ unsigned long long dyn[];          // stage: 4096 records, then their 4096 destinations
     T* stage = reinterpret_cast<T*>(dyn);
     unsigned long long* sidx = dyn + sc_round<T>() * 4 * sizeof(T) / sizeof(unsigned long long);
+    typedef T vec4_t __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x;
     cnt[tid] = 0;
     __syncthreads();
@@ -767,22 +722,46 @@ scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, si
         z[u] = bp[3 * rel + 2];
         m[u] = SW == 4 && mass ? mass[p0 + rel] : (T)1;
     }
+    unsigned long long ndrop = 0;
 #pragma unroll
     for (int u = 0; u < SC_PER_THREAD; ++u) {
-        const size_t p = p0 + (size_t)u * SC_THREADS + tid;
         where[u] = 0xffffffffu;
-        if (p < np) {
-            const uint32_t key = tile_of<T, W, PLAINX>(x[u], y[u], z[u], g, nullptr);
+        if ((uint32_t)(u * SC_THREADS + tid) <= last) {
+            const uint32_t key = tile_of<T, W, PLAINX>(x[u], y[u], z[u], g, col_flags);
             if (key != 0xffffffffu) {
                 const uint32_t b = key / tpb;
                 where[u] = (b << 16) | atomicAdd(&cnt[b], 1u);
+            } else {
+                ++ndrop;                                  // base plane outside the buffer (slab buffers only)
             }
         }
     }
     __syncthreads();
-    if (cnt[tid]) base[tid] = atomicAdd(&cursor[(blockIdx.x % SC_GROUPS) * SC_BUCKETS + tid], (unsigned long long)cnt[tid]);
-    const uint32_t total = block_exclusive_scan(cnt, lstart, SC_BUCKETS, wsum);
-    staged_store<T, SW>(x, y, z, m, where, lstart, base, nullptr, total, staging, stage, sidx);
+    const uint32_t grp = blockIdx.x % SC_GROUPS;
+    __shared__ int any_full;
+    if (tid == 0) any_full = 0;
+    __syncthreads();
+    if (cnt[tid]) {
+        const unsigned long long old = atomicAdd(&cursor[grp * SC_BUCKETS + tid], (unsigned long long)cnt[tid]);
+        const uint32_t bs = (uint32_t)min(old, (unsigned long long)cap_bg);
+        base[tid] = ((unsigned long long)tid * SC_GROUPS + grp) * cap_bg + bs;
+        room[tid] = cap_bg - bs;
+        if (cnt[tid] > cap_bg - bs) any_full = 1;
+    }
+    const uint32_t total = block_exclusive_scan(cnt, lstart, SC_BUCKETS, wsum);          // (barriers inside: any_full is settled)
+    const bool full = any_full != 0;                      // uniform; a full segment is rare (strongly clustered input)
+    if (full) {
+#pragma unroll
+        for (int u = 0; u < SC_PER_THREAD; ++u) {         // the records that do not fit go to the late list
+            if (where[u] != 0xffffffffu && (where[u] & 0xffffu) >= room[where[u] >> 16]) {
+                const unsigned long long k = atomicAdd(late, 1ull);
+                if (k < late_cap) reinterpret_cast<vec4_t*>(late_list)[k] = vec4_t{x[u], y[u], z[u], m[u]};
+                else ++ndrop;
+            }
+        }
+    }
+    staged_store<T, SW>(x, y, z, m, where, lstart, base, full ? room : nullptr, total, staging, stage, sidx);
+    if (dropped && ndrop) atomicAdd(dropped, ndrop);
 }
 
 // one record deposited with global atomics (a full tile segment): overflow_deposit_kernel's body
@@ -824,7 +803,7 @@ late_deposit_kernel(const T* __restrict__ late_list, const unsigned long long* _
 
 template <typename T, int W, bool PLAINX, int SW>
 __global__ void __launch_bounds__(SC_THREADS)
-scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* __restrict__ bstart, TileGeom g, uint32_t tpb,
+scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* __restrict__ cursor, uint32_t cap_bg, TileGeom g, uint32_t tpb,
                        unsigned long long* __restrict__ fill64, T* __restrict__ strays, uint32_t scap,
                        T* __restrict__ late_list, unsigned long long late_cap, unsigned long long* __restrict__ late,
                        unsigned long long* dropped) {
@@ -835,10 +814,14 @@ scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* 
     unsigned long long* sidx = dyn + sc_round<T>() * 4 * sizeof(T) / sizeof(unsigned long long);
     const int tid = threadIdx.x;
     const uint32_t bucket = blockIdx.x;
-    const size_t b0 = (size_t)bstart[bucket * SC_GROUPS], b1 = (size_t)bstart[(bucket + 1) * SC_GROUPS];     // all its sub-ranges
+    // the bucket's SC_GROUPS segments of the staging array, gridDim.y / SC_GROUPS workgroups each (blocks with equal
+    // blockIdx.x - one bucket - share an XCD like the groups that wrote the segments)
+    const uint32_t grp = blockIdx.y % SC_GROUPS, sub = blockIdx.y / SC_GROUPS, nsub = gridDim.y / SC_GROUPS;
+    const size_t b0 = ((size_t)bucket * SC_GROUPS + grp) * cap_bg;
+    const size_t b1 = b0 + (size_t)min(cursor[grp * SC_BUCKETS + bucket], (unsigned long long)cap_bg);
     typedef T vec4_t __attribute__((ext_vector_type(4)));
     struct Rec3 { T x, y, z; };
-    for (size_t c0 = b0 + (size_t)blockIdx.y * SC_CHUNK; c0 < b1; c0 += (size_t)gridDim.y * SC_CHUNK) {
+    for (size_t c0 = b0 + (size_t)sub * SC_CHUNK; c0 < b1; c0 += (size_t)nsub * SC_CHUNK) {
         for (uint32_t t = tid; t < tpb; t += SC_THREADS) cnt[t] = 0;
         __syncthreads();
         T x[SC_PER_THREAD], y[SC_PER_THREAD], z[SC_PER_THREAD], m[SC_PER_THREAD];
@@ -1742,9 +1725,8 @@ struct Workspace {
     void* strays;                    // [tile][scap] x {x, y, z, m}
     uint32_t rcap, scap;
     // AST_PAINT_SCATTERED: two-level bucket scatter
-    unsigned long long* bcount;      // [SC_BUCKETS * SC_GROUPS] records per (coarse bucket, chunk label)
-    unsigned long long* bstart;      // [SC_BUCKETS * SC_GROUPS + 1] their exclusive scan
-    unsigned long long* bcursor;     // [SC_BUCKETS * SC_GROUPS] level A write cursors
+    unsigned long long* bcursor;     // [SC_GROUPS][SC_BUCKETS] level A write cursors = records per (chunk label, coarse bucket)
+    uint32_t cap_bg;                 // records per (bucket, label) segment of the staging array
     unsigned long long* late;        // records that found their tile's segment full (deposited on the spot)
     void* staging;                   // [np] x {x, y, z, m}, bucket-major
     uint32_t tpb;                    // tiles per bucket (0: the scatter path does not apply)
@@ -1779,7 +1761,9 @@ Workspace carve(void* base, size_t np, uint32_t ntiles, uint32_t ncols, int flag
     const bool scattered = compact && (flags & AST_PAINT_SCATTERED);
     w.tpb = scattered ? (ntiles + SC_BUCKETS - 1) / SC_BUCKETS : 0;
     if (w.tpb > SC_TPB_MAX || np < (size_t)SC_CHUNK) w.tpb = 0;      // huge grids / tiny inputs: the grouping kernel does it
-    w.bcount = (unsigned long long*)take(w.tpb ? SC_BUCKETS * SC_GROUPS * 8 : 0);
+    w.bcursor = (unsigned long long*)take(w.tpb ? SC_BUCKETS * SC_GROUPS * 8 : 0);      // (inside the part run_tiled zeroes)
+    // a (bucket, label) segment holds twice its mean share of the particles
+    w.cap_bg = w.tpb ? (uint32_t)((2 * ((np + SC_BUCKETS * SC_GROUPS - 1) / (SC_BUCKETS * SC_GROUPS)) + 1024 + 63) / 64 * 64) : 0;
     w.late = (unsigned long long*)take(w.tpb ? 8 : 0);
     w.tile_off = (uint32_t*)take((size_t)ntiles * 4);
     w.block_sums = (uint32_t*)take((size_t)((ntiles + 1023) / 1024 + 1) * 4);
@@ -1789,9 +1773,7 @@ Workspace carve(void* base, size_t np, uint32_t ntiles, uint32_t ncols, int flag
     w.index = (uint32_t*)take(two_pass ? np * 4 : compact ? 0 : (size_t)ntiles * w.cap * 4);
     w.recs = (GroupRec*)take((size_t)ntiles * w.rcap * sizeof(GroupRec));
     w.strays = take((size_t)ntiles * w.scap * 4 * esz);
-    w.bstart = (unsigned long long*)take(w.tpb ? (SC_BUCKETS * SC_GROUPS + 1) * 8 : 0);
-    w.bcursor = (unsigned long long*)take(w.tpb ? SC_BUCKETS * SC_GROUPS * 8 : 0);
-    w.staging = take(w.tpb ? np * 4 * esz : 0);
+    w.staging = take(w.tpb ? (size_t)SC_BUCKETS * SC_GROUPS * w.cap_bg * 4 * esz : 0);
     w.ovf = (uint32_t*)take(two_pass ? 0 : np * 4);
     w.rec = take(rec_bytes);
     w.zrec = (unsigned long long*)take(zrec_bytes);
@@ -1917,11 +1899,6 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
             auto run = [&](auto px, auto sw) -> int {
                 constexpr bool PX = decltype(px)::value;
                 constexpr int SW = decltype(sw)::value;
-                {
-                    AST_PROF("paint_tiled.count", s);
-                    scatter_count_kernel<T, W, PX><<<nchunks, SC_THREADS, 0, s>>>(pos, np, g, w.tpb, w.bcount, w.col_flags, dropped);
-                    scatter_scan_kernel<<<1, SC_BUCKETS, 0, s>>>(w.bcount, w.bstart, w.bcursor);
-                }
                 const size_t stage_lds = sc_round<T>() * (4 * sizeof(T) + sizeof(unsigned long long));
                 static ast::PerDeviceOnce attr_once;
                 if (attr_once.need()) {
@@ -1931,14 +1908,15 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds));
                     attr_once.mark();
                 }
+                const unsigned long long late_cap = np / 4 * sizeof(uint32_t) / sizeof(T);       // the overflow list's room
                 {
                     AST_PROF("paint_tiled.level_a", s);
-                    scatter_level_a_kernel<T, W, PX, SW><<<nchunks, SC_THREADS, stage_lds, s>>>(pos, mass, np, g, w.tpb, w.bcursor, (T*)w.staging);
+                    scatter_level_a_kernel<T, W, PX, SW><<<nchunks, SC_THREADS, stage_lds, s>>>(
+                        pos, mass, np, g, w.tpb, w.bcursor, (T*)w.staging, w.cap_bg, w.col_flags, (T*)w.ovf, late_cap, w.late, dropped);
                 }
-                const unsigned long long late_cap = np / 4 * sizeof(uint32_t) / sizeof(T);       // the overflow list's room
                 AST_PROF("paint_tiled.level_b", s);
                 scatter_level_b_kernel<T, W, PX, SW><<<dim3(SC_BUCKETS, 32), SC_THREADS, stage_lds, s>>>(
-                    (const T*)w.staging, w.bstart, g, w.tpb, w.fill64, (T*)w.strays, w.scap, (T*)w.ovf, late_cap, w.late, dropped);
+                    (const T*)w.staging, w.bcursor, w.cap_bg, g, w.tpb, w.fill64, (T*)w.strays, w.scap, (T*)w.ovf, late_cap, w.late, dropped);
                 return AST_OK;
             };
             using S3 = std::integral_constant<int, 3>;

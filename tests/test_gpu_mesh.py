@@ -531,3 +531,21 @@ def test_xsorted_pipeline_matches_plain_paint(dev, monkeypatch, window, streams)
         assert st["overflow"] > 0
         np.testing.assert_allclose(got, omesh.paint(shuf, None, n2, L, window), rtol=2e-6, atol=2e-6)
     _env(monkeypatch, AST_PAINT_XCHUNK_MB=None, AST_PAINT_XSTREAMS=None)
+
+
+def test_scattered_paint_with_full_staging_segments(dev):
+    """The unordered paint has no counting pass: a (bucket, label) segment of its staging array holds twice the mean.  A
+    blob that overfills some segments sends the surplus through the late list (global atomics) - no retry, nothing lost."""
+    n, L = 128, 1000.0
+    rng = np.random.default_rng(17)
+    uniform = rng.uniform(0, L, size=(3_400_000, 3))
+    blob = 0.5 * L + rng.uniform(-0.06, 0.06, size=(600_000, 3)) * L
+    pos = np.concatenate([uniform, blob]).astype(np.float32)
+    rng.shuffle(pos)
+    st = {}
+    got = dev.paint(dev.as_device(pos), None, n, L, "cic", method="tiled", accumulate=False, hint="scattered",
+                    check_dropped=False, stats=st).cpu().numpy()
+    assert st["scattered"] and 0 < st["overflow"] < pos.shape[0] // 4
+    ref = omesh.paint(pos, None, n, L, "cic")
+    np.testing.assert_allclose(got, ref, rtol=2e-6, atol=2e-6 * ref.max())
+    assert got.sum(dtype=np.float64) == pytest.approx(pos.shape[0], rel=1e-6)
