@@ -1141,8 +1141,17 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
 #ifndef WALK_PZ
 #define WALK_PZ 0
 #endif
-    constexpr int PZ = WALK_PZ > LZ ? WALK_PZ : LZ;
-    __shared__ unsigned long long tile[LX * LY * PZ];        // ((a * LY + b) * PZ + slot), slot fastest
+    // WALK_ODD_PITCH (measured, not adopted): row pitches odd, in cells, for both neighbour directions (y: PZ, x: LYP * PZ) so
+    // that, with the lanes of a half wave split even / odd (load_pos), a particle moved by one row lands on the banks of a
+    // cell of the other parity.  CIC's 33 and 9 * 33 are odd as they are; TSC (34, 10 rows) padded to 35 and 11 rows costs
+    // a workgroup of occupancy (33 KB) and gains nothing: 11.5 -> 11.6 ms.
+#ifndef WALK_ODD_PITCH
+#define WALK_ODD_PITCH 0
+#endif
+    constexpr int PZ = WALK_PZ > LZ ? WALK_PZ : (WALK_ODD_PITCH ? (LZ | 1) : LZ);
+    constexpr int LYP = WALK_ODD_PITCH ? (LY | 1) : LY;      // rows per x-plane of the tile (>= LY)
+    __shared__ unsigned long long tile[LX * LYP * PZ];       // ((a * LYP + b) * PZ + slot), slot fastest
+    auto trow = [](int ab) { return LYP == LY ? ab : (ab / LY) * LYP + ab % LY; };      // logical (a, b) pair -> row of the LDS tile
     // the launch walks the columns col0 .. col0 + gridDim.x - 1 (mod the column count: the x-sorted pipeline's last
     // launch wraps around to the tile rows it held back)
     // nseg > 1: the column is cut into nseg z-segments of ntz / nseg tiles, one workgroup each (more, shorter
@@ -1158,7 +1167,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     const int ox = tx * TX, oy = ty * TY;
     const bool x_periodic = g.nx_alloc == g.n;
     unsigned long long ndrop = 0;
-    for (int i = threadIdx.x; i < LX * LY * PZ; i += 256) tile[i] = BIAS;
+    for (int i = threadIdx.x; i < LX * LYP * PZ; i += 256) tile[i] = BIAS;
     // where the z line of LDS column (a, b) goes: the owned cells' grid line (bit 1 set: `offset`
     // is subtracted there, in double, before the one rounding to T) or the halo ring's record line
     // (bit 0: a halo that points outside a slab buffer, counted as dropped when non-zero);
@@ -1230,6 +1239,17 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
     // slots.  Nothing may be computed from the loaded values here: that would wait for them on the spot, and with
     // them for everything else in flight.  (A stray block re-reads the tile's last record, or the segment's first
     // slot when the tile has none: unconditional loads.)
+#ifndef WALK_LANE_PERM
+#define WALK_LANE_PERM 1
+#endif
+    // which of the batch's 32-particle entries (0 .. 7 per slot u) and which of its particles a lane takes:
+    //   0  half wave h = entry, lane = particle
+    //   1  half wave h = entry, lanes 0-15 the even particles, 16-31 the odd ones
+    //   2  the wave's two entries interleaved over its four 16-lane groups: group g holds the particles = g (mod 4) of both
+    const uint32_t lane6 = threadIdx.x & 63u, wave2 = (threadIdx.x >> 6) << 1;
+    const uint32_t my_entry = WALK_LANE_PERM == 2 ? wave2 + ((lane6 >> 3) & 1u) : (threadIdx.x >> 5);
+    const uint32_t my_part = WALK_LANE_PERM == 2 ? 4u * (lane6 & 7u) + (lane6 >> 4)
+                           : WALK_LANE_PERM == 1 ? (((lane6 & 15u) << 1) | ((lane6 >> 4) & 1u)) : (lane6 & 31u);
     auto load_idx = [&](const Batch& bt, GroupRec (&rec)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1237,7 +1257,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
                 const uint32_t i = bt.i0 + u * 256 + threadIdx.x;
                 rec[u].first = wl_index[bt.off + min(i, bt.cnt - 1)];
             } else {
-                const uint32_t r = bt.i0 + u * 8 + (threadIdx.x >> 5);
+                const uint32_t r = bt.i0 + u * 8 + my_entry;
                 const uint32_t rr = min(min(r, bt.cnt - 1), bt.nrec ? bt.nrec - 1 : 0u);
                 rec[u] = wl_recs[(size_t)bt.off * wl.rcap + rr];
             }
@@ -1252,7 +1272,11 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
         for (int u = 0; u < U; ++u) {
             if (FMT != 0) {
                 constexpr int SW = FMT == 2 ? 3 : 4;                            // stray copies: {x, y, z, m} or {x, y, z}
-                const uint32_t r = bt.i0 + u * 8 + (threadIdx.x >> 5), b = threadIdx.x & 31;
+                // lane -> particle of the 32-particle entry: lanes 0-15 take the even particles, 16-31 the odd ones.  In
+                // z-ordered input the particles of a window sit in consecutive cells; a particle that the jitter moved
+                // to a neighbouring (x, y) row lands one cell (y) or nine (x) further in the banks - on the banks of
+                // an ODD neighbour, which is now in the other half of the lanes (WALK_LANE_PERM 0: identity)
+                const uint32_t r = bt.i0 + u * 8 + my_entry, b = my_part;
                 const bool st = r >= bt.nrec;                                   // uniform per half wave
                 const uint32_t sidx = (r - bt.nrec) * 32u + b;
                 const bool on = st ? (r < bt.cnt && sidx < bt.nst) : ((rec[u].mask >> b) & 1u) != 0;
@@ -1331,7 +1355,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
             unsigned long long* slot[W];          // (lx, ly) row at the ring slots of planes lz + c
             int sl = lz + sh;
             sl = sl >= LZ ? sl - LZ : sl;
-            unsigned long long* const row0 = &tile[(lx * LY + ly) * PZ];
+            unsigned long long* const row0 = &tile[(lx * LYP + ly) * PZ];
 #pragma unroll
             for (int c = 0; c < W; ++c) {
                 slot[c] = row0 + sl;
@@ -1347,7 +1371,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
                     for (int c = 0; c < W; ++c) {
                         long long v = __double_as_longlong(__fma_rn(mab, wz[c], 6755399441055744.0));   // |mab wz| < 2^50
                         if (!RAW) v -= 0x4338000000000000ll;
-                        unsigned long long* cell = slot[c] + (a * LY + b) * PZ;
+                        unsigned long long* cell = slot[c] + (a * LYP + b) * PZ;
                         if (ablate & 2) asm volatile("" ::"v"(v), "v"(cell)); else atomicAdd(cell, (unsigned long long)v);
                     }
                 }
@@ -1402,8 +1426,8 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
                 bool any = false;
 #pragma unroll
                 for (int i = 0; i < VW; ++i) {
-                    const unsigned long long raw = tile[ab * PZ + sl[i]];
-                    tile[ab * PZ + sl[i]] = BIAS;
+                    const unsigned long long raw = tile[trow(ab) * PZ + sl[i]];
+                    tile[trow(ab) * PZ + sl[i]] = BIAS;
                     any |= raw != BIAS;
                     if (ftz == 0 && c0 + i < H) first_planes[ab * H + c0 + i] = raw;     // (stored below, rewritten at the end)
                     if (RAW) {
@@ -1489,7 +1513,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
             int sl = k + sh;
             sl = sl >= LZ ? sl - LZ : sl;
             zf[i] = first_planes[i];
-            zf[LX * LY * H + i] = tile[ab * PZ + sl];
+            zf[LX * LY * H + i] = tile[trow(ab) * PZ + sl];
         }
         if (dropped && ndrop) atomicAdd(dropped, ndrop);
         return;
@@ -1498,7 +1522,7 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
         const int k = i % H, ab = i / H;
         int sl = k + sh;
         sl = sl >= LZ ? sl - LZ : sl;
-        const unsigned long long raw = first_planes[i] + tile[ab * PZ + sl] - BIAS;
+        const unsigned long long raw = first_planes[i] + tile[trow(ab) * PZ + sl] - BIAS;
         const unsigned long long d = dest[ab];
         bool any;
         const T v = fixed_to_value<T>(raw, q, (d & 2ull) ? offset : 0.0, any);
