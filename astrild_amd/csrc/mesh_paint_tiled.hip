@@ -1355,7 +1355,8 @@ column_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, Til
             unsigned long long* slot[W];          // (lx, ly) row at the ring slots of planes lz + c
             int sl = lz + sh;
             sl = sl >= LZ ? sl - LZ : sl;
-            unsigned long long* const row0 = &tile[(lx * LYP + ly) * PZ];
+            // (24-bit multiplies: the plain expression compiles to a quarter-rate v_mad_u64_u32 and v_mul_lo_u32 per particle)
+            unsigned long long* const row0 = &tile[__umul24(__umul24((unsigned)lx, (unsigned)LYP) + (unsigned)ly, (unsigned)PZ)];
 #pragma unroll
             for (int c = 0; c < W; ++c) {
                 slot[c] = row0 + sl;
