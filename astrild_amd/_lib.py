@@ -92,6 +92,7 @@ SIGNATURES = {
     "ast_lens_rows_inverse": (_i, [_vp, _sz, _sz, _d, _vp, _vp]),
     "ast_lens_cols_forward": (_i, [_vp, _sz, _sz, _sz, _sz, _vp]),
     "ast_lens_cols_inverse": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "ast_lens_cols_convolve": (_i, [_vp, _sz, _sz, _sz, _sz, _vp, _vp, _i, _sz, _vp]),
     "ast_kappa_to_alphas": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "ast_kappa_to_phi": (_i, [_vp, _vp, _vp, _vp]),
     "kappa0_to_alphas": (None, [_vp, _i, _d, _vp, _vp]),

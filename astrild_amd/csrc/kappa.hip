@@ -294,6 +294,7 @@ struct ast_lens_plan {
     // two-pass column transforms of lens_fft.hip (which skip the zero half and leave the spectra in their permuted row
     // order - every spectrum of this plan goes the same way).  Otherwise: rocFFT's 2-D plans r2c / c2r.
     bool cols = false;
+    bool split_cols = false;               // AST_LENS_SPLIT_COLS: the kappa spectrum goes through memory (A / B measurements)
     bool rows = false;                     // with cols: the nc non-zero rows by lens_fft.hip's row kernels too (nc = 128 .. 4096):
                                            // kappa is read unpadded, the inverse stores the scaled corner
     ast_fft_plan* rows_fwd = nullptr;      // nc rows of 2nc reals -> nc rows of nc + 1 complex
@@ -364,6 +365,7 @@ extern "C" int ast_lens_plan_create(ast_lens_plan** out, int nc, double bsz) {
     int rc = AST_OK;
     p->cols = ast_lens_cols_supported(n2) != 0 && !getenv("AST_LENS_ROCFFT_2D");
     p->rows = p->cols && ast_lens_rows_supported((size_t)nc) != 0 && !getenv("AST_LENS_ROCFFT_ROWS");
+    p->split_cols = getenv("AST_LENS_SPLIT_COLS") != nullptr;
     if (p->rows) {
         // hand-written rows and columns: no rocFFT plan at all
     } else if (p->cols) {
@@ -411,38 +413,62 @@ static int lens_kernel_spectrum(ast_lens_plan* p, int which, hipStream_t s) {
     return AST_OK;
 }
 
-static int lens_forward(ast_lens_plan* p, const double* kappa, hipStream_t s) {
-    if (p->rows) {
-        const size_t n2 = 2 * (size_t)p->nc, nh = n2 / 2 + 1;
-        AST_FWD(ast_lens_rows_forward(kappa, (size_t)p->nc, p->spec, nh, s));
-        return ast_lens_cols_forward(p->spec, n2, nh, nh, (size_t)p->nc, s);
-    }
+// rows of the padded kappa -> p->spec (nc rows of nc + 1 complex; the column transform is the caller's)
+static int lens_rows_forward(ast_lens_plan* p, const double* kappa, hipStream_t s) {
+    const size_t n2 = 2 * (size_t)p->nc, nh = n2 / 2 + 1;
+    if (p->rows) return ast_lens_rows_forward(kappa, (size_t)p->nc, p->spec, nh, s);
     {
         AST_PROF("lens.zero_pad", s);
         pad_corner_kernel<<<ast::stream_grid((size_t)p->nc * p->nc, 256), 256, 0, s>>>(kappa, p->nc, p->pad_in);
     }
     AST_CHECK_LAUNCH();
-    if (p->cols) {
-        const size_t n2 = 2 * (size_t)p->nc, nh = n2 / 2 + 1;
-        AST_FWD(ast_fft_exec(p->rows_fwd, p->pad_in, p->spec, s));          // rows 0 .. nc - 1; the rest is never read
-        return ast_lens_cols_forward(p->spec, n2, nh, nh, (size_t)p->nc, s);
-    }
-    return ast_fft_exec(p->r2c, p->pad_in, p->spec, s);       // out of place: the real-to-complex transform leaves its input alone
+    return ast_fft_exec(p->rows_fwd, p->pad_in, p->spec, s);                // rows 0 .. nc - 1; the rest is never read
 }
 
-// cols path: out = corner of irfft2(spec * kspec[which]) - product fused into the first inverse column pass
-static int lens_convolve_cols(ast_lens_plan* p, int which, double* out, hipStream_t s) {
+// the row part after the columns: out = corner of the inverse row transforms of prod, scaled
+static int lens_rows_inverse(ast_lens_plan* p, double2* prod, double* out, hipStream_t s) {
     const size_t n2 = 2 * (size_t)p->nc, nh = n2 / 2 + 1;
-    AST_FWD(ast_lens_cols_inverse(p->spec, p->kspec[which], p->prod, n2, nh, nh, (size_t)p->nc, s));
     if (p->rows) {                                                          // corner_matrix and out / (nx ny) * dx dy in the store
         const double dsx = p->bsz / (double)p->nc;
-        return ast_lens_rows_inverse(p->prod, nh, (size_t)p->nc, dsx * dsx / (double)(n2 * n2), out, s);
+        return ast_lens_rows_inverse(prod, nh, (size_t)p->nc, dsx * dsx / (double)(n2 * n2), out, s);
     }
-    AST_FWD(ast_fft_exec(p->rows_inv, p->prod, p->pad, s));                 // nc rows of 2nc reals
+    AST_FWD(ast_fft_exec(p->rows_inv, prod, p->pad, s));                    // nc rows of 2nc reals
     AST_PROF("lens.crop_scale", s);
     crop_scale_kernel<<<ast::stream_grid((size_t)p->nc * p->nc, 256), 256, 0, s>>>(p->pad, p->nc, p->bsz / (double)p->nc, out);
     AST_CHECK_LAUNCH();
     return AST_OK;
+}
+
+// cols path: outs[m] = corner of irfft2(rfft2(padded kappa) * kspec[which[m]]), m < nmul <= 2.  Columns: one forward
+// pass, one pass that finishes the forward transform, multiplies and starts the inverse(s), one inverse pass per output
+// (ast_lens_cols_convolve); AST_LENS_SPLIT_COLS=1 keeps the spectrum in memory instead (forward, then one inverse per
+// kernel with the product fused into its first pass: three array passes more for two outputs).
+static int lens_convolve_cols(ast_lens_plan* p, const double* kappa, const int* which, double* const* outs, int nmul, hipStream_t s) {
+    const size_t n2 = 2 * (size_t)p->nc, nh = n2 / 2 + 1;
+    AST_FWD(lens_rows_forward(p, kappa, s));
+    if (p->split_cols) {
+        AST_FWD(ast_lens_cols_forward(p->spec, n2, nh, nh, (size_t)p->nc, s));
+        for (int m = 0; m < nmul; ++m) {
+            AST_FWD(ast_lens_cols_inverse(p->spec, p->kspec[which[m]], p->prod, n2, nh, nh, (size_t)p->nc, s));
+            AST_FWD(lens_rows_inverse(p, p->prod, outs[m], s));
+        }
+        return AST_OK;
+    }
+    if (nmul == 2 && !p->prod2) AST_CHECK_HIP(hipMalloc(&p->prod2, n2 * nh * sizeof(double2)));
+    const void* muls[2] = {p->kspec[which[0]], p->kspec[which[nmul - 1]]};
+    void* prods[2] = {p->prod, nmul == 2 ? (void*)p->prod2 : (void*)p->prod};
+    AST_FWD(ast_lens_cols_convolve(p->spec, n2, nh, nh, (size_t)p->nc, muls, prods, nmul, (size_t)p->nc, s));
+    for (int m = 0; m < nmul; ++m) AST_FWD(lens_rows_inverse(p, (double2*)prods[m], outs[m], s));
+    return AST_OK;
+}
+
+static int lens_forward(ast_lens_plan* p, const double* kappa, hipStream_t s) {       // rocFFT 2-D route
+    {
+        AST_PROF("lens.zero_pad", s);
+        pad_corner_kernel<<<ast::stream_grid((size_t)p->nc * p->nc, 256), 256, 0, s>>>(kappa, p->nc, p->pad_in);
+    }
+    AST_CHECK_LAUNCH();
+    return ast_fft_exec(p->r2c, p->pad_in, p->spec, s);       // out of place: the real-to-complex transform leaves its input alone
 }
 
 static int lens_crop(ast_lens_plan* p, double2* prod, double* out, hipStream_t s) {     // prod is overwritten (rocFFT C2R)
@@ -468,13 +494,12 @@ extern "C" int ast_kappa_to_alphas(ast_lens_plan* p, const double* kappa, double
     hipStream_t s = ast::as_stream(stream);
     AST_FWD(lens_kernel_spectrum(p, 0, s));
     AST_FWD(lens_kernel_spectrum(p, 1, s));
-    AST_FWD(lens_forward(p, kappa, s));
     if (p->cols) {
-        // (one call forming both products from a single read of the kappa spectrum was measured: 1.42 ms against 1.26
-        // for two calls - the doubled register set halves the occupancy of the first inverse pass)
-        AST_FWD(lens_convolve_cols(p, 0, alpha1, s));
-        return lens_convolve_cols(p, 1, alpha2, s);
+        const int which[2] = {0, 1};
+        double* const outs[2] = {alpha1, alpha2};
+        return lens_convolve_cols(p, kappa, which, outs, 2, s);
     }
+    AST_FWD(lens_forward(p, kappa, s));
     const size_t n2 = 2 * (size_t)p->nc, nh = n2 / 2 + 1;
     if (!p->prod2) AST_CHECK_HIP(hipMalloc(&p->prod2, n2 * nh * sizeof(double2)));
     {
@@ -491,8 +516,12 @@ extern "C" int ast_kappa_to_phi(ast_lens_plan* p, const double* kappa, double* p
     AST_CHECK_ARG(p && kappa && phi);
     hipStream_t s = ast::as_stream(stream);
     AST_FWD(lens_kernel_spectrum(p, 2, s));
+    if (p->cols) {
+        const int which[1] = {2};
+        double* const outs[1] = {phi};
+        return lens_convolve_cols(p, kappa, which, outs, 1, s);
+    }
     AST_FWD(lens_forward(p, kappa, s));
-    if (p->cols) return lens_convolve_cols(p, 2, phi, s);
     AST_FWD(lens_convolve(p, 2, phi, s));
     return AST_OK;
 }

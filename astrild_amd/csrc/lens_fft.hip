@@ -15,6 +15,8 @@
 // Frequency k = k1 + N1 k2 therefore ends up at row N2 k1 + k2: a fixed permutation of the rows.  Nothing downstream
 // needs the natural order - the spectra are only multiplied point by point with kernel spectra that went through the
 // same two passes, and the inverse (pass B backwards, conjugate twiddle, pass A backwards) undoes it.
+// A convolution (ast_lens_cols_convolve) runs forward pass B, the product(s) and inverse pass B as ONE pass
+// (col_mid_kernel): they touch the same N2 rows x 16 columns, and the spectrum is then never written to memory.
 // Zero padding: the forward pass A reads the first `in_points` of its N1 points only (rows >= Nc hold zeros that are
 // never stored either), the last inverse pass writes the first `out_points` only (the corner that is kept).
 // Each workgroup works on 16 adjacent columns (256-byte row pieces): R1 x R2 register FFTs with one LDS exchange,
@@ -25,6 +27,12 @@
 #include <cmath>
 #include <mutex>
 #include <vector>
+
+#define LENS_FWD(call)                 \
+    do {                               \
+        int rc_ = (call);              \
+        if (rc_ != AST_OK) return rc_; \
+    } while (0)
 
 namespace {
 
@@ -141,6 +149,95 @@ col_pass_kernel(const double2* __restrict__ in, const double2* __restrict__ mul,
                 if (twist) x = cmul(x, tw_big[(size_t)((g * j) % big_len)]);     // W_L^{g j}; INV: conjugated below with x
                 if (INV) x.y = -x.y;
                 out[base + (size_t)j * pstride] = x;
+            }
+        }
+    }
+}
+
+// The middle of a column convolution in one pass: the forward transform's second pass (group g = k1, points n2 at
+// consecutive rows), the product with NMUL kernel spectra and the inverse's first pass (back to n2, times conj W_L^{k1 n2})
+// all work on the same NP rows x C columns, so the spectrum itself is never written: `in` holds pass A's output, out_m
+// what the inverse's last pass (pass A backwards) reads.  Forward as NP = RA * RB (RA-point transforms in registers, LDS
+// exchange, RB-point transforms), which leaves thread (c, sub < RA) with the points sub + RA k2 - exactly the input
+// layout of an inverse split the other way round (RB-point transforms first), so the products are formed in place.
+template <int RA, int RB, int C, int NMUL>
+__global__ void __launch_bounds__(C * (RA > RB ? RA : RB))
+col_mid_kernel(const double2* __restrict__ in, const double2* __restrict__ mul0, const double2* __restrict__ mul1,
+               double2* __restrict__ out0, double2* __restrict__ out1, size_t pitch, int ncols,
+               const double2* __restrict__ tw_big, int big_len) {
+    constexpr int NP = RA * RB;
+    constexpr int NT = C * (RA > RB ? RA : RB);
+    __shared__ double2 Y[NP * C];
+    __shared__ double2 tw[NP];                            // e^{-2 pi i m / NP}
+    for (int i = threadIdx.x; i < NP; i += NT) tw[i] = tw_big[(size_t)i * (big_len / NP)];
+    const int c = threadIdx.x % C, sub = threadIdx.x / C;
+    const size_t c0 = (size_t)blockIdx.x * C;
+    const int g = blockIdx.y;
+    const bool col_ok = c0 + c < (size_t)ncols;
+    const size_t base = (size_t)g * NP * pitch + min(c0 + c, (size_t)ncols - 1);
+    double2 m[RB];                                        // the kernel spectrum at this thread's points (sub < RA)
+    auto fetch_mul = [&](const double2* __restrict__ mul) {
+#pragma unroll
+        for (int k2 = 0; k2 < RB; ++k2) m[k2] = mul[base + (size_t)(sub + RA * k2) * pitch];
+    };
+    if (sub < RB) {                                       // forward stage 1: task (c, n2 = sub)
+        double2 v[RA];
+#pragma unroll
+        for (int n1 = 0; n1 < RA; ++n1) v[n1] = in[base + (size_t)(n1 * RB + sub) * pitch];
+        if (sub < RA) fetch_mul(mul0);                    // in flight across the exchange
+        fft_reg<RA>(v);
+        __syncthreads();                                  // the twiddle table is in LDS
+#pragma unroll
+        for (int k1 = 0; k1 < RA; ++k1) {
+            double2 y = v[bitrev(k1, ilog2(RA))];
+            if (k1 != 0) y = cmul(y, tw[sub * k1]);
+            Y[(sub * RA + k1) * C + c] = y;
+        }
+    } else {
+        if (sub < RA) fetch_mul(mul0);
+        __syncthreads();
+    }
+    __syncthreads();
+    double2 X[RB];                                        // sub < RA: spectrum point sub + RA k2 in X[bitrev(k2)]
+    if (sub < RA) {
+#pragma unroll
+        for (int n2 = 0; n2 < RB; ++n2) X[n2] = Y[(n2 * RA + sub) * C + c];
+        fft_reg<RB>(X);
+    }
+#pragma unroll
+    for (int which = 0; which < NMUL; ++which) {
+        double2* __restrict__ out = which ? out1 : out0;
+        __syncthreads();                                  // Y has been read by everyone
+        if (sub < RA) {                                   // inverse stage 1: task (c, n2' = sub), points n1' RA + sub, n1' = k2
+            double2 w[RB];
+#pragma unroll
+            for (int k2 = 0; k2 < RB; ++k2) {
+                w[k2] = cmul(X[bitrev(k2, ilog2(RB))], m[k2]);
+                w[k2].y = -w[k2].y;
+            }
+            if (which + 1 < NMUL) fetch_mul(mul1);
+            fft_reg<RB>(w);
+#pragma unroll
+            for (int k1 = 0; k1 < RB; ++k1) {
+                double2 y = w[bitrev(k1, ilog2(RB))];
+                if (k1 != 0) y = cmul(y, tw[sub * k1]);
+                Y[(sub * RB + k1) * C + c] = y;
+            }
+        }
+        __syncthreads();
+        if (sub < RB) {                                   // inverse stage 2: task (c, k1' = sub)
+            double2 u[RA];
+#pragma unroll
+            for (int n2 = 0; n2 < RA; ++n2) u[n2] = Y[(n2 * RB + sub) * C + c];
+            fft_reg<RA>(u);
+            if (col_ok) {
+#pragma unroll
+                for (int k2 = 0; k2 < RA; ++k2) {
+                    const int j = sub + RB * k2;          // output point n2
+                    double2 x = cmul(u[bitrev(k2, ilog2(RA))], tw_big[(size_t)((g * j) % big_len)]);
+                    x.y = -x.y;
+                    out[base + (size_t)j * pitch] = x;
+                }
             }
         }
     }
@@ -393,6 +490,28 @@ int pass_of(int np, const double2* in, const double2* mul, double2* out, size_t 
     }
 }
 
+template <int RA, int RB, int NMUL>
+int launch_mid(const double2* in, const double2* const* muls, double2* const* outs, size_t pitch, int ncols, int groups,
+               const double2* tw_big, int big_len, hipStream_t s) {
+    constexpr int C = 16, NT = C * (RA > RB ? RA : RB);
+    const dim3 grid((unsigned)((ncols + C - 1) / C), (unsigned)groups);
+    col_mid_kernel<RA, RB, C, NMUL><<<grid, NT, 0, s>>>(in, muls[0], muls[NMUL - 1], outs[0], outs[NMUL - 1], pitch, ncols, tw_big,
+                                                        big_len);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+template <int NMUL>
+int mid_of(int np, const double2* in, const double2* const* muls, double2* const* outs, size_t pitch, int ncols, int groups,
+           const double2* tw_big, int big_len, hipStream_t s) {
+    switch (np) {
+        case 128: return launch_mid<16, 8, NMUL>(in, muls, outs, pitch, ncols, groups, tw_big, big_len, s);
+        case 64: return launch_mid<8, 8, NMUL>(in, muls, outs, pitch, ncols, groups, tw_big, big_len, s);
+        case 32: return launch_mid<4, 8, NMUL>(in, muls, outs, pitch, ncols, groups, tw_big, big_len, s);
+        default: return launch_mid<4, 4, NMUL>(in, muls, outs, pitch, ncols, groups, tw_big, big_len, s);
+    }
+}
+
 }  // namespace
 
 extern "C" int ast_lens_cols_supported(size_t len) {
@@ -443,6 +562,45 @@ extern "C" int ast_lens_cols_inverse(const void* spec, const void* mul, void* ou
     // pass A backwards: group = n2, points k1 at rows N2 apart -> n1; rows >= len / 2 are points n1 >= N1 / 2
     return pass_of<true>(sp.n1, o, nullptr, o, pitch, (int)ncols, sp.n2, 1, (size_t)sp.n2, sp.n1,
                          keep_rows == len ? sp.n1 : sp.n1 / 2, 0, tw, (int)len, s);
+}
+
+// out_m = the first keep_rows rows of IFFT_cols(FFT_cols(data) * mul_m) (unnormalised, natural order), m < nmul <= 2:
+// forward pass A in place on data_d, then ONE pass that finishes the forward transform, forms the products and starts
+// the inverses (col_mid_kernel: the spectrum is never written), then pass A backwards on each out_m.  mul_m are spectra
+// in the permuted order ast_lens_cols_forward leaves.
+extern "C" int ast_lens_cols_convolve(void* data, size_t len, size_t pitch, size_t ncols, size_t nonzero_rows,
+                                      const void* const* muls, void* const* outs, int nmul, size_t keep_rows, void* stream) {
+    AST_CHECK_ARG(data != nullptr && muls != nullptr && outs != nullptr && ncols >= 1 && ncols <= pitch);
+    AST_CHECK_ARG(nmul == 1 || nmul == 2);
+    for (int i = 0; i < nmul; ++i) AST_CHECK_ARG(muls[i] != nullptr && outs[i] != nullptr && outs[i] != data && outs[i] != muls[i]);
+    AST_CHECK_ARG(nmul == 1 || outs[0] != outs[1]);
+    Split sp;
+    AST_CHECK_ARG(split_of(len, sp));
+    AST_CHECK_ARG(nonzero_rows == len || nonzero_rows == len / 2);
+    AST_CHECK_ARG(keep_rows == len || keep_rows == len / 2);
+    hipStream_t s = ast::as_stream(stream);
+    const double2* tw = g_tw.get((int)len, s);
+    if (!tw) { ast::set_error("ast_lens_cols_convolve: twiddle table allocation failed"); return AST_ERR_HIP; }
+    double2* d = (double2*)data;
+    {
+        AST_PROF("lens.cols_fwd", s);
+        LENS_FWD(pass_of<false>(sp.n1, d, nullptr, d, pitch, (int)ncols, sp.n2, 1, (size_t)sp.n2,
+                               nonzero_rows == len ? sp.n1 : sp.n1 / 2, sp.n1, 1, tw, (int)len, s));
+    }
+    {
+        AST_PROF("lens.cols_mid", s);
+        const double2* const* m = (const double2* const*)muls;
+        double2* const* o = (double2* const*)outs;
+        LENS_FWD(nmul == 2 ? mid_of<2>(sp.n2, d, m, o, pitch, (int)ncols, sp.n1, tw, (int)len, s)
+                          : mid_of<1>(sp.n2, d, m, o, pitch, (int)ncols, sp.n1, tw, (int)len, s));
+    }
+    AST_PROF("lens.cols_inv", s);
+    for (int i = 0; i < nmul; ++i) {
+        double2* o = (double2*)outs[i];
+        LENS_FWD(pass_of<true>(sp.n1, o, nullptr, o, pitch, (int)ncols, sp.n2, 1, (size_t)sp.n2, sp.n1,
+                              keep_rows == len ? sp.n1 : sp.n1 / 2, 0, tw, (int)len, s));
+    }
+    return AST_OK;
 }
 
 extern "C" int ast_lens_rows_supported(size_t nc) {

@@ -446,6 +446,13 @@ int ast_lens_rows_inverse(const void* spec_d, size_t pitch, size_t nc, double sc
 int ast_lens_cols_forward(void* data_d, size_t len, size_t pitch, size_t ncols, size_t nonzero_rows, void* stream);
 int ast_lens_cols_inverse(const void* spec_d, const void* mul_d, void* out_d, size_t len, size_t pitch, size_t ncols,
                           size_t keep_rows, void* stream);
+/* The whole column part of a convolution with nmul (1 or 2) kernel spectra mul_d[m] (permuted order, as
+ * ast_lens_cols_forward leaves them): out_d[m] = the first keep_rows rows of IFFT_cols(FFT_cols(data_d) * mul_d[m]),
+ * unnormalised, natural order.  data_d is overwritten (forward pass A in place); the second forward pass, the products
+ * and the first inverse pass are one kernel, so the spectrum of data_d never goes to memory (3 array passes fewer for
+ * kappa -> alpha1, alpha2 than forward + 2 x inverse).  muls / outs are host arrays of device pointers. */
+int ast_lens_cols_convolve(void* data_d, size_t len, size_t pitch, size_t ncols, size_t nonzero_rows, const void* const* muls,
+                           void* const* outs, int nmul, size_t keep_rows, void* stream);
 
 /* Device-pointer variants (fp64, C-contiguous nc*nc). */
 int ast_kappa_to_alphas(ast_lens_plan* plan, const double* kappa_d, double* alpha1_d,

@@ -363,6 +363,50 @@ def test_lens_column_transforms_against_numpy(hip, dev, length):
     assert hip.ast_lens_cols_supported(8192) == 1 and hip.ast_lens_cols_supported(100) == 0
 
 
+@pytest.mark.parametrize("length,nmul", [(256, 2), (512, 1), (1024, 2), (2048, 2), (4096, 1), (8192, 2), (16384, 2)])
+def test_lens_column_convolution_in_three_passes(hip, dev, length, nmul):
+    """ast_lens_cols_convolve: out_m = ifft(fft(x) * mul_m) along axis 0 (unnormalised, the rows that are kept), with the
+    spectrum of x never stored - against numpy, and against the forward + inverse calls it replaces."""
+    import ctypes as ct
+    from astrild_amd import _lib
+    n1, n2 = _LENS_SPLIT[length]
+    pitch, ncols = 40, 37
+    rng = np.random.default_rng(7 * length + nmul)
+    x = rng.standard_normal((length, pitch)) + 1j * rng.standard_normal((length, pitch))
+    perm = np.array([(r // n2) + n1 * (r % n2) for r in range(length)])
+    muls_nat = [rng.standard_normal((length, ncols)) + 1j * rng.standard_normal((length, ncols)) for _ in range(nmul)]
+    mds = []
+    for m in muls_nat:
+        mp = np.zeros((length, pitch), dtype=np.complex128)
+        mp[:, :ncols] = m[perm]
+        mds.append(dev.as_device(mp))
+    for nonzero, keep in [(length, length), (length // 2, length // 2)]:
+        xz = x.copy()
+        xz[nonzero:] = 0.0
+        spec = np.fft.fft(xz[:, :ncols], axis=0)
+        xin = x.copy()
+        xin[nonzero:] = np.nan                               # never read
+        d = dev.as_device(xin)
+        outs = [dev.as_device(np.full((length, pitch), np.nan + 0j)) for _ in range(nmul)]
+        marr = (ct.c_void_p * nmul)(*[dev.ptr(t) for t in mds])
+        oarr = (ct.c_void_p * nmul)(*[dev.ptr(t) for t in outs])
+        _lib.check(hip.ast_lens_cols_convolve(dev.ptr(d), length, pitch, ncols, nonzero, marr, oarr, nmul, keep, dev.stream()))
+        # the calls it replaces, on the same input
+        d2 = dev.as_device(xin)
+        _lib.check(hip.ast_lens_cols_forward(dev.ptr(d2), length, pitch, ncols, nonzero, dev.stream()))
+        for m, md, out in zip(muls_nat, mds, outs):
+            want = np.fft.ifft(spec * m, axis=0) * length
+            o = out.cpu().numpy()
+            assert np.abs(o[:keep, :ncols] - want[:keep]).max() < 2e-13 * np.abs(want).max()
+            assert np.isnan(o[:, ncols:]).all()              # columns past ncols untouched
+            old = dev.as_device(np.full((length, pitch), np.nan + 0j))
+            _lib.check(hip.ast_lens_cols_inverse(dev.ptr(d2), dev.ptr(md), dev.ptr(old), length, pitch, ncols, keep, dev.stream()))
+            assert np.abs(o[:keep, :ncols] - old.cpu().numpy()[:keep, :ncols]).max() < 2e-13 * np.abs(want).max()
+    bad = (ct.c_void_p * 1)(dev.ptr(d))
+    assert hip.ast_lens_cols_convolve(dev.ptr(d), length, pitch, ncols, length, marr, bad, 1, length, dev.stream()) < 0   # out == data
+    assert hip.ast_lens_cols_convolve(dev.ptr(d), length, pitch, ncols, length, marr, oarr, 3, length, dev.stream()) < 0
+
+
 @pytest.mark.parametrize("npix,sigma_px", [(1000, 2.5), (777, 4.3), (2048, 7.5), (64, 3.0), (1500, 18.8), (256, 12.0)])
 def test_gaussian_fft_smoothing_real_space_route_equals_fft_route(lens, dev, npix, sigma_px, monkeypatch):
     """For 2.5 <= sigma_px <= 18.8 "gaussianFFT" runs as two periodic real-space passes; the FFT route (forced through
