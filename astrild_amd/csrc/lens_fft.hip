@@ -160,8 +160,16 @@ col_pass_kernel(const double2* __restrict__ in, const double2* __restrict__ mul,
 // what the inverse's last pass (pass A backwards) reads.  Forward as NP = RA * RB (RA-point transforms in registers, LDS
 // exchange, RB-point transforms), which leaves thread (c, sub < RA) with the points sub + RA k2 - exactly the input
 // layout of an inverse split the other way round (RB-point transforms first), so the products are formed in place.
+// measured at 8192 rows, two kernels: three workgroups per CU without prefetching the second kernel spectrum 0.585 ms,
+// with it (34 registers spilled) 0.629; two per CU with the prefetch and nothing spilled 0.690
+#ifndef MID_PREFETCH
+#define MID_PREFETCH 0
+#endif
+#ifndef MID_WAVES
+#define MID_WAVES 3
+#endif
 template <int RA, int RB, int C, int NMUL>
-__global__ void __launch_bounds__(C * (RA > RB ? RA : RB))
+__global__ void __launch_bounds__(C * (RA > RB ? RA : RB)) __attribute__((amdgpu_waves_per_eu(MID_WAVES)))
 col_mid_kernel(const double2* __restrict__ in, const double2* __restrict__ mul0, const double2* __restrict__ mul1,
                double2* __restrict__ out0, double2* __restrict__ out1, size_t pitch, int ncols,
                const double2* __restrict__ tw_big, int big_len) {
@@ -174,16 +182,18 @@ col_mid_kernel(const double2* __restrict__ in, const double2* __restrict__ mul0,
     const size_t c0 = (size_t)blockIdx.x * C;
     const int g = blockIdx.y;
     const bool col_ok = c0 + c < (size_t)ncols;
-    const size_t base = (size_t)g * NP * pitch + min(c0 + c, (size_t)ncols - 1);
+    // addresses: a uniform row base per point plus ONE 32-bit lane offset (host check: (NP + 1) * pitch < 2^28)
+    const size_t gbase = (size_t)g * NP * pitch;
+    const uint32_t voff = (uint32_t)sub * (uint32_t)pitch + min((uint32_t)c0 + (uint32_t)c, (uint32_t)ncols - 1u);
     double2 m[RB];                                        // the kernel spectrum at this thread's points (sub < RA)
     auto fetch_mul = [&](const double2* __restrict__ mul) {
 #pragma unroll
-        for (int k2 = 0; k2 < RB; ++k2) m[k2] = mul[base + (size_t)(sub + RA * k2) * pitch];
+        for (int k2 = 0; k2 < RB; ++k2) m[k2] = (mul + gbase + (size_t)(RA * k2) * pitch)[voff];
     };
     if (sub < RB) {                                       // forward stage 1: task (c, n2 = sub)
         double2 v[RA];
 #pragma unroll
-        for (int n1 = 0; n1 < RA; ++n1) v[n1] = in[base + (size_t)(n1 * RB + sub) * pitch];
+        for (int n1 = 0; n1 < RA; ++n1) v[n1] = (in + gbase + (size_t)(n1 * RB) * pitch)[voff];
         if (sub < RA) fetch_mul(mul0);                    // in flight across the exchange
         fft_reg<RA>(v);
         __syncthreads();                                  // the twiddle table is in LDS
@@ -208,6 +218,7 @@ col_mid_kernel(const double2* __restrict__ in, const double2* __restrict__ mul0,
     for (int which = 0; which < NMUL; ++which) {
         double2* __restrict__ out = which ? out1 : out0;
         __syncthreads();                                  // Y has been read by everyone
+        if (!MID_PREFETCH && which && sub < RA) fetch_mul(mul1);
         if (sub < RA) {                                   // inverse stage 1: task (c, n2' = sub), points n1' RA + sub, n1' = k2
             double2 w[RB];
 #pragma unroll
@@ -215,7 +226,7 @@ col_mid_kernel(const double2* __restrict__ in, const double2* __restrict__ mul0,
                 w[k2] = cmul(X[bitrev(k2, ilog2(RB))], m[k2]);
                 w[k2].y = -w[k2].y;
             }
-            if (which + 1 < NMUL) fetch_mul(mul1);
+            if (MID_PREFETCH && which + 1 < NMUL) fetch_mul(mul1);
             fft_reg<RB>(w);
 #pragma unroll
             for (int k1 = 0; k1 < RB; ++k1) {
@@ -236,7 +247,7 @@ col_mid_kernel(const double2* __restrict__ in, const double2* __restrict__ mul0,
                     const int j = sub + RB * k2;          // output point n2
                     double2 x = cmul(u[bitrev(k2, ilog2(RA))], tw_big[(size_t)((g * j) % big_len)]);
                     x.y = -x.y;
-                    out[base + (size_t)j * pitch] = x;
+                    (out + gbase + (size_t)(RB * k2) * pitch)[voff] = x;
                 }
             }
         }

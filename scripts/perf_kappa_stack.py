@@ -1,17 +1,35 @@
-"""Time the kappa stack alone (64 planes x 4096^2 fp64, weighted and unweighted) - dev tool for build variants."""
+"""Time the kappa stack alone (64 planes x 4096^2 fp64, weighted and unweighted) - dev tool for build variants.
+usage: perf_kappa_stack.py [pad_bytes ...]   planes are carved from ONE buffer, 2^27 + pad bytes apart (default: the
+planes as lensing.synth_kappa_planes allocates them)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from astrild_amd import lensing
-planes = lensing.synth_kappa_planes(64, 4096)
+base = lensing.synth_kappa_planes(64, 4096)
 wnum, wden = lensing.synth_plane_weights(64)
 out = torch.empty((4096, 4096), dtype=torch.float64, device="cuda")
-for name, w in (("weighted", (wnum, wden)), ("unweighted", (None, None))):
-    lensing.kappa_stack(planes, *w, out=out)
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(7)]
-    for a, b in ev:
-        a.record(); lensing.kappa_stack(planes, *w, out=out); b.record()
-    torch.cuda.synchronize()
-    ms = sorted(a.elapsed_time(b) for a, b in ev)[3]
-    print(f"{name:10s} {ms:.3f} ms  {65 * 4096 * 4096 * 8 / ms / 1e9:.2f} TB/s  checksum {float(out.sum()):.10e}", flush=True)
+n = 4096 * 4096
+
+
+def run(tag, planes):
+    for name, w in (("weighted", (wnum, wden)), ("unweighted", (None, None))):
+        lensing.kappa_stack(planes, *w, out=out)
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(7)]
+        for a, b in ev:
+            a.record(); lensing.kappa_stack(planes, *w, out=out); b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in ev)[3]
+        print(f"{tag:22s} {name:10s} {ms:.3f} ms  {65 * n * 8 / ms / 1e9:.2f} TB/s  checksum {float(out.sum()):.10e}", flush=True)
+
+
+print("plane addresses mod 2^27:", sorted({p.data_ptr() % (1 << 27) for p in base}))
+run("as allocated", base)
+for pad in [int(a) for a in sys.argv[1:]]:
+    stride = n + pad // 8
+    buf = torch.empty(64 * stride, dtype=torch.float64, device="cuda")
+    planes = [buf[i * stride:i * stride + n].view(4096, 4096) for i in range(64)]
+    for p, b in zip(planes, base):
+        p.copy_(b)
+    run(f"pad {pad} B", planes)
+    del planes, buf
