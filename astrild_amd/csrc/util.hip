@@ -115,12 +115,14 @@ __device__ inline double key2d(unsigned long long k) {
 }
 
 // V elements per load (16 bytes when the buffer is aligned), four loads in flight per thread, extrema reduced over the
-// wave and then over the workgroup: ONE pair of atomics per workgroup.  (One pair per WAVE - 8192 waves hammering two
-// addresses - took 0.2 ms for a 134 MB map that streams in 0.03: the same-address atomics serialise at the memory side.)
+// wave and then over the workgroup: ONE pair of atomics per workgroup, and few workgroups (1024 threads, two per CU).
+// The same-address atomics serialise at the memory side: one pair per WAVE (8192 waves) took 0.2 ms for a 134 MB map
+// that streams in 0.03, one pair per 256-thread workgroup (2048 of them) 0.057 ms.
+constexpr int MINMAX_BLOCK = 1024, MINMAX_GRID = 512;
 template <typename T, int V>
-__global__ void __launch_bounds__(256) minmax_kernel(const T* __restrict__ buf, size_t n, unsigned long long* keys) {
+__global__ void __launch_bounds__(MINMAX_BLOCK) minmax_kernel(const T* __restrict__ buf, size_t n, unsigned long long* keys) {
     typedef T vec_t __attribute__((ext_vector_type(V)));
-    __shared__ double slo[4], shi[4];
+    __shared__ double slo[MINMAX_BLOCK / 64], shi[MINMAX_BLOCK / 64];
     const size_t nvec = n / V;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -153,9 +155,15 @@ __global__ void __launch_bounds__(256) minmax_kernel(const T* __restrict__ buf, 
     hi = wave_max(hi);
     if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicMin(&keys[0], d2key(fmin(fmin(slo[0], slo[1]), fmin(slo[2], slo[3]))));
-        atomicMax(&keys[1], d2key(fmax(fmax(shi[0], shi[1]), fmax(shi[2], shi[3]))));
+    if (threadIdx.x < 64) {
+        lo = threadIdx.x < MINMAX_BLOCK / 64 ? slo[threadIdx.x] : DBL_MAX;
+        hi = threadIdx.x < MINMAX_BLOCK / 64 ? shi[threadIdx.x] : -DBL_MAX;
+        lo = wave_min(lo);
+        hi = wave_max(hi);
+        if (threadIdx.x == 0) {
+            atomicMin(&keys[0], d2key(lo));
+            atomicMax(&keys[1], d2key(hi));
+        }
     }
 }
 
@@ -198,11 +206,17 @@ __global__ void sum_stage2_kernel(const double* __restrict__ part, int nparts, d
 //   v >= edge[idx+1] && idx != nbins-1 -> idx+1.   edges = linspace(lo, hi, nbins+1).
 // range_d (or null): {lo, hi} on the device (ast_minmax's output) - the range=None case of np.histogram without a
 // host round trip; a degenerate range is widened by +-0.5 like numpy does.
-template <typename T, int MAXB>
-__global__ void hist_kernel(const T* buf, size_t n, double lo, double hi, int nbins,
-                            unsigned long long* counts, const double* __restrict__ range_d = nullptr) {
-    __shared__ unsigned int lh[MAXB];
-    for (int i = threadIdx.x; i < nbins; i += blockDim.x) lh[i] = 0;
+// V elements per load (16 bytes when the buffer is aligned), four loads in flight; the workgroup's LDS histogram is kept
+// in `copies` replicas (lane mod copies picks one) so that the lanes of a wave that hit the same popular bin do not
+// queue on one LDS word; 1024-thread workgroups, at most 512 of them: nbins global atomics each at the end.
+constexpr int HIST_BLOCK = 1024, HIST_GRID = 512, HIST_MAXB = 4096;
+template <typename T, int V>
+__global__ void __launch_bounds__(HIST_BLOCK)
+hist_kernel(const T* __restrict__ buf, size_t n, double lo, double hi, int nbins, int copies, unsigned long long* counts,
+            const double* __restrict__ range_d = nullptr) {
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    __shared__ unsigned int lh[HIST_MAXB];
+    for (int i = threadIdx.x; i < nbins * copies; i += HIST_BLOCK) lh[i] = 0;
     if (range_d) {
         lo = range_d[0];
         hi = range_d[1];
@@ -211,22 +225,58 @@ __global__ void hist_kernel(const T* buf, size_t n, double lo, double hi, int nb
     __syncthreads();
     const double norm = (double)nbins / (hi - lo);
     const double step = (hi - lo) / (double)nbins;
-    size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        double v = (double)buf[i];
-        if (!(v >= lo && v <= hi)) continue;
+    unsigned int* mine = lh + (threadIdx.x & (copies - 1)) * nbins;
+    auto put = [&](double v) {
+        if (!(v >= lo && v <= hi)) return;
         int idx = (int)((v - lo) * norm);
         if (idx == nbins) idx = nbins - 1;
         // numpy's linspace: edge[i] = lo + i*step (last forced to hi)
-        double e0 = lo + idx * step;
-        double e1 = (idx + 1 == nbins) ? hi : lo + (idx + 1) * step;
+        const double e0 = lo + idx * step;
+        const double e1 = (idx + 1 == nbins) ? hi : lo + (idx + 1) * step;
         if (v < e0) idx -= 1;
         else if (v >= e1 && idx != nbins - 1) idx += 1;
-        atomicAdd(&lh[idx], 1u);
+        atomicAdd(&mine[idx], 1u);
+    };
+    const size_t nvec = n / V;
+    const size_t stride = (size_t)gridDim.x * HIST_BLOCK;
+    size_t i = (size_t)blockIdx.x * HIST_BLOCK + threadIdx.x;
+    const vec_t* vb = reinterpret_cast<const vec_t*>(buf);
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+        vec_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = vb[i + j * stride];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) put((double)v[j][k]);
+        }
     }
+    for (; i < nvec; i += stride) {
+        const vec_t v = vb[i];
+#pragma unroll
+        for (int k = 0; k < V; ++k) put((double)v[k]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - nvec * V) put((double)buf[nvec * V + threadIdx.x]);   // past the last whole vector
     __syncthreads();
-    for (int i = threadIdx.x; i < nbins; i += blockDim.x)
-        if (lh[i]) atomicAdd(&counts[i], (unsigned long long)lh[i]);
+    for (int b = threadIdx.x; b < nbins; b += HIST_BLOCK) {
+        unsigned long long total = 0;
+        for (int c = 0; c < copies; ++c) total += lh[c * nbins + b];
+        if (total) atomicAdd(&counts[b], total);
+    }
+}
+
+template <typename T>
+void launch_hist(const T* buf, size_t count, double lo, double hi, int nbins, unsigned long long* counts, const double* range_d,
+                 hipStream_t s) {
+    int copies = 1;
+    while (copies < 32 && 2 * copies * nbins <= HIST_MAXB) copies *= 2;
+    constexpr int W = 16 / (int)sizeof(T);
+    const bool wide = ((uintptr_t)buf & 15) == 0;
+    const size_t per = wide ? W : 1;
+    const size_t need = ((count + per - 1) / per + HIST_BLOCK - 1) / HIST_BLOCK;
+    const unsigned g = (unsigned)(need > (size_t)HIST_GRID ? (size_t)HIST_GRID : need);
+    if (wide) hist_kernel<T, W><<<g, HIST_BLOCK, 0, s>>>(buf, count, lo, hi, nbins, copies, counts, range_d);
+    else hist_kernel<T, 1><<<g, HIST_BLOCK, 0, s>>>(buf, count, lo, hi, nbins, copies, counts, range_d);
 }
 
 // ---- counter-based normal generator for the synthetic particle set ----
@@ -323,13 +373,14 @@ extern "C" int ast_minmax(const void* buf, int dtype, size_t count, double* out,
     minmax_init<<<1, 1, 0, s>>>(keys);
     const bool wide = ((uintptr_t)buf & 15) == 0;
     const size_t per = wide ? 16 / (dtype == AST_F32 ? 4 : 8) : 1;
-    unsigned g = ast::stream_grid((count + per - 1) / per, 256);
+    const size_t need = ((count + per - 1) / per + MINMAX_BLOCK - 1) / MINMAX_BLOCK;
+    const unsigned g = (unsigned)(need > (size_t)MINMAX_GRID ? (size_t)MINMAX_GRID : need);
     if (dtype == AST_F32) {
-        if (wide) minmax_kernel<float, 4><<<g, 256, 0, s>>>((const float*)buf, count, keys);
-        else minmax_kernel<float, 1><<<g, 256, 0, s>>>((const float*)buf, count, keys);
+        if (wide) minmax_kernel<float, 4><<<g, MINMAX_BLOCK, 0, s>>>((const float*)buf, count, keys);
+        else minmax_kernel<float, 1><<<g, MINMAX_BLOCK, 0, s>>>((const float*)buf, count, keys);
     } else {
-        if (wide) minmax_kernel<double, 2><<<g, 256, 0, s>>>((const double*)buf, count, keys);
-        else minmax_kernel<double, 1><<<g, 256, 0, s>>>((const double*)buf, count, keys);
+        if (wide) minmax_kernel<double, 2><<<g, MINMAX_BLOCK, 0, s>>>((const double*)buf, count, keys);
+        else minmax_kernel<double, 1><<<g, MINMAX_BLOCK, 0, s>>>((const double*)buf, count, keys);
     }
     minmax_finish<<<1, 1, 0, s>>>(keys);
     AST_CHECK_LAUNCH();
@@ -356,12 +407,9 @@ extern "C" int ast_histogram(const void* buf, int dtype, size_t count, double lo
     AST_CHECK_ARG(nbins > 0 && nbins <= 4096);
     AST_CHECK_ARG(hi > lo);
     if (count == 0) return AST_OK;
-    unsigned g = ast::stream_grid(count, 256);
     auto* c = reinterpret_cast<unsigned long long*>(counts);
-    if (dtype == AST_F32)
-        hist_kernel<float, 4096><<<g, 256, 0, ast::as_stream(stream)>>>((const float*)buf, count, lo, hi, nbins, c);
-    else
-        hist_kernel<double, 4096><<<g, 256, 0, ast::as_stream(stream)>>>((const double*)buf, count, lo, hi, nbins, c);
+    if (dtype == AST_F32) launch_hist((const float*)buf, count, lo, hi, nbins, c, nullptr, ast::as_stream(stream));
+    else launch_hist((const double*)buf, count, lo, hi, nbins, c, nullptr, ast::as_stream(stream));
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
@@ -375,12 +423,9 @@ extern "C" int ast_histogram_auto(const void* buf, int dtype, size_t count, int 
     AST_CHECK_ARG(nbins > 0 && nbins <= 4096);
     const int rc = ast_minmax(buf, dtype, count, range_d, stream);
     if (rc != AST_OK) return rc;
-    unsigned g = ast::stream_grid(count, 256);
     auto* c = reinterpret_cast<unsigned long long*>(counts);
-    if (dtype == AST_F32)
-        hist_kernel<float, 4096><<<g, 256, 0, ast::as_stream(stream)>>>((const float*)buf, count, 0.0, 1.0, nbins, c, range_d);
-    else
-        hist_kernel<double, 4096><<<g, 256, 0, ast::as_stream(stream)>>>((const double*)buf, count, 0.0, 1.0, nbins, c, range_d);
+    if (dtype == AST_F32) launch_hist((const float*)buf, count, 0.0, 1.0, nbins, c, range_d, ast::as_stream(stream));
+    else launch_hist((const double*)buf, count, 0.0, 1.0, nbins, c, range_d, ast::as_stream(stream));
     AST_CHECK_LAUNCH();
     return AST_OK;
 }

@@ -200,6 +200,24 @@ def test_histogram_of_a_constant_map_and_ragged_minmax(lens, dev):
         assert lo == v.min() and hi == v.max()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_histogram_wide_loads_replicas_and_unaligned_views(lens, dev, dtype):
+    """The counting kernel's paths: 16-byte loads with a ragged tail, an unaligned view (scalar loads), 1 .. 32 LDS
+    replicas of the bins (nbins 4096 .. 64), more workgroups than the grid cap - counts equal numpy's, bin for bin."""
+    rng = np.random.default_rng(23)
+    v = (rng.standard_normal(3_000_001) * 0.02).astype(dtype)
+    v[::7] = np.round(v[::7], 2)                              # many values on or near edges
+    t = dev.as_device(v)
+    for view, ref in ((t, v), (t[1:], v[1:]), (t[: 4 * 1024 * 512 + 3], v[: 4 * 1024 * 512 + 3])):
+        for nbins in (64, 100, 2048, 4096):
+            counts, edges = lens.histogram(view, nbins)
+            rc, re = np.histogram(ref.astype(np.float64), bins=nbins)
+            assert np.array_equal(counts, rc), (nbins, ref.size)
+            npt.assert_allclose(edges, re, rtol=1e-15, atol=0)
+        c2, _ = lens.histogram(view, 33, range=(-0.01, 0.015))
+        assert np.array_equal(c2, np.histogram(ref.astype(np.float64), bins=33, range=(-0.01, 0.015))[0])
+
+
 def test_histogram_values_on_bin_edges(lens, dev):
     # values exactly on edges: left-closed bins, right-most bin closed
     img = np.array([0.0, 0.1, 0.2, 0.3, 0.5, 0.7, 1.0, 1.0, 0.9999999999999999, 0.30000000000000004])
