@@ -395,6 +395,12 @@ lens_rows_forward_kernel(const double* __restrict__ kappa, size_t in_pitch, doub
         }
     }
     three_stage<RA, RB, RC>(va, vc, Y, twM, t);
+    // the untangling twiddles of this thread's outputs, in flight across the exchange below
+    constexpr int IT = (M / 2) / G::NT;
+    static_assert(IT * G::NT == M / 2, "row length and thread count");
+    double2 wk[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) wk[it] = twL[t + it * G::NT];
     __syncthreads();                                      // everyone has read its stage-3 inputs: Y becomes Z[k]
     if (t < G::T3) {
 #pragma unroll
@@ -402,20 +408,27 @@ lens_rows_forward_kernel(const double* __restrict__ kappa, size_t in_pitch, doub
     }
     __syncthreads();
     double2* orow = spec + row * pitch;
-    for (int k = t; k <= M / 2; k += G::NT) {
+    auto emit = [&](int k, double2 w) {
         const double2 zk = Y[lds_pad(k)];
-        if (k == 0) {
-            orow[0] = make_double2((zk.x + zk.y) * scale, 0.0);
-            orow[M] = make_double2((zk.x - zk.y) * scale, 0.0);
-            continue;
-        }
         const double2 zm = Y[lds_pad(M - k)];
         const double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));      // (Zk + conj Zm) / 2
         const double2 o = make_double2(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));      // (Zk - conj Zm) / 2
-        const double2 tt = cmul(o, twL[k]);                                             // w^k o, w = e^{-2 pi i / L}
+        const double2 tt = cmul(o, w);                                                  // w^k o, w = e^{-2 pi i / L}
         orow[k] = make_double2((e.x + tt.y) * scale, (e.y - tt.x) * scale);             // e - i t
         orow[M - k] = make_double2((e.x - tt.y) * scale, (-e.y - tt.x) * scale);        // conj(e + i t)
+    };
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int k = t + it * G::NT;
+        if (k == 0) {
+            const double2 zk = Y[lds_pad(0)];
+            orow[0] = make_double2((zk.x + zk.y) * scale, 0.0);
+            orow[M] = make_double2((zk.x - zk.y) * scale, 0.0);
+        } else {
+            emit(k, wk[it]);
+        }
     }
+    if (t == 0) emit(M / 2, twL[M / 2]);
 }
 
 // rows of the product spectrum -> the kept corner: out[row][0 .. nc) = scale * (first nc reals of the length-2nc C2R)
@@ -430,16 +443,30 @@ lens_rows_inverse_kernel(const double2* __restrict__ spec, size_t pitch, int nc,
     const size_t row = blockIdx.x;
     const double2* xrow = spec + row * pitch;
     // Z[k] = (X[k] + conj X[M-k]) / 2 + i w^{-k} (X[k] - conj X[M-k]) / 2, conjugated for the conj-FFT-conj inverse
-    for (int k = t; k <= M / 2; k += G::NT) {
-        const double2 xk = xrow[k], xm = xrow[M - k];
+    auto emit = [&](int k, double2 xk, double2 xm, double2 w) {
         const double2 e = make_double2(0.5 * (xk.x + xm.x), 0.5 * (xk.y - xm.y));
         const double2 d = make_double2(0.5 * (xk.x - xm.x), 0.5 * (xk.y + xm.y));
-        const double2 w = twL[k];
         const double2 tt = make_double2(fma(d.x, w.x, d.y * w.y), fma(d.y, w.x, -d.x * w.y));       // conj(w^k) d
         // Z[k] = e + i t;  Z[M-k] follows from the same formula with k -> M - k:
         //   e' = conj e, d' = -conj d, w^{-(M-k)} = -conj(w^{-k})  ->  t' = conj t,  Z[M-k] = conj(e) + i conj(t)
         if (k < M) Y[lds_pad(k)] = make_double2(e.x - tt.y, -(e.y + tt.x));                         // conj(Z[k])
         if (k != 0 && k != M / 2) Y[lds_pad(M - k)] = make_double2(e.x + tt.y, -(tt.x - e.y));      // conj(Z[M-k]) = e - i t
+    };
+    // the whole row in flight before the first use: (M / 2) / NT pairs per thread, k = M / 2 by thread 0
+    constexpr int IT = (M / 2) / G::NT;
+    static_assert(IT * G::NT == M / 2, "row length and thread count");
+    {
+        double2 xk[IT], xm[IT], wk[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int k = t + it * G::NT;
+            xk[it] = xrow[k];
+            xm[it] = xrow[M - k];
+            wk[it] = twL[k];
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) emit(t + it * G::NT, xk[it], xm[it], wk[it]);
+        if (t == 0) emit(M / 2, xrow[M / 2], xrow[M / 2], twL[M / 2]);
     }
     __syncthreads();
     double2 va[RA], vc[RC];
