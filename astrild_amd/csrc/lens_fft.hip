@@ -182,7 +182,7 @@ col_mid_kernel(const double2* __restrict__ in, const double2* __restrict__ mul0,
     const size_t c0 = (size_t)blockIdx.x * C;
     const int g = blockIdx.y;
     const bool col_ok = c0 + c < (size_t)ncols;
-    // addresses: a uniform row base per point plus ONE 32-bit lane offset (host check: (NP + 1) * pitch < 2^28)
+    // addresses: a uniform row base per point plus ONE 32-bit lane offset (host check: pitch < 2^24)
     const size_t gbase = (size_t)g * NP * pitch;
     const uint32_t voff = (uint32_t)sub * (uint32_t)pitch + min((uint32_t)c0 + (uint32_t)c, (uint32_t)ncols - 1u);
     double2 m[RB];                                        // the kernel spectrum at this thread's points (sub < RA)
@@ -610,6 +610,7 @@ extern "C" int ast_lens_cols_convolve(void* data, size_t len, size_t pitch, size
                                       const void* const* muls, void* const* outs, int nmul, size_t keep_rows, void* stream) {
     AST_CHECK_ARG(data != nullptr && muls != nullptr && outs != nullptr && ncols >= 1 && ncols <= pitch);
     AST_CHECK_ARG(nmul == 1 || nmul == 2);
+    AST_CHECK_ARG(pitch < ((size_t)1 << 24));             // col_mid_kernel: 16 rows of lane offset in 32-bit BYTES
     for (int i = 0; i < nmul; ++i) AST_CHECK_ARG(muls[i] != nullptr && outs[i] != nullptr && outs[i] != data && outs[i] != muls[i]);
     AST_CHECK_ARG(nmul == 1 || outs[0] != outs[1]);
     Split sp;
