@@ -610,15 +610,28 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
 // ------------------------------------------------------------------------------------
 // AST_PAINT_SCATTERED: particles WITHOUT spatial order in memory.  The grouping kernel above degenerates there
 // (every particle is a stray of a tile no neighbour shares: one returning global atomic and one 16-byte scattered
-// store per particle, 74 ms at 1024^3).  Two radix levels instead, every workgroup handling 16384 records so that a
-// bucket receives a run of records (16 at the first level, 32 at the second) for ONE reservation atomic:
+// store per particle, 74 ms at 1024^3).  Two radix levels instead, every workgroup handling 4096 / 8192 records so that a
+// destination receives a run of records (4 at the first level, 16 at the second, at 1024^3) for ONE reservation atomic:
 //   level A   particle -> 16-byte record {x, y, z, m} in its coarse bucket's (SC_BUCKETS buckets of tpb consecutive tiles)
 //             fixed-capacity segment of a staging array (no counting pass, see scatter_level_a_kernel);
 //   level B   bucket by bucket, record -> the stray segment of its tile (the format the column walk reads), slots
 //             reserved per (workgroup, tile) from the tile's fill64 counter.
 // The walk then finds only stray copies (no group records) and reads them contiguously.  A record that does not fit
 // its tile's segment (strongly clustered input) is deposited on the spot with global atomics.
-constexpr int SC_THREADS = 1024, SC_PER_THREAD = 8, SC_CHUNK = SC_THREADS * SC_PER_THREAD;      // 16 per thread spills (128 VGPRs at 1024 threads)
+// Workgroup shape per level (threads, records per thread).  A workgroup's phases - load, rank, reserve, scan, staged store -
+// run one after the other between barriers, so what is idle in one phase can only be used by ANOTHER workgroup of the CU.
+// Level A, 512 x 8: 68 KB of LDS, two workgroups per CU - 8.0 -> 6.8 ms at 1024^3 although its runs are half as long (4
+// records per bucket and workgroup).  Level B keeps 1024 x 8 (one workgroup per CU): with 512 x 8 its runs into the tile
+// segments (16 -> 8 records) cost more than the overlap gains, 8.9 -> 10.7 ms.  Measured and without effect (the loads
+// are not what the phases wait for): prefetching the next chunk's records during the staged store, in either level.
+#ifndef SCA_NT
+#define SCA_NT 512
+#endif
+#ifndef SCB_NT
+#define SCB_NT 1024
+#endif
+constexpr int SC_PER_THREAD = 8;                                 // (16 per thread spills at the 128 VGPRs either shape allows)
+constexpr int SCA_THREADS = SCA_NT, SCB_THREADS = SCB_NT;
 constexpr uint32_t SC_BUCKETS = 1024, SC_TPB_MAX = 2048;        // buckets; most tiles per bucket (LDS counters of level B)
 // Every bucket's range of the staging array is cut into SC_GROUPS sub-ranges, and chunk c writes into sub-range
 // c mod 8.  Blocks b and b + 8 share an XCD (observed placement; nothing here depends on it for correctness: the
@@ -627,11 +640,12 @@ constexpr uint32_t SC_BUCKETS = 1024, SC_TPB_MAX = 2048;        // buckets; most
 // different XCDs' L2s and went to HBM as partial writes: level A's stores ran at 2 TB/s.
 constexpr uint32_t SC_GROUPS = 8;
 
-// records staged per round: 96 KB of LDS either way
-template <typename T> constexpr uint32_t sc_round() { return sizeof(T) == 4 ? 4096u : 2048u; }
+// records staged per round: four (float) or two (double) per thread - 96 KB of LDS per 1024 threads
+template <typename T, int NT> constexpr uint32_t sc_round() { return (sizeof(T) == 4 ? 4u : 2u) * (uint32_t)NT; }
 
-// Exclusive scan of cnt[0 .. table) into lstart[] by the whole workgroup (SC_THREADS threads, table <= 2 * SC_THREADS);
+// Exclusive scan of cnt[0 .. table) into lstart[] by the whole workgroup (NT threads, table <= 2 * NT);
 // returns the total.  wsum: 16 words of LDS.
+template <int NT>
 __device__ inline uint32_t block_exclusive_scan(const uint32_t* cnt, uint32_t* lstart, uint32_t table, uint32_t* wsum) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t i0 = 2u * tid, a = i0 < table ? cnt[i0] : 0u, b = i0 + 1 < table ? cnt[i0 + 1] : 0u;
@@ -641,7 +655,7 @@ __device__ inline uint32_t block_exclusive_scan(const uint32_t* cnt, uint32_t* l
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
     uint32_t woff = 0, total = 0;
-    for (int k = 0; k < SC_THREADS / 64; ++k) { if (k < wave) woff += wsum[k]; total += wsum[k]; }
+    for (int k = 0; k < NT / 64; ++k) { if (k < wave) woff += wsum[k]; total += wsum[k]; }
     const uint32_t ex = woff + inc - (a + b);
     if (i0 < table) lstart[i0] = ex;
     if (i0 + 1 < table) lstart[i0 + 1] = ex + a;
@@ -657,7 +671,7 @@ __device__ inline uint32_t block_exclusive_scan(const uint32_t* cnt, uint32_t* l
 // lstart[]: the entries' first slots in the workgroup's destination order, base[]: their first index in `out`,
 // room[] (or null): how many records of an entry `out` still takes - the rest is not stored (the caller deposits them).
 // SW: words per record - 4 {x, y, z, m}, or 3 {x, y, z} when there are no masses (a quarter less staging traffic).
-template <typename T, int SW>
+template <typename T, int SW, int NT>
 __device__ inline void staged_store(const T (&rx)[SC_PER_THREAD], const T (&ry)[SC_PER_THREAD], const T (&rz)[SC_PER_THREAD],
                                     const T (&rm)[SC_PER_THREAD], const uint32_t (&where)[SC_PER_THREAD],
                                     const uint32_t* lstart, const unsigned long long* base, const uint32_t* room,
@@ -665,7 +679,7 @@ __device__ inline void staged_store(const T (&rx)[SC_PER_THREAD], const T (&ry)[
                                     unsigned long long* sidx /* [SC_ROUND] */) {
     typedef T vec4_t __attribute__((ext_vector_type(4)));
     struct Rec3 { T x, y, z; };
-    constexpr uint32_t ROUND = sc_round<T>();
+    constexpr uint32_t ROUND = sc_round<T, NT>();
     for (uint32_t q0 = 0; q0 < total; q0 += ROUND) {
 #pragma unroll
         for (int u = 0; u < SC_PER_THREAD; ++u) {
@@ -680,7 +694,7 @@ __device__ inline void staged_store(const T (&rx)[SC_PER_THREAD], const T (&ry)[
         }
         __syncthreads();
         const uint32_t here = min(ROUND, total - q0);
-        for (uint32_t i = threadIdx.x; i < here; i += SC_THREADS) {
+        for (uint32_t i = threadIdx.x; i < here; i += NT) {
             const unsigned long long d = sidx[i];
             if (d == ~0ull) continue;
             if (SW == 4) *reinterpret_cast<vec4_t*>(out + 4 * (size_t)d) = reinterpret_cast<const vec4_t*>(stage)[i];
@@ -695,7 +709,7 @@ __device__ inline void staged_store(const T (&rx)[SC_PER_THREAD], const T (&ry)[
 // that does not fit its segment (strongly clustered input) goes to the late list like one that does not fit its tile's
 // stray segment in level B, and is deposited with global atomics; device.paint sees the count and repaints two-pass.
 template <typename T, int W, bool PLAINX, int SW>
-__global__ void __launch_bounds__(SC_THREADS)
+__global__ void __launch_bounds__(SCA_THREADS)
 scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t np, TileGeom g, uint32_t tpb,
                        unsigned long long* __restrict__ cursor, T* __restrict__ staging, uint32_t cap_bg,
                        uint32_t* __restrict__ col_flags, T* __restrict__ late_list, unsigned long long late_cap,
@@ -704,10 +718,11 @@ scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, si
     __shared__ unsigned long long base[SC_BUCKETS];
     extern __shared__ unsigned long long dyn[];          // stage: 4096 records, then their 4096 destinations
     T* stage = reinterpret_cast<T*>(dyn);
-    unsigned long long* sidx = dyn + sc_round<T>() * 4 * sizeof(T) / sizeof(unsigned long long);
+    constexpr int NT = SCA_THREADS, SC_CHUNK = NT * SC_PER_THREAD;
+    unsigned long long* sidx = dyn + sc_round<T, NT>() * 4 * sizeof(T) / sizeof(unsigned long long);
     typedef T vec4_t __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x;
-    cnt[tid] = 0;
+    for (uint32_t b = tid; b < SC_BUCKETS; b += NT) cnt[b] = 0;
     __syncthreads();
     const size_t p0 = (size_t)blockIdx.x * SC_CHUNK;
     T x[SC_PER_THREAD], y[SC_PER_THREAD], z[SC_PER_THREAD], m[SC_PER_THREAD];
@@ -716,7 +731,7 @@ scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, si
     const uint32_t last = (uint32_t)min(np - 1 - p0, (size_t)(SC_CHUNK - 1));
 #pragma unroll
     for (int u = 0; u < SC_PER_THREAD; ++u) {
-        const uint32_t rel = min((uint32_t)(u * SC_THREADS + tid), last);      // unconditional loads
+        const uint32_t rel = min((uint32_t)(u * NT + tid), last);      // unconditional loads
         x[u] = bp[3 * rel];
         y[u] = bp[3 * rel + 1];
         z[u] = bp[3 * rel + 2];
@@ -726,7 +741,7 @@ scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, si
 #pragma unroll
     for (int u = 0; u < SC_PER_THREAD; ++u) {
         where[u] = 0xffffffffu;
-        if ((uint32_t)(u * SC_THREADS + tid) <= last) {
+        if ((uint32_t)(u * NT + tid) <= last) {
             const uint32_t key = tile_of<T, W, PLAINX>(x[u], y[u], z[u], g, col_flags);
             if (key != 0xffffffffu) {
                 const uint32_t b = key / tpb;
@@ -741,14 +756,15 @@ scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, si
     __shared__ int any_full;
     if (tid == 0) any_full = 0;
     __syncthreads();
-    if (cnt[tid]) {
-        const unsigned long long old = atomicAdd(&cursor[grp * SC_BUCKETS + tid], (unsigned long long)cnt[tid]);
+    for (uint32_t b = tid; b < SC_BUCKETS; b += NT) {
+        if (!cnt[b]) continue;
+        const unsigned long long old = atomicAdd(&cursor[grp * SC_BUCKETS + b], (unsigned long long)cnt[b]);
         const uint32_t bs = (uint32_t)min(old, (unsigned long long)cap_bg);
-        base[tid] = ((unsigned long long)tid * SC_GROUPS + grp) * cap_bg + bs;
-        room[tid] = cap_bg - bs;
-        if (cnt[tid] > cap_bg - bs) any_full = 1;
+        base[b] = ((unsigned long long)b * SC_GROUPS + grp) * cap_bg + bs;
+        room[b] = cap_bg - bs;
+        if (cnt[b] > cap_bg - bs) any_full = 1;
     }
-    const uint32_t total = block_exclusive_scan(cnt, lstart, SC_BUCKETS, wsum);          // (barriers inside: any_full is settled)
+    const uint32_t total = block_exclusive_scan<NT>(cnt, lstart, SC_BUCKETS, wsum);          // (barriers inside: any_full is settled)
     const bool full = any_full != 0;                      // uniform; a full segment is rare (strongly clustered input)
     if (full) {
 #pragma unroll
@@ -760,7 +776,7 @@ scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, si
             }
         }
     }
-    staged_store<T, SW>(x, y, z, m, where, lstart, base, full ? room : nullptr, total, staging, stage, sidx);
+    staged_store<T, SW, NT>(x, y, z, m, where, lstart, base, full ? room : nullptr, total, staging, stage, sidx);
     if (dropped && ndrop) atomicAdd(dropped, ndrop);
 }
 
@@ -802,7 +818,7 @@ late_deposit_kernel(const T* __restrict__ late_list, const unsigned long long* _
 }
 
 template <typename T, int W, bool PLAINX, int SW>
-__global__ void __launch_bounds__(SC_THREADS)
+__global__ void __launch_bounds__(SCB_THREADS)
 scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* __restrict__ cursor, uint32_t cap_bg, TileGeom g, uint32_t tpb,
                        unsigned long long* __restrict__ fill64, T* __restrict__ strays, uint32_t scap,
                        T* __restrict__ late_list, unsigned long long late_cap, unsigned long long* __restrict__ late,
@@ -811,7 +827,8 @@ scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* 
     __shared__ unsigned long long base[SC_TPB_MAX];
     extern __shared__ unsigned long long dyn[];
     T* stage = reinterpret_cast<T*>(dyn);
-    unsigned long long* sidx = dyn + sc_round<T>() * 4 * sizeof(T) / sizeof(unsigned long long);
+    constexpr int NT = SCB_THREADS, SC_CHUNK = NT * SC_PER_THREAD;
+    unsigned long long* sidx = dyn + sc_round<T, NT>() * 4 * sizeof(T) / sizeof(unsigned long long);
     const int tid = threadIdx.x;
     const uint32_t bucket = blockIdx.x;
     // the bucket's SC_GROUPS segments of the staging array, gridDim.y / SC_GROUPS workgroups each (blocks with equal
@@ -822,13 +839,13 @@ scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* 
     typedef T vec4_t __attribute__((ext_vector_type(4)));
     struct Rec3 { T x, y, z; };
     for (size_t c0 = b0 + (size_t)sub * SC_CHUNK; c0 < b1; c0 += (size_t)nsub * SC_CHUNK) {
-        for (uint32_t t = tid; t < tpb; t += SC_THREADS) cnt[t] = 0;
+        for (uint32_t t = tid; t < tpb; t += NT) cnt[t] = 0;
         __syncthreads();
         T x[SC_PER_THREAD], y[SC_PER_THREAD], z[SC_PER_THREAD], m[SC_PER_THREAD];
         uint32_t where[SC_PER_THREAD];               // tile in bucket << 16 | rank (< 16384)
 #pragma unroll
         for (int u = 0; u < SC_PER_THREAD; ++u) {
-            const size_t ri = min(c0 + (size_t)u * SC_THREADS + tid, b1 - 1);
+            const size_t ri = min(c0 + (size_t)u * NT + tid, b1 - 1);
             if (SW == 4) {
                 const vec4_t r = reinterpret_cast<const vec4_t*>(staging)[ri];
                 x[u] = r.x; y[u] = r.y; z[u] = r.z; m[u] = r.w;
@@ -840,13 +857,13 @@ scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* 
 #pragma unroll
         for (int u = 0; u < SC_PER_THREAD; ++u) {
             where[u] = 0xffffffffu;
-            if (c0 + (size_t)u * SC_THREADS + tid < b1) {
+            if (c0 + (size_t)u * NT + tid < b1) {
                 const uint32_t lt = tile_of<T, W, PLAINX>(x[u], y[u], z[u], g, nullptr) - bucket * tpb;
                 where[u] = (lt << 16) | atomicAdd(&cnt[lt], 1u);
             }
         }
         __syncthreads();
-        for (uint32_t t = tid; t < tpb; t += SC_THREADS) {
+        for (uint32_t t = tid; t < tpb; t += NT) {
             if (!cnt[t]) continue;
             const uint32_t tile = bucket * tpb + t;
             const uint32_t old = (uint32_t)atomicAdd(&fill64[tile], (unsigned long long)cnt[t]);
@@ -854,7 +871,7 @@ scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* 
             base[t] = (unsigned long long)tile * scap + bs;
             room[t] = scap - bs;
         }
-        const uint32_t total = block_exclusive_scan(cnt, lstart, tpb, wsum);
+        const uint32_t total = block_exclusive_scan<NT>(cnt, lstart, tpb, wsum);
 #pragma unroll
         for (int u = 0; u < SC_PER_THREAD; ++u) {         // a full tile segment (rare): the record goes to the late list
             if (where[u] != 0xffffffffu && (where[u] & 0xffffu) >= room[where[u] >> 16]) {
@@ -863,7 +880,7 @@ scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* 
                 else if (dropped) atomicAdd(dropped, 1ull);            // more than a quarter of all particles: reported, not lost silently
             }
         }
-        staged_store<T, SW>(x, y, z, m, where, lstart, base, room, total, strays, stage, sidx);
+        staged_store<T, SW, NT>(x, y, z, m, where, lstart, base, room, total, strays, stage, sidx);
     }
 }
 
@@ -1785,7 +1802,7 @@ Workspace carve(void* base, size_t np, uint32_t ntiles, uint32_t ncols, int flag
     w.fill64 = (unsigned long long*)take(compact ? (size_t)ntiles * 8 : 0);
     const bool scattered = compact && (flags & AST_PAINT_SCATTERED);
     w.tpb = scattered ? (ntiles + SC_BUCKETS - 1) / SC_BUCKETS : 0;
-    if (w.tpb > SC_TPB_MAX || np < (size_t)SC_CHUNK) w.tpb = 0;      // huge grids / tiny inputs: the grouping kernel does it
+    if (w.tpb > SC_TPB_MAX || np < (size_t)(SCB_THREADS * SC_PER_THREAD)) w.tpb = 0;      // huge grids / tiny inputs: the grouping kernel does it
     w.bcursor = (unsigned long long*)take(w.tpb ? SC_BUCKETS * SC_GROUPS * 8 : 0);      // (inside the part run_tiled zeroes)
     // a (bucket, label) segment holds twice its mean share of the particles
     w.cap_bg = w.tpb ? (uint32_t)((2 * ((np + SC_BUCKETS * SC_GROUPS - 1) / (SC_BUCKETS * SC_GROUPS)) + 1024 + 63) / 64 * 64) : 0;
@@ -1920,27 +1937,28 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
         deposit_pass(w.tile_off, w.tile_count, 0);
     } else if (overwrite && w.tpb) {
         {
-            const unsigned nchunks = (unsigned)((np + SC_CHUNK - 1) / SC_CHUNK);
+            const unsigned nchunks = (unsigned)((np + SCA_THREADS * SC_PER_THREAD - 1) / (SCA_THREADS * SC_PER_THREAD));
             auto run = [&](auto px, auto sw) -> int {
                 constexpr bool PX = decltype(px)::value;
                 constexpr int SW = decltype(sw)::value;
-                const size_t stage_lds = sc_round<T>() * (4 * sizeof(T) + sizeof(unsigned long long));
+                const size_t lds_a = sc_round<T, SCA_THREADS>() * (4 * sizeof(T) + sizeof(unsigned long long));
+                const size_t lds_b = sc_round<T, SCB_THREADS>() * (4 * sizeof(T) + sizeof(unsigned long long));
                 static ast::PerDeviceOnce attr_once;
                 if (attr_once.need()) {
                     AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_level_a_kernel<T, W, PX, SW>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds));
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
                     AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_level_b_kernel<T, W, PX, SW>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds));
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
                     attr_once.mark();
                 }
                 const unsigned long long late_cap = np / 4 * sizeof(uint32_t) / sizeof(T);       // the overflow list's room
                 {
                     AST_PROF("paint_tiled.level_a", s);
-                    scatter_level_a_kernel<T, W, PX, SW><<<nchunks, SC_THREADS, stage_lds, s>>>(
+                    scatter_level_a_kernel<T, W, PX, SW><<<nchunks, SCA_THREADS, lds_a, s>>>(
                         pos, mass, np, g, w.tpb, w.bcursor, (T*)w.staging, w.cap_bg, w.col_flags, (T*)w.ovf, late_cap, w.late, dropped);
                 }
                 AST_PROF("paint_tiled.level_b", s);
-                scatter_level_b_kernel<T, W, PX, SW><<<dim3(SC_BUCKETS, 32), SC_THREADS, stage_lds, s>>>(
+                scatter_level_b_kernel<T, W, PX, SW><<<dim3(SC_BUCKETS, 32), SCB_THREADS, lds_b, s>>>(
                     (const T*)w.staging, w.bcursor, w.cap_bg, g, w.tpb, w.fill64, (T*)w.strays, w.scap, (T*)w.ovf, late_cap, w.late, dropped);
                 return AST_OK;
             };
