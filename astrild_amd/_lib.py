@@ -113,6 +113,7 @@ SIGNATURES = {
     "ast_add_patch": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
     "ast_dgd_filter": (_i, [_vp, _vp, _vp, _i, _d, _d, _i, _i, _vp]),
     "ast_hann_apodize": (_i, [_vp, _vp, _i, _vp]),
+    "ast_zoom_linear": (_i, [_vp, _i, _vp, _i, _vp]),
     "ast_gaussian_filter_order": (_i, [_vp, _vp, _vp, _sz, _i, _d, _i, _i, _i, _vp]),
     "ast_convolve2d": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "ast_aperture_photometry": (_i, [_vp, _vp, _vp, _i, _d, _vp]),

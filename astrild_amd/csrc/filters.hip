@@ -225,6 +225,27 @@ std::vector<double> gaussian_kernel1d(double sigma, int order, int radius) {
     return rev;
 }
 
+// scipy.ndimage.zoom(img, nout / nin, order=1, grid_mode=True) for nout <= nin: output pixel o samples the input at
+// (o + 1/2) nin / nout - 1/2 (pixel centres, NI_ZoomShift with grid_mode) by bilinear interpolation; shrinking never
+// reaches past the border, so no boundary mode is involved (the far neighbour of the last pixel carries weight zero).
+__global__ void __launch_bounds__(256)
+zoom_linear_kernel(const double* __restrict__ in, int nin, double* __restrict__ out, int nout) {
+    const size_t total = (size_t)nout * nout;
+    const double zoom = (double)nin / (double)nout;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int oi = (int)(idx / nout), oj = (int)(idx % nout);
+        const double ci = ((double)oi + 0.5) * zoom - 0.5, cj = ((double)oj + 0.5) * zoom - 0.5;
+        const int i0 = (int)floor(ci), j0 = (int)floor(cj);
+        const double ti = ci - (double)i0, tj = cj - (double)j0;
+        const int i1 = min(i0 + 1, nin - 1), j1 = min(j0 + 1, nin - 1);
+        const double wi[2] = {1.0 - ti, ti}, wj[2] = {1.0 - tj, tj};
+        const double a = in[(size_t)i0 * nin + j0], b = in[(size_t)i0 * nin + j1];
+        const double c = in[(size_t)i1 * nin + j0], d = in[(size_t)i1 * nin + j1];
+        // the order of ni_interpolation.c's loop over the 2 x 2 support: rows outer, columns inner
+        out[idx] = ((a * (wi[0] * wj[0]) + b * (wi[0] * wj[1])) + c * (wi[1] * wj[0])) + d * (wi[1] * wj[1]);
+    }
+}
+
 }  // namespace
 
 // out = img * d^order/d(axis)^order [ G(sigma/2) - G(sigma) + G(2 sigma) ]  (order 3, DGD3)  or
@@ -246,6 +267,17 @@ extern "C" int ast_dgd_filter(const double* img, double* out, double* work, int 
         double* t = a; a = b; b = t;
     }
     multiply_kernel<<<g, 256, 0, s>>>(a, img, out, total);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+// The resampling half of skimage.transform.resize(img, (nout, nout), anti_aliasing=True) as SkyArray.resize uses it
+// (sky_array.py:475-496; the Gaussian prefilter half is ast_gaussian_smooth mode 1 with sigma = (nin / nout - 1) / 2).
+extern "C" int ast_zoom_linear(const double* img, int nin, double* out, int nout, void* stream) {
+    AST_CHECK_ARG(img && out && img != out && nout >= 1 && nout <= nin);
+    hipStream_t s = ast::as_stream(stream);
+    AST_PROF("zoom_linear", s);
+    zoom_linear_kernel<<<ast::stream_grid((size_t)nout * nout, 256), 256, 0, s>>>(img, nin, out, nout);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }

@@ -156,6 +156,31 @@ def smooth_plan(npix):
     return _smooth_plans[key]
 
 
+def resize_antialiased(img, npix):
+    """``skimage.transform.resize(img, (npix, npix), anti_aliasing=True)`` of a square fp64 map for npix <= len(img), the
+    call behind ``SkyArray.resize`` (sky_array.py:475-496).  scikit-image is not in the reference's lock file; this is
+    the algorithm of scikit-image >= 0.19: ``scipy.ndimage.gaussian_filter`` (reflect, truncate 4) with sigma =
+    (len(img) / npix - 1) / 2, then ``scipy.ndimage.zoom(order=1, grid_mode=True)`` - both on the device.  Returns a
+    device tensor; the input is left alone."""
+    npix = int(npix)
+    if torch.is_tensor(img):
+        t = img.to(device="cuda", dtype=torch.float64).contiguous().clone()
+    else:
+        from .device import as_device
+        t = as_device(np.ascontiguousarray(img, dtype=np.float64))
+    if t.dim() != 2 or t.shape[0] != t.shape[1]:
+        raise ValueError("resize_antialiased: a square 2-D map is expected")
+    nin = int(t.shape[0])
+    if not 1 <= npix <= nin:
+        raise NotImplementedError("resize_antialiased lowers the pixel count (sky_array.py:484): 1 <= npix <= len(img)")
+    sigma = max(0.0, (nin / npix - 1.0) / 2.0)
+    if sigma > 0.0:
+        smooth_plan(nin).gaussian(t, sigma, "gaussian")
+    out = torch.empty((npix, npix), dtype=torch.float64, device=t.device)
+    check(_lib.lib().ast_zoom_linear(ptr(t), nin, ptr(out), npix, stream()), "ast_zoom_linear")
+    return out
+
+
 def minmax(t):
     out = torch.empty(2, dtype=torch.float64, device=t.device)
     check(_lib.lib().ast_minmax(ptr(t), real_code(t), t.numel(), ptr(out), stream()), "ast_minmax")

@@ -132,6 +132,20 @@ class SkyArray:
         _kappa = (_kappa[1:] + _kappa[:-1]) / 2
         return pd.DataFrame(data={"kappa": _kappa, "counts": _hist})
 
+    def resize(self, npix, of: Optional[str] = None, img: Optional[np.ndarray] = None, rtn: bool = False,
+               orig_data: str = None) -> Union[np.ndarray, None]:
+        """Lower the nr. of pixels of an image (sky_array.py:475-496: ``skimage.transform.resize(img, (npix, npix),
+        anti_aliasing=True)``), on the device (``lensing.resize_antialiased``).  The reference never reads
+        ``self.data[of]`` (it resizes ``img`` or fails on None, :491); here ``of`` alone selects the stored map."""
+        if img is None and of is not None:
+            assert of in list(self.data.keys()), "Map does not exist."
+            img = self.data[of]
+        img = self._manage_img_data(img, orig_data)
+        img = lensing.resize_antialiased(img, npix).cpu().numpy()
+        if rtn:
+            return img
+        self.data[of] = img
+
     def crop(self, xlimit, ylimit, of: Optional[str] = None, img: Optional[np.ndarray] = None,
              rtn: bool = False, orig_data: str = None) -> Union[np.ndarray, None]:
         """sky_array.py:498-540."""

@@ -559,6 +559,13 @@ int ast_dgd_filter(const double* img_d, double* out_d, double* work_d, int npix,
 /* Filters.apodization (filters.py:150-178): img * outer(hann(npix), hann(npix)). */
 int ast_hann_apodize(const double* img_d, double* out_d, int npix, void* stream);
 
+/* SkyArray.resize (sky_array.py:475-496: skimage.transform.resize(img, (nout, nout), anti_aliasing=True), "lower the
+ * nr. of pixels"), resampling half: scipy.ndimage.zoom(img, nout / nin, order=1, grid_mode=True) - bilinear samples at
+ * (o + 1/2) nin / nout - 1/2 - for nout <= nin, fp64, out of place.  The anti-aliasing half is ast_gaussian_smooth
+ * (mode 1, sigma = (nin / nout - 1) / 2) on the input first.  scikit-image is not pinned by the reference's lock file:
+ * this is the algorithm of scikit-image >= 0.19 (Gaussian prefilter + ndimage.zoom), restated. */
+int ast_zoom_linear(const double* img_d, int nin, double* out_d, int nout, void* stream);
+
 /* scipy.ndimage.gaussian_filter(img, sigma, order=(order0, order1), mode) as called by
  * Filters.gaussian_third_derivative_convolution (filters.py:260-304): mode 0 "reflect", 1 "nearest".
  * work_d: npix^2 + 2 (2 r + 1) doubles, r = int(4 sigma + 0.5). */

@@ -332,6 +332,21 @@ def dgd_filter(img, theta_deg, theta_i_deg, direction, order=3):
     return np.multiply(w, img)
 
 
+def resize_antialiased(img, npix):
+    """SkyArray.resize (sky_array.py:475-496) = skimage.transform.resize(img, (npix, npix), anti_aliasing=True), restated
+    from scikit-image >= 0.19 (transform/_warps.py resize: Gaussian prefilter with sigma = (in / out - 1) / 2 in the
+    boundary mode of the resampling, then scipy.ndimage.zoom with grid_mode=True), with scipy doing what it does there.
+    PARITY UNPINNED: scikit-image is neither importable here nor pinned by the reference's lock file, and no reference
+    test holds a value."""
+    from scipy import ndimage
+    img = np.asarray(img, dtype=np.float64)
+    nin = img.shape[0]
+    sigma = max(0.0, (nin / npix - 1.0) / 2.0)
+    if sigma > 0.0:
+        img = ndimage.gaussian_filter(img, (sigma, sigma), cval=0.0, mode="reflect")
+    return ndimage.zoom(img, (npix / nin, npix / nin), order=1, mode="reflect", cval=0.0, grid_mode=True)
+
+
 def apodization(img):
     """rays/utils/filters.py:150-178 with scipy.signal.hann(n) = 0.5 - 0.5 cos(2 pi k / (n-1))."""
     n = len(img)

@@ -112,3 +112,38 @@ def test_skyarray_filter_dispatches_new_filters(dt_map):
     out = sky.filter({"gaussian_third_derivative": {"theta_i": 0.05, "direction": 1, "abbrev": "dgd3"}},
                      on="orig", rtn=True)
     _close(out, ok.dgd_filter(dt_map, 1.0, 0.05, 1, 3))
+
+
+@pytest.mark.parametrize("nin,npix", [(100, 50), (256, 100), (777, 100), (64, 64), (1024, 128), (333, 332)])
+def test_resize_antialiased_against_scipy_restatement(nin, npix):
+    """SkyArray.resize (sky_array.py:475-496, skimage.transform.resize(.., anti_aliasing=True)): Gaussian prefilter
+    (reflect, truncate 4, sigma = (nin / npix - 1) / 2) + bilinear zoom at pixel centres, on the device, against the
+    oracle's scipy.ndimage restatement - integer and ragged factors, no-op size, a factor so close to one that the
+    prefilter's kernel is a single tap."""
+    from astrild_amd import lensing
+    rng = np.random.default_rng(nin * 1000 + npix)
+    img = rng.standard_normal((nin, nin)) * 0.02 + np.linspace(0.0, 1.0, nin)[None, :]
+    keep = img.copy()
+    want = ok.resize_antialiased(img, npix)
+    got = lensing.resize_antialiased(img, npix).cpu().numpy()
+    assert got.shape == (npix, npix)
+    npt.assert_allclose(got, want, rtol=0, atol=1e-13 * np.abs(want).max())
+    assert np.array_equal(img, keep)                         # the input is left alone
+    t = torch.as_tensor(img, device="cuda")
+    got_t = lensing.resize_antialiased(t, npix).cpu().numpy()
+    assert np.array_equal(got_t, got) and np.array_equal(t.cpu().numpy(), keep)
+    with pytest.raises(NotImplementedError):
+        lensing.resize_antialiased(img, nin + 1)
+
+
+def test_skyarray_resize_of_and_img():
+    from astrild_amd.rays import SkyMap
+    rng = np.random.default_rng(9)
+    m = rng.standard_normal((128, 128))
+    sky = SkyMap.from_array(m.copy(), 128, 10.0, "kappa_2", "/tmp/")
+    want = ok.resize_antialiased(m, 32)
+    r = sky.resize(32, img=m.copy(), rtn=True)
+    npt.assert_allclose(r, want, rtol=0, atol=1e-13 * np.abs(want).max())
+    sky.resize(32, of="orig")                                # stored map, in place of the original
+    assert sky.data["orig"].shape == (32, 32)
+    npt.assert_allclose(sky.data["orig"], want, rtol=0, atol=1e-13 * np.abs(want).max())

@@ -187,3 +187,20 @@ def test_flat_bispectrum_brute_force_counts_triangles():
     # every ordered closed triangle built from +-(m1, m2, m3): 3! orderings x 2 signs, each (n^2/2)^3
     expect = 12 * (n * n / 2.0) ** 3 / ntri[1] * np.deg2rad(theta) ** 4 / float(n) ** 6
     npt.assert_allclose(b[1], expect, rtol=1e-10)
+
+
+def test_resize_antialiased_properties():
+    """The oracle's restatement of SkyArray.resize (parity unpinned: no scikit-image here): a constant map stays
+    constant, the same size is the identity, and a factor-2 reduction without the prefilter is the 2 x 2 block mean -
+    bilinear samples at pixel centres sit in the middle of each block."""
+    from scipy import ndimage
+    c = np.full((64, 64), 0.37)
+    npt.assert_allclose(ok.resize_antialiased(c, 16), 0.37, rtol=1e-14)
+    rng = np.random.default_rng(3)
+    m = rng.standard_normal((64, 64))
+    assert np.array_equal(ok.resize_antialiased(m, 64), m)
+    z = ndimage.zoom(m, (0.5, 0.5), order=1, mode="reflect", grid_mode=True)
+    npt.assert_allclose(z, m.reshape(32, 2, 32, 2).mean(axis=(1, 3)), rtol=0, atol=1e-14)
+    # the prefilter of a factor-2 reduction has sigma = 1/2
+    want = ndimage.zoom(ndimage.gaussian_filter(m, 0.5, mode="reflect"), (0.5, 0.5), order=1, mode="reflect", grid_mode=True)
+    assert np.array_equal(ok.resize_antialiased(m, 32), want)
