@@ -175,17 +175,25 @@ __device__ inline int reflect_idx(int i, int n) {
     if (m < 0) m += period;
     return m < n ? m : period - 1 - m;
 }
+// mode="mirror" (d c b | a b c d | c b a): whole-sample symmetric, the edge pixel is not repeated; period 2n - 2
+__device__ inline int mirror_idx(int i, int n) {
+    if (n == 1) return 0;
+    const int period = 2 * n - 2;
+    int m = i % period;
+    if (m < 0) m += period;
+    return m < n ? m : period - m;
+}
 
 __global__ void __launch_bounds__(256)
 gauss_real_pass_kernel(const double* __restrict__ in, double* __restrict__ out, int npix, int axis,
-                       const double* __restrict__ w, int radius) {
+                       const double* __restrict__ w, int radius, int mirror) {
     const size_t total = (size_t)npix * npix;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
         const int i = (int)(idx / npix), j = (int)(idx % npix);
         const int c = axis == 0 ? i : j;
         auto at = [&](int k) -> double {
-            const int r = reflect_idx(k, npix);
+            const int r = mirror ? mirror_idx(k, npix) : reflect_idx(k, npix);
             return axis == 0 ? in[(size_t)r * npix + j] : in[(size_t)i * npix + r];
         };
         // ni_filters.c NI_Correlate1D symmetric branch: centre tap, then pairs
@@ -611,7 +619,7 @@ extern "C" int ast_smooth_plan_create(ast_smooth_plan** out, int npix) {
 }
 
 extern "C" int ast_gaussian_smooth(ast_smooth_plan* p, double* img, double sigma_px, int mode, void* stream) {
-    AST_CHECK_ARG(p && img && sigma_px > 0.0 && (mode == 0 || mode == 1));
+    AST_CHECK_ARG(p && img && sigma_px > 0.0 && mode >= 0 && mode <= 2);
     hipStream_t s = ast::as_stream(stream);
     const int npix = p->npix;
     if (mode == 0 && sigma_px >= 2.5 && (int)std::ceil(8.5 * sigma_px) <= GP_RMAX && npix >= 2 &&
@@ -663,8 +671,8 @@ extern "C" int ast_gaussian_smooth(ast_smooth_plan* p, double* img, double sigma
     for (auto& v : p->w_h) v /= sum;
     AST_CHECK_HIP(hipMemcpyAsync(p->w_d, p->w_h.data(), p->w_h.size() * sizeof(double), hipMemcpyHostToDevice, s));
     unsigned g = ast::stream_grid((size_t)npix * npix, 256);
-    gauss_real_pass_kernel<<<g, 256, 0, s>>>(img, p->tmp, npix, 0, p->w_d, radius);
-    gauss_real_pass_kernel<<<g, 256, 0, s>>>(p->tmp, img, npix, 1, p->w_d, radius);
+    gauss_real_pass_kernel<<<g, 256, 0, s>>>(img, p->tmp, npix, 0, p->w_d, radius, mode == 2);
+    gauss_real_pass_kernel<<<g, 256, 0, s>>>(p->tmp, img, npix, 1, p->w_d, radius, mode == 2);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }

@@ -783,7 +783,7 @@ scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, si
 // one record deposited with global atomics (a full tile segment): overflow_deposit_kernel's body
 template <typename T, int W>
 __device__ __noinline__ void deposit_record_global(T x, T y, T z, T m, const TileGeom& g, double scale, T* __restrict__ grid,
-                                                   unsigned long long* dropped) {
+                                                   unsigned long long* dropped, int x_lo = 0, int x_hi = 0x7fffffff) {
     constexpr int LO = Window<W>::LO;
     double fx, fy, fz;
     const int bx = ast::locate<W>(grid_coord(x, g), g.n, fx);
@@ -797,7 +797,8 @@ __device__ __noinline__ void deposit_record_global(T x, T y, T z, T m, const Til
     for (int a = 0; a < W; ++a) {
         int px = ast::wrap1(bx - LO + a, g.n) - g.x_start;
         if (px < 0) px += g.n;
-        if (px >= g.nx_alloc) { if (dropped) atomicAdd(dropped, 1ull); continue; }
+        if (px >= g.nx_alloc) { if (dropped && x_hi >= g.nx_alloc) atomicAdd(dropped, 1ull); continue; }
+        if (px < x_lo || px >= x_hi) continue;
         for (int b = 0; b < W; ++b) {
             T* row = grid + ((size_t)px * g.n + ast::wrap1(by - LO + b, g.n)) * g.n;
             for (int c = 0; c < W; ++c) atomicAdd(row + ast::wrap1(bz - LO + c, g.n), mm * wx[a] * wy[b] * wz[c]);
@@ -809,12 +810,12 @@ __device__ __noinline__ void deposit_record_global(T x, T y, T z, T m, const Til
 template <typename T, int W>
 __global__ void __launch_bounds__(256)
 late_deposit_kernel(const T* __restrict__ late_list, const unsigned long long* __restrict__ late, unsigned long long late_cap,
-                    TileGeom g, double scale, T* __restrict__ grid, unsigned long long* dropped) {
+                    TileGeom g, double scale, T* __restrict__ grid, unsigned long long* dropped, int x_lo, int x_hi) {
     const unsigned long long n = min(*late, late_cap);
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * blockDim.x)
         deposit_record_global<T, W>(late_list[4 * i], late_list[4 * i + 1], late_list[4 * i + 2], late_list[4 * i + 3], g, scale,
-                                    grid, dropped);
+                                    grid, dropped, x_lo, x_hi);
 }
 
 template <typename T, int W, bool PLAINX, int SW>
@@ -890,7 +891,9 @@ template <typename T, int W>
 __global__ void __launch_bounds__(256)
 overflow_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, const uint32_t* __restrict__ ovf,
                         const unsigned long long* __restrict__ ovf_count, TileGeom g, double scale,
-                        T* __restrict__ grid, unsigned long long* dropped) {
+                        T* __restrict__ grid, unsigned long long* dropped, int x_lo, int x_hi) {
+    // [x_lo, x_hi): the buffer planes this launch deposits into (the staged paint runs it tile row by tile row; a
+    // deposit outside the buffer is counted by the launch that holds the buffer's last plane)
     constexpr int LO = Window<W>::LO;
     const unsigned long long n = *ovf_count;
     unsigned long long ndrop = 0;
@@ -910,7 +913,8 @@ overflow_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, c
         for (int a = 0; a < W; ++a) {
             int px = ast::wrap1(bx - LO + a, g.n) - g.x_start;
             if (px < 0) px += g.n;
-            if (px >= g.nx_alloc) { ++ndrop; continue; }
+            if (px >= g.nx_alloc) { ndrop += x_hi >= g.nx_alloc; continue; }
+            if (px < x_lo || px >= x_hi) continue;
 #pragma unroll
             for (int b = 0; b < W; ++b) {
                 T* row = grid + ((size_t)px * g.n + ast::wrap1(by - LO + b, g.n)) * g.n;
@@ -1621,14 +1625,14 @@ walk_test_kernel(const T* __restrict__ pos, TileGeom g, const uint32_t* __restri
 // loads/stores along z, sources added in a fixed order.
 template <typename T, int W>
 __global__ void __launch_bounds__(256)
-column_fold_kernel(const T* __restrict__ rec, TileGeom g, T* __restrict__ grid) {
+column_fold_kernel(const T* __restrict__ rec, TileGeom g, T* __restrict__ grid, int col0) {
     constexpr int LO = Window<W>::LO;
     using RM = RingMap<W>;
     constexpr int VW = 16 / (int)sizeof(T);
     typedef T vec_t __attribute__((ext_vector_type(VW)));          // lines are 16-byte aligned (n % 32 == 0)
     __shared__ unsigned long long line_dst[TX * TY], line_src[TX * TY][3];
     __shared__ int nlines;
-    const int col = blockIdx.x;
+    const int col = col0 + (int)blockIdx.x;
     const int ty = col % g.nty, tx = col / g.nty;
     const int ox = tx * TX, oy = ty * TY;
     const bool x_periodic = g.nx_alloc == g.n;
@@ -1698,6 +1702,11 @@ SidePipe* side_pipe(int nevents) {
     }
     return &p;
 }
+
+// ast_paint_tiled_stage: which part of the single-pass overwrite paint a call runs (tile rows [row0, row0 + nrows))
+struct StageSel {
+    int stage = AST_PAINT_STAGE_ALL, row0 = 0, nrows = 0;
+};
 
 // How the single-pass overwrite paint is cut up: z-segments per column (walk workgroups = columns x nseg) and, with
 // AST_PAINT_XSORTED, chunks of `chunk_planes` buffer planes' worth of particles.  A function of the geometry, np and
@@ -1851,7 +1860,8 @@ inline size_t record_bytes(int window, const TileGeom& g, size_t esz, int flags)
 
 template <typename T, int W>
 int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntiles, double scale, T* grid,
-              void* workspace, unsigned long long* dropped, int flags, double mass_bound, double offset, hipStream_t s) {
+              void* workspace, unsigned long long* dropped, int flags, double mass_bound, double offset, hipStream_t s,
+              StageSel sel = StageSel{}) {
     const bool two_pass = (flags & AST_PAINT_TWO_PASS) != 0;
     const bool overwrite = (flags & AST_PAINT_OVERWRITE) != 0;
     const unsigned ncols = (unsigned)(g.ntx * g.nty);
@@ -1860,7 +1870,8 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
                         record_bytes(W == 3 ? AST_WIN_TSC : AST_WIN_CIC, g, sizeof(T), flags),
                         seam_bytes(W == 3 ? AST_WIN_TSC : AST_WIN_CIC, g, np, sizeof(T), flags));
     // ovf_count, col_flags, tile_count, tile_fill and fill64 are contiguous at the front of the workspace
-    AST_CHECK_HIP(hipMemsetAsync(w.ovf_count, 0, (size_t)((char*)w.tile_off - (char*)w.ovf_count), s));
+    if (sel.stage == AST_PAINT_STAGE_ALL || sel.stage == AST_PAINT_STAGE_GROUP)
+        AST_CHECK_HIP(hipMemsetAsync(w.ovf_count, 0, (size_t)((char*)w.tile_off - (char*)w.ovf_count), s));
     const size_t per_interval = (size_t)256 * IDX_UNROLL * AGG_TRIPS;
     const size_t nintervals = (np + per_interval - 1) / per_interval;
     // grid of the index pass: ONE interval per workgroup.  Measured at 1024^3: 8192 workgroups of 32
@@ -1906,7 +1917,7 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
         }
         if (!(flags & AST_PAINT_DEFER_FOLD)) {
             AST_PROF("paint_tiled.fold", s);
-            column_fold_kernel<T, W><<<ncols, 256, 0, s>>>((const T*)w.rec, g, grid);
+            column_fold_kernel<T, W><<<ncols, 256, 0, s>>>((const T*)w.rec, g, grid, 0);
         }
     };
     auto deposit_pass = [&](const uint32_t* tile_off, const uint32_t* tile_count, uint32_t cap) {
@@ -1918,6 +1929,98 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
             tile_deposit_kernel<T, W><<<ntiles, 256, 0, s>>>(pos, mass, g, scale, w.index, tile_off, tile_count, cap, grid, dropped);
         }
     };
+    // AST_PAINT_SCATTERED: the two bucket levels (particles -> staging -> the tiles' stray segments)
+    auto scatter_pass = [&]() -> int {
+    {
+        const unsigned nchunks = (unsigned)((np + SCA_THREADS * SC_PER_THREAD - 1) / (SCA_THREADS * SC_PER_THREAD));
+        auto run = [&](auto px, auto sw) -> int {
+            constexpr bool PX = decltype(px)::value;
+            constexpr int SW = decltype(sw)::value;
+            const size_t lds_a = sc_round<T, SCA_THREADS>() * (4 * sizeof(T) + sizeof(unsigned long long));
+            const size_t lds_b = sc_round<T, SCB_THREADS>() * (4 * sizeof(T) + sizeof(unsigned long long));
+            static ast::PerDeviceOnce attr_once;
+            if (attr_once.need()) {
+                AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_level_a_kernel<T, W, PX, SW>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+                AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_level_b_kernel<T, W, PX, SW>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+                attr_once.mark();
+            }
+            const unsigned long long late_cap = np / 4 * sizeof(uint32_t) / sizeof(T);       // the overflow list's room
+            {
+                AST_PROF("paint_tiled.level_a", s);
+                scatter_level_a_kernel<T, W, PX, SW><<<nchunks, SCA_THREADS, lds_a, s>>>(
+                    pos, mass, np, g, w.tpb, w.bcursor, (T*)w.staging, w.cap_bg, w.col_flags, (T*)w.ovf, late_cap, w.late, dropped);
+            }
+            AST_PROF("paint_tiled.level_b", s);
+            scatter_level_b_kernel<T, W, PX, SW><<<dim3(SC_BUCKETS, 32), SCB_THREADS, lds_b, s>>>(
+                (const T*)w.staging, w.bcursor, w.cap_bg, g, w.tpb, w.fill64, (T*)w.strays, w.scap, (T*)w.ovf, late_cap, w.late, dropped);
+            return AST_OK;
+        };
+        using S3 = std::integral_constant<int, 3>;
+        using S4 = std::integral_constant<int, 4>;
+        const int rc = mass ? (plainx ? run(std::true_type{}, S4{}) : run(std::false_type{}, S4{}))
+                            : (plainx ? run(std::true_type{}, S3{}) : run(std::false_type{}, S3{}));
+        if (rc != AST_OK) return rc;
+    }
+        return AST_OK;
+    };
+    auto group_pass = [&](size_t pb, size_t pe, uint32_t closed_lo, uint32_t closed_n) {
+        AST_PROF("paint_tiled.fill", s);
+        const size_t nint = (pe - pb + per_interval - 1) / per_interval;
+        const unsigned gg = (unsigned)(nint > want ? want : nint);
+        if (plainx)
+            tile_group_kernel<T, W, true><<<gg, 256, 0, s>>>(pos, mass, pb, pe, g, w.fill64, w.recs, w.rcap, (T*)w.strays, w.scap,
+                                                             w.ovf, w.ovf_count, w.col_flags, dropped, closed_lo, closed_n);
+        else
+            tile_group_kernel<T, W, false><<<gg, 256, 0, s>>>(pos, mass, pb, pe, g, w.fill64, w.recs, w.rcap, (T*)w.strays, w.scap,
+                                                              w.ovf, w.ovf_count, w.col_flags, dropped, closed_lo, closed_n);
+    };
+    if (sel.stage != AST_PAINT_STAGE_ALL) {
+        // the single-pass overwrite paint in three parts, so that a caller can interleave tile rows with what consumes
+        // them (the slab pipeline: walk -> fold -> transform -> send, plane range by plane range)
+        if (two_pass || !overwrite || (flags & (AST_PAINT_DEFER_FOLD | AST_PAINT_XSORTED))) {
+            ast::set_error("ast_paint_tiled_stage: needs AST_PAINT_OVERWRITE without TWO_PASS / DEFER_FOLD / XSORTED");
+            return AST_ERR_ARG;
+        }
+        if (sel.stage == AST_PAINT_STAGE_GROUP) {
+            if (w.tpb) { const int rc = scatter_pass(); if (rc != AST_OK) return rc; }
+            else group_pass(0, np, 0u, 0u);
+            AST_CHECK_LAUNCH();
+            return AST_OK;
+        }
+        if (sel.row0 < 0 || sel.nrows < 1 || sel.row0 + sel.nrows > g.ntx) {
+            ast::set_error("ast_paint_tiled_stage: tile rows [%d, %d) outside [0, %d)", sel.row0, sel.row0 + sel.nrows, g.ntx);
+            return AST_ERR_ARG;
+        }
+        const int col0 = sel.row0 * g.nty;
+        const unsigned ncol = (unsigned)(sel.nrows * g.nty);
+        if (sel.stage == AST_PAINT_STAGE_WALK) {
+            walk_pass(nullptr, nullptr, col0, ncol, s);
+            if (plan.nseg > 1) {
+                AST_PROF("paint_tiled.seams", s);
+                z_seam_kernel<T, W><<<ncol, 256, 0, s>>>(w.zrec, g, scale, (uint32_t)std::min<unsigned long long>(5ull * w.cap, 0x3fffffffull),
+                                                          mass ? mass_bound : 1.0, grid, (T*)w.rec, offset, dropped, col0, plan.nseg);
+            }
+        } else if (sel.stage == AST_PAINT_STAGE_FOLD) {
+            {
+                AST_PROF("paint_tiled.fold", s);
+                column_fold_kernel<T, W><<<ncol, 256, 0, s>>>((const T*)w.rec, g, grid, col0);
+            }
+            // the overflow / late list's deposits into these rows' planes (the lists are complete after the GROUP stage)
+            AST_PROF("paint_tiled.overflow", s);
+            const int x_lo = sel.row0 * TX, x_hi = std::min(g.nx_alloc, (sel.row0 + sel.nrows) * TX);
+            if (w.tpb)
+                late_deposit_kernel<T, W><<<128, 256, 0, s>>>((const T*)w.ovf, w.late, np / 4 * sizeof(uint32_t) / sizeof(T), g, scale, grid, dropped, x_lo, x_hi);
+            else
+                overflow_deposit_kernel<T, W><<<128, 256, 0, s>>>(pos, mass, w.ovf, w.ovf_count, g, scale, grid, dropped, x_lo, x_hi);
+        } else {
+            ast::set_error("ast_paint_tiled_stage: unknown stage %d", sel.stage);
+            return AST_ERR_ARG;
+        }
+        AST_CHECK_LAUNCH();
+        return AST_OK;
+    }
     if (two_pass) {
         {
             AST_PROF("paint_tiled.count", s);
@@ -1936,54 +2039,12 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
         }
         deposit_pass(w.tile_off, w.tile_count, 0);
     } else if (overwrite && w.tpb) {
-        {
-            const unsigned nchunks = (unsigned)((np + SCA_THREADS * SC_PER_THREAD - 1) / (SCA_THREADS * SC_PER_THREAD));
-            auto run = [&](auto px, auto sw) -> int {
-                constexpr bool PX = decltype(px)::value;
-                constexpr int SW = decltype(sw)::value;
-                const size_t lds_a = sc_round<T, SCA_THREADS>() * (4 * sizeof(T) + sizeof(unsigned long long));
-                const size_t lds_b = sc_round<T, SCB_THREADS>() * (4 * sizeof(T) + sizeof(unsigned long long));
-                static ast::PerDeviceOnce attr_once;
-                if (attr_once.need()) {
-                    AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_level_a_kernel<T, W, PX, SW>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
-                    AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_level_b_kernel<T, W, PX, SW>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-                    attr_once.mark();
-                }
-                const unsigned long long late_cap = np / 4 * sizeof(uint32_t) / sizeof(T);       // the overflow list's room
-                {
-                    AST_PROF("paint_tiled.level_a", s);
-                    scatter_level_a_kernel<T, W, PX, SW><<<nchunks, SCA_THREADS, lds_a, s>>>(
-                        pos, mass, np, g, w.tpb, w.bcursor, (T*)w.staging, w.cap_bg, w.col_flags, (T*)w.ovf, late_cap, w.late, dropped);
-                }
-                AST_PROF("paint_tiled.level_b", s);
-                scatter_level_b_kernel<T, W, PX, SW><<<dim3(SC_BUCKETS, 32), SCB_THREADS, lds_b, s>>>(
-                    (const T*)w.staging, w.bcursor, w.cap_bg, g, w.tpb, w.fill64, (T*)w.strays, w.scap, (T*)w.ovf, late_cap, w.late, dropped);
-                return AST_OK;
-            };
-            using S3 = std::integral_constant<int, 3>;
-            using S4 = std::integral_constant<int, 4>;
-            const int rc = mass ? (plainx ? run(std::true_type{}, S4{}) : run(std::false_type{}, S4{}))
-                                : (plainx ? run(std::true_type{}, S3{}) : run(std::false_type{}, S3{}));
-            if (rc != AST_OK) return rc;
-        }
+        { const int rc = scatter_pass(); if (rc != AST_OK) return rc; }
         deposit_pass(nullptr, nullptr, 0);
         AST_PROF("paint_tiled.overflow", s);
         late_deposit_kernel<T, W><<<1024, 256, 0, s>>>((const T*)w.ovf, w.late, np / 4 * sizeof(uint32_t) / sizeof(T), g, scale, grid,
-                                                       dropped);
+                                                       dropped, 0, g.nx_alloc);
     } else if (overwrite) {
-        auto group_pass = [&](size_t pb, size_t pe, uint32_t closed_lo, uint32_t closed_n) {
-            AST_PROF("paint_tiled.fill", s);
-            const size_t nint = (pe - pb + per_interval - 1) / per_interval;
-            const unsigned gg = (unsigned)(nint > want ? want : nint);
-            if (plainx)
-                tile_group_kernel<T, W, true><<<gg, 256, 0, s>>>(pos, mass, pb, pe, g, w.fill64, w.recs, w.rcap, (T*)w.strays, w.scap,
-                                                                 w.ovf, w.ovf_count, w.col_flags, dropped, closed_lo, closed_n);
-            else
-                tile_group_kernel<T, W, false><<<gg, 256, 0, s>>>(pos, mass, pb, pe, g, w.fill64, w.recs, w.rcap, (T*)w.strays, w.scap,
-                                                                  w.ovf, w.ovf_count, w.col_flags, dropped, closed_lo, closed_n);
-        };
         // AST_PAINT_XSORTED: the particles come in ascending x (buffer planes).  They are grouped chunk by chunk
         // (plan.chunk_planes planes' worth each); a tile row is walked as soon as the chunks cover its planes plus a
         // margin - while the chunk's positions are still in the Infinity Cache, so the walk's gather does not go to
@@ -2038,7 +2099,7 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
             fold_pass();
         }
         AST_PROF("paint_tiled.overflow", s);
-        overflow_deposit_kernel<T, W><<<1024, 256, 0, s>>>(pos, mass, w.ovf, w.ovf_count, g, scale, grid, dropped);
+        overflow_deposit_kernel<T, W><<<1024, 256, 0, s>>>(pos, mass, w.ovf, w.ovf_count, g, scale, grid, dropped, 0, g.nx_alloc);
     } else {
         {
             AST_PROF("paint_tiled.fill", s);
@@ -2052,7 +2113,7 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
         }
 #endif
         AST_PROF("paint_tiled.overflow", s);
-        overflow_deposit_kernel<T, W><<<1024, 256, 0, s>>>(pos, mass, w.ovf, w.ovf_count, g, scale, grid, dropped);
+        overflow_deposit_kernel<T, W><<<1024, 256, 0, s>>>(pos, mass, w.ovf, w.ovf_count, g, scale, grid, dropped, 0, g.nx_alloc);
     }
     AST_CHECK_LAUNCH();
     return AST_OK;
@@ -2127,11 +2188,11 @@ extern "C" int ast_paint_tiled_list_stats(void* workspace, int window, int dtype
     return AST_OK;
 }
 
-extern "C" int ast_paint_tiled(int window, int dtype, const void* pos, const void* mass, size_t np, int nmesh,
-                               double boxsize, double scale, int x_start, int nx_alloc, void* grid,
-                               void* workspace, size_t workspace_bytes, unsigned long long* dropped,
-                               int flags, double mass_bound, double offset, int offset_start, int offset_count,
-                               double shift_cells, void* stream) {
+static int paint_tiled_impl(int window, int dtype, const void* pos, const void* mass, size_t np, int nmesh,
+                            double boxsize, double scale, int x_start, int nx_alloc, void* grid,
+                            void* workspace, size_t workspace_bytes, unsigned long long* dropped,
+                            int flags, double mass_bound, double offset, int offset_start, int offset_count,
+                            double shift_cells, void* stream, StageSel sel) {
     AST_CHECK_ARG(window == AST_WIN_CIC || window == AST_WIN_TSC);
     AST_CHECK_ARG(dtype == AST_F32 || dtype == AST_F64);
     AST_CHECK_ARG(nmesh > 0 && boxsize > 0.0);
@@ -2139,7 +2200,7 @@ extern "C" int ast_paint_tiled(int window, int dtype, const void* pos, const voi
     AST_CHECK_ARG(grid != nullptr);
     AST_CHECK_ARG(np < 0xffffffffull - 64);
     if (np == 0) {
-        if (flags & AST_PAINT_OVERWRITE)
+        if ((flags & AST_PAINT_OVERWRITE) && (sel.stage == AST_PAINT_STAGE_ALL || sel.stage == AST_PAINT_STAGE_GROUP))
             AST_CHECK_HIP(hipMemsetAsync(grid, 0, (size_t)nx_alloc * nmesh * nmesh * (dtype == AST_F32 ? 4 : 8),
                                          ast::as_stream(stream)));
         return AST_OK;
@@ -2170,10 +2231,40 @@ extern "C" int ast_paint_tiled(int window, int dtype, const void* pos, const voi
     hipStream_t s = ast::as_stream(stream);
     if (dtype == AST_F32) {
         if (window == AST_WIN_CIC)
-            return run_tiled<float, 2>((const float*)pos, (const float*)mass, np, g, ntiles, scale, (float*)grid, workspace, dropped, flags, mass_bound, offset, s);
-        return run_tiled<float, 3>((const float*)pos, (const float*)mass, np, g, ntiles, scale, (float*)grid, workspace, dropped, flags, mass_bound, offset, s);
+            return run_tiled<float, 2>((const float*)pos, (const float*)mass, np, g, ntiles, scale, (float*)grid, workspace, dropped, flags, mass_bound, offset, s, sel);
+        return run_tiled<float, 3>((const float*)pos, (const float*)mass, np, g, ntiles, scale, (float*)grid, workspace, dropped, flags, mass_bound, offset, s, sel);
     }
     if (window == AST_WIN_CIC)
-        return run_tiled<double, 2>((const double*)pos, (const double*)mass, np, g, ntiles, scale, (double*)grid, workspace, dropped, flags, mass_bound, offset, s);
-    return run_tiled<double, 3>((const double*)pos, (const double*)mass, np, g, ntiles, scale, (double*)grid, workspace, dropped, flags, mass_bound, offset, s);
+        return run_tiled<double, 2>((const double*)pos, (const double*)mass, np, g, ntiles, scale, (double*)grid, workspace, dropped, flags, mass_bound, offset, s, sel);
+    return run_tiled<double, 3>((const double*)pos, (const double*)mass, np, g, ntiles, scale, (double*)grid, workspace, dropped, flags, mass_bound, offset, s, sel);
 }
+
+extern "C" int ast_paint_tiled(int window, int dtype, const void* pos, const void* mass, size_t np, int nmesh,
+                               double boxsize, double scale, int x_start, int nx_alloc, void* grid,
+                               void* workspace, size_t workspace_bytes, unsigned long long* dropped,
+                               int flags, double mass_bound, double offset, int offset_start, int offset_count,
+                               double shift_cells, void* stream) {
+    return paint_tiled_impl(window, dtype, pos, mass, np, nmesh, boxsize, scale, x_start, nx_alloc, grid, workspace,
+                            workspace_bytes, dropped, flags, mass_bound, offset, offset_start, offset_count, shift_cells,
+                            stream, StageSel{});
+}
+
+// One part of the single-pass overwrite paint (see include/astrild_hip.h): GROUP once, then WALK and FOLD per range of
+// tile rows, every call with the SAME arguments as the others.
+extern "C" int ast_paint_tiled_stage(int window, int dtype, const void* pos, const void* mass, size_t np, int nmesh,
+                                     double boxsize, double scale, int x_start, int nx_alloc, void* grid,
+                                     void* workspace, size_t workspace_bytes, unsigned long long* dropped,
+                                     int flags, double mass_bound, double offset, int offset_start, int offset_count,
+                                     double shift_cells, int stage, int row0, int nrows, void* stream) {
+    AST_CHECK_ARG(stage == AST_PAINT_STAGE_GROUP || stage == AST_PAINT_STAGE_WALK || stage == AST_PAINT_STAGE_FOLD);
+    StageSel sel;
+    sel.stage = stage;
+    sel.row0 = row0;
+    sel.nrows = nrows;
+    return paint_tiled_impl(window, dtype, pos, mass, np, nmesh, boxsize, scale, x_start, nx_alloc, grid, workspace,
+                            workspace_bytes, dropped, flags, mass_bound, offset, offset_start, offset_count, shift_cells,
+                            stream, sel);
+}
+
+extern "C" int ast_paint_tile_rows(int nx_alloc) { return (nx_alloc + TX - 1) / TX; }
+extern "C" int ast_paint_tile_row_planes(void) { return TX; }

@@ -130,9 +130,10 @@ class SmoothPlan(_Plan):
 
     def gaussian(self, img, sigma_px, kind="gaussianFFT"):
         """In place.  kind: "gaussianFFT" (periodic) or "gaussian" (real space,
-        reflect, truncate 4) — lenstools ConvergenceMap.smooth's two branches."""
+        reflect, truncate 4) — lenstools ConvergenceMap.smooth's two branches; "gaussian_mirror": the real-space
+        kernel with scipy's "mirror" boundary (the prefilter of skimage.transform.resize)."""
         assert img.is_cuda and img.dtype == torch.float64 and img.numel() == self.npix ** 2 and img.is_contiguous()
-        mode = {"gaussianFFT": 0, "gaussian": 1}[kind]
+        mode = {"gaussianFFT": 0, "gaussian": 1, "gaussian_mirror": 2}[kind]
         check(_lib.lib().ast_gaussian_smooth(self.handle, ptr(img), float(sigma_px), mode, stream()),
               "ast_gaussian_smooth")
         return img
@@ -159,9 +160,12 @@ def smooth_plan(npix):
 def resize_antialiased(img, npix):
     """``skimage.transform.resize(img, (npix, npix), anti_aliasing=True)`` of a square fp64 map for npix <= len(img), the
     call behind ``SkyArray.resize`` (sky_array.py:475-496).  scikit-image is not in the reference's lock file; this is
-    the algorithm of scikit-image >= 0.19: ``scipy.ndimage.gaussian_filter`` (reflect, truncate 4) with sigma =
-    (len(img) / npix - 1) / 2, then ``scipy.ndimage.zoom(order=1, grid_mode=True)`` - both on the device.  Returns a
-    device tensor; the input is left alone."""
+    the algorithm of scikit-image >= 0.19: ``scipy.ndimage.gaussian_filter`` (truncate 4) with sigma =
+    (len(img) / npix - 1) / 2, then ``scipy.ndimage.zoom(order=1, grid_mode=True)`` - both on the device, both in
+    ndimage's "mirror" boundary: resize's default ``mode="reflect"`` is numpy.pad's naming, which skimage's
+    ``_to_ndimage_mode`` translates to ndimage "mirror" (edge pixel not repeated).  For npix <= len(img) the zoom's
+    sample points stay inside the map, so only the prefilter sees the boundary.  Returns a device tensor; the input
+    is left alone."""
     npix = int(npix)
     if torch.is_tensor(img):
         t = img.to(device="cuda", dtype=torch.float64).contiguous().clone()
@@ -175,7 +179,7 @@ def resize_antialiased(img, npix):
         raise NotImplementedError("resize_antialiased lowers the pixel count (sky_array.py:484): 1 <= npix <= len(img)")
     sigma = max(0.0, (nin / npix - 1.0) / 2.0)
     if sigma > 0.0:
-        smooth_plan(nin).gaussian(t, sigma, "gaussian")
+        smooth_plan(nin).gaussian(t, sigma, "gaussian_mirror")
     out = torch.empty((npix, npix), dtype=torch.float64, device=t.device)
     check(_lib.lib().ast_zoom_linear(ptr(t), nin, ptr(out), npix, stream()), "ast_zoom_linear")
     return out

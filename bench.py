@@ -56,7 +56,7 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(sample, window, boxsize):
+def cpu_baseline(sample, window, boxsize, dev=None):
     """The oracle (numpy port of the reference's CPU path: pmesh-convention paint,
     rfftn, FFTPower binning; float64 like the reference) on a bounded sample of the
     workload: sample^3 particles on a sample^3 grid.  `value` is the single-thread figure
@@ -70,8 +70,25 @@ def cpu_baseline(sample, window, boxsize):
     t0 = time.perf_counter()
     grid = omesh.paint(pos, None, sample, boxsize, window)
     t1 = time.perf_counter()
-    offt.fftpower_1d(grid, boxsize)
+    ref = offt.fftpower_1d(grid, boxsize)
     t2 = time.perf_counter()
+    check = None
+    if dev is not None:
+        # the spectrum the CPU leg has just computed is the checker for the device on the SAME sample: float64 (the
+        # reference's dtype) and the fp32 pipeline that `value` times (north_star: 1e-6)
+        d64 = dev.paint_power_1d(dev.as_device(pos), None, sample, boxsize, window)
+        p32 = dev.as_device(pos.astype(np.float32))
+        d32 = dev.paint_power_1d(p32, None, sample, boxsize, window)
+        d64b = dev.paint_power_1d(p32.double(), None, sample, boxsize, window)
+        check = {"modes_equal": bool(np.array_equal(d64["modes"], ref["modes"]) and np.array_equal(d32["modes"], ref["modes"])),
+                 "cpu_check_max_rel": float(np.max(np.abs(d64["power"] / ref["power"].real - 1.0))),
+                 "fp32_pipeline_max_rel": float(np.max(np.abs(d32["power"] / d64b["power"] - 1.0))),
+                 "note": "cpu_check_max_rel: device float64 P(k) / the oracle's P(k) - 1 over all shells, same particles (the "
+                         "spectrum this CPU leg computed anyway); fp32_pipeline_max_rel: the fp32 pipeline that `value` times "
+                         "against that float64 device path on the same fp32-rounded positions (north_star: 1e-6)"}
+        del p32
+        torch.cuda.empty_cache()
+    t2b = time.perf_counter()
     spec = scipy.fft.rfftn(grid, workers=ncpu) / grid.size
     t3 = time.perf_counter()
     p3d = (spec * np.conj(spec)).real * boxsize ** 3
@@ -84,14 +101,14 @@ def cpu_baseline(sample, window, boxsize):
         "sample": f"{sample}^3 particles on a {sample}^3 grid, float64, numpy bincount paint {t1 - t0:.2f}s + "
                   f"numpy rfftn/shell binning {t2 - t1:.2f}s (1024^3 is not run: the numpy port's temporaries "
                   f"need > 100 GB of host RAM)",
-        "threaded": {"value": n / ((t1 - t0) + (t4 - t2)), "cores": ncpu,
-                     "fft_s": round(t3 - t2, 3), "binning_s": round(t4 - t3, 3), "paint_s_single_thread": round(t1 - t0, 3),
+        "threaded": {"value": n / ((t1 - t0) + (t4 - t2b)), "cores": ncpu,
+                     "fft_s": round(t3 - t2b, 3), "binning_s": round(t4 - t3, 3), "paint_s_single_thread": round(t1 - t0, 3),
                      "note": f"scipy.fft.rfftn(workers={ncpu}) + numpy shell binning; paint as in the single-thread leg"},
-        "cpu_model": _cpu_model(), "logical_cores": ncpu,
+        "cpu_model": _cpu_model(), "logical_cores": ncpu, "check": check,
         # the same port on the benchmark's own configuration, by particle count (its paint, binning and FFT are all
         # O(N) or O(N log N) in the 8x larger problem): a projection, not a measurement
         "projected_1024_cubed": {"seconds_single_thread": round(1024 ** 3 / (n / (t2 - t0)), 1),
-                                 "seconds_threaded_fft": round(1024 ** 3 / (n / ((t1 - t0) + (t4 - t2))), 1),
+                                 "seconds_threaded_fft": round(1024 ** 3 / (n / ((t1 - t0) + (t4 - t2b))), 1),
                                  "note": "particles of the 1024^3 workload / the sample's particles per second"},
     }
 
@@ -279,7 +296,7 @@ def main():
                                            "stages": {k: {"ms": v["ms"], "frac": v["frac"]} for k, v in lg["roofline"]["stages"].items()}}
             out["legs"] = legs
         if args.cpu_sample:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.window, L)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.window, L, dev)
         torch.cuda.empty_cache()
         if args.bispec:
             out["bispectrum"] = bispectrum_leg(dev)

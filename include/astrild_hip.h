@@ -166,6 +166,32 @@ int ast_paint_tiled(int window, int dtype, const void* pos_d, const void* mass_d
                     void* grid_d, void* workspace_d, size_t workspace_bytes,
                     unsigned long long* dropped_d, int flags, double mass_bound, double offset,
                     int offset_start, int offset_count, double shift_cells, void* stream);
+/* The single-pass AST_PAINT_OVERWRITE paint in parts (no TWO_PASS / DEFER_FOLD / XSORTED), for callers that consume the
+ * grid plane range by plane range while the rest is still being painted - the slab pipeline (the
+ * reference paints on one rank, stats_subfind.py:130-131): every call takes the arguments of ast_paint_tiled, all of
+ * them identical from call to call, plus
+ *   AST_PAINT_STAGE_GROUP          once: the particle lists of every tile (and the scatter levels of AST_PAINT_SCATTERED);
+ *   AST_PAINT_STAGE_WALK  row0 n   the column walk (and z seams) of tile rows [row0, row0 + n): their owned cells are
+ *                                  stored, their x / y halo goes to the rows' records;
+ *   AST_PAINT_STAGE_FOLD  row0 n   adds the neighbours' records (and the overflow list's deposits) into these rows'
+ *                                  planes: needs the WALK of rows row0 - 1 .. row0 + n (CIC: row0 - 1 .. row0 + n - 1)
+ *                                  that exist in the buffer, and completes buffer planes [row0 * P, (row0 + n) * P),
+ *                                  P = ast_paint_tile_row_planes().
+ * A tile row is P consecutive buffer planes, row 0 starting at buffer plane 0; ast_paint_tile_rows(nx_alloc) rows.
+ * After GROUP, WALK of every row and FOLD of every row the grid equals ast_paint_tiled's, bit for bit.  Calls may go to
+ * different streams; ordering them as above is the caller's business. */
+#define AST_PAINT_STAGE_ALL (-1)
+#define AST_PAINT_STAGE_GROUP 0
+#define AST_PAINT_STAGE_WALK 1
+#define AST_PAINT_STAGE_FOLD 2
+int ast_paint_tiled_stage(int window, int dtype, const void* pos_d, const void* mass_d, size_t np,
+                          int nmesh, double boxsize, double scale, int x_start, int nx_alloc,
+                          void* grid_d, void* workspace_d, size_t workspace_bytes,
+                          unsigned long long* dropped_d, int flags, double mass_bound, double offset,
+                          int offset_start, int offset_count, double shift_cells, int stage, int row0, int nrows,
+                          void* stream);
+int ast_paint_tile_rows(int nx_alloc);
+int ast_paint_tile_row_planes(void);
 /* Where a paint with AST_PAINT_OVERWRITE | AST_PAINT_DEFER_FOLD and these parameters left its halo
  * records inside workspace_d (for ast_fft_tile_power_3d_halo). */
 int ast_paint_tiled_halo(void* workspace_d, int window, int dtype, size_t np, int nmesh, int nx_alloc, int flags,
@@ -473,6 +499,10 @@ typedef struct ast_smooth_plan ast_smooth_plan;
  *          l from (r)fftfreq(npix) — periodic.
  *   mode 1 "gaussian": separable real-space kernel, reflect boundary,
  *          truncate 4 sigma (scipy.ndimage.gaussian_filter).
+ *   mode 2: as mode 1 with scipy's "mirror" boundary (d c b | a b c d | c b a, the edge
+ *          pixel not repeated) - what skimage.transform.resize(mode="reflect", numpy's
+ *          naming) hands to ndimage for its anti-aliasing prefilter (SkyArray.resize,
+ *          rays/skys/sky_array.py:475-496).
  * In place on img_d. */
 int ast_smooth_plan_create(ast_smooth_plan** plan, int npix);
 int ast_smooth_plan_destroy(ast_smooth_plan* plan);

@@ -336,6 +336,7 @@ def resize_antialiased(img, npix):
     """SkyArray.resize (sky_array.py:475-496) = skimage.transform.resize(img, (npix, npix), anti_aliasing=True), restated
     from scikit-image >= 0.19 (transform/_warps.py resize: Gaussian prefilter with sigma = (in / out - 1) / 2 in the
     boundary mode of the resampling, then scipy.ndimage.zoom with grid_mode=True), with scipy doing what it does there.
+    resize's default mode="reflect" is numpy.pad's name; _to_ndimage_mode maps it to ndimage's "mirror".
     PARITY UNPINNED: scikit-image is neither importable here nor pinned by the reference's lock file, and no reference
     test holds a value."""
     from scipy import ndimage
@@ -343,8 +344,8 @@ def resize_antialiased(img, npix):
     nin = img.shape[0]
     sigma = max(0.0, (nin / npix - 1.0) / 2.0)
     if sigma > 0.0:
-        img = ndimage.gaussian_filter(img, (sigma, sigma), cval=0.0, mode="reflect")
-    return ndimage.zoom(img, (npix / nin, npix / nin), order=1, mode="reflect", cval=0.0, grid_mode=True)
+        img = ndimage.gaussian_filter(img, (sigma, sigma), cval=0.0, mode="mirror")
+    return ndimage.zoom(img, (npix / nin, npix / nin), order=1, mode="mirror", cval=0.0, grid_mode=True)
 
 
 def apodization(img):

@@ -136,6 +136,18 @@ def test_resize_antialiased_against_scipy_restatement(nin, npix):
         lensing.resize_antialiased(img, nin + 1)
 
 
+def test_resize_border_pixels_against_hand_computed_mirror_padding():
+    """the device prefilter uses ndimage's "mirror" boundary (what skimage.transform.resize's default
+    mode="reflect" means); checked against a convolution written out over numpy.pad(mode="reflect")."""
+    from astrild_amd import lensing
+    from tests.test_oracle_kappa import mirror_resize_by_hand
+    rng = np.random.default_rng(12)
+    for nin, npix in ((96, 24), (100, 40), (64, 7)):
+        m = rng.standard_normal((nin, nin)) + np.linspace(0, 3, nin)[:, None]
+        got = lensing.resize_antialiased(m, npix).cpu().numpy()
+        npt.assert_allclose(got, mirror_resize_by_hand(m, npix), rtol=0, atol=1e-13 * np.abs(m).max())
+
+
 def test_skyarray_resize_of_and_img():
     from astrild_amd.rays import SkyMap
     rng = np.random.default_rng(9)

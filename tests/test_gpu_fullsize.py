@@ -166,8 +166,10 @@ def test_config_e_bispectrum_512(dev):
     dev.clear_plan_cache()
 
 
-def test_bench_path_at_1024_against_the_float64_pipeline(dev):
-    """What bench.py times, at the size it times it: fp32 paint(defer_fold, offset=mean, x-sorted pipeline) +
+@pytest.mark.parametrize("hint", [None, "xsorted"])
+def test_bench_path_at_1024_against_the_float64_pipeline(dev, hint):
+    """What bench.py times, at the size it times it (hint=None is bench.py's own call for natural order: two big
+    launches, tflags 6; "xsorted" the chunked pipeline): fp32 paint(defer_fold, offset=mean) +
     power_sums_fused(halo=) (rows_r2c with the halo fold and the low-k z sums, the x pass fused with the shell
     binning) against the float64 pipeline on the SAME fp32 positions: mode counts equal, every shell within 1e-6
     (north_star), and the shell sums of the fused path equal to those of its own folded grid transformed separately."""
@@ -175,7 +177,7 @@ def test_bench_path_at_1024_against_the_float64_pipeline(dev):
     pos = dev.synth_lattice_particles(n, n, L, seed=20240601, dtype=torch.float32)
     mean = pos.shape[0] / float(n) ** 3
     grid, halo = dev.paint(pos, None, n, L, "cic", method="tiled", accumulate=False, defer_fold=True, offset=mean,
-                           hint="xsorted", check_dropped=False)
+                           hint=hint, check_dropped=False)
     r32 = dev.finish_power(*dev.power_sums_fused(grid, L, halo=halo))
     del grid, halo
     r64 = dev.paint_power_1d(pos.double(), None, n, L, "cic")
@@ -215,3 +217,28 @@ def test_shuffled_tsc_at_512_against_the_float64_pipeline(dev):
     r64 = dev.paint_power_1d(pos.double(), None, n, L, "tsc")
     assert np.array_equal(r32["modes"], r64["modes"])
     np.testing.assert_allclose(r32["power"], r64["power"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("window,shuffle", [("cic", False), ("tsc", True)])
+def test_config_b_512_against_the_oracle(dev, window, shuffle):
+    """BASELINE.json configs[1] at its stated size against the ORACLE itself (not another HIP pipeline): 512^3
+    device-generated fp32 positions -> host -> oracle paint + fftpower_1d in float64 (power_spectrum_3d.py:183-224,
+    stats_subfind.py:130-150), against paint_power_1d on the same positions in float64 (modes equal, k 1e-12, every
+    shell 1e-9) and in fp32 (the fused path bench.py times; every shell 1e-6, north_star).  The second case is the
+    unordered TSC input that stats_subfind.py:125-131 feeds the paint (scattered path)."""
+    from oracle import mesh as omesh, fftpower as offt
+    n, L = 512, 1000.0
+    pos = dev.synth_lattice_particles(n, n, L, seed=20240601, dtype=torch.float32, shuffle=shuffle)
+    host = pos.cpu().numpy()
+    ref = offt.fftpower_1d(omesh.paint(host, None, n, L, window), L)
+    del host
+    r64 = dev.paint_power_1d(pos.double(), None, n, L, window)
+    np.testing.assert_array_equal(r64["modes"], ref["modes"])
+    np.testing.assert_allclose(r64["k"], ref["k"], rtol=1e-12)
+    np.testing.assert_allclose(r64["power"], ref["power"].real, rtol=1e-9)
+    mean = pos.shape[0] / float(n) ** 3
+    grid, halo = dev.paint(pos, None, n, L, window, method="tiled", accumulate=False, defer_fold=True, offset=mean,
+                           hint="scattered" if shuffle else None, check_dropped=False)
+    r32 = dev.finish_power(*dev.power_sums_fused(grid, L, halo=halo))
+    np.testing.assert_array_equal(r32["modes"], ref["modes"])
+    np.testing.assert_allclose(r32["power"], ref["power"].real, rtol=1e-6)

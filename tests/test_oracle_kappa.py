@@ -202,5 +202,36 @@ def test_resize_antialiased_properties():
     z = ndimage.zoom(m, (0.5, 0.5), order=1, mode="reflect", grid_mode=True)
     npt.assert_allclose(z, m.reshape(32, 2, 32, 2).mean(axis=(1, 3)), rtol=0, atol=1e-14)
     # the prefilter of a factor-2 reduction has sigma = 1/2
-    want = ndimage.zoom(ndimage.gaussian_filter(m, 0.5, mode="reflect"), (0.5, 0.5), order=1, mode="reflect", grid_mode=True)
+    want = ndimage.zoom(ndimage.gaussian_filter(m, 0.5, mode="mirror"), (0.5, 0.5), order=1, mode="mirror", grid_mode=True)
     assert np.array_equal(ok.resize_antialiased(m, 32), want)
+
+
+def mirror_resize_by_hand(img, npix):
+    """skimage.transform.resize(img, (npix, npix), anti_aliasing=True) written out without ndimage: numpy.pad's
+    "reflect" (= ndimage "mirror": d c b | a b c d | c b a) around the map, the truncated, normalised Gaussian of
+    sigma = (nin / npix - 1) / 2 as explicit tap sums, then bilinear samples at (o + 1/2) nin / npix - 1/2."""
+    nin = img.shape[0]
+    sigma = (nin / npix - 1.0) / 2.0
+    r = int(4.0 * sigma + 0.5)
+    w = np.exp(-0.5 * (np.arange(-r, r + 1) / sigma) ** 2)
+    w /= w.sum()
+    pad = np.pad(img, r, mode="reflect")
+    rows = sum(w[k] * pad[k:k + nin, :] for k in range(2 * r + 1))
+    sm = sum(w[k] * rows[:, k:k + nin] for k in range(2 * r + 1))
+    c = (np.arange(npix) + 0.5) * nin / npix - 0.5
+    i0 = np.clip(np.floor(c).astype(int), 0, nin - 2)
+    f = c - i0
+    a = sm[i0] * (1 - f)[:, None] + sm[i0 + 1] * f[:, None]
+    return a[:, i0] * (1 - f)[None, :] + a[:, i0 + 1] * f[None, :]
+
+
+def test_resize_antialiased_border_is_mirror_not_reflect():
+    """resize's default mode="reflect" is numpy.pad's naming -> ndimage "mirror".  Border pixels of the
+    oracle equal a hand-computed mirror-padded convolution and differ from ndimage's "reflect" (edge repeated)."""
+    from scipy import ndimage
+    rng = np.random.default_rng(12)
+    m = rng.standard_normal((96, 96)) + np.linspace(0, 3, 96)[:, None]
+    got = ok.resize_antialiased(m, 24)
+    npt.assert_allclose(got, mirror_resize_by_hand(m, 24), rtol=0, atol=1e-13)
+    wrong = ndimage.zoom(ndimage.gaussian_filter(m, 1.5, mode="reflect"), (0.25, 0.25), order=1, mode="reflect", grid_mode=True)
+    assert np.abs(got - wrong)[0].max() > 1e-3 and np.abs(got - wrong)[8:16, 8:16].max() < 1e-12
