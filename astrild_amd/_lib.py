@@ -38,6 +38,9 @@ SIGNATURES = {
     "ast_paint": (_i, [_i, _i, _vp, _vp, _sz, _i, _d, _d, _i, _i, _vp, _vp, _d, _vp]),
     "ast_paint_tiled_workspace_bytes": (_sz, [_i, _i, _sz, _i, _i, _i]),
     "ast_paint_tiled": (_i, [_i, _i, _vp, _vp, _sz, _i, _d, _d, _i, _i, _vp, _vp, _sz, _vp, _i, _d, _d, _i, _i, _d, _vp]),
+    "ast_paint_tiled_stage": (_i, [_i, _i, _vp, _vp, _sz, _i, _d, _d, _i, _i, _vp, _vp, _sz, _vp, _i, _d, _d, _i, _i, _d, _i, _i, _i, _vp]),
+    "ast_paint_tile_rows": (_i, [_i]),
+    "ast_paint_tile_row_planes": (_i, []),
     "ast_paint_tiled_list_stats": (_i, [_vp, _i, _i, _sz, _i, _i, _i, _vp, _vp]),
     "ast_route_count": (_i, [_vp, _i, _sz, _i, _d, _i, _i, _vp, _vp]),
     "ast_route_scatter": (_i, [_vp, _vp, _i, _sz, _i, _d, _i, _i, _vp, _vp, _vp, _vp]),
@@ -51,7 +54,7 @@ SIGNATURES = {
     "ast_fft_plan_destroy": (_i, [_vp]),
     "ast_fft_tile_supported": (_i, [_i, _sz]),
     "ast_fft_tile_c2c": (_i, [_vp, _i, _sz, _sz, _sz, _sz, _sz, _d, _vp]),
-    "ast_fft_tile_c2c_packed": (_i, [_vp, _vp, _i, _sz, _sz, _sz, _i, _i, _vp, _d, _vp]),
+    "ast_fft_tile_c2c_packed": (_i, [_vp, _vp, _i, _sz, _sz, _sz, _sz, _i, _i, _vp, _d, _vp]),
     "ast_fft_tile_rows_r2c": (_i, [_vp, _vp, _i, _sz, _sz, _sz, _sz, _d, _vp]),
     "ast_fft_tile_r2c_3d": (_i, [_vp, _vp, _i, _sz, _d, _vp]),
     "ast_fft_tile_c2r_3d": (_i, [_vp, _vp, _vp, _i, _sz, _i, _i, _d, _vp]),
@@ -64,6 +67,8 @@ SIGNATURES = {
     "ast_lowk_work_bytes": (_sz, [_sz, _sz]),
     "ast_lowk_mode_count": (_i, []),
     "ast_lowk_shell_count": (_i, []),
+    "ast_fft_tile_rows_r2c_lowz": (_i, [_vp, _vp, _i, _sz, _sz, _sz, _sz, _d, _vp, _vp]),
+    "ast_lowk_modes_from_z": (_i, [_sz, _sz, _sz, _i, _vp, _vp, _sz, _vp]),
     "ast_lowk_modes": (_i, [_vp, _i, _sz, _sz, _sz, _i, _vp, _vp, _sz, _vp]),
     "ast_lowk_shell_sums": (_i, [_vp, _sz, _d, _i, _vp, _vp]),
     "ast_paint_tiled_halo": (_i, [_vp, _i, _i, _sz, _i, _i, _i, ct.POINTER(ct.c_void_p)]),

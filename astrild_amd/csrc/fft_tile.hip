@@ -135,9 +135,9 @@ __global__ void tile_isqrt_table_kernel(int* out, int count) {
 struct ShellMask { const float2* src; long long lo2, hi2; int ky0 = 0; int pass = 0; };     // ky0 (POWER): global k_y index of batch 0 (slab blocks)
 
 // PACK: the stores go to `pack.out` in the layout the slab transpose sends (what ast_slab_pack makes of the array): row
-// k_y of batch (plane) b lands in part k_y / c1 at ((part * nbatch + b) * c1 + k_y % c1) * ncols + column.
-// Part `self_part` (the rank's own piece, which never travels) goes to self_out instead, as (nbatch, c1, ncols).
-struct PackDst { float2* out = nullptr; unsigned c1_log2 = 0; unsigned nbatch = 0; float2* self_out = nullptr; unsigned self_part = ~0u; };
+// k_y of batch (plane) b lands in part k_y / c1 at ((part * nbatch + b) * c1 + k_y % c1) * pitch + column.
+// Part `self_part` (the rank's own piece, which never travels) goes to self_out instead, as (nbatch, c1, pitch).
+struct PackDst { float2* out = nullptr; unsigned c1_log2 = 0; unsigned nbatch = 0; float2* self_out = nullptr; unsigned self_part = ~0u; unsigned pitch = 0; };
 
 template <int R1, int R2, int C, bool POWER, bool INV = false, bool PACK = false>
 __global__ void __launch_bounds__(C * (R1 > R2 ? R1 : R2))
@@ -267,9 +267,13 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
                 x.x *= scale;
                 x.y *= INV ? -scale : scale;
                 if (PACK) {
-                    const unsigned row = sub + R1 * k2, part = row >> pack.c1_log2, jl = row & ((1u << pack.c1_log2) - 1u);
-                    if (part == pack.self_part) pack.self_out[((((size_t)b) << pack.c1_log2) + jl) * ncols + c0 + c] = x;
-                    else pack.out[((((size_t)part * pack.nbatch + b) << pack.c1_log2) + jl) * ncols + c0 + c] = x;
+                    // c1 = rows per part >= R1 (host-checked): the part of row sub + R1 k2 and its row block inside the
+                    // part do not depend on the lane - a uniform base per k2 plus ONE 32-bit lane offset for all stores
+                    const unsigned part = (unsigned)(R1 * k2) >> pack.c1_log2, r0 = (unsigned)(R1 * k2) & ((1u << pack.c1_log2) - 1u);
+                    float2* const ub = part == pack.self_part
+                        ? pack.self_out + ((((size_t)b) << pack.c1_log2) + r0) * pack.pitch
+                        : pack.out + ((((size_t)part * pack.nbatch + b) << pack.c1_log2) + r0) * pack.pitch;
+                    st_stream<(N >= 1024)>(ub + ((uint32_t)sub * pack.pitch + (uint32_t)c0 + (uint32_t)cs), x);
                 } else {
                     st_stream<(!INV && N >= 1024)>(base + (size_t)(sub + R1 * k2) * elem_stride, x);
                 }
@@ -962,7 +966,8 @@ template <int R1, int R2, int C>
 int launch_c2c_pack(float2* data, const float2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride,
                     float scale, PackDst pack, hipStream_t s) {
     constexpr int N = R1 * R2, NT = C * (R1 > R2 ? R1 : R2);
-    const size_t lds = (size_t)(N * C + N) * sizeof(float2);
+    constexpr bool SPLIT = C > 16 && R1 == R2 && N * C * sizeof(float2) > 64 * 1024;       // as in the kernel
+    const size_t lds = (size_t)((SPLIT ? N / 2 : N) * C + N) * sizeof(float2);
     static ast::PerDeviceOnce attr_once;
     if (attr_once.need()) {
         AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&strided_c2c_kernel<R1, R2, C, false, false, true>),
@@ -1061,26 +1066,35 @@ extern "C" int ast_fft_tile_c2c(void* data, int dtype, size_t n, size_t elem_str
 // write of the spectrum.  planes_d is left untouched.  parts: a power of two dividing n.  With self_out_d, part
 // `self_part` (the rank's own piece) is written there as (nplanes, n / parts, ncols) - straight into the receive block -
 // and its slot in packed_d stays unwritten (packed_d may be NULL when parts == 1).
-extern "C" int ast_fft_tile_c2c_packed(const void* planes, void* packed, int dtype, size_t n, size_t ncols, size_t nplanes,
-                                       int parts, int self_part, void* self_out, double scale, void* stream) {
-    AST_CHECK_ARG(planes != nullptr && planes != packed && planes != self_out && ncols >= 1 && nplanes >= 1);
+extern "C" int ast_fft_tile_c2c_packed(const void* planes, void* packed, int dtype, size_t n, size_t ncols, size_t pitch,
+                                       size_t nplanes, int parts, int self_part, void* self_out, double scale, void* stream) {
+    AST_CHECK_ARG(planes != nullptr && planes != packed && planes != self_out && ncols >= 1 && nplanes >= 1 && pitch >= ncols);
     AST_CHECK_ARG((self_out == nullptr) || (self_part >= 0 && self_part < parts));
     AST_CHECK_ARG(packed != nullptr || (self_out != nullptr && parts == 1));
     AST_CHECK_ARG(ast_fft_tile_supported(dtype, n));
     AST_CHECK_ARG(parts >= 1 && (parts & (parts - 1)) == 0 && n % (size_t)parts == 0);
+    AST_CHECK_ARG(n / (size_t)parts >= (n == 1024 ? 32u : 16u));       // rows per part >= the first radix (uniform store bases)
+    AST_CHECK_ARG(pitch < (1u << 24));
     const float2* tw = g_tw.get((int)n);
     if (!tw) { ast::set_error("ast_fft_tile_c2c_packed: twiddle table allocation failed"); return AST_ERR_HIP; }
     hipStream_t s = ast::as_stream(stream);
     PackDst pack;
     pack.out = (float2*)packed;
     pack.nbatch = (unsigned)nplanes;
+    pack.pitch = (unsigned)pitch;
     if (self_out) { pack.self_out = (float2*)self_out; pack.self_part = (unsigned)self_part; }
     for (size_t c1 = n / (size_t)parts; c1 > 1; c1 >>= 1) ++pack.c1_log2;
     AST_PROF("fft_tile.c2c", s);
     float2* d = (float2*)const_cast<void*>(planes);
-    if (n == 1024) return launch_c2c_pack<32, 32, 16>(d, tw, ncols, ncols, nplanes, n * ncols, (float)scale, pack, s);
-    if (n == 512) return launch_c2c_pack<16, 32, 16>(d, tw, ncols, ncols, nplanes, n * ncols, (float)scale, pack, s);
-    return launch_c2c_pack<16, 16, 16>(d, tw, ncols, ncols, nplanes, n * ncols, (float)scale, pack, s);
+    // N = 1024: 16-column tiles.  Measured at the 8-rank slab shape (128 planes, rows pitched to whole lines, 528):
+    // 16 columns 0.27 ms, 32 columns (256-byte row pieces, the split exchange of the single-GPU y pass; 8 VGPRs
+    // spilled by the extra store addressing) 0.30 - AST_FFT_PACK_C32=1 selects it for A/B runs.  Unpitched rows (513):
+    // 0.44-0.60 ms, every 128-byte piece straddling two lines.
+    if (n == 1024 && pitch % 16 == 0 && getenv("AST_FFT_PACK_C32"))
+        return launch_c2c_pack<32, 32, FWD_C>(d, tw, pitch, ncols, nplanes, n * pitch, (float)scale, pack, s);
+    if (n == 1024) return launch_c2c_pack<32, 32, 16>(d, tw, pitch, ncols, nplanes, n * pitch, (float)scale, pack, s);
+    if (n == 512) return launch_c2c_pack<16, 32, 16>(d, tw, pitch, ncols, nplanes, n * pitch, (float)scale, pack, s);
+    return launch_c2c_pack<16, 16, 16>(d, tw, pitch, ncols, nplanes, n * pitch, (float)scale, pack, s);
 }
 
 // lane factors of the fused low-k z sums (rows_r2c_kernel<.., LOWK>): [n2 < R2][kz <= 6][A, B],
@@ -1169,6 +1183,14 @@ extern "C" int ast_fft_tile_isqrt_table(int* out, int count, void* stream) {
 extern "C" int ast_fft_tile_rows_r2c(const void* in, void* out, int dtype, size_t n, size_t nrows, size_t in_pitch,
                                      size_t out_pitch, double scale, void* stream) {
     return rows_r2c_impl(in, out, dtype, n, nrows, in_pitch, out_pitch, scale, 0.0, stream);
+}
+
+// The z pass of `nrows` rows that also leaves the low-k channel's z sums of those rows at lowz (nrows x 7 complex128,
+// [row][kz]: what the first kernel of ast_lowk_modes would compute from a second read of the planes).
+extern "C" int ast_fft_tile_rows_r2c_lowz(const void* in, void* out, int dtype, size_t n, size_t nrows, size_t in_pitch,
+                                          size_t out_pitch, double scale, void* lowz, void* stream) {
+    AST_CHECK_ARG(lowz != nullptr);
+    return rows_r2c_impl(in, out, dtype, n, nrows, in_pitch, out_pitch, scale, 0.0, stream, nullptr, 0, (double*)lowz);
 }
 
 // The three passes of an (n, n, n) real -> (n, n, n/2+1) half-spectrum transform,
@@ -1359,6 +1381,18 @@ extern "C" int ast_lowk_modes(const void* planes, int dtype, size_t n, size_t x0
     hipStream_t s = ast::as_stream(stream);
     AST_PROF("fft_tile.lowk", s);
     return lowk_modes((const float*)planes, nullptr, 0, (int)n, (int)x0, (int)nx, accumulate, (double2*)modes, (double2*)work, s);
+}
+
+// ast_lowk_modes for planes whose z sums are already at the start of work_d ([plane][y][kz], nx * n * 7 complex128,
+// written by ast_fft_tile_rows_r2c_lowz plane range by plane range): the y and x sums only.
+extern "C" int ast_lowk_modes_from_z(size_t n, size_t x0, size_t nx, int accumulate, void* modes, void* work, size_t work_bytes,
+                                     void* stream) {
+    AST_CHECK_ARG(modes && work && nx >= 1 && x0 + nx <= n);
+    AST_CHECK_ARG(ast_fft_tile_supported(AST_F32, n));
+    AST_CHECK_ARG(work_bytes >= ast_lowk_work_bytes(n, nx));
+    hipStream_t s = ast::as_stream(stream);
+    AST_PROF("fft_tile.lowk", s);
+    return lowk_modes(nullptr, nullptr, 0, (int)n, (int)x0, (int)nx, accumulate, (double2*)modes, (double2*)work, s, true);
 }
 
 extern "C" int ast_lowk_shell_sums(const void* modes, size_t n, double boxsize, int binning, double* sums, void* stream) {

@@ -190,22 +190,24 @@ col_mid_kernel(const double2* __restrict__ in, const double2* __restrict__ mul0,
 #pragma unroll
         for (int k2 = 0; k2 < RB; ++k2) m[k2] = (mul + gbase + (size_t)(RA * k2) * pitch)[voff];
     };
-    if (sub < RB) {                                       // forward stage 1: task (c, n2 = sub)
-        double2 v[RA];
+    // (every barrier of this kernel is reached by ALL threads outside any branch: ADVICE r3 - the <16, 8> shape used to
+    // execute two different s_barrier instructions in the two arms of `if (sub < RB)`)
+    const bool task1 = sub < RB;                          // forward stage 1: task (c, n2 = sub)
+    double2 v[RA];
+    if (task1) {
 #pragma unroll
         for (int n1 = 0; n1 < RA; ++n1) v[n1] = (in + gbase + (size_t)(n1 * RB) * pitch)[voff];
-        if (sub < RA) fetch_mul(mul0);                    // in flight across the exchange
-        fft_reg<RA>(v);
-        __syncthreads();                                  // the twiddle table is in LDS
+    }
+    if (sub < RA) fetch_mul(mul0);                        // in flight across the exchange
+    if (task1) fft_reg<RA>(v);
+    __syncthreads();                                      // the twiddle table is in LDS
+    if (task1) {
 #pragma unroll
         for (int k1 = 0; k1 < RA; ++k1) {
             double2 y = v[bitrev(k1, ilog2(RA))];
             if (k1 != 0) y = cmul(y, tw[sub * k1]);
             Y[(sub * RA + k1) * C + c] = y;
         }
-    } else {
-        if (sub < RA) fetch_mul(mul0);
-        __syncthreads();
     }
     __syncthreads();
     double2 X[RB];                                        // sub < RA: spectrum point sub + RA k2 in X[bitrev(k2)]

@@ -269,6 +269,77 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     return out
 
 
+class StagedPaint:
+    """The single-pass overwrite paint of ``paint(..., method="tiled", accumulate=False)`` in parts
+    (``ast_paint_tiled_stage``): ``group()`` once, then ``walk(row0, nrows)`` and ``fold(row0, nrows)`` per range of tile
+    rows (``row_planes`` consecutive buffer planes each, ``nrows_total`` rows), in any order that walks a row's
+    neighbours (``fold_needs``) before the row is folded.  After every row has been walked and folded ``out`` equals
+    the one-call paint bit for bit.  Calls go to the current stream; the workspace lives as long as the object.
+    The reference paints on one rank in one call (stats_subfind.py:130-131); this is what lets the slab pipeline send
+    finished planes while the rest of the slab is still being painted."""
+
+    def __init__(self, pos, mass, nmesh, boxsize, window, out, x_start=0, nx_alloc=None, scale=1.0, offset=0.0,
+                 offset_planes=None, hint=None, shift=0.0):
+        L = _lib.lib()
+        self.n = int(nmesh)
+        self.nx = self.n if nx_alloc is None else int(nx_alloc)
+        assert pos.is_cuda and pos.dim() == 2 and pos.shape[1] == 3 and pos.is_contiguous()
+        assert out.is_cuda and out.dtype == pos.dtype and out.numel() == self.nx * self.n * self.n and out.is_contiguous()
+        if hint not in (None, "scattered"):
+            raise ValueError(hint)
+        self.pos, self.mass, self.out = pos, mass, out
+        self.code = real_code(pos)
+        self.win = _lib.WIN[window.lower()]
+        self.window = window.lower()
+        self.flags = 2 | (8 if hint == "scattered" else 0)                  # OVERWRITE [| SCATTERED]
+        self.npart = pos.shape[0]
+        self.ws_bytes = int(L.ast_paint_tiled_workspace_bytes(self.win, self.code, self.npart, self.n, self.nx, self.flags))
+        if self.ws_bytes == 0 or self.win == 0 or self.npart >= 2**32 - 65:
+            raise _lib.AstrildHipError("staged paint needs a CIC/TSC window and nmesh a multiple of 32")
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=pos.device)
+        self.dropped = torch.zeros(1, dtype=torch.int64, device=pos.device)
+        self.mass_bound = 1.0
+        if mass is not None and self.npart:
+            lo_hi = torch.empty(2, dtype=torch.float64, device=pos.device)
+            check(L.ast_minmax(ptr(mass), self.code, self.npart, ptr(lo_hi), stream()), "ast_minmax")
+            self.mass_bound = float(lo_hi.abs().max()) or 1.0
+        off = (0, -1) if offset_planes is None else offset_planes
+        self.args = (float(boxsize), float(scale), int(x_start), self.nx)
+        self.tail = (self.mass_bound, float(offset), int(off[0]), int(off[1]), float(shift))
+        self.row_planes = int(L.ast_paint_tile_row_planes())
+        self.nrows_total = int(L.ast_paint_tile_rows(self.nx))
+        self.periodic = self.nx == self.n and int(x_start) == 0
+
+    def _stage(self, stage, row0, nrows):
+        check(_lib.lib().ast_paint_tiled_stage(self.win, self.code, ptr(self.pos), ptr(self.mass), self.npart, self.n,
+                                               *self.args, ptr(self.out), ptr(self.ws), self.ws_bytes, ptr(self.dropped),
+                                               self.flags, *self.tail, int(stage), int(row0), int(nrows), stream()),
+              "ast_paint_tiled_stage")
+
+    def fold_needs(self, row):
+        """Tile rows whose walk must be complete before ``fold(row, 1)``: the row itself and the neighbours whose
+        window reaches into it (CIC deposits reach one plane up, TSC one plane either way)."""
+        rows = [row - 1, row] + ([row + 1] if self.window == "tsc" else [])
+        if self.periodic:
+            return sorted({r % self.nrows_total for r in rows})
+        return [r for r in rows if 0 <= r < self.nrows_total]
+
+    def group(self):
+        self.dropped.zero_()
+        self._stage(0, 0, 0)
+
+    def walk(self, row0, nrows):
+        self._stage(1, row0, nrows)
+
+    def fold(self, row0, nrows):
+        self._stage(2, row0, nrows)
+
+    def check(self):
+        nd = int(self.dropped.item())
+        if nd:
+            raise _lib.AstrildHipError(f"{nd} deposits fell outside the grid buffer (x_start={self.args[2]}, nx_alloc={self.nx})")
+
+
 def synth_lattice_particles(npside, nmesh, boxsize, seed=20240601, sigma_cells=0.5, shuffle=False,
                             dtype=torch.float32, first=0, count=None):
     """Synthetic particle set of SURVEY.md §8(d), generated directly in HBM."""

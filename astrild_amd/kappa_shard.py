@@ -13,6 +13,9 @@ lives on rank ``p mod P`` (each rank also only LOADS its own files).  Per output
   3. rank j adds the P chunks it received IN RANK ORDER (``ast_kappa_stack`` again);
   4. the summed chunks are gathered on the root (or on every rank, ``all_ranks=True``).
 
+A stream of maps (``MapStream``) rotates the root: rank m mod P receives map m and runs its per-map stages
+(smoothing, kappa -> alpha, PDF) on a second stream while all ranks stack map m + 1.
+
 Summation order: sum over ranks r = 0..P-1 of (sum over the planes p = r, r+P, ... of rank r) - fixed,
 so the result is bit-reproducible for a given P; it differs from the single-GPU running sum
 (planes 0, 1, 2, ... in order) by re-association only (<= P * 2^-53 relative; the tests bound it).
@@ -51,6 +54,106 @@ def my_plane_ids(nplanes, group=None):
     return list(range(dist.get_rank(group), int(nplanes), dist.get_world_size(group)))
 
 
+class ShardedStacker:
+    """The buffers and the collective sequence of one sharded stack of ``n``-pixel maps, reusable map after map (no
+    allocation, no size negotiation per map).  ``stack(..., root=)`` is asynchronous where the backend is (RCCL): it
+    enqueues on the current stream and returns the root's result buffer - one of ``depth`` rotating buffers, so that a
+    consumer on another stream may still be reading map m while map m + 1 is gathered."""
+
+    def __init__(self, n, group=None, ops=None, depth=2):
+        self.ops = ops or HipStackOps()
+        self.group, self.n = group, int(n)
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.chunk = (self.n + self.world - 1) // self.world
+        o = self.ops
+        self.send = o.zeros(self.world * self.chunk)          # zero padding past n; a rank without planes sends zeros
+        self.recv = o.empty(self.world * self.chunk) if self.world > 1 else None
+        self.mine = o.empty(self.chunk) if self.world > 1 else None
+        self.full = [o.empty(self.world * self.chunk) for _ in range(max(1, int(depth)))]
+        self.uses = 0                      # result buffers handed out by THIS rank (they rotate per use, not per map)
+
+    def stack(self, planes, wnum=None, wden=None, root=0, all_ranks=False):
+        """Returns the summed map (flat, n pixels; a view of a rotating buffer) on ``root`` (a rank of the group) - on
+        every rank with ``all_ranks`` - and None elsewhere."""
+        from .slab import comm_ready
+        o, world, rank, chunk, n, group = self.ops, self.world, self.rank, self.chunk, self.n, self.group
+        planes = [o.to_device(p).reshape(-1) for p in planes]
+        if planes and planes[0].numel() != n:
+            raise ValueError(f"rank {rank}: planes of {planes[0].numel()} pixels, the stacker was made for {n}")
+        full = None
+        if world == 1 or all_ranks or rank == root:
+            full = self.full[self.uses % len(self.full)]
+            self.uses += 1
+        if world == 1:
+            if not planes:
+                raise ValueError("no rank holds a plane")
+            o.stack(planes, wnum, wden, out=full[:n])
+            return full[:n]
+        if planes:
+            o.stack(planes, wnum, wden, out=self.send[:n])
+        else:
+            self.send.zero_()
+        comm_ready(group)
+        dist.all_to_all_single(self.recv, self.send, group=group)       # chunk j of every rank -> rank j
+        o.stack([self.recv[s * chunk:(s + 1) * chunk] for s in range(world)], out=self.mine)      # rank order: fixed
+        comm_ready(group)
+        if all_ranks:
+            dist.all_gather_into_tensor(full, self.mine, group=group)
+            return full[:n]
+        # `root` is a rank of `group`; dist.gather's dst is a GLOBAL rank
+        parts = list(full.split(chunk)) if rank == root else None
+        dist.gather(self.mine, parts, dst=dist.get_global_rank(group, root) if group is not None else root, group=group)
+        return full[:n] if rank == root else None
+
+
+class MapStream:
+    """A stream of output maps over the P ranks of ``group`` (the loops of simcoll.py:267-336 and rayramses.py:186-232,
+    one stacked map per iteration): every rank stacks its planes of map m, the partial maps are reduced onto rank
+    m mod P - the root ROTATES - and that rank runs ``tail(m, map)`` (smoothing, kappa -> alpha, PDF ...) on a second
+    stream while all ranks already stack map m + 1.  With one GPU per rank each rank runs a tail every P-th map, so the
+    per-map stages are spread over all GPUs instead of idling P - 1 of them behind rank 0.
+
+    push() returns what ``tail`` returned on the map's root and None elsewhere; tails must not synchronise the host (queue
+    their results, e.g. lensing.PendingHistogram, and collect them after finish())."""
+
+    def __init__(self, npix2, group=None, ops=None):
+        self.stacker = ShardedStacker(npix2, group, ops, depth=2)
+        self.group = group
+        self.world, self.rank = self.stacker.world, self.stacker.rank
+        self.m = 0
+        self.on_gpu = torch.cuda.is_available() and self.stacker.send.is_cuda
+        self.tail_stream = torch.cuda.Stream() if self.on_gpu else None
+        self._tail_done = []               # events: the tails that read the rotating result buffers
+
+    def root_of(self, m):
+        return m % self.world
+
+    def push(self, planes, wnum=None, wden=None, tail=None):
+        m = self.m
+        self.m += 1
+        root = self.root_of(m)
+        if self.on_gpu and self.rank == root and len(self._tail_done) >= len(self.stacker.full):
+            # the buffer this map is gathered into was read by the tail of my map before last
+            torch.cuda.current_stream().wait_event(self._tail_done.pop(0))
+        res = self.stacker.stack(planes, wnum, wden, root=root)
+        if self.rank != root or tail is None:
+            return None
+        if not self.on_gpu:
+            return tail(m, res)
+        self.tail_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.tail_stream):
+            out = tail(m, res)
+            ev = torch.cuda.Event()
+            ev.record(self.tail_stream)
+        self._tail_done.append(ev)
+        return out
+
+    def finish(self):
+        if self.on_gpu:
+            torch.cuda.current_stream().wait_stream(self.tail_stream)
+        self._tail_done = []
+
+
 def kappa_stack_sharded(planes, wnum=None, wden=None, group=None, root=0, all_ranks=False, ops=None):
     """Weighted sum of ALL ranks' planes.  ``planes``: this rank's planes (flat or 2-D, equal shapes; may be
     empty), ``wnum`` / ``wden``: their weights (or None).  Returns the summed map (flat, length of one
@@ -68,25 +171,4 @@ def kappa_stack_sharded(planes, wnum=None, wden=None, group=None, root=0, all_ra
         raise ValueError("no rank holds a plane")
     if planes and n_local != n:
         raise ValueError(f"rank {rank}: planes of {n_local} pixels, other ranks have {n}")
-    chunk = (n + world - 1) // world
-    send = ops.zeros(world * chunk)                       # zero padding past n; ranks without planes send zeros
-    if planes:
-        ops.stack(planes, wnum, wden, out=send[:n])
-    if world == 1:
-        return send[:n]
-    recv = ops.empty(world * chunk)
-    from .slab import comm_ready
-    comm_ready(group)
-    dist.all_to_all_single(recv, send, group=group)       # chunk j of every rank -> rank j
-    mine = ops.stack([recv[s * chunk:(s + 1) * chunk] for s in range(world)])      # rank order: fixed
-    comm_ready(group)
-    if all_ranks:
-        full = ops.empty(world * chunk)
-        dist.all_gather_into_tensor(full, mine, group=group)
-        return full[:n]
-    # `root` is a rank of `group`; dist.gather's dst is a GLOBAL rank
-    parts = [ops.empty(chunk) for _ in range(world)] if rank == root else None
-    dist.gather(mine, parts, dst=dist.get_global_rank(group, root) if group is not None else root, group=group)
-    if rank != root:
-        return None
-    return torch.cat(parts)[:n]
+    return ShardedStacker(n, group, ops, depth=1).stack(planes, wnum, wden, root=root, all_ranks=all_ranks)

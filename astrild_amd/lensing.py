@@ -421,12 +421,30 @@ def synth_plane_weights(nplanes):
     return translate_redshift_weights(mid - half, mid + half, 1100.0, 1000.0)
 
 
+def kappa_map_tail(lp, sp, sigma_px, keep=None):
+    """The per-map stages behind the stack (sky_utils.py:318-339, filters.py:181-225, sky_array.py:428-433, 780-817) as one
+    callable for kappa_shard.MapStream: / c^2 -> Gaussian FFT smoothing -> 100-bin PDF (queued) -> kappa -> (alpha1, alpha2).
+    Nothing in it waits for the GPU; the PDFs are collected from the returned PendingHistogram afterwards."""
+    def tail(m, kappa_flat):
+        npix = lp.nc
+        img = kappa_flat.view(npix, npix)
+        convert_code_to_phy_units("kappa_2", img)
+        sp.gaussian(img, sigma_px, "gaussianFFT")
+        pdf = PendingHistogram(img, 100, density=True)
+        a1, a2 = lp.alphas(img)
+        if keep is not None:
+            keep[m] = (img.clone(), a1, a2)
+        return pdf
+    return tail
+
+
 def bench_kappa_pipeline(nplanes=64, npix=4096, steps=3, warmup=1, theta_deg=20.0, sigma_arcmin=1.0, group=None):
     """kappa-maps/s at npix^2 for one full map: stack nplanes planes (weighted) ->
     / c^2 -> Gaussian FFT smoothing -> kappa -> (alpha1, alpha2) -> 100-bin PDF.
-    With a process group of P > 1 ranks the planes are sharded (plane p on rank p mod P,
-    kappa_shard.kappa_stack_sharded) and rank 0 runs the single-map stages; the time is the
-    slowest rank's, between barriers."""
+    With a process group of P > 1 ranks the planes are sharded (plane p on rank p mod P) and the maps are a STREAM
+    (kappa_shard.MapStream; the loops of simcoll.py:267-336 / rayramses.py:186-232 produce one stacked map per
+    iteration): map m is reduced onto rank m mod P, which runs its single-map stages on a second stream while all ranks
+    stack map m + 1 - a step is then P maps (every rank is root once); the time is the slowest rank's, between barriers."""
     from . import device as dev
     world, rank = 1, 0
     if group is not None:
@@ -439,20 +457,19 @@ def bench_kappa_pipeline(nplanes=64, npix=4096, steps=3, warmup=1, theta_deg=20.
     wnum, wden = wnum[ids], wden[ids]
     bsz = np.deg2rad(theta_deg)
     sigma_px = sigma_arcmin / 60.0 * npix / theta_deg
-    lp = sp = None
-    if rank == 0:
-        lp = lens_plan(npix, bsz)
-        sp = smooth_plan(npix)
+    lp = lens_plan(npix, bsz)
+    sp = smooth_plan(npix)
     out = torch.empty((npix, npix), dtype=torch.float64, device="cuda")
+    maps_per_step = world if world > 1 else 1
+    stream = kappa_shard.MapStream(npix * npix, group) if world > 1 else None
+    tail = kappa_map_tail(lp, sp, sigma_px)
 
     def step():
         if world > 1:
-            res = kappa_shard.kappa_stack_sharded(planes, wnum, wden, group=group, root=0)
-            if rank != 0:
-                return None
-            out.view(-1).copy_(res)
-        else:
-            kappa_stack(planes, wnum, wden, out=out)
+            # the PDFs are collected by the caller after ALL maps have been queued: waiting for one here would hold
+            # back this rank's part of the next maps' collectives
+            return [p for p in (stream.push(planes, wnum, wden, tail) for _ in range(maps_per_step)) if p is not None]
+        kappa_stack(planes, wnum, wden, out=out)
         convert_code_to_phy_units("kappa_2", out)
         sp.gaussian(out, sigma_px, "gaussianFFT")
         pdf = PendingHistogram(out, 100, density=True)          # queued; fetched after kappa -> alpha has been launched,
@@ -464,22 +481,34 @@ def bench_kappa_pipeline(nplanes=64, npix=4096, steps=3, warmup=1, theta_deg=20.
             dist.barrier(group)
         torch.cuda.synchronize()
 
+    def finish(pending):
+        if world > 1:
+            stream.finish()
+            for p in pending:
+                p.result()
+
+    pend = []
     for _ in range(warmup):
-        step()
+        pend += step() if world > 1 else []
+    finish(pend)
     barrier()
     dev.profile_enable(True)
     t0 = time.perf_counter()
+    pend = []
     for _ in range(steps):
-        step()
+        r = step()
+        if world > 1:
+            pend += r
+    finish(pend)
     barrier()
-    dt = (time.perf_counter() - t0) / steps
+    dt = (time.perf_counter() - t0) / (steps * maps_per_step)
     prof = dev.profile_report()
     dev.profile_enable(False)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
         dt = float(tmax.item())
-    stack_ms = prof.get("kappa_stack", (0, 0.0))[1] / steps
+    stack_ms = prof.get("kappa_stack", (0, 0.0))[1] / (steps * maps_per_step)
     nloc = len(ids)
     stack_bytes = (nloc + 1) * npix * npix * 8 + (0 if world == 1 else 2 * npix * npix * 8)     # + chunk sums
     # SURVEY.md §8(d) algorithmic bytes of the whole per-map pipeline: stack (P + 1) maps, FFT smoothing 8 map
@@ -489,13 +518,15 @@ def bench_kappa_pipeline(nplanes=64, npix=4096, steps=3, warmup=1, theta_deg=20.
     res = {
         "metric": f"kappa-maps/s at {npix}^2 ({nplanes}-plane weighted stack + smoothing + kappa->alpha + PDF, fp64)",
         "value": 1.0 / dt, "unit": "maps/s", "ms_per_map": dt * 1e3, "n_gpus": world,
-        "planes_per_rank": nloc,
+        "planes_per_rank": nloc, "maps_per_step": maps_per_step,
+        "mode": "one GPU" if world == 1 else f"stream of maps over {world} ranks: rotating reduce root (map m on rank m mod P), "
+                                             "per-map stages on a second stream beside the next maps' stacks",
         "stack": {"ms": round(stack_ms, 4), "alg_GB": round(stack_bytes / 1e9, 3),
                   "GBps": round(stack_bytes / stack_ms / 1e6, 1) if stack_ms else None,
                   "frac": round(stack_bytes / stack_ms / 1e6 / 8000.0, 4) if stack_ms else None},
         "roofline": {"bound": "hbm", "scope": "whole per-map pipeline, all GPUs", "alg_GB": round(pipeline_bytes / 1e9, 3),
                      "achieved": round(pipeline_bytes / dt / 1e9, 1), "peak": 8000.0 * world, "unit": "GB/s",
                      "frac": round(pipeline_bytes / dt / 1e9 / (8000.0 * world), 4)},
-        "kernels_ms": {k: round(v[1] / steps, 4) for k, v in prof.items()},
+        "kernels_ms": {k: round(v[1] / (steps * maps_per_step), 4) for k, v in prof.items()},
     }
     return res

@@ -48,6 +48,11 @@ class HipSlabOps:
         return self.dev.paint(pos, mass, n, boxsize, window, out=out, x_start=x_start, nx_alloc=nx_alloc,
                               check_dropped=check, accumulate=False, offset=offset, offset_planes=owned, hint=hint)
 
+    def staged_paint(self, pos, mass, n, boxsize, window, out, x_start, nx_alloc, offset=0.0, owned=None, hint=None):
+        """The same paint in parts (device.StagedPaint): group once, then walk / fold tile row by tile row."""
+        return self.dev.StagedPaint(pos, mass, n, boxsize, window, out, x_start=x_start, nx_alloc=nx_alloc, offset=offset,
+                                    offset_planes=owned, hint=hint)
+
     def lowk_supported(self, n):
         return self.dtype == torch.float32 and self._tile_ok(0, n)
 
@@ -85,19 +90,50 @@ class HipSlabOps:
 
     def packed_supported(self, planes, parts):
         nloc, n1, n2 = planes.shape
-        return n1 == n2 and self._tile_ok(self.dev.real_code(planes), n1) and parts & (parts - 1) == 0
+        return n1 == n2 and self._tile_ok(self.dev.real_code(planes), n1) and parts & (parts - 1) == 0 \
+            and n1 // parts >= (32 if n1 == 1024 else 16)
 
-    def fft2d_planes_packed(self, planes, spec, packed, parts, self_part, self_dst):
+    def spectrum_pitch(self, n, parts):
+        """Row pitch (complex elements) of the slab's half-spectrum buffers - the local planes after the z pass, the send
+        buffer, the received block: n/2+1 rounded up to whole 128-byte lines where the hand-written passes run (every row
+        piece of the y pass and of the axis-0 pass then sits on whole lines; 3 % more on the wire at n = 1024), else n/2+1."""
+        nz = n // 2 + 1
+        if self.dtype == torch.float32 and self._tile_ok(0, n) and parts & (parts - 1) == 0 \
+                and n // parts >= (32 if n == 1024 else 16) and self.axis0_power_supported(n):
+            return (nz + 15) // 16 * 16
+        return nz
+
+    def lowz_work(self, n, nloc):
+        """Work area of the low-k channel for nloc planes; its first nloc * n * 7 complex128 are the z sums [plane][y][kz]
+        that fft2d_planes_packed(..., lowz=) fills plane range by plane range."""
+        from ._lib import lib
+        return torch.empty(int(lib().ast_lowk_work_bytes(n, nloc)) // 16, dtype=torch.complex128, device=self.device)
+
+    def lowk_modes_from_z(self, work, n, x0, nloc):
+        from ._lib import check, lib
+        out = torch.empty(int(lib().ast_lowk_mode_count()), dtype=torch.complex128, device=self.device)
+        check(lib().ast_lowk_modes_from_z(n, int(x0), nloc, 0, self.dev.ptr(out), self.dev.ptr(work), work.numel() * 16,
+                                          self.dev.stream()), "ast_lowk_modes_from_z")
+        return out
+
+    def fft2d_planes_packed(self, planes, spec, packed, parts, self_part, self_dst, lowz=None):
         """fft2d_planes + pack in two kernels instead of three: the y pass stores straight into the send buffer
-        (piece s of `packed`) and the rank's own piece into ``self_dst`` (its place in the receive block)."""
+        (piece s of `packed`) and the rank's own piece into ``self_dst`` (its place in the receive block).
+        lowz: (nplanes * n * 7) complex128 that receives the low-k channel's z sums of these planes from the z pass."""
         from ._lib import check, lib
         nloc, n1, n2 = planes.shape
         code = self.dev.real_code(planes)
-        nz = n2 // 2 + 1
+        nz, pitch = n2 // 2 + 1, spec.shape[-1]
         assert self_dst.is_contiguous() and packed.is_contiguous() and spec.is_contiguous()
-        check(lib().ast_fft_tile_rows_r2c(self.dev.ptr(planes), self.dev.ptr(spec), code, n2, nloc * n1, n2, nz,
-                                          1.0, self.dev.stream()), "ast_fft_tile_rows_r2c")
-        check(lib().ast_fft_tile_c2c_packed(self.dev.ptr(spec), self.dev.ptr(packed), code, n1, nz, nloc, parts,
+        assert packed.shape[-1] == pitch and self_dst.shape[-1] == pitch
+        if lowz is not None:
+            assert lowz.is_contiguous() and lowz.dtype == torch.complex128 and lowz.numel() == nloc * n1 * 7
+            check(lib().ast_fft_tile_rows_r2c_lowz(self.dev.ptr(planes), self.dev.ptr(spec), code, n2, nloc * n1, n2, pitch,
+                                                   1.0, self.dev.ptr(lowz), self.dev.stream()), "ast_fft_tile_rows_r2c_lowz")
+        else:
+            check(lib().ast_fft_tile_rows_r2c(self.dev.ptr(planes), self.dev.ptr(spec), code, n2, nloc * n1, n2, pitch,
+                                              1.0, self.dev.stream()), "ast_fft_tile_rows_r2c")
+        check(lib().ast_fft_tile_c2c_packed(self.dev.ptr(spec), self.dev.ptr(packed), code, n1, nz, pitch, nloc, parts,
                                             self_part, self.dev.ptr(self_dst), 1.0, self.dev.stream()),
               "ast_fft_tile_c2c_packed")
 
@@ -170,6 +206,11 @@ class HipSlabOps:
                                                 first=first, count=count)
 
 
+def _peer(group, r):
+    """P2POp / send / recv take GLOBAL ranks; r is a rank of `group`."""
+    return r if group is None else dist.get_global_rank(group, r)
+
+
 def comm_ready(group=None):
     """RCCL orders a collective after the kernels already queued on the current stream.  The gloo backend (CPU tests,
     and the one-GPU rehearsals that put several ranks on one card) reads device buffers from its own threads: there
@@ -197,10 +238,10 @@ class GhostExchange:
         left, right = (rank - 1) % world, (rank + 1) % world
         comm_ready(self.group)
         self.reqs = dist.batch_isend_irecv([
-            dist.P2POp(dist.isend, self.buf[:self.gl], left, self.group),
-            dist.P2POp(dist.isend, self.buf[self.gl + self.nloc:], right, self.group),
-            dist.P2POp(dist.irecv, self.from_right, right, self.group),
-            dist.P2POp(dist.irecv, self.from_left, left, self.group),
+            dist.P2POp(dist.isend, self.buf[:self.gl], _peer(self.group, left), self.group),
+            dist.P2POp(dist.isend, self.buf[self.gl + self.nloc:], _peer(self.group, right), self.group),
+            dist.P2POp(dist.irecv, self.from_right, _peer(self.group, right), self.group),
+            dist.P2POp(dist.irecv, self.from_left, _peer(self.group, left), self.group),
         ])
 
     def finish(self):
@@ -222,26 +263,31 @@ def ghost_fold(buf, nloc, gl, gh, ops, group=None):
     return buf[gl: gl + nloc]
 
 
-def exchange_chunk(packed_c, block, chunk, pc, nloc, group=None, self_done=False):
-    """Step 4 for one chunk of `pc` local planes.  packed_c: (P, pc, nly, nz) — piece s goes
-    to rank s; it lands in block[s_src*nloc + chunk*pc : ... + pc] of the receiver.  Returns
-    the outstanding work handles (the local piece is copied right away, unless the producer has
-    already written it into the block: ``self_done``)."""
+def exchange_planes(packed_c, block, p0, npl, nloc, group=None, self_done=False):
+    """Step 4 for the local planes [p0, p0 + npl).  packed_c: (P, npl, nly, nz) - piece s goes to rank s; it lands in
+    block[s_src*nloc + p0 : ... + npl] of the receiver.  Returns the outstanding work handles (the local piece is copied
+    right away, unless the producer has already written it into the block: ``self_done``).  Every rank calls this for
+    the same plane ranges in the same order, so the point-to-point operations of a pair match up."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     ops_list = []
     if world > 1:
         comm_ready(group)
     for s in range(world):
-        dst = block[s * nloc + chunk * pc: s * nloc + (chunk + 1) * pc]
+        dst = block[s * nloc + p0: s * nloc + p0 + npl]
         if s == rank:
             if not self_done:
                 dst.copy_(packed_c[s])
             continue
         # complex payload moved as (re, im) pairs of the real dtype: every c10d backend takes that
-        ops_list.append(dist.P2POp(dist.isend, torch.view_as_real(packed_c[s]), s, group))
-        ops_list.append(dist.P2POp(dist.irecv, torch.view_as_real(dst), s, group))
+        ops_list.append(dist.P2POp(dist.isend, torch.view_as_real(packed_c[s]), _peer(group, s), group))
+        ops_list.append(dist.P2POp(dist.irecv, torch.view_as_real(dst), _peer(group, s), group))
     return dist.batch_isend_irecv(ops_list) if ops_list else []
+
+
+def exchange_chunk(packed_c, block, chunk, pc, nloc, group=None, self_done=False):
+    """exchange_planes for chunk `chunk` of `pc` local planes."""
+    return exchange_planes(packed_c, block, chunk * pc, pc, nloc, group, self_done)
 
 
 def route_particles(pos, mass, n, boxsize, window, ops, group=None):
@@ -267,11 +313,63 @@ def route_particles(pos, mass, n, boxsize, window, ops, group=None):
     return out_pos, out_mass
 
 
+class Watchdog:
+    """First contact with RCCL must not hang a node: a daemon thread that ENDS THE PROCESS (os._exit - a fresh exit, never a
+    re-exec) with the rank, the host-side stage and the last schedule entry the GPU has completed on stderr when ``beat()``
+    has not been called for ``timeout_s`` seconds.  ``watch(pipe)`` names the pipeline whose ``stage_name`` / progress
+    markers are reported."""
+
+    def __init__(self, timeout_s=None, rank=0, exit_code=3):
+        import os
+        import threading
+        import time
+        self.timeout = float(timeout_s if timeout_s is not None else os.environ.get("ASTRILD_SLAB_TIMEOUT_S", "240"))
+        self.rank, self.exit_code, self.pipe, self.note = rank, exit_code, None, "start"
+        self.last = time.monotonic()
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, name="astrild-slab-watchdog", daemon=True)
+        self._thread.start()
+
+    def watch(self, pipe):
+        self.pipe = pipe
+
+    def beat(self, note=None):
+        import time
+        self.last = time.monotonic()
+        if note is not None:
+            self.note = note
+
+    def stop(self):
+        self._stop.set()
+
+    def report(self):
+        pipe = self.pipe
+        host = getattr(pipe, "stage_name", None)
+        dev = pipe.progress_report() if pipe is not None and hasattr(pipe, "progress_report") else None
+        return f"[astrild slab watchdog] rank {self.rank}: no progress for {self.timeout:.0f} s after '{self.note}'; " \
+               f"host stage: {host}; device: {dev}"
+
+    def _run(self):
+        import os
+        import sys
+        import time
+        while not self._stop.wait(1.0):
+            if time.monotonic() - self.last > self.timeout:
+                try:
+                    sys.stderr.write(self.report() + "\n")
+                    sys.stderr.flush()
+                    import faulthandler
+                    faulthandler.dump_traceback(file=sys.stderr, all_threads=True)     # where the host threads stand
+                    sys.stderr.flush()
+                finally:
+                    os._exit(self.exit_code)
+
+
 class SlabPowerPipeline:
     """CIC/TSC + slab FFT + P(k) for the synthetic lattice workload of bench.py."""
 
     def __init__(self, n, boxsize, npside, window="cic", dtype=torch.float32, seed=20240601, shuffle=False,
-                 ghost=4, ops=None, group=None, pos=None, chunks=None, route=False):
+                 ghost=4, ops=None, group=None, pos=None, chunks=None, route=False, pipeline=None, rows_per_stage=None):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -302,15 +400,17 @@ class SlabPowerPipeline:
             self.pos, _ = route_particles(self.pos, None, n, self.L, window, self.ops, group)
         o = self.ops
         self.buf = o.empty((self.nx_alloc, n, n))
-        self.spec2d = o.empty((self.nloc, n, self.nz), o.cdtype)
+        pitch_fn = getattr(o, "spectrum_pitch", None)
+        self.nzp = pitch_fn(n, P) if pitch_fn else self.nz          # row pitch of the half-spectrum buffers (>= nz)
+        self.spec2d = o.empty((self.nloc, n, self.nzp), o.cdtype)
         if chunks is None:
             chunks = 4 if self.nloc % 4 == 0 and self.nloc >= 16 else 1
         if self.nloc % chunks:
             raise ValueError(f"{self.nloc} local planes do not split into {chunks} chunks")
         self.chunks = chunks
         self.pc = self.nloc // chunks
-        self.packed = o.empty((chunks, P, self.pc, self.nloc, self.nz), o.cdtype)
-        self.block = o.empty((n, self.nloc, self.nz), o.cdtype)
+        self.packed = o.empty((chunks, P, self.pc, self.nloc, self.nzp), o.cdtype)
+        self.block = o.empty((n, self.nloc, self.nzp), o.cdtype)
         self.psum = o.zeros((n // 2 - 1,), torch.float64)
         self._side = None
         self._stage_s = {}
@@ -322,10 +422,35 @@ class SlabPowerPipeline:
         edge = {c for c in range(chunks) if c * self.pc < self.gh or (c + 1) * self.pc > self.nloc - self.gl}
         self.chunk_order = [c for c in range(chunks) if c not in edge] + sorted(edge)
         self.first_edge = len(self.chunk_order) - len(edge)
+        # "staged" (default where the ops can paint in parts and more than one rank takes part): the slab is painted,
+        # transformed and sent plane range by plane range - group once, then per stage walk -> fold -> z rows -> y pass in
+        # send order -> grouped send, ghost rows first - so the exchange starts after the grouping and one stage instead
+        # of after the whole paint.  "bulk": paint everything, then transform and send chunk by chunk (kept for A/B runs
+        # on hardware: ASTRILD_SLAB_PIPELINE=bulk).
+        import os
+        if pipeline is None:
+            pipeline = os.environ.get("ASTRILD_SLAB_PIPELINE") or ("staged" if P > 1 and hasattr(o, "staged_paint") else "bulk")
+        if pipeline not in ("staged", "bulk"):
+            raise ValueError(pipeline)
+        if pipeline == "staged" and not hasattr(o, "staged_paint"):
+            raise ValueError("these ops cannot paint in stages")
+        self.pipeline = pipeline
+        self.rows_per_stage = int(rows_per_stage or os.environ.get("ASTRILD_SLAB_ROWS_PER_STAGE") or 0)
+        self.staged = None
+        self.schedule = None
+        self.stage_name = "init"          # what the rank is doing (read by bench.py's watchdog)
+        self.trace = None                 # a list: (entry, event recorded after it was enqueued) per staged entry (perf scripts)
+        self._progress = None             # pinned host words the GPU writes after each schedule entry (step(progress=True))
         # the rank's OWN planes hold rho - mean (subtracted before the fp32 rounding); its ghost planes, which are
         # added onto the neighbours' cells, stay plain sums
         lowk_fn = getattr(self.ops, "lowk_supported", None)
         self.lowk = bool(lowk_fn and lowk_fn(n))
+        # the low-k channel's z sums come out of the FFT's z pass (no second read of the planes) where the packed
+        # transform runs; ASTRILD_SLAB_LOWK_SEPARATE=1 keeps the separate kernels on a side stream
+        self.lowz = None
+        if self.lowk and hasattr(o, "lowz_work") and not os.environ.get("ASTRILD_SLAB_LOWK_SEPARATE") \
+                and o.packed_supported(torch.empty((1, n, n), dtype=o.dtype, device="meta"), P):
+            self.lowz = o.lowz_work(n, self.nloc)
         total = torch.tensor([float(self.pos.shape[0])], dtype=torch.float64, device=self.pos.device)
         comm_ready(group)
         dist.all_reduce(total, group=group)
@@ -337,6 +462,248 @@ class SlabPowerPipeline:
         dist.all_reduce(self.ksum, group=group)
         dist.all_reduce(self.nmodes, group=group)
 
+    # ------------------------------------------------------------------ staged pipeline
+    def _make_schedule(self, sp):
+        """The static order of a staged step - the same on every rank (it depends on the geometry only), which is what
+        lets the ranks' point-to-point operations match up.  Entries: ("walk", row0, nrows), ("fold", row0, nrows),
+        ("ghost_start",), ("ghost_finish",), ("fft", p0, npl) with p0 counted in OWNED planes."""
+        R, PR = sp.nrows_total, sp.row_planes
+        gl, gh, nloc = self.gl, self.gh, self.nloc
+        lo, hi = gl, gl + nloc                                       # owned planes in buffer coordinates
+        ghost_in = set(range(lo, lo + gh)) | set(range(hi - gl, hi)) if self.world > 1 else set()
+        sched, walked, folded, sent = [], set(), set(), set()
+        state = {"ghosts_in": self.world == 1}
+
+        def runs(items):
+            items = sorted(items)
+            out = []
+            for v in items:
+                if out and v == out[-1][0] + out[-1][1]:
+                    out[-1][1] += 1
+                else:
+                    out.append([v, 1])
+            return out
+
+        def walk(rows):
+            for r0, nr in runs(set(rows) - walked):
+                sched.append(("walk", r0, nr))
+            walked.update(rows)
+
+        def fold_ready(only=None):
+            ready = [r for r in range(R) if r not in folded and (only is None or r in only) and set(sp.fold_needs(r)) <= walked]
+            for r0, nr in runs(ready):
+                sched.append(("fold", r0, nr))
+            folded.update(ready)
+
+        def fft_ready():
+            planes = [p for r in folded for p in range(r * PR, min((r + 1) * PR, self.nx_alloc))
+                      if lo <= p < hi and p not in sent and (state["ghosts_in"] or p not in ghost_in)]
+            for p0, npl in runs(planes):
+                sched.append(("fft", p0 - lo, npl))
+            sent.update(planes)
+
+        if self.world > 1:
+            first = {p // PR for p in list(range(0, gl)) + list(range(hi, self.nx_alloc))}
+            need = set()
+            for r in first:
+                need.update(sp.fold_needs(r))
+            walk(need)
+            fold_ready(only=first)
+            sched.append(("ghost_start",))
+            fold_ready()
+            fft_ready()
+        rest = [r for r in range(R) if r not in walked]
+        per = self.rows_per_stage or max(1, (len(rest) + 3) // 4)
+        for i in range(0, len(rest), per):
+            walk(rest[i:i + per])
+            fold_ready()
+            fft_ready()
+        assert walked == set(range(R)) and folded == set(range(R))
+        if self.world > 1:
+            sched.append(("ghost_finish",))
+            state["ghosts_in"] = True
+            fft_ready()
+        assert sent == set(range(lo, hi))
+        return sched
+
+    def progress_report(self):
+        """Which schedule entries the GPU streams have completed (from the markers of a step(progress=True))."""
+        if self._progress is None or self.schedule is None:
+            return "no progress markers"
+        done = [int(v) for v in self._progress.tolist()]
+        names = ["group"] + ["%s%s" % (e[0], tuple(e[1:])) for e in self.schedule]
+
+        def name(i):
+            return "nothing yet" if i <= 0 else names[i - 1] if i <= len(names) else str(i)
+        return f"paint stream completed #{done[0]} ({name(done[0])}), transform stream completed #{done[1]} ({name(done[1])}) " \
+               f"of {len(names)} entries"
+
+    def _step_staged(self, check=False, progress=False):
+        import os
+        import time
+        o = self.ops
+        if self.staged is None:
+            self.staged = o.staged_paint(self.pos, None, self.n, self.L, self.window, self.buf, self.x_start, self.nx_alloc,
+                                         offset=self.mean_offset, owned=(self.gl, self.nloc) if self.mean_offset else None)
+            self.schedule = self._make_schedule(self.staged)
+            self.packed_flat = self.packed.reshape(-1)
+            # ASTRILD_SLAB_STREAMS=2: the paint stages (walk, fold) on the caller's stream, the transforms and the exchange
+            # of finished plane ranges on a second one, so that a stage's transform runs beside the next stage's walk.
+            # Measured on one GPU (rank 3 of 8, no exchange): 2.28 against 2.22 ms per step on ONE stream - both kinds of
+            # kernel are bandwidth bound and gain nothing from each other's company; one stream is the default (RCCL moves
+            # the data on its own stream either way)
+            self._fft_stream = None
+            if self.buf.is_cuda and os.environ.get("ASTRILD_SLAB_STREAMS", "1") == "2":
+                self._fft_stream = torch.cuda.Stream()
+        sp = self.staged
+        owned = self.buf[self.gl: self.gl + self.nloc] if self.world > 1 else self.buf
+        P, nloc, nz = self.world, self.nloc, self.nzp
+        pending = []
+        state = {"modes": None, "side": None}
+        packed_fn = getattr(o, "packed_supported", None)
+        main = torch.cuda.current_stream() if self.buf.is_cuda else None
+        side = self._fft_stream
+
+        if progress and self.buf.is_cuda and self._progress is None:
+            self._progress = torch.zeros(2, dtype=torch.int32).pin_memory()
+            self._progress_ids = torch.arange(0, len(self.schedule) + 2, dtype=torch.int32, device=self.buf.device)
+        if progress and self._progress is not None:
+            self._progress.zero_()
+        counter = {"i": 0}
+
+        def mark(entry, lane=0):
+            if entry[0] != "begin":
+                counter["i"] += 1
+            if progress and self._progress is not None and entry[0] != "begin":
+                # a 4-byte device-to-host copy in stream order: the host sees how far each stream has come
+                self._progress[lane:lane + 1].copy_(self._progress_ids[counter["i"]:counter["i"] + 1], non_blocking=True)
+            if self.trace is not None and self.buf.is_cuda:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(torch.cuda.current_stream())
+                self.trace.append((entry, ev))
+
+        def transform(p0, npl):
+            planes = owned[p0:p0 + npl]
+            spec = self.spec2d[p0:p0 + npl]
+            nly = self.n // P
+            packed = self.packed_flat[P * p0 * nly * nz: P * (p0 + npl) * nly * nz].view(P, npl, nly, nz)
+            if packed_fn and packed_fn(planes, P):
+                mine = self.block[self.rank * nloc + p0: self.rank * nloc + p0 + npl]
+                if self.lowz is not None:
+                    o.fft2d_planes_packed(planes, spec, packed, P, self.rank, mine, lowz=self._lowz_rows(p0, npl))
+                else:
+                    o.fft2d_planes_packed(planes, spec, packed, P, self.rank, mine)
+                return exchange_planes(packed, self.block, p0, npl, nloc, self.group, self_done=True)
+            o.fft2d_planes(planes, spec)
+            o.pack(spec, packed, P)
+            return exchange_planes(packed, self.block, p0, npl, nloc, self.group)
+
+        if side is not None:
+            side.wait_stream(main)            # the previous step's consumers of spec2d / packed / block are on `main`
+        self.stage_name = "paint.group"
+        t0 = time.perf_counter()
+        mark(("begin",))
+        sp.group()
+        self._tick("paint.group.enqueue", t0)
+        mark(("group",))
+        for entry in self.schedule:
+            kind = entry[0]
+            t0 = time.perf_counter()
+            self.stage_name = "%s%s" % (kind, tuple(entry[1:]))
+            if kind == "walk":
+                sp.walk(entry[1], entry[2])
+            elif kind == "fold":
+                sp.fold(entry[1], entry[2])
+            elif kind == "ghost_start":
+                self.ghosts.start()
+            elif kind == "ghost_finish":
+                self.ghosts.finish()
+                self._lowk_start(owned, state)
+            elif side is None:
+                pending += transform(entry[1], entry[2])
+            else:
+                side.wait_stream(main)        # the planes' folds (and the ghost add) are on `main`
+                with torch.cuda.stream(side):
+                    pending += transform(entry[1], entry[2])
+                    mark(entry, 1)
+            self._tick(kind + ".enqueue", t0)
+            if kind != "fft" or side is None:
+                mark(entry)
+        if self.world == 1:
+            self._lowk_start(owned, state)
+        if self.lowz is not None:             # every plane's z sums are in: the low-k modes' y and x sums
+            self._lowk_from_z(state, side)
+        if check:
+            sp.check()
+        if side is not None:
+            main.wait_stream(side)
+        self.stage_name = "exchange.wait"
+        t0 = time.perf_counter()
+        for work in pending:
+            work.wait()
+        self._tick("exchange.wait", t0)
+        self.stage_name = "axis0"
+        return self._finish_step(state)
+
+    def _lowz_rows(self, p0, npl):
+        """The z sums of the owned planes [p0, p0 + npl) inside the low-k work area ([plane][y][kz])."""
+        return self.lowz[p0 * self.n * 7:(p0 + npl) * self.n * 7]
+
+    def _lowk_from_z(self, state, after):
+        """The y and x sums of the low-k modes from the z sums the z passes left (a few latency-bound launches on 15 MB):
+        on a side stream behind stream `after` (default: the current one), beside the exchange wait and the axis-0 pass."""
+        if not self.buf.is_cuda:
+            state["modes"] = self.ops.lowk_modes_from_z(self.lowz, self.n, self.rank * self.nloc, self.nloc)
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        self._side.wait_stream(after if after is not None else torch.cuda.current_stream())
+        with torch.cuda.stream(self._side):
+            state["modes"], state["side"] = self.ops.lowk_modes_from_z(self.lowz, self.n, self.rank * self.nloc, self.nloc), self._side
+
+    def _lowk_start(self, owned, state):
+        """The lowest shells from double-precision DFT sums of the rank's own (complete) planes
+        (device.power_sums_fused's low-k channel, split over the slabs): one more all-reduce, of 1183 complex numbers.
+        It only reads the planes: on the GPU it runs on a side stream beside the FFT chunks and their exchange."""
+        if not self.lowk or self.lowz is not None:       # (lowz: the z pass of every plane range leaves the z sums)
+            return
+        if owned.is_cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            state["side"] = self._side
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                state["modes"] = self.ops.lowk_modes(owned, self.n, self.rank * self.nloc)
+        else:
+            state["modes"] = self.ops.lowk_modes(owned, self.n, self.rank * self.nloc)
+
+    def _finish_step(self, state, block=None):
+        """Axis-0 pass + shell binning of the received block, all-reduces, low-k patch."""
+        import time
+        fused_fn = getattr(self.ops, "axis0_power_supported", None)
+        if fused_fn and fused_fn(self.n):
+            # axis-0 pass and shell binning in one kernel (the spectrum block is not written back)
+            self.ops.fft1d_axis0_power(self.block, 1.0 / float(self.n) ** 3, self.n, self.L, self.rank * self.nloc, self.psum,
+                                       5 if self.lowk else 0)
+        else:
+            blk = self.ops.fft1d_axis0(self.block, 1.0 / float(self.n) ** 3)
+            self.ops.power_bin(blk, self.n, self.L, self.i0, self.i1, self.psum)
+        modes, side = state["modes"], state["side"]
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            modes.record_stream(torch.cuda.current_stream())      # allocated under the side stream, used from here on
+        self.stage_name = "allreduce"
+        t0 = time.perf_counter()
+        comm_ready(self.group)
+        dist.all_reduce(self.psum, group=self.group)
+        if modes is not None:
+            modes_r = torch.view_as_real(modes)
+            dist.all_reduce(modes_r, group=self.group)
+            self.ops.lowk_patch(modes, self.n, self.L, self.psum)
+        self._tick("allreduce.enqueue", t0)
+        self.stage_name = "idle"
+        return self.ksum, self.psum, self.nmodes
+
     def wire_bytes(self):
         """What one step of this rank puts on the links: ghost planes to the two ring neighbours, its pieces of the
         half spectrum to the P - 1 peers, and the all-reduced sums."""
@@ -344,7 +711,7 @@ class SlabPowerPipeline:
             return {"ghost": 0, "transpose": 0, "allreduce": 0}
         esz = torch.empty((), dtype=self.ops.dtype).element_size() if hasattr(self.ops, "dtype") else 4
         return {"ghost": (self.gl + self.gh) * self.n * self.n * esz,
-                "transpose": (self.world - 1) * self.nloc * self.nloc * self.nz * 2 * esz,
+                "transpose": (self.world - 1) * self.nloc * self.nloc * self.nzp * 2 * esz,
                 "allreduce": (self.n // 2 - 1) * 8 + (1183 * 16 if self.lowk else 0)}
 
     def stage_ms(self, steps):
@@ -392,7 +759,11 @@ class SlabPowerPipeline:
             if packed_fn and packed_fn(planes, self.world):
                 # y pass stores in send order; the rank's own piece goes straight into the receive block
                 mine = self.block[self.rank * self.nloc + c * self.pc: self.rank * self.nloc + (c + 1) * self.pc]
-                o.fft2d_planes_packed(planes, spec, self.packed[c], self.world, self.rank, mine)
+                if self.lowz is not None:
+                    o.fft2d_planes_packed(planes, spec, self.packed[c], self.world, self.rank, mine,
+                                          lowz=self._lowz_rows(c * self.pc, self.pc))
+                else:
+                    o.fft2d_planes_packed(planes, spec, self.packed[c], self.world, self.rank, mine)
                 pending += exchange_chunk(self.packed[c], self.block, c, self.pc, self.nloc, self.group, self_done=True)
                 continue
             o.fft2d_planes(planes, spec)
@@ -409,9 +780,15 @@ class SlabPowerPipeline:
             return self.block
         return o.fft1d_axis0(self.block, 1.0 / float(self.n) ** 3)
 
-    def step(self, check=False):
+    def step(self, check=False, progress=False):
+        """One paint -> FFT -> P(k) step.  check: synchronise and raise if a deposit fell outside the ghost zone.
+        progress (staged, GPU): the streams report every completed schedule entry to pinned host memory (a 4-byte copy
+        each) for the watchdog - for the first, untimed step."""
+        if self.pipeline == "staged":
+            return self._step_staged(check, progress)
         import time
         t0 = time.perf_counter()
+        self.stage_name = "paint"
         owned = self.paint(check, fold=False)
         self._tick("paint.enqueue", t0)
         state = {"modes": None, "side": None}
@@ -421,40 +798,11 @@ class SlabPowerPipeline:
             if self.ghosts is not None:
                 self.ghosts.finish()
             self._tick("ghost.wait+add", t1)
-            if self.lowk:
-                # the lowest shells from double-precision DFT sums of the rank's own (complete) planes
-                # (device.power_sums_fused's low-k channel, split over the slabs): one more all-reduce, of 1183
-                # complex numbers.  It only reads the planes: on the GPU it runs on a side stream beside the FFT
-                # chunks and their exchange.
-                if owned.is_cuda:
-                    if self._side is None:
-                        self._side = torch.cuda.Stream()
-                    state["side"] = self._side
-                    self._side.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(self._side):
-                        state["modes"] = self.ops.lowk_modes(owned, self.n, self.rank * self.nloc)
-                else:
-                    state["modes"] = self.ops.lowk_modes(owned, self.n, self.rank * self.nloc)
+            self._lowk_start(owned, state)
 
-        fused_fn = getattr(self.ops, "axis0_power_supported", None)
-        if fused_fn and fused_fn(self.n):
-            # axis-0 pass and shell binning in one kernel (the spectrum block is not written back)
-            block = self.forward_fft(owned, last_pass=False, before_edge=finish_ghosts)
-            self.ops.fft1d_axis0_power(block, 1.0 / float(self.n) ** 3, self.n, self.L, self.rank * self.nloc, self.psum,
-                                       5 if self.lowk else 0)
-        else:
-            block = self.forward_fft(owned, before_edge=finish_ghosts)
-            self.ops.power_bin(block, self.n, self.L, self.i0, self.i1, self.psum)
-        modes, side = state["modes"], state["side"]
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
-            modes.record_stream(torch.cuda.current_stream())      # allocated under the side stream, used from here on
-        t0 = time.perf_counter()
-        comm_ready(self.group)
-        dist.all_reduce(self.psum, group=self.group)
-        if modes is not None:
-            modes_r = torch.view_as_real(modes)
-            dist.all_reduce(modes_r, group=self.group)
-            self.ops.lowk_patch(modes, self.n, self.L, self.psum)
-        self._tick("allreduce.enqueue", t0)
-        return self.ksum, self.psum, self.nmodes
+        self.stage_name = "fft2d+exchange"
+        self.forward_fft(owned, last_pass=False, before_edge=finish_ghosts)
+        if self.lowz is not None:
+            self._lowk_from_z(state, None)
+        self.stage_name = "axis0"
+        return self._finish_step(state)

@@ -235,12 +235,21 @@ def main():
         if rehearsal:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            import datetime
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=int(os.environ.get("ASTRILD_SLAB_TIMEOUT_S", "240"))))
 
     from astrild_amd import device as dev
     n = args.ngrid
     npside = args.npside or n
     L = 1000.0
+    wd = None
+    if use_slab:
+        # every wait of a multi-rank run is bounded: the watchdog ends THIS process (a fresh non-zero exit, never a re-exec)
+        # with the rank, its host stage, the last schedule entry its GPU completed and the host threads' stacks
+        from astrild_amd import slab
+        wd = slab.Watchdog(rank=rank)
+        wd.beat("pipeline construction (particles, geometry all-reduces)")
 
     def barrier():
         if use_slab:
@@ -250,7 +259,7 @@ def main():
     if not use_slab:
         leg = power_leg(dev, n, npside, L, args.window, args.order, args.dtype, args.method, args.steps, args.warmup)
     else:
-        leg = slab_leg(dev, dist, n, npside, L, args, world, barrier)
+        leg = slab_leg(dev, dist, n, npside, L, args, world, barrier, wd)
     ms_per_step = leg["ms_per_step"]
     npart_total = npside ** 3
     value = npart_total / (ms_per_step * 1e-3)
@@ -308,7 +317,12 @@ def main():
         # config D on N GPUs: lens planes sharded over the ranks (every rank takes part)
         del leg
         torch.cuda.empty_cache()
+        if wd is not None:
+            wd.watch(None)
+            wd.beat("kappa leg (planes sharded over the ranks)")
         kl = kappa_leg(dev, args.steps, args.warmup, group=dist.group.WORLD)
+        if wd is not None:
+            wd.beat("kappa leg done")
         if rank == 0:
             out["kappa"] = kl
     if rank == 0:
@@ -316,6 +330,8 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_slab:
         dist.destroy_process_group()
+    if wd is not None:
+        wd.stop()
 
 
 def _stage_table(prof, steps, npart_rank, ng_rank, esz, fused_bin, concurrent=()):
@@ -449,7 +465,7 @@ def power_leg(dev, n, npside, L, window, order, dtype, method, steps, warmup):
     return {"ms_per_step": ms_per_step, "roofline": roofline}
 
 
-def slab_leg(dev, dist, n, npside, L, args, world, barrier):
+def slab_leg(dev, dist, n, npside, L, args, world, barrier, wd):
     from astrild_amd import slab
     tdt = torch.float32 if args.dtype == "f32" else torch.float64
     esz = 4 if args.dtype == "f32" else 8
@@ -457,23 +473,41 @@ def slab_leg(dev, dist, n, npside, L, args, world, barrier):
     pipe = slab.SlabPowerPipeline(n, L, npside, window=args.window, dtype=tdt, seed=20240601,
                                   shuffle=(args.order == "shuffled"), route=(args.order == "shuffled"),
                                   ghost=3)     # base cells up to 3 planes (6 sigma of the jitter) outside the slab; checked below
-    pipe.step(check=True)             # once, untimed: no deposit may fall outside the ghost zone
+    # first contact with RCCL at N > 1: every wait below is bounded by the watchdog, which exits this process non-zero
+    # with the rank, its host stage and the last schedule entry its GPU completed (a fresh exit, never a re-exec)
+    wd.watch(pipe)
+    wd.beat("first step (checked, with progress markers)")
+    pipe.step(check=True, progress=True)      # once, untimed: no deposit may fall outside the ghost zone
+    torch.cuda.synchronize()
+    wd.beat("warm-up steps")
     for _ in range(args.warmup):
         pipe.step()
     barrier()
-    dev.profile_enable(True)
+    wd.beat("timed steps")
+    # the timed steps run WITHOUT the per-launch-site event pairs: a staged step makes ~45 small launches, and the events
+    # around them cost 0.2-0.4 ms per step (measured, scripts/perf_slab_staged.py); the per-site kernel times of the line
+    # come from `prof_steps` extra steps right after the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         sums = pipe.step()
     barrier()
     elapsed = time.perf_counter() - t0
+    wd.beat("timed steps done; profiled steps")
+    prof_steps = max(2, min(args.steps, 5))
+    pipe.stage_ms(args.steps)            # (reset the host-stage clock)
+    dev.profile_enable(True)
+    for _ in range(prof_steps):
+        pipe.step()
+    barrier()
     prof = dev.profile_report()
     dev.profile_enable(False)
+    prof = {k: (v[0], v[1] * args.steps / prof_steps) for k, v in prof.items()}      # scaled to the timed step count
+    wd.beat("profiled steps done")
     # diagnostics of the N > 1 line: every rank's own wall time and per-site kernel times, and what a step puts on
     # the links (so that the first run on real xGMI says where the time went)
     mine = {"rank": dist.get_rank(), "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "kernels_ms": {k: round(v[1] / args.steps, 4) for k, v in prof.items()},
-            "stage_ms": {k: round(v, 4) for k, v in pipe.stage_ms(args.steps).items()}}
+            "stage_ms": {k: round(v, 4) for k, v in pipe.stage_ms(prof_steps).items()}}
     per_rank = [None] * world
     dist.all_gather_object(per_rank, mine)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -497,8 +531,11 @@ def slab_leg(dev, dist, n, npside, L, args, world, barrier):
     }
     return {"ms_per_step": ms_per_step, "roofline": roofline,
             "diag": {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
-                     "wire_bytes_per_step_per_rank": pipe.wire_bytes(), "chunks": pipe.chunks,
-                     "nx_alloc": pipe.nx_alloc, "per_rank": per_rank}}
+                     "wire_bytes_per_step_per_rank": pipe.wire_bytes(), "pipeline": pipe.pipeline,
+                     "kernel_times_from": f"{prof_steps} steps run right after the timed region with the per-site events on "
+                                          "(the timed steps run without them)",
+                     "schedule": [list(e) for e in pipe.schedule] if pipe.schedule else None, "chunks": pipe.chunks,
+                     "spectrum_row_pitch": pipe.nzp, "nx_alloc": pipe.nx_alloc, "per_rank": per_rank}}
 
 
 if __name__ == "__main__":

@@ -271,16 +271,22 @@ int ast_fft_tile_supported(int dtype, size_t n);
 int ast_fft_tile_c2c(void* data_d, int dtype, size_t n, size_t elem_stride, size_t ncols, size_t batch,
                      size_t batch_stride, double scale, void* stream);
 
-/* ast_fft_tile_c2c over the k_y axis of a rank's local planes (planes_d: (nplanes, n, ncols) complex, left intact)
- * with ast_slab_pack fused into the stores: packed_d receives `parts` blocks of (nplanes, n / parts, ncols), the send
- * buffer of the slab transpose (pmesh's r2c transposes inside the reference's FFTPower call,
- * power_spectrum_3d.py:203-208).  parts: a power of two dividing n.  With self_out_d, part self_part (the rank's own
- * piece, which never travels) is written there instead, as (nplanes, n / parts, ncols); packed_d may then be NULL when
- * parts == 1. */
-int ast_fft_tile_c2c_packed(const void* planes_d, void* packed_d, int dtype, size_t n, size_t ncols, size_t nplanes,
-                            int parts, int self_part, void* self_out_d, double scale, void* stream);
+/* ast_fft_tile_c2c over the k_y axis of a rank's local planes (planes_d: (nplanes, n, pitch) complex of which the first
+ * ncols columns of every row are data; left intact) with ast_slab_pack fused into the stores: packed_d receives `parts`
+ * blocks of (nplanes, n / parts, pitch), the send buffer of the slab transpose (pmesh's r2c transposes inside the
+ * reference's FFTPower call, power_spectrum_3d.py:203-208).  parts: a power of two dividing n.  pitch >= ncols: a pitch
+ * that is a multiple of 16 keeps every row piece on whole 128-byte lines (the columns ncols .. pitch - 1 are neither
+ * read nor written).  With self_out_d, part self_part (the rank's own piece, which never travels) is written there
+ * instead, as (nplanes, n / parts, pitch); packed_d may then be NULL when parts == 1. */
+int ast_fft_tile_c2c_packed(const void* planes_d, void* packed_d, int dtype, size_t n, size_t ncols, size_t pitch,
+                            size_t nplanes, int parts, int self_part, void* self_out_d, double scale, void* stream);
 int ast_fft_tile_rows_r2c(const void* in_d, void* out_d, int dtype, size_t n, size_t nrows, size_t in_pitch,
                           size_t out_pitch, double scale, void* stream);
+/* ast_fft_tile_rows_r2c that also leaves the low-k channel's z sums of its rows (sum_z f e^{-2 pi i kz z / n}, kz <= 6,
+ * in double, from the samples the pass holds in registers anyway) at lowz_d: nrows x 7 complex128, [row][kz] - the
+ * first stage of ast_lowk_modes without its second read of the planes.  fp32, n in {256, 512, 1024}. */
+int ast_fft_tile_rows_r2c_lowz(const void* in_d, void* out_d, int dtype, size_t n, size_t nrows, size_t in_pitch,
+                               size_t out_pitch, double scale, void* lowz_d, void* stream);
 int ast_fft_tile_r2c_3d(const void* in_d, void* out_d, int dtype, size_t n, double scale, void* stream);
 /* The unnormalised inverse in three tile passes (x, y, z): out_d[x] = scale * sum_k spec_k e^{+ikx} for an (n, n, n/2+1)
  * half spectrum (fp32, n in {256, 512, 1024}).  spec_d is not modified; work_d (as large as spec_d) is scratch.
@@ -333,6 +339,10 @@ int ast_lowk_mode_count(void);
 int ast_lowk_shell_count(void);
 int ast_lowk_modes(const void* planes_d, int dtype, size_t n, size_t x0, size_t nx, int accumulate, void* modes_d,
                    void* work_d, size_t work_bytes, void* stream);
+/* The same from z sums that ast_fft_tile_rows_r2c_lowz has already left at the START of work_d ([plane][y][kz] for the
+ * nx planes x0 .. x0 + nx - 1, any plane ranges in any order): the y and x sums only, no read of the planes. */
+int ast_lowk_modes_from_z(size_t n, size_t x0, size_t nx, int accumulate, void* modes_d, void* work_d, size_t work_bytes,
+                          void* stream);
 /* sums_d[s] = L^3 sum w |modes / n^3|^2 over the modes of shell s (membership by `binning`), s < ast_lowk_shell_count(). */
 int ast_lowk_shell_sums(const void* modes_d, size_t n, double boxsize, int binning, double* sums_d, void* stream);
 

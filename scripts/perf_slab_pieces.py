@@ -36,15 +36,23 @@ dev.profile_enable(False)
 owned = buf[gl:gl + nloc]
 line("ghost add (2 x %d planes)" % gl, timeit(lambda: (ops.add_into(buf[gl:2 * gl], buf[:gl]), ops.add_into(buf[nloc:nloc + gl], buf[nloc + gl:]))))
 line("low-k modes of the owned planes (side stream in the pipeline)", timeit(lambda: ops.lowk_modes(owned, n, 0)))
-spec2d = ops.empty((nloc, n, nz), ops.cdtype)
+nzp = ops.spectrum_pitch(n, P) if not os.environ.get("SLAB_UNPADDED") else nz
+print(f"    spectrum row pitch {nzp} (n/2+1 = {nz})")
+spec2d = ops.empty((nloc, n, nzp), ops.cdtype)
 chunks = 4
 pc = nloc // chunks
-packed = ops.empty((chunks, P, pc, nloc, nz), ops.cdtype)
-block = ops.empty((n, nloc, nz), ops.cdtype)
+packed = ops.empty((chunks, P, pc, nloc, nzp), ops.cdtype)
+block = ops.empty((n, nloc, nzp), ops.cdtype)
 def ffts():
     for c in range(chunks):
         ops.fft2d_planes_packed(owned[c * pc:(c + 1) * pc], spec2d[c * pc:(c + 1) * pc], packed[c], P, 0, block[c * pc:(c + 1) * pc])
 line(f"z rows + y pass storing in send order, {chunks} chunks", timeit(ffts))
+dev.profile_enable(True)
+for _ in range(5):
+    ffts()
+torch.cuda.synchronize()
+print("    fft kernels:", {k: round(v[1] / 5, 3) for k, v in dev.profile_report().items()}, flush=True)
+dev.profile_enable(False)
 psum = ops.zeros((n // 2 - 1,), torch.float64)
 line("axis-0 pass fused with the block's shell binning", timeit(lambda: ops.fft1d_axis0_power(block, 1.0 / n ** 3, n, L, 0, psum, 5)))
 print(f"{'sum (the low-k line overlaps the FFT chunks)':55s} {total:7.3f} ms")

@@ -1,0 +1,85 @@
+"""One rank of P (default: rank 3 of 8) of the 1024^3 slab pipeline on ONE GPU with the communication stubbed out: the
+rank's real host sequence and every kernel it launches per step, staged (walk -> fold -> transform per stage) against
+bulk (paint everything, then transform), with the times at which each plane range is ready to be sent.
+    python scripts/perf_slab_staged.py [P] [rank] [ghost]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.distributed as dist
+from astrild_amd import device as dev, slab
+
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+RANK = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+GHOST = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+n, L = 1024, 1000.0
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+dist.init_process_group("gloo", rank=0, world_size=1)
+# the geometry of rank RANK of P, no exchange: sends / receives are dropped (the receive block keeps whatever it holds),
+# all-reduces act on the rank's own values
+dist_world, dist_rank = dist.get_world_size, dist.get_rank
+dist.get_world_size = lambda group=None: P
+dist.get_rank = lambda group=None: RANK
+dist.all_reduce = lambda t, *a, **k: None
+slab.exchange_planes = lambda *a, **k: []
+slab.GhostExchange.start = lambda self: None
+def _finish(self):
+    owned = self.buf[self.gl: self.gl + self.nloc]
+    self.ops.add_into(owned[self.nloc - self.gl:], self.from_right)
+    self.ops.add_into(owned[:self.gh], self.from_left)
+slab.GhostExchange.finish = _finish
+slab.comm_ready = lambda group=None: None
+
+
+def run(pipeline, rps=None, streams=2, reps=7):
+    os.environ["ASTRILD_SLAB_STREAMS"] = str(streams)
+    pipe = slab.SlabPowerPipeline(n, L, n, window="cic", dtype=torch.float32, ghost=GHOST, pipeline=pipeline, rows_per_stage=rps)
+    if pipe.ghosts is not None:
+        pipe.ghosts.from_left.zero_(); pipe.ghosts.from_right.zero_()
+    for _ in range(2):
+        pipe.step()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:                      # plain steps: what a rank does per step
+        a.record(); pipe.step(); b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in ev)
+    import time
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pipe.step()
+    host_ms = (time.perf_counter() - t0) / reps * 1e3       # host time to ENQUEUE a step (the GPU runs behind)
+    torch.cuda.synchronize()
+    ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    dev.profile_enable(True)             # the same with an event pair around every launch site
+    for a, b in ev2:
+        a.record(); pipe.step(); b.record()
+    torch.cuda.synchronize()
+    prof = dev.profile_report()
+    dev.profile_enable(False)
+    ms_prof = sorted(a.elapsed_time(b) for a, b in ev2)[reps // 2]
+    print(f"--- {pipeline} rows_per_stage={rps or 'auto'} streams={streams}: step (compute only, no exchange) median {ms[reps // 2]:.3f} ms, min {ms[0]:.3f}; "
+          f"buffer {pipe.nx_alloc} planes; with per-site profiling events {ms_prof:.3f} ms; host enqueue {host_ms:.3f} ms per step", flush=True)
+    print("    kernels per step:", {k: round(v[1] / reps, 3) for k, v in prof.items()}, " sum", round(sum(v[1] for v in prof.values()) / reps, 3))
+    print("    host enqueue ms per step:", {k: round(v, 3) for k, v in pipe.stage_ms(reps + 2).items()})
+    if pipeline == "staged":
+        pipe.trace = []
+        pipe.step()
+        torch.cuda.synchronize()
+        t0 = pipe.trace[0][1]
+        sent = 0
+        for entry, e in sorted(pipe.trace[1:], key=lambda t: t0.elapsed_time(t[1])):
+            tag = ""
+            if entry[0] == "fft":
+                sent += entry[2]
+                tag = f"   -> {sent}/{pipe.nloc} planes ready to send"
+            print(f"    {t0.elapsed_time(e):7.3f} ms  {entry}{tag}")
+        pipe.trace = None
+    del pipe
+    torch.cuda.empty_cache()
+
+
+run("bulk")
+for streams in (1, 2):
+    for rps in (None, 2, 3, 5):
+        run("staged", rps, streams)
+dist.destroy_process_group()

@@ -27,6 +27,25 @@ def main():
             np.save(out, res.cpu().numpy())
         else:
             assert res is None
+        if len(sys.argv) > 7 and sys.argv[7] == "stream":
+            # a stream of 2 P + 1 maps: rotating root, the per-map stages on the root's second stream
+            nmaps = 2 * world + 1
+            lp, sp = lensing.lens_plan(npix, np.deg2rad(20.0)), lensing.smooth_plan(npix)
+            keep = {}
+            tail = lensing.kappa_map_tail(lp, sp, 3.4, keep=keep)
+            stream = kappa_shard.MapStream(npix * npix)
+            pend = {}
+            for m in range(nmaps):
+                scale = 1.0 + 0.25 * m                       # every map its own weights
+                p = stream.push(planes, wnum[ids] * scale, wden[ids], tail)
+                assert (p is not None) == (rank == m % world)
+                if p is not None:
+                    pend[m] = p
+            stream.finish()
+            torch.cuda.synchronize()
+            np.savez(out + f".stream{rank}.npz", **{f"pdf{m}": p.result()[0] for m, p in pend.items()},
+                     **{f"map{m}": v[0].cpu().numpy() for m, v in keep.items()},
+                     **{f"a1_{m}": v[1].cpu().numpy() for m, v in keep.items()})
     finally:
         dist.destroy_process_group()
 

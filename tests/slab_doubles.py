@@ -25,6 +25,9 @@ class NumpySlabOps:
             raise RuntimeError("deposits fell outside the slab buffer")
         return out
 
+    def staged_paint(self, pos, mass, n, boxsize, window, out, x_start, nx_alloc, offset=0.0, owned=None, hint=None):
+        return StagedPaintDouble(self, pos, mass, n, boxsize, window, out, x_start, nx_alloc, offset, owned)
+
     def add_into(self, dst, src):
         dst += src
 
@@ -65,3 +68,54 @@ class NumpySlabOps:
     def route_scatter(self, pos, mass, n, boxsize, window, parts, counts):
         order = np.argsort(self._dest(pos, n, boxsize, window, parts), kind="stable")
         return pos[torch.from_numpy(order)].contiguous(), None if mass is None else mass[torch.from_numpy(order)].contiguous()
+
+
+class StagedPaintDouble:
+    """device.StagedPaint for the CPU tests: tile rows of ROW_PLANES buffer planes; a row's planes hold NaN until the
+    row is FOLDED (and folding asserts that the rows it depends on have been walked), so a pipeline that transforms
+    or sends a plane too early poisons its result."""
+    ROW_PLANES = 2
+
+    def __init__(self, ops, pos, mass, n, boxsize, window, out, x_start, nx_alloc, offset, owned):
+        self.ops, self.pos, self.mass, self.n, self.L, self.window = ops, pos, mass, n, boxsize, window.lower()
+        self.out, self.x_start, self.nx, self.offset, self.owned = out, x_start, nx_alloc, offset, owned
+        self.row_planes = self.ROW_PLANES
+        self.nrows_total = (nx_alloc + self.row_planes - 1) // self.row_planes
+        self.periodic = nx_alloc == n and x_start == 0
+        self.walked, self.folded, self.full = set(), set(), None
+        self.lost = False
+
+    def fold_needs(self, row):
+        rows = [row - 1, row] + ([row + 1] if self.window == "tsc" else [])
+        if self.periodic:
+            return sorted({r % self.nrows_total for r in rows})
+        return [r for r in rows if 0 <= r < self.nrows_total]
+
+    def group(self):
+        full = omesh.paint(self.pos.numpy(), None if self.mass is None else self.mass.numpy(), self.n, self.L, self.window)
+        planes = (self.x_start + np.arange(self.nx)) % self.n
+        self.lost = not np.isclose(full.sum(), full[planes].sum(), rtol=1e-12)
+        self.full = torch.from_numpy(full[planes])
+        if self.offset:
+            first, count = self.owned if self.owned is not None else (0, self.nx)
+            self.full[first:first + count] -= self.offset
+        self.out.fill_(float("nan"))
+        self.walked, self.folded = set(), set()
+
+    def walk(self, row0, nrows):
+        assert self.full is not None, "walk before group"
+        for r in range(row0, row0 + nrows):
+            assert r not in self.walked, "row walked twice"
+            self.walked.add(r)
+
+    def fold(self, row0, nrows):
+        for r in range(row0, row0 + nrows):
+            assert set(self.fold_needs(r)) <= self.walked, f"row {r} folded before its neighbours were walked"
+            assert r not in self.folded, "row folded twice"
+            self.folded.add(r)
+            a, b = r * self.row_planes, min((r + 1) * self.row_planes, self.nx)
+            self.out[a:b] = self.full[a:b]
+
+    def check(self):
+        if self.lost:
+            raise RuntimeError("deposits fell outside the slab buffer")

@@ -17,7 +17,8 @@ def main():
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         from astrild_amd import device as dev, slab
-        pipe = slab.SlabPowerPipeline(n, 1000.0, n, window="cic", dtype=dtype, seed=5, chunks=2)
+        pipe = slab.SlabPowerPipeline(n, 1000.0, n, window=os.environ.get("SLAB_TEST_WINDOW", "cic"), dtype=dtype, seed=5, chunks=2)
+        assert pipe.pipeline == os.environ.get("ASTRILD_SLAB_PIPELINE", "staged")
         ks, ps, nm = pipe.step(check=True)
         res = dev.finish_power(ks, ps, nm)
         if rank == 0:

@@ -234,6 +234,17 @@ def test_add_galaxy_shape_noise(lens, dev):
 
 @pytest.mark.parametrize("world,nplanes,npix", [(2, 9, 512), (4, 64, 4096)])
 def test_sharded_stack_ranks_share_one_gpu(hip, tmp_path, world, nplanes, npix):
+    _sharded_stack_ranks_share_one_gpu(tmp_path, world, nplanes, npix, False)
+
+
+@pytest.mark.parametrize("world,nplanes,npix", [(3, 10, 512), (4, 16, 2048)])
+def test_map_stream_ranks_share_one_gpu(hip, tmp_path, world, nplanes, npix):
+    """kappa_shard.MapStream with the real ops: 2 P + 1 maps, map m reduced onto rank m mod P, which smooths it, takes
+    its PDF and its deflection field on a second stream; against the single-GPU pipeline on the sequential stack."""
+    _sharded_stack_ranks_share_one_gpu(tmp_path, world, nplanes, npix, True)
+
+
+def _sharded_stack_ranks_share_one_gpu(tmp_path, world, nplanes, npix, stream):
     """Config D rehearsal: `world` processes on cuda:0 over gloo, plane p on rank p mod P, HipStackOps + the
     all-to-all chunk exchange of kappa_shard, against the single-GPU sequential stack (64 planes x 4096^2 fp64
     at the stated size).  Re-association only: <= P ulp of the sum of |planes|."""
@@ -248,8 +259,8 @@ def test_sharded_stack_ranks_share_one_gpu(hip, tmp_path, world, nplanes, npix):
         port = s.getsockname()[1]
     out = str(tmp_path / "stack.npy")
     worker = os.path.join(os.path.dirname(__file__), "kappa_gpu_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(nplanes), str(npix), out])
-             for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(nplanes), str(npix), out] +
+                              (["stream"] if stream else [])) for r in range(world)]
     assert [p.wait(timeout=600) for p in procs] == [0] * world
     got = np.load(out).reshape(npix, npix)
     planes = lensing.synth_kappa_planes(nplanes, npix)
@@ -258,6 +269,23 @@ def test_sharded_stack_ranks_share_one_gpu(hip, tmp_path, world, nplanes, npix):
     bound = sum(abs(float(wnum[p] / wden[p])) * float(planes[p].abs().max()) for p in range(nplanes))
     npt.assert_allclose(got, seq, rtol=0, atol=world * 2.0 ** -52 * bound)
     assert np.abs(got - seq).max() <= 1e-15 * np.abs(seq).max() * 4
+    if not stream:
+        return
+    lp, sp = lensing.lens_plan(npix, np.deg2rad(20.0)), lensing.smooth_plan(npix)
+    res = [np.load(out + f".stream{r}.npz") for r in range(world)]
+    for m in range(2 * world + 1):
+        r = m % world
+        assert f"map{m}" in res[r].files and all(f"map{m}" not in res[q].files for q in range(world) if q != r)
+        ref = lensing.kappa_stack(planes, wnum * (1.0 + 0.25 * m), wden)
+        lensing.convert_code_to_phy_units("kappa_2", ref)
+        sp.gaussian(ref, 3.4, "gaussianFFT")
+        counts, _ = lensing.histogram(ref, 100, density=True)
+        a1, _ = lp.alphas(ref)
+        scale = float(ref.abs().max())
+        npt.assert_allclose(res[r][f"map{m}"], ref.cpu().numpy(), rtol=0, atol=1e-13 * scale)
+        npt.assert_allclose(res[r][f"a1_{m}"], a1.cpu().numpy(), rtol=0, atol=1e-12 * float(a1.abs().max()))
+        # the PDF of a map that differs by 1e-16 may move a pixel across a bin edge
+        assert np.abs(res[r][f"pdf{m}"] - counts).sum() <= 4e-6 * counts.sum()
 
 
 @pytest.mark.parametrize("npix,conv,limits", [(64, "", None), (257, "normalize", None), (512, "", (-0.5, 1.5))])

@@ -83,39 +83,46 @@ def test_slab_pack_unpack_round_trip(hip):
     assert hip.ast_slab_pack(dev.ptr(x), dev.ptr(packed), 0, n0, n1, n2, 5, dev.stream()) < 0     # 12 % 5 != 0
 
 
-@pytest.mark.parametrize("n,nplanes,parts", [(256, 3, 4), (512, 2, 8), (256, 2, 1)])
-def test_y_pass_with_fused_pack_equals_y_pass_then_pack(hip, n, nplanes, parts):
+@pytest.mark.parametrize("n,nplanes,parts,pad", [(256, 3, 4, 0), (512, 2, 8, 0), (256, 2, 1, 0), (1024, 2, 8, 0),
+                                                  (1024, 3, 8, 15), (1024, 2, 32, 15), (512, 3, 4, 7), (256, 2, 16, 15)])
+def test_y_pass_with_fused_pack_equals_y_pass_then_pack(hip, n, nplanes, parts, pad):
     """ast_fft_tile_c2c_packed == ast_fft_tile_c2c followed by ast_slab_pack, bit for bit; the rank's own piece lands
-    in its separate destination and its slot of the send buffer stays untouched."""
+    in its separate destination and its slot of the send buffer stays untouched.  pad > 0: rows pitched to whole
+    128-byte lines (n = 1024: the 32-column tiles); the padding columns are neither read (NaN there) nor written."""
     from astrild_amd import device as dev, _lib
     torch.cuda.set_device(0)
     nz = n // 2 + 1
+    pitch = nz + pad
     g = torch.Generator(device="cuda").manual_seed(n + parts)
     x = torch.view_as_complex(torch.randn((nplanes, n, nz, 2), dtype=torch.float32, device="cuda", generator=g))
-    keep = x.clone()
     ref = x.clone()
     _lib.check(hip.ast_fft_tile_c2c(dev.ptr(ref), 0, n, nz, nz, nplanes, n * nz, 1.0, dev.stream()))
     ref_packed = torch.empty((parts, nplanes, n // parts, nz), dtype=torch.complex64, device="cuda")
     _lib.check(hip.ast_slab_pack(dev.ptr(ref), dev.ptr(ref_packed), 0, nplanes, n, nz, parts, dev.stream()))
-    packed = torch.empty_like(ref_packed)
-    _lib.check(hip.ast_fft_tile_c2c_packed(dev.ptr(x), dev.ptr(packed), 0, n, nz, nplanes, parts, -1, None, 1.0, dev.stream()))
-    assert torch.equal(x, keep)
-    assert torch.equal(packed, ref_packed)
+    xp = torch.full((nplanes, n, pitch), float("nan"), dtype=torch.complex64, device="cuda")
+    xp[:, :, :nz] = x
+    keep = xp.clone()
+    packed = torch.full((parts, nplanes, n // parts, pitch), 5.0, dtype=torch.complex64, device="cuda")
+    _lib.check(hip.ast_fft_tile_c2c_packed(dev.ptr(xp), dev.ptr(packed), 0, n, nz, pitch, nplanes, parts, -1, None, 1.0, dev.stream()))
+    assert torch.equal(torch.view_as_real(xp).nan_to_num(nan=-1.0), torch.view_as_real(keep).nan_to_num(nan=-1.0))
+    assert torch.equal(packed[..., :nz], ref_packed)
+    assert bool(torch.all(packed[..., nz:] == 5.0))
     me = parts - 1
-    packed2 = torch.full_like(ref_packed, 7.0)
-    mine = torch.empty((nplanes, n // parts, nz), dtype=torch.complex64, device="cuda")
-    _lib.check(hip.ast_fft_tile_c2c_packed(dev.ptr(x), dev.ptr(packed2), 0, n, nz, nplanes, parts, me, dev.ptr(mine), 1.0,
+    packed2 = torch.full_like(packed, 7.0)
+    mine = torch.full((nplanes, n // parts, pitch), 9.0, dtype=torch.complex64, device="cuda")
+    _lib.check(hip.ast_fft_tile_c2c_packed(dev.ptr(xp), dev.ptr(packed2), 0, n, nz, pitch, nplanes, parts, me, dev.ptr(mine), 1.0,
                                            dev.stream()))
-    assert torch.equal(mine, ref_packed[me])
+    assert torch.equal(mine[..., :nz], ref_packed[me]) and bool(torch.all(mine[..., nz:] == 9.0))
     assert torch.all(packed2[me] == 7.0)
     for s in range(parts):
         if s != me:
-            assert torch.equal(packed2[s], ref_packed[s])
-    assert hip.ast_fft_tile_c2c_packed(dev.ptr(x), dev.ptr(packed), 0, n, nz, nplanes, 3, -1, None, 1.0, dev.stream()) < 0
+            assert torch.equal(packed2[s][..., :nz], ref_packed[s])
+    assert hip.ast_fft_tile_c2c_packed(dev.ptr(xp), dev.ptr(packed), 0, n, nz, pitch, nplanes, 3, -1, None, 1.0, dev.stream()) < 0
+    assert hip.ast_fft_tile_c2c_packed(dev.ptr(xp), dev.ptr(packed), 0, n, nz, nz - 1, nplanes, parts, -1, None, 1.0, dev.stream()) < 0
     if parts == 1:
         only = torch.empty_like(mine)
-        _lib.check(hip.ast_fft_tile_c2c_packed(dev.ptr(x), None, 0, n, nz, nplanes, 1, 0, dev.ptr(only), 1.0, dev.stream()))
-        assert torch.equal(only, ref_packed[0])
+        _lib.check(hip.ast_fft_tile_c2c_packed(dev.ptr(xp), None, 0, n, nz, pitch, nplanes, 1, 0, dev.ptr(only), 1.0, dev.stream()))
+        assert torch.equal(only[..., :nz], ref_packed[0])
 
 
 def test_slab_pipeline_object_on_one_gpu_over_nccl(hip):
@@ -141,17 +148,27 @@ def test_slab_pipeline_object_on_one_gpu_over_nccl(hip):
         assert np.array_equal(res["modes"], ref["modes"])
         np.testing.assert_allclose(res["k"], ref["k"], rtol=1e-12)
         np.testing.assert_allclose(res["power"], ref["power"], rtol=2e-6)
+        # the staged order on the whole periodic grid (no ghosts): same bits in the buffer, same spectrum
+        assert pipe.pipeline == "bulk"
+        keep = pipe.buf.clone()
+        pipe2 = slab.SlabPowerPipeline(n, L, n, window="cic", dtype=torch.float32, seed=5, pipeline="staged", rows_per_stage=5)
+        ks2, ps2, nm2 = pipe2.step(check=True)
+        assert torch.equal(pipe2.buf, keep)
+        res2 = dev.finish_power(ks2, ps2, nm2)
+        np.testing.assert_allclose(res2["power"], res["power"], rtol=1e-12)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,dt,rtol", [(2, 64, "f64", 1e-9), (4, 256, "f32", 2e-6),
-                                             # config C rehearsal at its stated size: the 1024^3 problem on 2 / 4 ranks
-                                             # (fp32 slabs hold rho - mean, lowest shells from the low-k channel)
-                                             (2, 1024, "f32", 2e-6), (4, 1024, "f32", 2e-6)])
-def test_ranks_share_one_gpu_over_gloo(hip, tmp_path, world, n, dt, rtol):
-    """The real multi-rank data flow (ghost fold, chunked exchange, all-reduces) with HipSlabOps:
-    `world` processes, all on cuda:0, gloo instead of RCCL (one GPU here), against the single-GPU path."""
+@pytest.mark.parametrize("world,n,dt,rtol,pipeline,window", [
+    (2, 64, "f64", 1e-9, "staged", "cic"), (4, 256, "f32", 2e-6, "staged", "cic"), (3, 384, "f64", 1e-9, "staged", "tsc"),
+    (2, 64, "f64", 1e-9, "bulk", "cic"), (4, 256, "f32", 2e-6, "bulk", "tsc"),
+    # config C rehearsal at its stated size: the 1024^3 problem on 2 / 4 ranks (fp32 slabs hold rho - mean, lowest
+    # shells from the low-k channel), in the staged order (the default) and once in the bulk order
+    (2, 1024, "f32", 2e-6, "staged", "cic"), (4, 1024, "f32", 2e-6, "staged", "cic"), (4, 1024, "f32", 2e-6, "bulk", "cic")])
+def test_ranks_share_one_gpu_over_gloo(hip, tmp_path, world, n, dt, rtol, pipeline, window):
+    """The real multi-rank data flow (staged paint, ghost exchange, per-stage transform + exchange, all-reduces) with
+    HipSlabOps: `world` processes, all on cuda:0, gloo instead of RCCL (one GPU here), against the single-GPU path."""
     import os
     import socket
     import subprocess
@@ -163,13 +180,15 @@ def test_ranks_share_one_gpu_over_gloo(hip, tmp_path, world, n, dt, rtol):
         port = s.getsockname()[1]
     out = str(tmp_path / "rank0.npz")
     worker = os.path.join(os.path.dirname(__file__), "slab_gpu_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(n), out, dt]) for r in range(world)]
+    env = dict(os.environ, ASTRILD_SLAB_PIPELINE=pipeline, SLAB_TEST_WINDOW=window)
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(n), out, dt], env=env)
+             for r in range(world)]
     codes = [p.wait(timeout=900) for p in procs]
     assert codes == [0] * world
     got = np.load(out)
     dtype = torch.float64 if dt == "f64" else torch.float32
     pos = dev.synth_lattice_particles(n, n, 1000.0, seed=5, dtype=dtype)
-    ref = dev.paint_power_1d(pos, None, n, 1000.0, "cic")       # fp32: rho - mean grid, fused FFT + low-k channel
+    ref = dev.paint_power_1d(pos, None, n, 1000.0, window)       # fp32: rho - mean grid, fused FFT + low-k channel
     assert np.array_equal(got["modes"], ref["modes"])
     np.testing.assert_allclose(got["k"], ref["k"], rtol=1e-12)
     np.testing.assert_allclose(got["power"], ref["power"], rtol=rtol)

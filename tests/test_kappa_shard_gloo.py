@@ -169,3 +169,51 @@ def test_sharded_stack_on_a_subgroup_that_does_not_start_at_global_rank_0(tmp_pa
     expect = (planes[0] + planes[2] + planes[4]) + (planes[1] + planes[3])
     got = np.load(tmp_path / "sub.npy").reshape(NPIX, NPIX)
     np.testing.assert_array_equal(got, expect)
+
+
+def _stream_worker(rank, world, port, nplanes, nmaps, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from astrild_amd import kappa_shard
+        from tests.kappa_doubles import NumpyStackOps
+        planes = _planes(nplanes)
+        ids = kappa_shard.my_plane_ids(nplanes)
+        stream = kappa_shard.MapStream(NPIX * NPIX, ops=NumpyStackOps())
+        got = {}
+        for m in range(nmaps):
+            # every map of the stream has its own weights (the source plane moves): a mixed-up buffer would show
+            wn = np.linspace(0.5, 1.5, nplanes) * (m + 1)
+            wd = np.full(nplanes, 2.0)
+            res = stream.push([planes[i] for i in ids], wn[ids], wd[ids], tail=lambda mm, t: (mm, t.clone()))
+            assert (res is not None) == (rank == m % world) and stream.root_of(m) == m % world
+            if res is not None:
+                assert res[0] == m
+                got[m] = res[1].numpy()
+        stream.finish()
+        np.savez(os.path.join(out_dir, f"stream{rank}.npz"), **{str(k): v for k, v in got.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nplanes,nmaps", [(2, 7, 5), (3, 4, 7)])
+def test_map_stream_rotates_the_root_and_keeps_maps_apart(tmp_path, world, nplanes, nmaps):
+    """kappa_shard.MapStream: map m is reduced onto rank m mod P (rotating root, rotating result buffers) and handed to
+    the tail there; every map equals the rank-ordered sum of the ranks' weighted partial sums, bit for bit."""
+    mp.spawn(_stream_worker, args=(world, _free_port(), nplanes, nmaps, str(tmp_path)), nprocs=world, join=True)
+    planes = _planes(nplanes)
+    res = [np.load(tmp_path / f"stream{r}.npz") for r in range(world)]
+    for m in range(nmaps):
+        wn = np.linspace(0.5, 1.5, nplanes) * (m + 1)
+        expect = None
+        for r in range(world):
+            part = None
+            for p in range(r, nplanes, world):
+                q = planes[p] * wn[p] / 2.0
+                part = q.copy() if part is None else part + q
+            if part is None:
+                part = np.zeros_like(planes[0])
+            expect = part.copy() if expect is None else expect + part
+        for r in range(world):
+            assert (str(m) in res[r].files) == (r == m % world)
+        np.testing.assert_array_equal(res[m % world][str(m)].reshape(NPIX, NPIX), expect)

@@ -26,7 +26,7 @@ def _particles(n=N, nps=NPS):
     return omesh.lattice_particles(nps, n, L, seed=7, sigma_cells=0.5)
 
 
-def _worker(rank, world, port, window, out_dir, chunks=2, n=N, nps=NPS, ghost=2):
+def _worker(rank, world, port, window, out_dir, chunks=2, n=N, nps=NPS, ghost=2, pipeline="bulk", rows_per_stage=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -36,9 +36,19 @@ def _worker(rank, world, port, window, out_dir, chunks=2, n=N, nps=NPS, ghost=2)
         ppr = len(pos) // world
         mine = torch.from_numpy(np.ascontiguousarray(pos[rank * ppr:(rank + 1) * ppr]))
         pipe = slab.SlabPowerPipeline(n, L, nps, window=window, dtype=torch.float64, ghost=ghost,
-                                      ops=NumpySlabOps(), pos=mine, chunks=chunks)
-        owned = pipe.paint(check=True).clone()
+                                      ops=NumpySlabOps(), pos=mine, chunks=chunks, pipeline=pipeline,
+                                      rows_per_stage=rows_per_stage)
+        assert pipe.pipeline == pipeline
         ks, ps, nm = pipe.step(check=True)
+        ks, ps, nm = pipe.step(check=True)          # a second step reuses buffers, schedule and staged paint
+        owned = (pipe.buf[pipe.gl: pipe.gl + pipe.nloc] if world > 1 else pipe.buf).clone()
+        if pipeline == "staged" and world > 1:
+            kinds = [e[0] for e in pipe.schedule]
+            # the ghost exchange starts before the interior is walked, and planes leave before the ghosts are waited for
+            assert kinds.index("ghost_start") < len(kinds) - 1 - kinds[::-1].index("walk")
+            if pipe.nloc > pipe.gl + pipe.gh:
+                assert "fft" in kinds[kinds.index("ghost_start"):kinds.index("ghost_finish")]
+            assert sum(e[2] for e in pipe.schedule if e[0] == "fft") == pipe.nloc
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), owned=owned.numpy(), ks=ks.numpy(), ps=ps.numpy(),
                  nm=nm.numpy(), block=pipe.block.numpy())
     finally:
@@ -47,12 +57,16 @@ def _worker(rank, world, port, window, out_dir, chunks=2, n=N, nps=NPS, ghost=2)
 
 # world 8 is the driver's scaling run: 8 planes per rank, ghost 3 + 1 on each side, the interior chunks transformed and
 # sent while the ghost planes travel, the edge chunks after them
-@pytest.mark.parametrize("window,chunks,world,n,nps,ghost", [("cic", 1, 2, N, NPS, 2), ("cic", 4, 2, N, NPS, 2),
-                                                             ("tsc", 2, 2, N, NPS, 2), ("cic", 4, 8, 64, 32, 3),
-                                                             ("tsc", 8, 8, 64, 32, 3)])
-def test_slab_pipeline_ranks_match_single_process_oracle(tmp_path, window, chunks, world, n, nps, ghost):
+@pytest.mark.parametrize("window,chunks,world,n,nps,ghost,pipeline,rps", [
+    ("cic", 1, 2, N, NPS, 2, "bulk", None), ("cic", 4, 2, N, NPS, 2, "bulk", None), ("tsc", 2, 2, N, NPS, 2, "bulk", None),
+    ("cic", 4, 8, 64, 32, 3, "bulk", None), ("tsc", 8, 8, 64, 32, 3, "bulk", None),
+    # the staged order (group, ghost rows first, then walk -> fold -> transform -> send per stage): the double poisons
+    # every plane until its tile row has been folded
+    ("cic", 1, 2, N, NPS, 2, "staged", None), ("tsc", 1, 2, N, NPS, 2, "staged", 1), ("cic", 1, 2, N, NPS, 3, "staged", 2),
+    ("cic", 1, 8, 64, 32, 3, "staged", None), ("tsc", 1, 8, 64, 32, 3, "staged", 1), ("tsc", 1, 4, 64, 32, 2, "staged", 3)])
+def test_slab_pipeline_ranks_match_single_process_oracle(tmp_path, window, chunks, world, n, nps, ghost, pipeline, rps):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, window, str(tmp_path), chunks, n, nps, ghost), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, window, str(tmp_path), chunks, n, nps, ghost, pipeline, rps), nprocs=world, join=True)
     pos = _particles(n, nps)
     full = omesh.paint(pos, None, n, L, window)
     ref = offt.fftpower_1d(full, L)
@@ -128,3 +142,21 @@ def test_particle_routing_all_to_all_v(tmp_path, window, world):
         assert np.all((base >= r * nloc) & (base < (r + 1) * nloc))
         np.testing.assert_array_equal(res[r]["nm"], ref["modes"])
         np.testing.assert_allclose(res[r]["ps"] / res[r]["nm"], ref["power"].real, rtol=1e-9)
+
+
+def test_watchdog_ends_a_stuck_rank_with_its_stage(tmp_path):
+    """slab.Watchdog: a rank that stops making progress is ended (exit code 3, no re-exec) with its rank, the note of the
+    last beat and the pipeline's host stage on stderr; a rank that keeps beating is left alone."""
+    import subprocess
+    import sys
+    code = ("import sys, time, types; sys.path.insert(0, %r)\n"
+            "from astrild_amd import slab\n"
+            "wd = slab.Watchdog(timeout_s=1.0, rank=5)\n"
+            "wd.watch(types.SimpleNamespace(stage_name='exchange.wait', progress_report=lambda: 'entry 7 of 21'))\n"
+            "for _ in range(4):\n    time.sleep(0.5); wd.beat('warm-up')\n"
+            "print('alive', flush=True)\n"
+            "time.sleep(30)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert proc.returncode == 3
+    assert "alive" in proc.stdout
+    assert "rank 5" in proc.stderr and "warm-up" in proc.stderr and "exchange.wait" in proc.stderr and "entry 7 of 21" in proc.stderr
