@@ -1686,6 +1686,7 @@ column_fold_kernel(const T* __restrict__ rec, TileGeom g, T* __restrict__ grid, 
 struct SidePipe {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ev;
+    std::mutex run;          // held for a whole pipelined paint: one set of events and one side stream per device
 };
 SidePipe* side_pipe(int nevents) {
     static std::mutex mu;
@@ -2063,11 +2064,17 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
             SidePipe* sp = two_streams ? side_pipe(2 * g.ntx + 4) : nullptr;
             if (two_streams && !sp) { ast::set_error("ast_paint_tiled: no side stream"); return AST_ERR_HIP; }
             AST_PROF("paint_tiled.pipeline", s);
+            // two host threads painting on one device share the side stream and its events: the pipeline is serialised
+            // per device; and whatever happens in the loop, `s` is joined with the side stream before this
+            // function returns - the caller may free or reuse the workspace on `s` right after
+            std::unique_lock<std::mutex> pipe_lock;
+            if (two_streams) pipe_lock = std::unique_lock<std::mutex>(sp->run);
             const bool x_periodic = g.nx_alloc == g.n;
             const int m0 = x_periodic ? 1 : 0;                         // rows [0, m0) are held back to the end
             const uint32_t rs = (uint32_t)(g.nty * g.ntz);             // tiles per row
             int prev = m0, nev = 0;
             hipEvent_t walk_done[2] = {nullptr, nullptr};              // the last two walks on the side stream
+            auto chunk_loop = [&]() -> int {
             for (int k = 0; k < K; ++k) {
                 const size_t pb = (size_t)((double)k / K * (double)np) / per_interval * per_interval;
                 const size_t pe = k + 1 == K ? np : (size_t)((double)(k + 1) / K * (double)np) / per_interval * per_interval;
@@ -2095,7 +2102,19 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
                     prev = r;
                 }
             }
-            if (two_streams && walk_done[0]) AST_CHECK_HIP(hipStreamWaitEvent(s, walk_done[0], 0));
+            return AST_OK;
+            };
+            const int loop_rc = chunk_loop();
+            if (two_streams) {
+                if (loop_rc != AST_OK) {
+                    // an enqueue failed half way: whatever already runs on the side stream still reads the workspace
+                    (void)hipStreamSynchronize(sp->side);
+                    return loop_rc;
+                }
+                if (walk_done[0]) AST_CHECK_HIP(hipStreamWaitEvent(s, walk_done[0], 0));
+            } else if (loop_rc != AST_OK) {
+                return loop_rc;
+            }
             fold_pass();
         }
         AST_PROF("paint_tiled.overflow", s);

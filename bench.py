@@ -142,8 +142,17 @@ def bispectrum_leg(dev, n=512, width=8):
     import glob
     tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bispectrum.json")))
     if tf:                                    # PMC passes kept under profiles/ (scripts/refresh_profiles.sh): NOT measured by this run
-        traffic = {"GB_per_call": json.load(open(tf[-1])).get("numerator_corrected_GB_per_call"),
-                   "file": os.path.relpath(tf[-1], ROOT), "measured_in_this_run": False}
+        import hashlib
+        doc = json.load(open(tf[-1]))
+        now = {f: hashlib.sha256(open(os.path.join(ROOT, "astrild_amd", "csrc", f), "rb").read()).hexdigest()[:16]
+               for f in ("fft_tile.hip", "power_bin.hip")}
+        want = {"n": n, "shell_width": width, "shells": nsh, "triangle_bins": len(tri)}
+        # quoted only if the file was made for THIS grid, these shells and triangles and the kernel sources as they are now
+        same = doc.get("config") == want and doc.get("src_sha256_16") == now
+        traffic = {"GB_per_call": doc.get("numerator_corrected_GB_per_call") if same else None,
+                   "file": os.path.relpath(tf[-1], ROOT), "measured_in_this_run": False, "matches_this_run": same,
+                   "profiled": {"config": doc.get("config"), "src_sha256_16": doc.get("src_sha256_16")},
+                   "current": {"config": want, "src_sha256_16": now}}
     # per shell: the three passes of an UNPRUNED inverse transform (read + write of the half spectrum twice, read of it
     # and write of the real cube once = 24 B per cell) + one read of the cube by the triangle sums.  The transform
     # skips the parts of the spectrum that a shell leaves zero, so the bytes really moved are fewer.

@@ -2,7 +2,13 @@
 `bench.py --cpu-sample 0 --kappa 0 --legs 0 --steps 1 --warmup 0`, whose bispectrum leg calls the estimator twice (the
 first call also computes the cached triangle counts).  Corrected bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB (MI355X_MICROARCH.md).
 usage: pmc_bispec_json.py <fetch_dir> <write_dir> <out.json>"""
-import csv, glob, json, sys, collections
+import csv, glob, hashlib, json, os, sys, collections
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def src_sha(name):
+    return hashlib.sha256(open(os.path.join(ROOT, "astrild_amd", "csrc", name), "rb").read()).hexdigest()[:16]
 
 
 def per_kernel(d, counter):
@@ -34,5 +40,9 @@ for key, what in numerator.items():
     gb = (2 * f + w) * 1024 / 1e9 / CALLS
     out[key] = {"what": what, "launches_per_call": n / CALLS, "corrected_GB_per_call": round(gb, 3)}
     total += gb
-json.dump({"_doc": __doc__, "kernels": out, "numerator_corrected_GB_per_call": round(total, 2)}, open(sys.argv[3], "w"), indent=1)
+# what the file belongs to: bench.py's bispectrum leg (n = 512, shells of width 8 k_F, its triangle list) and the kernel
+# sources profiled - bench.py quotes the file only while all of them still match
+json.dump({"_doc": __doc__, "kernels": out, "numerator_corrected_GB_per_call": round(total, 2),
+           "config": {"n": 512, "shell_width": 8, "shells": 31, "triangle_bins": 75},
+           "src_sha256_16": {f: src_sha(f) for f in ("fft_tile.hip", "power_bin.hip")}}, open(sys.argv[3], "w"), indent=1)
 print("bispectrum numerator, corrected GB per call:", round(total, 2))

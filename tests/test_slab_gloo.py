@@ -160,3 +160,37 @@ def test_watchdog_ends_a_stuck_rank_with_its_stage(tmp_path):
     assert proc.returncode == 3
     assert "alive" in proc.stdout
     assert "rank 5" in proc.stderr and "warm-up" in proc.stderr and "exchange.wait" in proc.stderr and "entry 7 of 21" in proc.stderr
+
+
+def _subgroup_slab_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from astrild_amd import slab
+        from tests.slab_doubles import NumpySlabOps
+        sub = dist.new_group([1, 2])                      # every rank creates it; global ranks 1 and 2 use it
+        if rank == 0:
+            return
+        pos = _particles(N, NPS)
+        r = dist.get_rank(sub)
+        ppr = len(pos) // 2
+        mine = torch.from_numpy(np.ascontiguousarray(pos[r * ppr:(r + 1) * ppr]))
+        for pipeline in ("staged", "bulk"):
+            pipe = slab.SlabPowerPipeline(N, L, NPS, window="cic", dtype=torch.float64, ghost=2, ops=NumpySlabOps(), pos=mine,
+                                          chunks=2, group=sub, pipeline=pipeline)
+            ks, ps, nm = pipe.step(check=True)
+            np.savez(os.path.join(out_dir, f"sub_{pipeline}_{r}.npz"), ps=ps.numpy(), nm=nm.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_slab_pipeline_on_a_subgroup_that_does_not_start_at_global_rank_0(tmp_path):
+    """the ghost exchange and the chunk exchange address their peers by GLOBAL rank (P2POp's convention) - a
+    sub-group whose ranks are not 0..P-1 of the world runs the pipeline and gets the single-process spectrum."""
+    mp.spawn(_subgroup_slab_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    ref = offt.fftpower_1d(omesh.paint(_particles(N, NPS), None, N, L, "cic"), L)
+    for pipeline in ("staged", "bulk"):
+        for r in range(2):
+            res = np.load(tmp_path / f"sub_{pipeline}_{r}.npz")
+            assert np.array_equal(res["nm"], ref["modes"])
+            np.testing.assert_allclose(res["ps"] / res["nm"], ref["power"].real, rtol=1e-10)
