@@ -52,6 +52,33 @@ gradient_kernel(const double* __restrict__ in, double* __restrict__ out, int npi
     }
 }
 
+// SkyUtils.convert_deflection_to_shear (sky_utils.py:342-362): np.gradient(.., h) with numpy's default edge_order = 1 -
+// interior (f[i+1] - f[i-1]) / (2h), edges (f[1] - f[0]) / h and (f[n-1] - f[n-2]) / h - of both deflection components
+// along both axes, then the reference's expressions term by term:
+//   al11 = 1 - d0 a1, al12 = -d1 a1, al21 = -d0 a2, al22 = 1 - d1 a2, shear1 = 0.5 (al11 - al22), shear2 = 0.5 (al21 + al12)
+// (no contraction: the library is built with -ffp-contract=off, so the result equals numpy's bit for bit)
+__device__ inline double grad1(const double* __restrict__ f, size_t idx, size_t step, int k, int n, double h) {
+    if (n == 1) return 0.0;
+    if (k == 0) return (f[idx + step] - f[idx]) / h;
+    if (k == n - 1) return (f[idx] - f[idx - step]) / h;
+    return (f[idx + step] - f[idx - step]) / (2.0 * h);
+}
+__global__ void __launch_bounds__(256)
+deflection_to_shear_kernel(const double* __restrict__ a1, const double* __restrict__ a2, int npix, double h,
+                           double* __restrict__ g1, double* __restrict__ g2) {
+    const size_t total = (size_t)npix * npix;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int i = (int)(idx / npix), j = (int)(idx % npix);
+        const double al11 = 1.0 - grad1(a1, idx, (size_t)npix, i, npix, h);
+        const double al12 = -grad1(a1, idx, 1, j, npix, h);
+        const double al21 = -grad1(a2, idx, (size_t)npix, i, npix, h);
+        const double al22 = 1.0 - grad1(a2, idx, 1, j, npix, h);
+        g1[idx] = 0.5 * (al11 - al22);
+        g2[idx] = 0.5 * (al21 + al12);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 multiply_kernel(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -273,6 +300,16 @@ extern "C" int ast_dgd_filter(const double* img, double* out, double* work, int 
 
 // The resampling half of skimage.transform.resize(img, (nout, nout), anti_aliasing=True) as SkyArray.resize uses it
 // (sky_array.py:475-496; the Gaussian prefilter half is ast_gaussian_smooth mode 1 with sigma = (nin / nout - 1) / 2).
+extern "C" int ast_deflection_to_shear(const double* alpha1, const double* alpha2, int npix, double h, double* gamma1,
+                                       double* gamma2, void* stream) {
+    AST_CHECK_ARG(alpha1 && alpha2 && gamma1 && gamma2 && npix >= 2 && h > 0.0);
+    AST_CHECK_ARG(gamma1 != alpha1 && gamma1 != alpha2 && gamma2 != alpha1 && gamma2 != alpha2 && gamma1 != gamma2);
+    deflection_to_shear_kernel<<<ast::stream_grid((size_t)npix * npix, 256), 256, 0, ast::as_stream(stream)>>>(alpha1, alpha2, npix, h,
+                                                                                                           gamma1, gamma2);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
 extern "C" int ast_zoom_linear(const double* img, int nin, double* out, int nout, void* stream) {
     AST_CHECK_ARG(img && out && img != out && nout >= 1 && nout <= nin);
     hipStream_t s = ast::as_stream(stream);

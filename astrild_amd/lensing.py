@@ -185,6 +185,21 @@ def resize_antialiased(img, npix):
     return out
 
 
+def deflection_to_shear(alpha1, alpha2, h):
+    """(gamma1, gamma2) of SkyUtils.convert_deflection_to_shear (sky_utils.py:342-362): np.gradient of both deflection
+    components at uniform spacing h (the pixel size in the unit of alpha) and the reference's combinations of them."""
+    a1, a2 = (t if torch.is_tensor(t) else None for t in (alpha1, alpha2))
+    from .device import as_device
+    a1 = as_device(np.ascontiguousarray(alpha1, dtype=np.float64)) if a1 is None else a1.to(device="cuda", dtype=torch.float64).contiguous()
+    a2 = as_device(np.ascontiguousarray(alpha2, dtype=np.float64)) if a2 is None else a2.to(device="cuda", dtype=torch.float64).contiguous()
+    if a1.dim() != 2 or a1.shape[0] != a1.shape[1] or a1.shape != a2.shape:
+        raise ValueError("deflection_to_shear: two square maps of equal size are expected")
+    g1, g2 = torch.empty_like(a1), torch.empty_like(a1)
+    check(_lib.lib().ast_deflection_to_shear(ptr(a1), ptr(a2), int(a1.shape[0]), float(h), ptr(g1), ptr(g2), stream()),
+          "ast_deflection_to_shear")
+    return g1, g2
+
+
 def minmax(t):
     out = torch.empty(2, dtype=torch.float64, device=t.device)
     check(_lib.lib().ast_minmax(ptr(t), real_code(t), t.numel(), ptr(out), stream()), "ast_minmax")

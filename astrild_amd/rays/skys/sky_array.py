@@ -267,6 +267,23 @@ class SkyArray:
         self.data["defltx"] = alpha_2
         self.data["deflty"] = alpha_1
 
+    def convert_deflection_to_shear(self, on: Optional[Tuple[str, str]] = None, img: Optional[Tuple[np.ndarray, np.ndarray]] = None,
+                                    rtn: bool = False, orig_data: str = None) -> Tuple[np.ndarray, np.ndarray]:
+        """sky_array.py:820-849.  Returns (gamma_2, gamma_1) - the reference's order - or stores them as
+        data["gammax"], data["gammay"].  The reference hands ONE array to a two-array function (its body is unfinished);
+        here `img` / `on` name the pair (alpha_1, alpha_2), default the stored data["deflty"], data["defltx"]."""
+        assert self.quantity in ["alpha"], "Shear can only be calculated from the deflection angle map"
+        if on:
+            img = (self.data[on[0]], self.data[on[1]])
+        if img is None:
+            img = (self.data["deflty"], self.data["defltx"])
+        a1, a2 = (self._manage_img_data(m, orig_data) for m in img)
+        gamma_1, gamma_2 = SkyUtils.convert_deflection_to_shear(a1, a2, self._npix, self._opening_angle)
+        if rtn:
+            return gamma_2, gamma_1
+        self.data["gammax"] = gamma_2
+        self.data["gammay"] = gamma_1
+
     @staticmethod
     def _manage_img_data(img: np.ndarray, orig_data: str = None) -> np.ndarray:
         if orig_data == "shallow":

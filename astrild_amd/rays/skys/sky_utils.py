@@ -97,5 +97,15 @@ class SkyUtils:
         return _call_alphas(kappa, npix, angle_value(opening_angle, "rad", "deg"))
 
     @staticmethod
+    def convert_deflection_to_shear(alpha1: np.ndarray, alpha2: np.ndarray, npix: int, opening_angle
+                                    ) -> Tuple[np.ndarray, np.ndarray]:
+        """shear1, shear2 from the two deflection components (sky_utils.py:342-362).  The reference's body is marked TODO
+        (`coord` is undefined there): np.gradient is taken at the uniform pixel spacing opening_angle / npix in radians
+        (opening_angle: astropy Quantity or degrees), the unit convert_convergence_to_deflection_ctypes returns alpha in."""
+        h = angle_value(opening_angle, "rad", "deg") / int(npix)
+        g1, g2 = lensing.deflection_to_shear(alpha1, alpha2, h)
+        return g1.cpu().numpy(), g2.cpu().numpy()
+
+    @staticmethod
     def convert_convergence_to_potential(kappa: np.ndarray, npix: int, opening_angle) -> np.ndarray:
         return _call_cal_phi(kappa, npix, angle_value(opening_angle, "rad", "deg"))

@@ -606,6 +606,14 @@ int ast_hann_apodize(const double* img_d, double* out_d, int npix, void* stream)
  * this is the algorithm of scikit-image >= 0.19 (Gaussian prefilter + ndimage.zoom), restated. */
 int ast_zoom_linear(const double* img_d, int nin, double* out_d, int nout, void* stream);
 
+/* SkyUtils.convert_deflection_to_shear (rays/skys/sky_utils.py:342-362, called by SkyArray.convert_deflection_to_shear,
+ * sky_array.py:820-849): gamma1 = 0.5 ((1 - d0 alpha1) - (1 - d1 alpha2)), gamma2 = 0.5 (-d0 alpha2 - d1 alpha1) with
+ * d0 / d1 = np.gradient along axis 0 / 1 (edge_order 1) at uniform spacing h.  The reference's body is unfinished (its
+ * `coord` is undefined and the call site passes one array): h is the pixel size, opening_angle / npix, in the unit of
+ * alpha.  npix x npix fp64 maps, out of place; bit-identical to the numpy expressions. */
+int ast_deflection_to_shear(const double* alpha1_d, const double* alpha2_d, int npix, double h, double* gamma1_d,
+                            double* gamma2_d, void* stream);
+
 /* scipy.ndimage.gaussian_filter(img, sigma, order=(order0, order1), mode) as called by
  * Filters.gaussian_third_derivative_convolution (filters.py:260-304): mode 0 "reflect", 1 "nearest".
  * work_d: npix^2 + 2 (2 r + 1) doubles, r = int(4 sigma + 0.5). */

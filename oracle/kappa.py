@@ -332,6 +332,18 @@ def dgd_filter(img, theta_deg, theta_i_deg, direction, order=3):
     return np.multiply(w, img)
 
 
+def deflection_to_shear(alpha1, alpha2, h):
+    """SkyUtils.convert_deflection_to_shear, rays/skys/sky_utils.py:342-362, with the undefined `coord` read as the
+    uniform pixel spacing h (np.gradient's scalar spacing; edge_order 1, numpy's default).  PARITY UNPINNED: the
+    reference's body is marked TODO and no reference test holds a value."""
+    a1, a2 = np.asarray(alpha1, dtype=np.float64), np.asarray(alpha2, dtype=np.float64)
+    al11 = 1 - np.gradient(a1, h, axis=0)
+    al12 = -np.gradient(a1, h, axis=1)
+    al21 = -np.gradient(a2, h, axis=0)
+    al22 = 1 - np.gradient(a2, h, axis=1)
+    return 0.5 * (al11 - al22), 0.5 * (al21 + al12)
+
+
 def resize_antialiased(img, npix):
     """SkyArray.resize (sky_array.py:475-496) = skimage.transform.resize(img, (npix, npix), anti_aliasing=True), restated
     from scikit-image >= 0.19 (transform/_warps.py resize: Gaussian prefilter with sigma = (in / out - 1) / 2 in the

@@ -543,3 +543,27 @@ def test_lens_plan_at_the_reference_default_npix_8192(lens, dev, monkeypatch):
     for a, r in ((a1, r1), (a2, r2)):
         assert float((a - r).abs().max()) <= 1e-11 * float(r.abs().max())
     assert float(a1.abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("npix", [2, 37, 512])
+def test_deflection_to_shear_bit_exact(lens, dev, npix):
+    """ast_deflection_to_shear (SkyUtils.convert_deflection_to_shear, sky_utils.py:342-362): np.gradient with edge_order 1
+    and the reference's combinations, term by term - equal to the numpy restatement bit for bit, edges included;
+    SkyUtils / SkyArray wrappers return the reference's (gamma_2, gamma_1) order."""
+    rng = np.random.default_rng(npix)
+    a1, a2 = rng.standard_normal((npix, npix)) * 1e-3, rng.standard_normal((npix, npix)) * 1e-3
+    h = np.deg2rad(10.0) / npix
+    w1, w2 = ok.deflection_to_shear(a1, a2, h)
+    g1, g2 = lens.deflection_to_shear(a1, a2, h)
+    assert np.array_equal(g1.cpu().numpy(), w1) and np.array_equal(g2.cpu().numpy(), w2)
+    from astrild_amd.rays.skys import SkyArray, SkyUtils
+    s1, s2 = SkyUtils.convert_deflection_to_shear(a1, a2, npix, 10.0)
+    assert np.array_equal(s1, w1) and np.array_equal(s2, w2)
+    sky = SkyArray.from_array(a1.copy(), opening_angle=10.0, quantity="alpha", dir_in="")
+    r2, r1 = sky.convert_deflection_to_shear(img=(a1, a2), rtn=True)
+    assert np.array_equal(r1, w1) and np.array_equal(r2, w2)
+    sky.data["deflty"], sky.data["defltx"] = a1, a2
+    sky.convert_deflection_to_shear()
+    assert np.array_equal(sky.data["gammay"], w1) and np.array_equal(sky.data["gammax"], w2)
+    with pytest.raises(Exception):
+        lens.deflection_to_shear(a1, a2[:-1], h)

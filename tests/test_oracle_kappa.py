@@ -235,3 +235,16 @@ def test_resize_antialiased_border_is_mirror_not_reflect():
     npt.assert_allclose(got, mirror_resize_by_hand(m, 24), rtol=0, atol=1e-13)
     wrong = ndimage.zoom(ndimage.gaussian_filter(m, 1.5, mode="reflect"), (0.25, 0.25), order=1, mode="reflect", grid_mode=True)
     assert np.abs(got - wrong)[0].max() > 1e-3 and np.abs(got - wrong)[8:16, 8:16].max() < 1e-12
+
+
+def test_deflection_to_shear_known_answer():
+    """sky_utils.py:342-362 restated: for alpha = (a x, b y) + c (x y, 0) on the pixel lattice np.gradient is exact in the
+    interior (linear and bilinear fields), so gamma1 = 0.5 ((1 - d0 a1) - (1 - d1 a2)) and gamma2 = 0.5 (-d0 a2 - d1 a1)
+    are known in closed form; axis 0 is the first index."""
+    n, h = 24, 0.01
+    i, j = np.meshgrid(np.arange(n) * h, np.arange(n) * h, indexing="ij")
+    a1 = 0.3 * i + 0.2 * i * j          # d0 a1 = 0.3 + 0.2 j, d1 a1 = 0.2 i
+    a2 = -0.1 * j + 0.05 * i            # d0 a2 = 0.05,        d1 a2 = -0.1
+    g1, g2 = ok.deflection_to_shear(a1, a2, h)
+    npt.assert_allclose(g1, 0.5 * ((1 - (0.3 + 0.2 * j)) - (1 + 0.1)), rtol=0, atol=1e-12)
+    npt.assert_allclose(g2, 0.5 * (-0.05 - 0.2 * i), rtol=0, atol=1e-12)
