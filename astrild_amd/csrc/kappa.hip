@@ -67,7 +67,7 @@ kappa_stack_kernel(const T* const* __restrict__ planes, const double* __restrict
 // form: the quarter plane i, j <= Ncc/2 is evaluated, the rest mirrored with
 // the reference's parities.  which: 0 = alpha1, 1 = alpha2, 2 = phi.
 __global__ void __launch_bounds__(256)
-iso_kernel_build(int ncc, double dcell, int which, double* __restrict__ out) {
+iso_kernel_build(int ncc, double dcell, int which, double* __restrict__ out, double rcut) {
     const size_t total = (size_t)ncc * ncc;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const int h = ncc / 2;
@@ -78,7 +78,7 @@ iso_kernel_build(int ncc, double dcell, int which, double* __restrict__ out) {
         const double y = (double)jj * dcell + 0.5 * dcell;
         const double r = sqrt(x * x + y * y);
         double v = 0.0;
-        if (!(r > dcell * (double)ncc / 2.0)) {
+        if (!(r > rcut)) {                                     // (the reference: r > Dcell * Ncc / 2)
             if (which == 0) v = x / (M_PI * r * r);
             else if (which == 1) v = y / (M_PI * r * r);
             else v = 1.0 / M_PI * log(r);
@@ -287,8 +287,16 @@ gauss_periodic_y_kernel(const double* __restrict__ in, double* __restrict__ out,
 }  // namespace
 
 struct ast_lens_plan {
-    int nc = 0;
+    int nc = 0;                   // the map: nc x nc pixels of side bsz / nc
+    int ncf = 0;                  // the transform: (2 ncf)^2.  ncf = nc, or - EMBEDDED - the next power of two >= nc
     double bsz = 0.0;
+    // embedded plans (nc is not a size the hand-written passes cover): the convolution the reference computes on its
+    // (2 nc)^2 periodic grid only ever pairs pixel offsets |d| < nc (kappa is zero outside its corner), so it is the
+    // LINEAR convolution with K(d) = +-f((|d| + 1/2) dx), cut at r > nc dx - which any periodic grid of >= 2 nc - 1 points
+    // computes as well.  kappa is copied into the corner of a zeroed ncf x ncf array, the kernels are sampled on the
+    // (2 ncf)^2 grid with the MAP's dx and cut-off, and the nc x nc corner of the result is copied out.
+    double* kin = nullptr;        // ncf x ncf staging input (zero outside the nc x nc corner, for the plan's lifetime)
+    double* kout[2] = {nullptr, nullptr};
     ast_fft_plan* r2c = nullptr;
     ast_fft_plan* c2r = nullptr;
     double* pad = nullptr;        // (2nc)^2 real: kernel images (plan set-up), c2r output
@@ -354,6 +362,8 @@ extern "C" int ast_lens_plan_destroy(ast_lens_plan* p) {
     ast_fft_plan_destroy(p->rows_fwd_all);
     ast_fft_plan_destroy(p->rows_inv);
     if (p->pad) (void)hipFree(p->pad);
+    if (p->kin) (void)hipFree(p->kin);
+    for (auto* k : p->kout) if (k) (void)hipFree(k);
     if (p->pad_in) (void)hipFree(p->pad_in);
     if (p->prod2) (void)hipFree(p->prod2);
     if (p->spec) (void)hipFree(p->spec);
@@ -363,16 +373,36 @@ extern "C" int ast_lens_plan_destroy(ast_lens_plan* p) {
     return AST_OK;
 }
 
+__global__ void __launch_bounds__(256)
+copy2d_kernel(const double* __restrict__ in, size_t in_pitch, double* __restrict__ out, size_t out_pitch, int rows, int cols) {
+    const size_t total = (size_t)rows * cols;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t r = i / cols, c = i % cols;
+        out[r * out_pitch + c] = in[r * in_pitch + c];
+    }
+}
+
 extern "C" int ast_lens_plan_create(ast_lens_plan** out, int nc, double bsz) {
     AST_CHECK_ARG(out != nullptr && nc >= 1 && nc <= 16384 && bsz > 0.0);
     auto* p = new ast_lens_plan();
     p->nc = nc;
+    p->ncf = nc;
     p->bsz = bsz;
-    const size_t n2 = 2 * (size_t)nc, nh = n2 / 2 + 1;
+    // a size the hand-written rows and columns do not cover is embedded in the next power of two that they do
+    // (AST_LENS_NO_EMBED=1: rocFFT plans of the exact size instead, as in rounds 1-3)
+    if (!(ast_lens_cols_supported(2 * (size_t)nc) && ast_lens_rows_supported((size_t)nc)) && nc <= 8192 && !getenv("AST_LENS_NO_EMBED") &&
+        !getenv("AST_LENS_ROCFFT_2D") && !getenv("AST_LENS_ROCFFT_ROWS")) {
+        int f = 128;
+        while (f < nc) f *= 2;
+        p->ncf = f;
+    }
+    const bool embedded = p->ncf != nc;
+    const size_t n2 = 2 * (size_t)p->ncf, nh = n2 / 2 + 1;
     const size_t lens[2] = {n2, n2};
     int rc = AST_OK;
     p->cols = ast_lens_cols_supported(n2) != 0 && !getenv("AST_LENS_ROCFFT_2D");
-    p->rows = p->cols && ast_lens_rows_supported((size_t)nc) != 0 && !getenv("AST_LENS_ROCFFT_ROWS");
+    p->rows = p->cols && ast_lens_rows_supported((size_t)p->ncf) != 0 && !getenv("AST_LENS_ROCFFT_ROWS");
     p->split_cols = getenv("AST_LENS_SPLIT_COLS") != nullptr;
     if (p->rows) {
         // hand-written rows and columns: no rocFFT plan at all
@@ -391,6 +421,13 @@ extern "C" int ast_lens_plan_create(ast_lens_plan** out, int nc, double bsz) {
     if (e == hipSuccess && !p->rows) e = hipMemset(p->pad_in, 0, n2 * n2 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&p->spec, n2 * nh * sizeof(double2));
     if (e == hipSuccess) e = hipMalloc(&p->prod, n2 * nh * sizeof(double2));
+    if (e == hipSuccess && embedded) {
+        const size_t sq = (size_t)p->ncf * p->ncf * sizeof(double);
+        e = hipMalloc(&p->kin, sq);
+        if (e == hipSuccess) e = hipMemset(p->kin, 0, sq);
+        if (e == hipSuccess) e = hipMalloc(&p->kout[0], sq);
+        if (e == hipSuccess) e = hipMalloc(&p->kout[1], sq);
+    }
     if (e != hipSuccess) {
         ast::set_error("ast_lens_plan_create: hipMalloc -> %s", hipGetErrorString(e));
         ast_lens_plan_destroy(p);
@@ -403,13 +440,15 @@ extern "C" int ast_lens_plan_create(ast_lens_plan** out, int nc, double bsz) {
 // kernel spectrum `which`, built on first use and cached in the plan
 static int lens_kernel_spectrum(ast_lens_plan* p, int which, hipStream_t s) {
     if (p->kready[which]) return AST_OK;
-    const size_t n2 = 2 * (size_t)p->nc, nh = n2 / 2 + 1;
+    const size_t n2 = 2 * (size_t)p->ncf, nh = n2 / 2 + 1;
     if (!p->kspec[which]) AST_CHECK_HIP(hipMalloc(&p->kspec[which], n2 * nh * sizeof(double2)));
     const double dsx = p->bsz / (double)p->nc;
-    iso_kernel_build<<<ast::stream_grid(n2 * n2, 256), 256, 0, s>>>((int)n2, dsx, which, p->pad);
+    // sampled with the MAP's pixel size and cut at the map's side nc dx (= Dcell * Ncc / 2 of lensing_funcs.c:58) - for an
+    // embedded plan on the larger grid
+    iso_kernel_build<<<ast::stream_grid(n2 * n2, 256), 256, 0, s>>>((int)n2, dsx, which, p->pad, dsx * (double)p->nc);
     AST_CHECK_LAUNCH();
     if (p->rows) {
-        AST_FWD(ast_lens_rows_forward_full(p->pad, (size_t)p->nc, n2, p->kspec[which], nh, s));
+        AST_FWD(ast_lens_rows_forward_full(p->pad, (size_t)p->ncf, n2, p->kspec[which], nh, s));
         AST_FWD(ast_lens_cols_forward(p->kspec[which], n2, nh, nh, n2, s));
     } else if (p->cols) {
         AST_FWD(ast_fft_exec(p->rows_fwd_all, p->pad, p->kspec[which], s));
@@ -423,8 +462,8 @@ static int lens_kernel_spectrum(ast_lens_plan* p, int which, hipStream_t s) {
 
 // rows of the padded kappa -> p->spec (nc rows of nc + 1 complex; the column transform is the caller's)
 static int lens_rows_forward(ast_lens_plan* p, const double* kappa, hipStream_t s) {
-    const size_t n2 = 2 * (size_t)p->nc, nh = n2 / 2 + 1;
-    if (p->rows) return ast_lens_rows_forward(kappa, (size_t)p->nc, p->spec, nh, s);
+    const size_t n2 = 2 * (size_t)p->ncf, nh = n2 / 2 + 1;
+    if (p->rows) return ast_lens_rows_forward(kappa, (size_t)p->ncf, p->spec, nh, s);
     {
         AST_PROF("lens.zero_pad", s);
         pad_corner_kernel<<<ast::stream_grid((size_t)p->nc * p->nc, 256), 256, 0, s>>>(kappa, p->nc, p->pad_in);
@@ -435,10 +474,10 @@ static int lens_rows_forward(ast_lens_plan* p, const double* kappa, hipStream_t 
 
 // the row part after the columns: out = corner of the inverse row transforms of prod, scaled
 static int lens_rows_inverse(ast_lens_plan* p, double2* prod, double* out, hipStream_t s) {
-    const size_t n2 = 2 * (size_t)p->nc, nh = n2 / 2 + 1;
+    const size_t n2 = 2 * (size_t)p->ncf, nh = n2 / 2 + 1;
     if (p->rows) {                                                          // corner_matrix and out / (nx ny) * dx dy in the store
         const double dsx = p->bsz / (double)p->nc;
-        return ast_lens_rows_inverse(prod, nh, (size_t)p->nc, dsx * dsx / (double)(n2 * n2), out, s);
+        return ast_lens_rows_inverse(prod, nh, (size_t)p->ncf, dsx * dsx / (double)(n2 * n2), out, s);
     }
     AST_FWD(ast_fft_exec(p->rows_inv, prod, p->pad, s));                    // nc rows of 2nc reals
     AST_PROF("lens.crop_scale", s);
@@ -451,23 +490,45 @@ static int lens_rows_inverse(ast_lens_plan* p, double2* prod, double* out, hipSt
 // pass, one pass that finishes the forward transform, multiplies and starts the inverse(s), one inverse pass per output
 // (ast_lens_cols_convolve); AST_LENS_SPLIT_COLS=1 keeps the spectrum in memory instead (forward, then one inverse per
 // kernel with the product fused into its first pass: three array passes more for two outputs).
-static int lens_convolve_cols(ast_lens_plan* p, const double* kappa, const int* which, double* const* outs, int nmul, hipStream_t s) {
-    const size_t n2 = 2 * (size_t)p->nc, nh = n2 / 2 + 1;
+static int lens_convolve_cols(ast_lens_plan* p, const double* kappa_in, const int* which, double* const* outs_in, int nmul, hipStream_t s) {
+    const size_t n2 = 2 * (size_t)p->ncf, nh = n2 / 2 + 1;
+    const bool embedded = p->ncf != p->nc;
+    const double* kappa = kappa_in;
+    double* outs[2] = {outs_in[0], nmul == 2 ? outs_in[1] : nullptr};
+    if (embedded) {                                   // map -> corner of the zeroed ncf x ncf array; results into staging arrays
+        AST_PROF("lens.embed", s);
+        copy2d_kernel<<<ast::stream_grid((size_t)p->nc * p->nc, 256), 256, 0, s>>>(kappa_in, (size_t)p->nc, p->kin, (size_t)p->ncf, p->nc, p->nc);
+        AST_CHECK_LAUNCH();
+        kappa = p->kin;
+        outs[0] = p->kout[0];
+        outs[1] = p->kout[1];
+    }
+    struct Crop {                                     // (runs on every return path below)
+        ast_lens_plan* p; double* const* dst; int nmul; hipStream_t s; bool on;
+        int run() const {
+            if (!on) return AST_OK;
+            AST_PROF("lens.embed", s);
+            for (int m = 0; m < nmul; ++m)
+                copy2d_kernel<<<ast::stream_grid((size_t)p->nc * p->nc, 256), 256, 0, s>>>(p->kout[m], (size_t)p->ncf, dst[m], (size_t)p->nc, p->nc, p->nc);
+            AST_CHECK_LAUNCH();
+            return AST_OK;
+        }
+    } crop{p, outs_in, nmul, s, embedded};
     AST_FWD(lens_rows_forward(p, kappa, s));
     if (p->split_cols) {
-        AST_FWD(ast_lens_cols_forward(p->spec, n2, nh, nh, (size_t)p->nc, s));
+        AST_FWD(ast_lens_cols_forward(p->spec, n2, nh, nh, (size_t)p->ncf, s));
         for (int m = 0; m < nmul; ++m) {
-            AST_FWD(ast_lens_cols_inverse(p->spec, p->kspec[which[m]], p->prod, n2, nh, nh, (size_t)p->nc, s));
+            AST_FWD(ast_lens_cols_inverse(p->spec, p->kspec[which[m]], p->prod, n2, nh, nh, (size_t)p->ncf, s));
             AST_FWD(lens_rows_inverse(p, p->prod, outs[m], s));
         }
-        return AST_OK;
+        return crop.run();
     }
     if (nmul == 2 && !p->prod2) AST_CHECK_HIP(hipMalloc(&p->prod2, n2 * nh * sizeof(double2)));
     const void* muls[2] = {p->kspec[which[0]], p->kspec[which[nmul - 1]]};
     void* prods[2] = {p->prod, nmul == 2 ? (void*)p->prod2 : (void*)p->prod};
-    AST_FWD(ast_lens_cols_convolve(p->spec, n2, nh, nh, (size_t)p->nc, muls, prods, nmul, (size_t)p->nc, s));
+    AST_FWD(ast_lens_cols_convolve(p->spec, n2, nh, nh, (size_t)p->ncf, muls, prods, nmul, (size_t)p->ncf, s));
     for (int m = 0; m < nmul; ++m) AST_FWD(lens_rows_inverse(p, (double2*)prods[m], outs[m], s));
-    return AST_OK;
+    return crop.run();
 }
 
 static int lens_forward(ast_lens_plan* p, const double* kappa, hipStream_t s) {       // rocFFT 2-D route
@@ -488,7 +549,7 @@ static int lens_crop(ast_lens_plan* p, double2* prod, double* out, hipStream_t s
 }
 
 static int lens_convolve(ast_lens_plan* p, int which, double* out, hipStream_t s) {
-    const size_t n2 = 2 * (size_t)p->nc, nh = n2 / 2 + 1;
+    const size_t n2 = 2 * (size_t)p->ncf, nh = n2 / 2 + 1;
     {
         AST_PROF("lens.cmul", s);
         cmul_kernel<<<ast::stream_grid(n2 * nh, 256), 256, 0, s>>>(p->spec, p->kspec[which], p->prod, n2 * nh);
@@ -508,7 +569,7 @@ extern "C" int ast_kappa_to_alphas(ast_lens_plan* p, const double* kappa, double
         return lens_convolve_cols(p, kappa, which, outs, 2, s);
     }
     AST_FWD(lens_forward(p, kappa, s));
-    const size_t n2 = 2 * (size_t)p->nc, nh = n2 / 2 + 1;
+    const size_t n2 = 2 * (size_t)p->ncf, nh = n2 / 2 + 1;
     if (!p->prod2) AST_CHECK_HIP(hipMalloc(&p->prod2, n2 * nh * sizeof(double2)));
     {
         AST_PROF("lens.cmul", s);

@@ -233,10 +233,17 @@ triple_sum_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __r
 // equal fields broadcast).  Every field is read from HBM once instead of once per triangle it appears in (75
 // triangles over 31 shells at 512^3: 16.6 GB instead of 121 GB).  Products and sums in double, fixed order:
 // partial[block][thread], then triple_reduce_kernel adds blocks and parts in index order - deterministic.
+#ifndef TRI_ABLATE
+#define TRI_ABLATE 0          // perf experiments: 1 = no products (loads + LDS staging only), 2 = no global loads
+#endif
 constexpr int TRI_CHUNK = 256;
 constexpr int TRI_THREADS = 256;
 constexpr int TRI_BLOCKS = 2048;          // persistent workgroups (8 per CU), grid-stride over the chunks
-template <typename T>
+// PIPE (nfields <= TRI_PIPE_FIELDS): the NEXT chunk's values are loaded into registers before the current chunk's products
+// are formed, so the global loads run beside the LDS-bound product loop instead of before it (measured at 512^3, 31 fields,
+// 75 triangles: loads + staging alone 2.9 ms, products alone 3.1 ms, one after the other per workgroup 4.5 ms).
+constexpr int TRI_PIPE_FIELDS = 32;
+template <typename T, bool PIPE>
 __global__ void __launch_bounds__(TRI_THREADS)
 triple_sums_kernel(const T* const* __restrict__ fields, int nfields, const int* __restrict__ tri, int ntri, int parts,
                    size_t n, double* __restrict__ partial) {
@@ -251,29 +258,55 @@ triple_sums_kernel(const T* const* __restrict__ fields, int nfields, const int* 
     const int c_lo = part * per, c_hi = min(c_lo + per, TRI_CHUNK);
     double acc = 0.0;
     const size_t nchunks = (n + TRI_CHUNK - 1) / TRI_CHUNK;
-    for (size_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-        // unconditional loads in groups of 8 (a predicated load is a branch plus a full wait each: 31 serial memory
-        // latencies per chunk); cells past the end re-read the last one and are zeroed
-        const size_t cell = ch * TRI_CHUNK + threadIdx.x;
-        const size_t lc = cell < n ? cell : n - 1;
-        const T keep = cell < n ? (T)1 : (T)0;
-        for (int f0 = 0; f0 < nfields; f0 += 8) {
-            T tmp[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j)                 // the pointers come from memory: say that they are global, or the loads are flat
-                tmp[j] = ((const __attribute__((address_space(1))) T*)fields[min(f0 + j, nfields - 1)])[lc];
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (f0 + j < nfields) v[(f0 + j) * P + threadIdx.x] = tmp[j] * keep;
-        }
-        __syncthreads();
-        if (worker) {                                 // two-level sum: a chunk's terms first (keeps the round-off of the
+    typedef const __attribute__((address_space(1))) T* gptr_t;   // the pointers come from memory: say that they are global, or the loads are flat
+    auto products = [&]() {
+        if (worker && !(TRI_ABLATE & 1)) {            // two-level sum: a chunk's terms first (keeps the round-off of the
             double sub = 0.0;                         // long running sum at sqrt(chunks), not sqrt(cells))
 #pragma unroll 4
             for (int c = c_lo; c < c_hi; ++c) sub += (double)v[ia + c] * (double)v[ib + c] * (double)v[ic + c];
             acc += sub;
         }
-        __syncthreads();
+    };
+    if (PIPE) {
+        T reg[TRI_PIPE_FIELDS];
+        auto fetch = [&](size_t ch) {                 // unconditional loads: cells past the end re-read the last one and are zeroed
+            const size_t cell = ch * TRI_CHUNK + threadIdx.x;
+            const size_t lc = cell < n ? cell : n - 1;
+            const T keep = cell < n ? (T)1 : (T)0;
+#pragma unroll
+            for (int f = 0; f < TRI_PIPE_FIELDS; ++f)
+                reg[f] = ((TRI_ABLATE & 2) ? (T)(lc & 7) : ((gptr_t)fields[min(f, nfields - 1)])[lc]) * keep;
+        };
+        if ((size_t)blockIdx.x < nchunks) fetch(blockIdx.x);
+        for (size_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+#pragma unroll
+            for (int f = 0; f < TRI_PIPE_FIELDS; ++f)
+                if (f < nfields) v[f * P + threadIdx.x] = reg[f];
+            __syncthreads();
+            if (ch + gridDim.x < nchunks) fetch(ch + gridDim.x);      // in flight across the product loop
+            products();
+            __syncthreads();
+        }
+    } else {
+        for (size_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+            // unconditional loads in groups of 8 (a predicated load is a branch plus a full wait each: 31 serial memory
+            // latencies per chunk); cells past the end re-read the last one and are zeroed
+            const size_t cell = ch * TRI_CHUNK + threadIdx.x;
+            const size_t lc = cell < n ? cell : n - 1;
+            const T keep = cell < n ? (T)1 : (T)0;
+            for (int f0 = 0; f0 < nfields; f0 += 8) {
+                T tmp[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    tmp[j] = (TRI_ABLATE & 2) ? (T)(lc & 7) : ((gptr_t)fields[min(f0 + j, nfields - 1)])[lc];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (f0 + j < nfields) v[(f0 + j) * P + threadIdx.x] = tmp[j] * keep;
+            }
+            __syncthreads();
+            products();
+            __syncthreads();
+        }
     }
     partial[(size_t)blockIdx.x * TRI_THREADS + threadIdx.x] = worker ? acc : 0.0;
 }
@@ -449,21 +482,27 @@ extern "C" int ast_triple_product_sums(const void* const* fields, int nfields, i
     if (dtype == AST_F32) {
         static ast::PerDeviceOnce attr_once;
         if (attr_once.need()) {
-            AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&triple_sums_kernel<float>),
+            AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&triple_sums_kernel<float, false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&triple_sums_kernel<float, true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_once.mark();
         }
-        triple_sums_kernel<float><<<blocks, TRI_THREADS, lds, s>>>((const float* const*)fields, nfields, tri, ntri, parts, count,
-                                                                   (double*)scratch);
+        if (nfields <= TRI_PIPE_FIELDS && !getenv("AST_TRI_NO_PIPE"))
+            triple_sums_kernel<float, true><<<blocks, TRI_THREADS, lds, s>>>((const float* const*)fields, nfields, tri, ntri, parts, count,
+                                                                             (double*)scratch);
+        else
+            triple_sums_kernel<float, false><<<blocks, TRI_THREADS, lds, s>>>((const float* const*)fields, nfields, tri, ntri, parts, count,
+                                                                              (double*)scratch);
     } else {
         static ast::PerDeviceOnce attr_once;
         if (attr_once.need()) {
-            AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&triple_sums_kernel<double>),
+            AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&triple_sums_kernel<double, false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_once.mark();
         }
-        triple_sums_kernel<double><<<blocks, TRI_THREADS, lds, s>>>((const double* const*)fields, nfields, tri, ntri, parts, count,
-                                                                    (double*)scratch);
+        triple_sums_kernel<double, false><<<blocks, TRI_THREADS, lds, s>>>((const double* const*)fields, nfields, tri, ntri, parts, count,
+                                                                           (double*)scratch);
     }
     AST_CHECK_LAUNCH();
     triple_reduce_kernel<<<ntri, 256, 0, s>>>((const double*)scratch, blocks, ntri, parts, out);

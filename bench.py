@@ -25,6 +25,7 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+LEG_STEPS, LEG_WARMUP = 5, 2    # the secondary legs (shuffled / TSC / float64): enough steps for figures that do not wander
 
 
 def parse():
@@ -301,13 +302,13 @@ def main():
                                        "natural_cic": ("cic", "natural")}.items():
                 if (win, order) == (args.window, args.order):
                     continue
-                lg = power_leg(dev, n, npside, L, win, order, args.dtype, args.method, steps=3, warmup=1)
+                lg = power_leg(dev, n, npside, L, win, order, args.dtype, args.method, steps=LEG_STEPS, warmup=LEG_WARMUP)
                 legs[name] = {"ms_per_step": round(lg["ms_per_step"], 3), "particles_per_s": npart_total / (lg["ms_per_step"] * 1e-3),
                               "end_to_end_frac": lg["roofline"]["end_to_end"]["frac"],
                               "stages": {k: {"ms": v["ms"], "frac": v["frac"]} for k, v in lg["roofline"]["stages"].items()}}
             if args.dtype == "f32":
                 # the reference's own dtype: float64 particles and grid through the double-precision passes
-                lg = power_leg(dev, n, npside, L, "cic", "natural", "f64", args.method, steps=3, warmup=1)
+                lg = power_leg(dev, n, npside, L, "cic", "natural", "f64", args.method, steps=LEG_STEPS, warmup=LEG_WARMUP)
                 legs["natural_cic_f64"] = {"ms_per_step": round(lg["ms_per_step"], 3),
                                            "particles_per_s": npart_total / (lg["ms_per_step"] * 1e-3),
                                            "end_to_end_frac": lg["roofline"]["end_to_end"]["frac"], "dtype": "f64",

@@ -567,3 +567,40 @@ def test_deflection_to_shear_bit_exact(lens, dev, npix):
     assert np.array_equal(sky.data["gammay"], w1) and np.array_equal(sky.data["gammax"], w2)
     with pytest.raises(Exception):
         lens.deflection_to_shear(a1, a2[:-1], h)
+
+
+@pytest.mark.parametrize("nc", [37, 100, 129, 1000, 3000])
+def test_lens_plan_of_any_size_is_embedded_in_a_power_of_two(lens, dev, monkeypatch, nc):
+    """Map sizes the hand-written passes do not cover (the reference's own test map is 100^2, test_skyutils.py:113-125;
+    SkyArray.convert_convergence_to_deflection takes any npix): the convolution only pairs pixel offsets |d| < nc, so it
+    is computed on the next power-of-two grid with the map's pixel size and cut-off - against the oracle (nc <= 129),
+    against the exact-size rocFFT 2-D route (AST_LENS_NO_EMBED=1), and without a rocFFT kernel in the profile."""
+    bsz = np.deg2rad(7.0)
+    g = torch.Generator(device="cuda").manual_seed(nc)
+    kd = torch.randn((nc, nc), generator=g, device="cuda", dtype=torch.float64) * 0.01
+    monkeypatch.delenv("AST_LENS_NO_EMBED", raising=False)
+    plan = lens.LensPlan(nc, bsz)
+    dev.profile_enable(True)
+    a1, a2 = plan.alphas(kd)
+    phi = plan.phi(kd)
+    torch.cuda.synchronize()
+    sites = set(dev.profile_report())
+    dev.profile_enable(False)
+    assert sites and all(k.startswith("lens.") for k in sites), sites
+    assert a1.shape == (nc, nc) and phi.shape == (nc, nc)
+    monkeypatch.setenv("AST_LENS_NO_EMBED", "1")
+    ref = lens.LensPlan(nc, bsz)
+    r1, r2 = ref.alphas(kd)
+    rp = ref.phi(kd)
+    monkeypatch.delenv("AST_LENS_NO_EMBED")
+    for got, want in ((a1, r1), (a2, r2), (phi, rp)):
+        assert float((got - want).abs().max()) <= 1e-11 * float(want.abs().max())
+    if nc <= 129:
+        k = kd.cpu().numpy()
+        o1, o2 = ok.kappa0_to_alphas(k, nc, bsz)
+        npt.assert_allclose(a1.cpu().numpy(), o1, rtol=0, atol=1e-10 * abs(o1).max())
+        npt.assert_allclose(a2.cpu().numpy(), o2, rtol=0, atol=1e-10 * abs(o2).max())
+        npt.assert_allclose(phi.cpu().numpy(), ok.kappa0_to_phi(k, nc, bsz), rtol=0, atol=1e-10 * abs(rp.cpu().numpy()).max())
+    a1b, _ = plan.alphas(kd)
+    assert torch.equal(a1, a1b)
+    del plan, ref
