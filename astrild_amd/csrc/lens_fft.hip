@@ -763,7 +763,22 @@ col3_kernel(double2* __restrict__ data, const double2* __restrict__ twM, size_t 
     extern __shared__ double2 lds64[];
     double* shell = reinterpret_cast<double*>(lds64 + C * LINE);          // [NB + 1] when POWER
     const int c = threadIdx.x % C, t = threadIdx.x / C;
-    const unsigned tile = blockIdx.x % tiles_per_batch, b = blockIdx.x / tiles_per_batch;
+    // C * 16 B < 128 B (N = 1024: four columns): a workgroup touches HALF of every 128-byte line, the workgroup of the next
+    // tile the other half.  Workgroups go to the 8 XCDs round robin, so those two ran behind different L2s and every line
+    // crossed HBM twice (x pass: 8.6 GB read in 3.3 ms = 2.6 TB/s apparent).  COL3_XCD_PAIR: consecutive tiles are mapped
+    // to consecutive launch slots of ONE XCD, so the second one finds the line in that L2.
+#ifndef COL3_XCD_PAIR
+#define COL3_XCD_PAIR 1
+#endif
+    unsigned bid = blockIdx.x;
+    if (COL3_XCD_PAIR && C * sizeof(double2) < 128) {
+        const unsigned full = gridDim.x / 16 * 16;
+        if (bid < full) {
+            const unsigned xcd = bid % 8, slot = bid / 8;
+            bid = ((slot >> 1) * 8 + xcd) * 2 + (slot & 1);
+        }
+    }
+    const unsigned tile = bid % tiles_per_batch, b = bid / tiles_per_batch;
     const size_t c0 = (size_t)tile * C;
     const bool col_ok = c0 + c < ncols;
     double2* base = data + (size_t)b * batch_stride + min(c0 + c, ncols - 1);

@@ -18,10 +18,11 @@ for k in sorted(set(fetch) | set(write)):
     kernels[k] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "corrected_GB": round((2 * f + w) * 1024 / 1e9, 3), "launches": nf.get(k, 0)}
 paint = sum(v["corrected_GB"] for k, v in kernels.items()
             if any(t in k for t in ("tile_index_kernel", "tile_group_kernel", "column_deposit_kernel", "column_fold_kernel",
-                                    "overflow_deposit_kernel", "tile_deposit_kernel")))
+                                    "overflow_deposit_kernel", "tile_deposit_kernel", "scatter_level_a_kernel",
+                                    "scatter_level_b_kernel", "late_deposit_kernel", "z_seam_kernel")))
 out = {
     "_doc": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 bench.py --cpu-sample 0 --kappa 0 --bispec 0 "
-            "--legs 0 --steps 2 --warmup 1` on MI355X. Counter values are KiB per launch (mean over launches). Corrected bytes = "
+            "--legs 0 --steps 2 --warmup 1" + (" " + " ".join(sys.argv[4:]) if len(sys.argv) > 4 else "") + "` on MI355X. Counter values are KiB per launch (mean over launches). Corrected bytes = "
             "(2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B). Calibration: the "
             "synth kernel writes the 12.885 GB of positions exactly once (WRITE_SIZE exact); the index kernel reads them once and "
             "2*FETCH_SIZE*1024 matches for 4/12-byte-per-lane loads. For 8/16-byte-per-lane loads (fft_tile, fold) the x2 "
