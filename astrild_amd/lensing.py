@@ -487,34 +487,37 @@ def bench_kappa_pipeline(nplanes=64, npix=4096, steps=3, warmup=1, theta_deg=20.
         kappa_stack(planes, wnum, wden, out=out)
         convert_code_to_phy_units("kappa_2", out)
         sp.gaussian(out, sigma_px, "gaussianFFT")
-        pdf = PendingHistogram(out, 100, density=True)          # queued; fetched after kappa -> alpha has been launched,
-        a1, a2 = lp.alphas(out)                                  # so the host is never waiting on an idle GPU
-        return pdf.result(), a1, a2
+        pdf = PendingHistogram(out, 100, density=True)          # queued; the host fetches it ONE MAP LATER (below), after the
+        a1, a2 = lp.alphas(out)                                  # next map has been enqueued: it never waits on an idle GPU
+        return [(pdf, a1, a2)]
 
     def barrier():
         if world > 1:
             dist.barrier(group)
         torch.cuda.synchronize()
 
-    def finish(pending):
+    def collect(item):
+        (item[0] if isinstance(item, tuple) else item).result()
+
+    def run(count):
+        # one GPU: map m's PDF is collected after map m + 1 has been enqueued (the loops of simcoll.py:267-336 produce a
+        # stream of maps; with the fetch right behind its own map the step time depended on how fast the host could
+        # refill the queue: 3.4 - 5.2 ms per map from box to box on the same kernels).  P ranks: after all maps.
+        pend = []
+        for _ in range(count):
+            pend += step()
+            while world == 1 and len(pend) > 1:
+                collect(pend.pop(0))
         if world > 1:
             stream.finish()
-            for p in pending:
-                p.result()
+        for item in pend:
+            collect(item)
 
-    pend = []
-    for _ in range(warmup):
-        pend += step() if world > 1 else []
-    finish(pend)
+    run(warmup)
     barrier()
     dev.profile_enable(True)
     t0 = time.perf_counter()
-    pend = []
-    for _ in range(steps):
-        r = step()
-        if world > 1:
-            pend += r
-    finish(pend)
+    run(steps)
     barrier()
     dt = (time.perf_counter() - t0) / (steps * maps_per_step)
     prof = dev.profile_report()

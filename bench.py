@@ -178,7 +178,7 @@ def kappa_leg(dev, steps, warmup, group=None):
     """64 planes x 4096^2 fp64 -> stack -> Gaussian FFT smoothing -> kappa->alpha (config D);
     with a process group the planes are sharded over its ranks."""
     from astrild_amd import lensing
-    return lensing.bench_kappa_pipeline(nplanes=64, npix=4096, steps=max(2, min(steps, 5)), warmup=min(warmup, 2),
+    return lensing.bench_kappa_pipeline(nplanes=64, npix=4096, steps=max(3, min(steps, 10)), warmup=min(warmup, 2),
                                         group=group)
 
 
