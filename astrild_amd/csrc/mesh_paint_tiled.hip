@@ -125,7 +125,11 @@ __device__ inline uint32_t tile_of(T x, T y, T z, const TileGeom& g, uint32_t* _
     // 24-bit multiplies (v_mad_u32_u24, full rate; a 32-bit multiply-add compiles to the quarter-rate v_mad_u64_u32):
     // tile rows, columns and tiles per column are all below 2^24 (tiled_geometry checks)
     const uint32_t col = __umul24(bx / TX, (unsigned)g.nty) + (unsigned)cy / TY;
-    if (far && col_flags) atomicOr(&col_flags[col], 1u);
+    // (tested with a device-scope load first: all far particles of a lattice plane - half of its 2^20 particles under the
+    // TSC rule, whose nearest cell is n for the last half cell - raise the flags of the same 128 columns, and 500 000 atomics
+    // queueing at 128 addresses cost the TSC grouping 1.4 of its 5.3 ms at 1024^3; once a flag is up nobody else writes it)
+    if (far && col_flags && !(__hip_atomic_load(&col_flags[col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u))
+        atomicOr(&col_flags[col], 1u);
     return __umul24(col, (unsigned)g.ntz) + (unsigned)cz / TZ;
 }
 
@@ -354,7 +358,13 @@ tile_index_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t* __
 // global atomic per distinct tile and interval: run count in the high word, stray count in the low),
 // a miss list for hash collisions, overflow list for what does not fit a tile's segments.
 constexpr int MINPOP = 8;              // records with fewer particles would waste the walk's lanes
-constexpr int GROUP_ITERS = 3;         // tiles that can get a record per 32-particle window
+#ifndef GROUP_ITERS_N
+#define GROUP_ITERS_N 3
+#endif
+#ifndef GROUP_CAND
+#define GROUP_CAND 16, 8, 24, 0
+#endif
+constexpr int GROUP_ITERS = GROUP_ITERS_N;         // tiles that can get a record per 32-particle window
 constexpr uint32_t LREC_CAP = 512;     // records parked in LDS per interval (128 windows x up to 3; rest: slow path)
 struct GroupRec { uint32_t first, mask; };
 
@@ -486,7 +496,7 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
                 bool pending = live, stray = false;
 #pragma unroll
                 for (int it = 0; it < GROUP_ITERS; ++it) {
-                    constexpr int cand[3] = {16, 8, 24};
+                    constexpr int cand[4] = {GROUP_CAND};
                     const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, cand[it]);
                     const uint32_t k1 = (uint32_t)__builtin_amdgcn_readlane((int)key, cand[it] + 32);
                     const bool match = pending && key == (half ? k1 : k0);
