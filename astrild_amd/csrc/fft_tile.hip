@@ -137,6 +137,13 @@ struct ShellMask { const float2* src; long long lo2, hi2; int ky0 = 0; int pass 
 // PACK: the stores go to `pack.out` in the layout the slab transpose sends (what ast_slab_pack makes of the array): row
 // k_y of batch (plane) b lands in part k_y / c1 at ((part * nbatch + b) * c1 + k_y % c1) * pitch + column.
 // Part `self_part` (the rank's own piece, which never travels) goes to self_out instead, as (nbatch, c1, pitch).
+// SHELL BATCH (inverse passes of the bispectrum): one launch transforms up to SHELL_BATCH shells, blockIdx.y = shell - its own
+// work array and radii.  Thirty-one shells used to be 93 launches of 0.06-0.4 ms each, most of them far too small to fill
+// the chip to the end; batched, the shells of a launch fill each other's tails.
+constexpr int SHELL_BATCH = 8;
+struct ShellBatch { int count = 0; float2* work[SHELL_BATCH]; long long lo2[SHELL_BATCH], hi2[SHELL_BATCH]; };
+struct C2RBatch { int count = 0; const float2* in[SHELL_BATCH]; float* out[SHELL_BATCH]; int kmax[SHELL_BATCH]; };
+
 struct PackDst { float2* out = nullptr; unsigned c1_log2 = 0; unsigned nbatch = 0; float2* self_out = nullptr; unsigned self_part = ~0u; unsigned pitch = 0; };
 
 template <int R1, int R2, int C, bool POWER, bool INV = false, bool PACK = false>
@@ -146,7 +153,7 @@ __attribute__((amdgpu_waves_per_eu((POWER || C > 16) && R1 * R2 >= 1024 ? 4 : 1,
 strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, size_t elem_stride,
                    size_t ncols, size_t batch_stride, unsigned tiles_per_batch, float scale,
                    double* __restrict__ partial, const unsigned* __restrict__ edge_fall, ShellMask mask = ShellMask{nullptr, 0, 0},
-                   PackDst pack = PackDst{}) {
+                   PackDst pack = PackDst{}, ShellBatch sb = ShellBatch{}) {
     constexpr int N = R1 * R2;
     constexpr int NT = C * (R1 > R2 ? R1 : R2);
     constexpr int NB = N / 2 - 1;    // shells when POWER
@@ -162,6 +169,11 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
     double* shell = reinterpret_cast<double*>(lds + YN * C + N);    // [NB + 1] when POWER
     const unsigned tile = blockIdx.x % tiles_per_batch, b = blockIdx.x / tiles_per_batch;
     const size_t c0 = (size_t)tile * C;
+    if (INV && sb.count > 0) {                        // this workgroup's shell of the batch (uniform)
+        data = sb.work[blockIdx.y];
+        mask.lo2 = sb.lo2[blockIdx.y];
+        mask.hi2 = sb.hi2[blockIdx.y];
+    }
     if (INV && mask.hi2 > 0) {                        // pruning: block-uniform exits before any barrier
         const long long kb = (long long)((int)b > N / 2 ? (int)b - N : (int)b);
         const long long r2 = (long long)(c0 * c0) + (mask.pass == 0 ? kb * kb : 0);
@@ -545,7 +557,8 @@ rows_r2c_kernel(const float* __restrict__ in, float2* __restrict__ out, const fl
 template <int R1, int R2, int C>
 __global__ void __launch_bounds__(C * R2)
 rows_c2r_kernel(const float2* __restrict__ in, float* __restrict__ out, const float2* __restrict__ tw_g,
-                size_t nrows, size_t in_pitch, size_t out_pitch, float scale, int kmax) {
+                size_t nrows, size_t in_pitch, size_t out_pitch, float scale, int kmax, C2RBatch cb = C2RBatch{}) {
+    if (cb.count > 0) { in = cb.in[blockIdx.y]; out = cb.out[blockIdx.y]; kmax = cb.kmax[blockIdx.y]; }      // this workgroup's shell
     constexpr int M = R1 * R2, N = 2 * M;
     constexpr int NT = C * R2;
     constexpr int R2P = R2 + 1;
@@ -961,7 +974,7 @@ int launch_c2c(float2* data, const float2* tw, size_t elem_stride, size_t ncols,
 
 template <int R1, int R2, int C>
 int launch_c2c_inv(float2* data, const float2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride,
-                   float scale, ShellMask mask, hipStream_t s) {
+                   float scale, ShellMask mask, hipStream_t s, ShellBatch sb = ShellBatch{}) {
     constexpr int N = R1 * R2, NT = C * (R1 > R2 ? R1 : R2);
     const size_t lds = (size_t)(N * C + N) * sizeof(float2);
     static ast::PerDeviceOnce attr_once;
@@ -973,8 +986,8 @@ int launch_c2c_inv(float2* data, const float2* tw, size_t elem_stride, size_t nc
     const size_t tiles = (ncols + C - 1) / C;
     AST_CHECK_ARG(tiles * batch < 0x7fffffffull);
     AST_CHECK_ARG((size_t)(R2 - 1) * elem_stride + ncols < (1ull << 29));      // the kernel's 32-bit lane offsets
-    strided_c2c_kernel<R1, R2, C, false, true><<<(unsigned)(tiles * batch), NT, lds, s>>>(data, tw, elem_stride, ncols, batch_stride,
-                                                                                        (unsigned)tiles, scale, nullptr, nullptr, mask);
+    strided_c2c_kernel<R1, R2, C, false, true><<<dim3((unsigned)(tiles * batch), (unsigned)(sb.count > 0 ? sb.count : 1)), NT, lds, s>>>(
+        data, tw, elem_stride, ncols, batch_stride, (unsigned)tiles, scale, nullptr, nullptr, mask, PackDst{}, sb);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
@@ -1001,10 +1014,10 @@ int launch_c2c_pack(float2* data, const float2* tw, size_t elem_stride, size_t n
 }
 
 int dispatch_c2c_inv(size_t n, float2* d, const float2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride,
-                     float scale, ShellMask mask, hipStream_t s) {
-    if (n == 1024) return launch_c2c_inv<32, 32, 16>(d, tw, elem_stride, ncols, batch, batch_stride, scale, mask, s);
-    if (n == 512) return launch_c2c_inv<16, 32, 16>(d, tw, elem_stride, ncols, batch, batch_stride, scale, mask, s);
-    return launch_c2c_inv<16, 16, 16>(d, tw, elem_stride, ncols, batch, batch_stride, scale, mask, s);
+                     float scale, ShellMask mask, hipStream_t s, ShellBatch sb = ShellBatch{}) {
+    if (n == 1024) return launch_c2c_inv<32, 32, 16>(d, tw, elem_stride, ncols, batch, batch_stride, scale, mask, s, sb);
+    if (n == 512) return launch_c2c_inv<16, 32, 16>(d, tw, elem_stride, ncols, batch, batch_stride, scale, mask, s, sb);
+    return launch_c2c_inv<16, 16, 16>(d, tw, elem_stride, ncols, batch, batch_stride, scale, mask, s, sb);
 }
 
 template <bool POWER>
@@ -1043,7 +1056,7 @@ int launch_r2c(const float* in, float2* out, const float2* tw, size_t nrows, siz
 
 template <int R1, int R2, int C>
 int launch_c2r(const float2* in, float* out, const float2* tw, size_t nrows, size_t in_pitch, size_t out_pitch, float scale,
-               int kmax, hipStream_t s) {
+               int kmax, hipStream_t s, C2RBatch cb = C2RBatch{}) {
     constexpr int M = R1 * R2, N = 2 * M, NT = C * R2;
     constexpr int BUF = C * (R1 * (R2 + 1) > M + 1 ? R1 * (R2 + 1) : M + 1);
     const size_t lds = (size_t)(BUF + N) * sizeof(float2);
@@ -1055,7 +1068,8 @@ int launch_c2r(const float2* in, float* out, const float2* tw, size_t nrows, siz
     }
     const size_t blocks = (nrows + C - 1) / C;
     AST_CHECK_ARG(blocks < 0x7fffffffull);
-    rows_c2r_kernel<R1, R2, C><<<(unsigned)blocks, NT, lds, s>>>(in, out, tw, nrows, in_pitch, out_pitch, scale, kmax);
+    rows_c2r_kernel<R1, R2, C><<<dim3((unsigned)blocks, (unsigned)(cb.count > 0 ? cb.count : 1)), NT, lds, s>>>(in, out, tw, nrows, in_pitch, out_pitch,
+                                                                                                        scale, kmax, cb);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
@@ -1450,6 +1464,51 @@ extern "C" int ast_fft_tile_c2r_3d(const void* spec, void* work, void* out, int 
     if (n == 1024) return launch_c2r<16, 32, 16>((const float2*)work, (float*)out, tw, n * n, nz, n, (float)scale, kmax, s);
     if (n == 512) return launch_c2r<16, 16, 16>((const float2*)work, (float*)out, tw, n * n, nz, n, (float)scale, kmax, s);
     return launch_c2r<8, 16, 16>((const float2*)work, (float*)out, tw, n * n, nz, n, (float)scale, kmax, s);
+}
+
+// ast_fft_tile_c2r_3d for up to SHELL_BATCH shells of ONE spectrum in three launches (x, y, z with blockIdx.y = shell):
+// works[i] / outs[i] are shell i's scratch spectrum and real output (host arrays of device pointers), m_lo[i] < m_hi[i] its
+// radii.  Same arithmetic per shell as the single call (bit-identical outputs).
+extern "C" int ast_fft_tile_c2r_3d_batch(const void* spec, void* const* works, void* const* outs, int dtype, size_t n,
+                                         const int* m_lo, const int* m_hi, int count, double scale, int passes, void* stream) {
+    AST_CHECK_ARG(spec != nullptr && works != nullptr && outs != nullptr && m_lo != nullptr && m_hi != nullptr);
+    AST_CHECK_ARG(passes >= 1 && passes <= 3);
+    AST_CHECK_ARG(count >= 1 && count <= SHELL_BATCH);
+    AST_CHECK_ARG(ast_fft_tile_supported(dtype, n));
+    const float2* tw = g_tw.get((int)n);
+    if (!tw) { ast::set_error("ast_fft_tile_c2r_3d_batch: twiddle table allocation failed"); return AST_ERR_HIP; }
+    hipStream_t s = ast::as_stream(stream);
+    const size_t nz = n / 2 + 1;
+    ShellBatch sb;
+    C2RBatch cb;
+    sb.count = cb.count = count;
+    for (int i = 0; i < SHELL_BATCH; ++i) {
+        const int j = i < count ? i : count - 1;                  // (unused slots repeat the last shell)
+        AST_CHECK_ARG(works[j] != nullptr && outs[j] != nullptr && works[j] != spec && works[j] != outs[j]);
+        AST_CHECK_ARG(m_lo[j] >= 0 && m_hi[j] > m_lo[j]);
+        sb.work[i] = (float2*)works[j];
+        sb.lo2[i] = (long long)m_lo[j] * m_lo[j];
+        sb.hi2[i] = (long long)m_hi[j] * m_hi[j];
+        cb.in[i] = (const float2*)works[j];
+        cb.out[i] = (float*)outs[j];
+        cb.kmax[i] = (size_t)m_hi[j] < nz ? m_hi[j] : (int)nz;
+    }
+    for (int i = 0; i < count; ++i)
+        for (int k = 0; k < i; ++k) AST_CHECK_ARG(works[i] != works[k] && outs[i] != outs[k]);
+    if (passes & 1) {
+        AST_PROF("fft_tile.c2c_inv", s);
+        ShellMask mx{(const float2*)spec, 0, 1};                 // radii come from the batch; hi2 > 0 switches the pruning on
+        int rc = dispatch_c2c_inv(n, sb.work[0], tw, n * nz, nz, n, nz, 1.0f, mx, s, sb);
+        if (rc != AST_OK) return rc;
+        ShellMask my{nullptr, 0, 1, 0, 1};
+        rc = dispatch_c2c_inv(n, sb.work[0], tw, nz, nz, n, n * nz, 1.0f, my, s, sb);
+        if (rc != AST_OK) return rc;
+    }
+    if (!(passes & 2)) return AST_OK;
+    AST_PROF("fft_tile.rows_c2r", s);
+    if (n == 1024) return launch_c2r<16, 32, 16>(cb.in[0], cb.out[0], tw, n * n, nz, n, (float)scale, cb.kmax[0], s, cb);
+    if (n == 512) return launch_c2r<16, 16, 16>(cb.in[0], cb.out[0], tw, n * n, nz, n, (float)scale, cb.kmax[0], s, cb);
+    return launch_c2r<8, 16, 16>(cb.in[0], cb.out[0], tw, n * n, nz, n, (float)scale, cb.kmax[0], s, cb);
 }
 
 // The last pass of a slab-decomposed transform fused with the shell binning: `block_d` is a rank's (n, nloc, pitch)
