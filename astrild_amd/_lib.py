@@ -38,7 +38,7 @@ SIGNATURES = {
     "ast_paint": (_i, [_i, _i, _vp, _vp, _sz, _i, _d, _d, _i, _i, _vp, _vp, _d, _vp]),
     "ast_paint_tiled_workspace_bytes": (_sz, [_i, _i, _sz, _i, _i, _i]),
     "ast_paint_tiled": (_i, [_i, _i, _vp, _vp, _sz, _i, _d, _d, _i, _i, _vp, _vp, _sz, _vp, _i, _d, _d, _i, _i, _d, _vp]),
-    "ast_paint_tiled_stage": (_i, [_i, _i, _vp, _vp, _sz, _i, _d, _d, _i, _i, _vp, _vp, _sz, _vp, _i, _d, _d, _i, _i, _d, _i, _i, _i, _vp]),
+    "ast_paint_tiled_stage": (_i, [_i, _i, _vp, _vp, _sz, _i, _d, _d, _i, _i, _vp, _vp, _sz, _vp, _i, _d, _d, _i, _i, _d, _i, _i, _i, _i, _i, _vp]),
     "ast_deflection_to_shear": (_i, [_vp, _vp, _i, _d, _vp, _vp, _vp]),
     "ast_paint_tile_rows": (_i, [_i]),
     "ast_paint_tile_row_planes": (_i, []),

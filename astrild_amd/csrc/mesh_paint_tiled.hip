@@ -422,7 +422,7 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
                   unsigned long long* __restrict__ fill64, GroupRec* __restrict__ recs, uint32_t rcap,
                   T* __restrict__ strays, uint32_t scap, uint32_t* __restrict__ ovf,
                   unsigned long long* __restrict__ ovf_count, uint32_t* __restrict__ col_flags,
-                  unsigned long long* dropped, uint32_t closed_lo, uint32_t closed_n) {
+                  unsigned long long* dropped, uint32_t closed_lo, uint32_t closed_n, uint32_t closed_mod = 0u) {
     __shared__ uint32_t skey[AGG_SLOTS], srun[AGG_SLOTS], sstray[AGG_SLOTS], sroom_run[AGG_SLOTS], sroom_stray[AGG_SLOTS];
     __shared__ unsigned long long sdst_run[AGG_SLOTS], sdst_stray[AGG_SLOTS];
     // group records: first, mask, tile key (phase 2 turns the key into slot << 16 | offset, DST_NONE = placed already)
@@ -484,8 +484,16 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
                 uint32_t key = tile_of<T, W, PLAINX>(x[u], y[u], z[u], g, col_flags);
                 if (!valid) key = 0xffffffffu;
                 if (!PLAINX && valid && key == 0xffffffffu) ++ndrop;
-                if (key - closed_lo < closed_n) {                   // (closed_n = 0: never; the dead key is far above any tile id)
+                // closed tiles: [closed_lo, closed_lo + closed_n), taken modulo closed_mod tiles when that is set (slab
+                // buffers, staged paint: the rows that hold the ghost planes are closed first, then rows 0, 1, ... - one
+                // range that wraps around the end of the buffer).  A particle for a closed tile of a STAGED paint cannot
+                // be deposited any more - its rows may have left the GPU already: it is counted as dropped, which is what
+                // tells the caller that the input was not ordered as promised.
+                uint32_t dkey = key - closed_lo;
+                if (!PLAINX && closed_mod && key < closed_lo) dkey += closed_mod;
+                if (dkey < closed_n && key != 0xffffffffu) {       // (closed_n = 0: never)
                     place_late_slow(p, ovf, ovf_count);
+                    if (!PLAINX && closed_mod) ++ndrop;
                     key = 0xffffffffu;
                 }
                 const bool live = key != 0xffffffffu;
@@ -1717,6 +1725,7 @@ SidePipe* side_pipe(int nevents) {
 // ast_paint_tiled_stage: which part of the single-pass overwrite paint a call runs (tile rows [row0, row0 + nrows))
 struct StageSel {
     int stage = AST_PAINT_STAGE_ALL, row0 = 0, nrows = 0;
+    int closed_row0 = 0, closed_nrows = 0;        // GROUP_PART: tile rows already walked (a range that may wrap around)
 };
 
 // How the single-pass overwrite paint is cut up: z-segments per column (walk workgroups = columns x nseg) and, with
@@ -1881,7 +1890,7 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
                         record_bytes(W == 3 ? AST_WIN_TSC : AST_WIN_CIC, g, sizeof(T), flags),
                         seam_bytes(W == 3 ? AST_WIN_TSC : AST_WIN_CIC, g, np, sizeof(T), flags));
     // ovf_count, col_flags, tile_count, tile_fill and fill64 are contiguous at the front of the workspace
-    if (sel.stage == AST_PAINT_STAGE_ALL || sel.stage == AST_PAINT_STAGE_GROUP)
+    if (sel.stage == AST_PAINT_STAGE_ALL || sel.stage == AST_PAINT_STAGE_GROUP || sel.stage == AST_PAINT_STAGE_RESET)
         AST_CHECK_HIP(hipMemsetAsync(w.ovf_count, 0, (size_t)((char*)w.tile_off - (char*)w.ovf_count), s));
     const size_t per_interval = (size_t)256 * IDX_UNROLL * AGG_TRIPS;
     const size_t nintervals = (np + per_interval - 1) / per_interval;
@@ -1976,7 +1985,7 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
     }
         return AST_OK;
     };
-    auto group_pass = [&](size_t pb, size_t pe, uint32_t closed_lo, uint32_t closed_n) {
+    auto group_pass = [&](size_t pb, size_t pe, uint32_t closed_lo, uint32_t closed_n, uint32_t closed_mod = 0u) {
         AST_PROF("paint_tiled.fill", s);
         const size_t nint = (pe - pb + per_interval - 1) / per_interval;
         const unsigned gg = (unsigned)(nint > want ? want : nint);
@@ -1985,7 +1994,7 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
                                                              w.ovf, w.ovf_count, w.col_flags, dropped, closed_lo, closed_n);
         else
             tile_group_kernel<T, W, false><<<gg, 256, 0, s>>>(pos, mass, pb, pe, g, w.fill64, w.recs, w.rcap, (T*)w.strays, w.scap,
-                                                              w.ovf, w.ovf_count, w.col_flags, dropped, closed_lo, closed_n);
+                                                              w.ovf, w.ovf_count, w.col_flags, dropped, closed_lo, closed_n, closed_mod);
     };
     if (sel.stage != AST_PAINT_STAGE_ALL) {
         // the single-pass overwrite paint in three parts, so that a caller can interleave tile rows with what consumes
@@ -1994,9 +2003,26 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
             ast::set_error("ast_paint_tiled_stage: needs AST_PAINT_OVERWRITE without TWO_PASS / DEFER_FOLD / XSORTED");
             return AST_ERR_ARG;
         }
+        if (sel.stage == AST_PAINT_STAGE_RESET) return AST_OK;                 // (the counters, above)
         if (sel.stage == AST_PAINT_STAGE_GROUP) {
             if (w.tpb) { const int rc = scatter_pass(); if (rc != AST_OK) return rc; }
             else group_pass(0, np, 0u, 0u);
+            AST_CHECK_LAUNCH();
+            return AST_OK;
+        }
+        if (sel.stage == AST_PAINT_STAGE_GROUP_PART) {
+            // part row0 of nrows equal parts of the particle array (boundaries on whole grouping intervals, as in the
+            // x-sorted pipeline); tile rows [closed_row0, closed_row0 + closed_nrows) (mod ntx) have been walked already
+            const int k = sel.row0, K = sel.nrows;
+            if (w.tpb || plainx || K < 1 || k < 0 || k >= K || sel.closed_nrows < 0 || sel.closed_nrows > g.ntx ||
+                sel.closed_row0 < 0 || sel.closed_row0 >= g.ntx) {
+                ast::set_error("ast_paint_tiled_stage: GROUP_PART needs a slab buffer (not the scattered path), 0 <= part < parts and closed rows inside the buffer");
+                return AST_ERR_ARG;
+            }
+            const size_t pb = (size_t)((double)k / K * (double)np) / per_interval * per_interval;
+            const size_t pe = k + 1 == K ? np : (size_t)((double)(k + 1) / K * (double)np) / per_interval * per_interval;
+            const uint32_t rs = (uint32_t)(g.nty * g.ntz);             // tiles per row
+            if (pe > pb) group_pass(pb, pe, (uint32_t)sel.closed_row0 * rs, (uint32_t)sel.closed_nrows * rs, ntiles);
             AST_CHECK_LAUNCH();
             return AST_OK;
         }
@@ -2284,12 +2310,16 @@ extern "C" int ast_paint_tiled_stage(int window, int dtype, const void* pos, con
                                      double boxsize, double scale, int x_start, int nx_alloc, void* grid,
                                      void* workspace, size_t workspace_bytes, unsigned long long* dropped,
                                      int flags, double mass_bound, double offset, int offset_start, int offset_count,
-                                     double shift_cells, int stage, int row0, int nrows, void* stream) {
-    AST_CHECK_ARG(stage == AST_PAINT_STAGE_GROUP || stage == AST_PAINT_STAGE_WALK || stage == AST_PAINT_STAGE_FOLD);
+                                     double shift_cells, int stage, int row0, int nrows, int closed_row0, int closed_nrows,
+                                     void* stream) {
+    AST_CHECK_ARG(stage == AST_PAINT_STAGE_GROUP || stage == AST_PAINT_STAGE_WALK || stage == AST_PAINT_STAGE_FOLD ||
+                  stage == AST_PAINT_STAGE_GROUP_PART || stage == AST_PAINT_STAGE_RESET);
     StageSel sel;
     sel.stage = stage;
     sel.row0 = row0;
     sel.nrows = nrows;
+    sel.closed_row0 = closed_row0;
+    sel.closed_nrows = closed_nrows;
     return paint_tiled_impl(window, dtype, pos, mass, np, nmesh, boxsize, scale, x_start, nx_alloc, grid, workspace,
                             workspace_bytes, dropped, flags, mass_bound, offset, offset_start, offset_count, shift_cells,
                             stream, sel);

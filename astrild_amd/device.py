@@ -310,10 +310,11 @@ class StagedPaint:
         self.nrows_total = int(L.ast_paint_tile_rows(self.nx))
         self.periodic = self.nx == self.n and int(x_start) == 0
 
-    def _stage(self, stage, row0, nrows):
+    def _stage(self, stage, row0, nrows, closed_row0=0, closed_nrows=0):
         check(_lib.lib().ast_paint_tiled_stage(self.win, self.code, ptr(self.pos), ptr(self.mass), self.npart, self.n,
                                                *self.args, ptr(self.out), ptr(self.ws), self.ws_bytes, ptr(self.dropped),
-                                               self.flags, *self.tail, int(stage), int(row0), int(nrows), stream()),
+                                               self.flags, *self.tail, int(stage), int(row0), int(nrows), int(closed_row0),
+                                               int(closed_nrows), stream()),
               "ast_paint_tiled_stage")
 
     def fold_needs(self, row):
@@ -328,6 +329,17 @@ class StagedPaint:
         self.dropped.zero_()
         self._stage(0, 0, 0)
 
+    def reset(self):
+        """Instead of group(), before the first group_part()."""
+        self.dropped.zero_()
+        self._stage(4, 0, 0)
+
+    def group_part(self, k, parts, closed_row0=0, closed_nrows=0):
+        """The lists of part k of `parts` equal parts of the particle array (x-ordered input, slab buffers).  closed_*: the
+        tile rows walked so far, one range modulo the buffer's rows; a particle that turns up for one of them is counted
+        as dropped (check() raises): the order that was promised did not hold."""
+        self._stage(3, k, parts, closed_row0, closed_nrows)
+
     def walk(self, row0, nrows):
         self._stage(1, row0, nrows)
 
@@ -337,7 +349,9 @@ class StagedPaint:
     def check(self):
         nd = int(self.dropped.item())
         if nd:
-            raise _lib.AstrildHipError(f"{nd} deposits fell outside the grid buffer (x_start={self.args[2]}, nx_alloc={self.nx})")
+            raise _lib.AstrildHipError(f"{nd} deposits fell outside the grid buffer (x_start={self.args[2]}, nx_alloc={self.nx}) "
+                                       f"or, with group_part(), belong to a tile row that had been walked already (the particles "
+                                       f"do not come in ascending x as promised)")
 
 
 def synth_lattice_particles(npside, nmesh, boxsize, seed=20240601, sigma_cells=0.5, shuffle=False,

@@ -232,16 +232,32 @@ class GhostExchange:
         self.from_left = torch.empty_like(buf[gl + nloc:])  # left neighbour's upper ghosts -> my bottom planes
         self.reqs = None
 
-    def start(self):
+    def _peers(self):
         world = dist.get_world_size(self.group)
         rank = dist.get_rank(self.group)
-        left, right = (rank - 1) % world, (rank + 1) % world
+        return (rank - 1) % world, (rank + 1) % world
+
+    def start(self):
+        self.start_upper()
+        self.start_lower()
+
+    def start_upper(self):
+        """My UPPER ghost planes go to the right neighbour; the left neighbour's upper ghosts arrive for my first planes.
+        (Every rank posts the same pair, so the operations of each pair of ranks match up.)"""
+        left, right = self._peers()
         comm_ready(self.group)
-        self.reqs = dist.batch_isend_irecv([
-            dist.P2POp(dist.isend, self.buf[:self.gl], _peer(self.group, left), self.group),
+        self.reqs = (self.reqs or []) + dist.batch_isend_irecv([
             dist.P2POp(dist.isend, self.buf[self.gl + self.nloc:], _peer(self.group, right), self.group),
-            dist.P2POp(dist.irecv, self.from_right, _peer(self.group, right), self.group),
             dist.P2POp(dist.irecv, self.from_left, _peer(self.group, left), self.group),
+        ])
+
+    def start_lower(self):
+        """My LOWER ghost planes go to the left neighbour; the right neighbour's lower ghosts arrive for my last planes."""
+        left, right = self._peers()
+        comm_ready(self.group)
+        self.reqs = (self.reqs or []) + dist.batch_isend_irecv([
+            dist.P2POp(dist.isend, self.buf[:self.gl], _peer(self.group, left), self.group),
+            dist.P2POp(dist.irecv, self.from_right, _peer(self.group, right), self.group),
         ])
 
     def finish(self):
@@ -369,7 +385,8 @@ class SlabPowerPipeline:
     """CIC/TSC + slab FFT + P(k) for the synthetic lattice workload of bench.py."""
 
     def __init__(self, n, boxsize, npside, window="cic", dtype=torch.float32, seed=20240601, shuffle=False,
-                 ghost=4, ops=None, group=None, pos=None, chunks=None, route=False, pipeline=None, rows_per_stage=None):
+                 ghost=4, ops=None, group=None, pos=None, chunks=None, route=False, pipeline=None, rows_per_stage=None,
+                 xsorted=None, group_chunks=None):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -436,6 +453,16 @@ class SlabPowerPipeline:
             raise ValueError("these ops cannot paint in stages")
         self.pipeline = pipeline
         self.rows_per_stage = int(rows_per_stage or os.environ.get("ASTRILD_SLAB_ROWS_PER_STAGE") or 0)
+        # grouping in parts (staged, P > 1): only for particles that come in ascending x within `ghost` planes of a uniform
+        # lattice - the synthetic set in natural order, or `pos` with xsorted=True (a violation is counted as dropped
+        # particles and step(check=True) raises).  ASTRILD_SLAB_GROUP_CHUNKS=1 groups everything first, as in the bulk order.
+        if xsorted is None:
+            xsorted = pos is None and not shuffle and not route
+        want = int(group_chunks or os.environ.get("ASTRILD_SLAB_GROUP_CHUNKS") or (4 if xsorted else 1))
+        ok = pipeline == "staged" and P > 1 and xsorted and not self.rows_per_stage and want > 1 and self.nloc % want == 0 \
+            and self.nloc // want >= 2 * (ghost + 1) and hasattr(o, "staged_paint")
+        self.group_chunks = want if ok else 1
+        self.send_planes = max(1, int(os.environ.get("ASTRILD_SLAB_SEND_PLANES") or 24))
         self.staged = None
         self.schedule = None
         self.stage_name = "init"          # what the rank is doing (read by bench.py's watchdog)
@@ -465,8 +492,9 @@ class SlabPowerPipeline:
     # ------------------------------------------------------------------ staged pipeline
     def _make_schedule(self, sp):
         """The static order of a staged step - the same on every rank (it depends on the geometry only), which is what
-        lets the ranks' point-to-point operations match up.  Entries: ("walk", row0, nrows), ("fold", row0, nrows),
-        ("ghost_start",), ("ghost_finish",), ("fft", p0, npl) with p0 counted in OWNED planes."""
+        lets the ranks' point-to-point operations match up.  Entries: ("group",) or ("reset",) and ("group_part", k, K,
+        closed_row0, closed_nrows); ("walk", row0, nrows); ("fold", row0, nrows); ("ghost_start",) or ("ghost_start_upper",) /
+        ("ghost_start_lower",); ("ghost_finish",); ("fft", p0, npl) with p0 counted in OWNED planes."""
         R, PR = sp.nrows_total, sp.row_planes
         gl, gh, nloc = self.gl, self.gh, self.nloc
         lo, hi = gl, gl + nloc                                       # owned planes in buffer coordinates
@@ -494,30 +522,116 @@ class SlabPowerPipeline:
             for r0, nr in runs(ready):
                 sched.append(("fold", r0, nr))
             folded.update(ready)
+            return ready
 
         def fft_ready():
             planes = [p for r in folded for p in range(r * PR, min((r + 1) * PR, self.nx_alloc))
                       if lo <= p < hi and p not in sent and (state["ghosts_in"] or p not in ghost_in)]
             for p0, npl in runs(planes):
-                sched.append(("fft", p0 - lo, npl))
+                # at most send_planes planes per transform + send: a piece travels while the next one is transformed, and
+                # what is left on the links after the last transform is one small piece
+                while npl > 0:
+                    take = min(npl, self.send_planes)
+                    sched.append(("fft", p0 - lo, take))
+                    p0, npl = p0 + take, npl - take
             sent.update(planes)
 
-        if self.world > 1:
-            first = {p // PR for p in list(range(0, gl)) + list(range(hi, self.nx_alloc))}
-            need = set()
-            for r in first:
-                need.update(sp.fold_needs(r))
-            walk(need)
-            fold_ready(only=first)
-            sched.append(("ghost_start",))
-            fold_ready()
-            fft_ready()
-        rest = [r for r in range(R) if r not in walked]
-        per = self.rows_per_stage or max(1, (len(rest) + 3) // 4)
-        for i in range(0, len(rest), per):
-            walk(rest[i:i + per])
-            fold_ready()
-            fft_ready()
+        upper_rows = {p // PR for p in range(hi, self.nx_alloc)}     # tile rows that hold the ghost planes
+        lower_rows = {p // PR for p in range(0, gl)}
+        K = self.group_chunks
+        if K > 1:
+            # GROUPING IN PARTS (x-ordered particles): part k holds the particles of the owned planes [k nloc / K,
+            # (k + 1) nloc / K) of the lattice they started from, displaced by at most `ghost` planes; its particles' tiles lie
+            # in the rows key_rows(k).  A row is walked once every part that can hold one of its particles is grouped.  The
+            # LAST part goes first: it completes the rows of the upper ghost planes, whose exchange can then start; then
+            # parts 0, 1, ... with the rows they complete - walk, fold, transform, send - so the first planes reach the links
+            # after a quarter of the grouping instead of all of it.
+            ghost = gl - 1
+
+            def key_rows(k):
+                first = (gl - ghost + k * nloc // K) // PR
+                last = (gl + ghost + (k + 1) * nloc // K - 1) // PR
+                return range(max(0, first), min(R - 1, last) + 1)
+
+            grouped = set()
+
+            def group(k):
+                # the walked rows form one range modulo R: a block that ends at R - 1 (walked first) and a block that starts at 0
+                high = sorted(r for r in walked if all(q in walked for q in range(r, R)))
+                row0 = high[0] if high else 0
+                sched.append(("group_part", k, K, row0 if walked else 0, len(walked)))
+                grouped.add(k)
+                assert not walked or set((row0 + i) % R for i in range(len(walked))) == walked, "walked rows must stay one cyclic range"
+
+            def walk_complete():
+                ok = [r for r in range(R) if r not in walked and all(k in grouped for k in range(K) if r in key_rows(k))]
+                # keep the walked set one cyclic range: the top block grows downwards only as far as it is contiguous with
+                # R - 1, the bottom block upwards from 0
+                top, r = [], R - 1
+                while r in ok or r in walked:
+                    if r in ok:
+                        top.append(r)
+                    r -= 1
+                bottom, r = [], 0
+                while (r in ok or r in walked) and r not in top:
+                    if r in ok:
+                        bottom.append(r)
+                    r += 1
+                walk(sorted(top))
+                walk(bottom)
+
+            sched.append(("reset",))
+            started = {"upper": False, "lower": False}
+            # parts per stage: the last part alone (the rows of the upper ghost planes), then two at a time, and the
+            # LAST stage one part again - what is still to be transformed and sent after the last walk is then small
+            order = list(range(K - 1))
+            stages = [[K - 1]]
+            while len(order) > 2:
+                stages.append([order.pop(0), order.pop(0)])
+            stages += [[k] for k in order]
+            for stage in stages:
+                for k in stage:
+                    group(k)
+                walk_complete()
+                fold_ready()
+                if not started["upper"] and upper_rows <= folded:
+                    sched.append(("ghost_start_upper",))
+                    started["upper"] = True
+                if not started["lower"] and lower_rows <= folded:
+                    sched.append(("ghost_start_lower",))
+                    started["lower"] = True
+                fft_ready()
+            assert started["upper"] and started["lower"]
+        else:
+            sched.append(("group",))
+            if self.world > 1:
+                first = upper_rows | lower_rows
+                need = set()
+                for r in first:
+                    need.update(sp.fold_needs(r))
+                walk(need)
+                fold_ready(only=first)
+                sched.append(("ghost_start",))
+                fold_ready()
+                fft_ready()
+            rest = [r for r in range(R) if r not in walked]
+            per = self.rows_per_stage or max(1, (len(rest) + 3) // 4)
+            # the FIRST stage is half as long (when rows_per_stage is not given): its planes reach the links sooner, and the
+            # exchange - the longer leg below ~70 GB/s per link - is serialised behind its first send
+            sizes = []
+            left = len(rest)
+            if not self.rows_per_stage and per >= 2 and self.world > 1:
+                sizes.append(per // 2)
+                left -= per // 2
+            while left > 0:
+                sizes.append(min(per, left))
+                left -= sizes[-1]
+            i = 0
+            for size in sizes:
+                walk(rest[i:i + size])
+                i += size
+                fold_ready()
+                fft_ready()
         assert walked == set(range(R)) and folded == set(range(R))
         if self.world > 1:
             sched.append(("ghost_finish",))
@@ -531,7 +645,7 @@ class SlabPowerPipeline:
         if self._progress is None or self.schedule is None:
             return "no progress markers"
         done = [int(v) for v in self._progress.tolist()]
-        names = ["group"] + ["%s%s" % (e[0], tuple(e[1:])) for e in self.schedule]
+        names = ["%s%s" % (e[0], tuple(e[1:])) for e in self.schedule]
 
         def name(i):
             return "nothing yet" if i <= 0 else names[i - 1] if i <= len(names) else str(i)
@@ -600,12 +714,7 @@ class SlabPowerPipeline:
 
         if side is not None:
             side.wait_stream(main)            # the previous step's consumers of spec2d / packed / block are on `main`
-        self.stage_name = "paint.group"
-        t0 = time.perf_counter()
         mark(("begin",))
-        sp.group()
-        self._tick("paint.group.enqueue", t0)
-        mark(("group",))
         for entry in self.schedule:
             kind = entry[0]
             t0 = time.perf_counter()
@@ -614,8 +723,18 @@ class SlabPowerPipeline:
                 sp.walk(entry[1], entry[2])
             elif kind == "fold":
                 sp.fold(entry[1], entry[2])
+            elif kind == "group":
+                sp.group()
+            elif kind == "reset":
+                sp.reset()
+            elif kind == "group_part":
+                sp.group_part(entry[1], entry[2], entry[3], entry[4])
             elif kind == "ghost_start":
                 self.ghosts.start()
+            elif kind == "ghost_start_upper":
+                self.ghosts.start_upper()
+            elif kind == "ghost_start_lower":
+                self.ghosts.start_lower()
             elif kind == "ghost_finish":
                 self.ghosts.finish()
                 self._lowk_start(owned, state)

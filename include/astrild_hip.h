@@ -184,12 +184,24 @@ int ast_paint_tiled(int window, int dtype, const void* pos_d, const void* mass_d
 #define AST_PAINT_STAGE_GROUP 0
 #define AST_PAINT_STAGE_WALK 1
 #define AST_PAINT_STAGE_FOLD 2
+/* Grouping in PARTS, for particles that come in ascending x (slab-ordered input; slab buffers only, not AST_PAINT_SCATTERED):
+ *   AST_PAINT_STAGE_RESET          once, instead of GROUP: clears the lists' counters;
+ *   AST_PAINT_STAGE_GROUP_PART k K the lists of part k of K equal parts of the particle array (row0 = k, nrows = K), in any
+ *                                  order of parts.  closed_row0 / closed_nrows name the tile rows that have been WALKED
+ *                                  already - one range, taken modulo the buffer's rows (the rows of the top ghost planes
+ *                                  first, then 0, 1, ...).  A particle of a later part whose tile lies in a closed row
+ *                                  cannot be painted any more (the row may have been transformed and sent): it is counted
+ *                                  in *dropped_d - the caller's promise about the order did not hold - and skipped.
+ * A row may be walked once every part that can hold a particle of it has been grouped; the walks, folds and the result
+ * are those of the one-part GROUP.  closed_row0 / closed_nrows are ignored by the other stages. */
+#define AST_PAINT_STAGE_GROUP_PART 3
+#define AST_PAINT_STAGE_RESET 4
 int ast_paint_tiled_stage(int window, int dtype, const void* pos_d, const void* mass_d, size_t np,
                           int nmesh, double boxsize, double scale, int x_start, int nx_alloc,
                           void* grid_d, void* workspace_d, size_t workspace_bytes,
                           unsigned long long* dropped_d, int flags, double mass_bound, double offset,
                           int offset_start, int offset_count, double shift_cells, int stage, int row0, int nrows,
-                          void* stream);
+                          int closed_row0, int closed_nrows, void* stream);
 int ast_paint_tile_rows(int nx_alloc);
 int ast_paint_tile_row_planes(void);
 /* Where a paint with AST_PAINT_OVERWRITE | AST_PAINT_DEFER_FOLD and these parameters left its halo

@@ -22,6 +22,8 @@ dist.get_rank = lambda group=None: RANK
 dist.all_reduce = lambda t, *a, **k: None
 slab.exchange_planes = lambda *a, **k: []
 slab.GhostExchange.start = lambda self: None
+slab.GhostExchange.start_upper = lambda self: None
+slab.GhostExchange.start_lower = lambda self: None
 def _finish(self):
     owned = self.buf[self.gl: self.gl + self.nloc]
     self.ops.add_into(owned[self.nloc - self.gl:], self.from_right)
@@ -30,9 +32,10 @@ slab.GhostExchange.finish = _finish
 slab.comm_ready = lambda group=None: None
 
 
-def run(pipeline, rps=None, streams=2, reps=7):
+def run(pipeline, rps=None, streams=1, reps=7, parts=None):
     os.environ["ASTRILD_SLAB_STREAMS"] = str(streams)
-    pipe = slab.SlabPowerPipeline(n, L, n, window="cic", dtype=torch.float32, ghost=GHOST, pipeline=pipeline, rows_per_stage=rps)
+    pipe = slab.SlabPowerPipeline(n, L, n, window="cic", dtype=torch.float32, ghost=GHOST, pipeline=pipeline, rows_per_stage=rps,
+                                  group_chunks=parts)
     if pipe.ghosts is not None:
         pipe.ghosts.from_left.zero_(); pipe.ghosts.from_right.zero_()
     for _ in range(2):
@@ -57,7 +60,7 @@ def run(pipeline, rps=None, streams=2, reps=7):
     prof = dev.profile_report()
     dev.profile_enable(False)
     ms_prof = sorted(a.elapsed_time(b) for a, b in ev2)[reps // 2]
-    print(f"--- {pipeline} rows_per_stage={rps or 'auto'} streams={streams}: step (compute only, no exchange) median {ms[reps // 2]:.3f} ms, min {ms[0]:.3f}; "
+    print(f"--- {pipeline} rows_per_stage={rps or 'auto'} streams={streams} group_parts={pipe.group_chunks} send_planes={pipe.send_planes}: step (compute only, no exchange) median {ms[reps // 2]:.3f} ms, min {ms[0]:.3f}; "
           f"buffer {pipe.nx_alloc} planes; with per-site profiling events {ms_prof:.3f} ms; host enqueue {host_ms:.3f} ms per step", flush=True)
     print("    kernels per step:", {k: round(v[1] / reps, 3) for k, v in prof.items()}, " sum", round(sum(v[1] for v in prof.values()) / reps, 3))
     print("    host enqueue ms per step:", {k: round(v, 3) for k, v in pipe.stage_ms(reps + 2).items()})
@@ -65,6 +68,7 @@ def run(pipeline, rps=None, streams=2, reps=7):
         pipe.trace = []
         pipe.step()
         torch.cuda.synchronize()
+        pipe_trace = list(pipe.trace)
         t0 = pipe.trace[0][1]
         sent = 0
         for entry, e in sorted(pipe.trace[1:], key=lambda t: t0.elapsed_time(t[1])):
@@ -74,12 +78,26 @@ def run(pipeline, rps=None, streams=2, reps=7):
                 tag = f"   -> {sent}/{pipe.nloc} planes ready to send"
             print(f"    {t0.elapsed_time(e):7.3f} ms  {entry}{tag}")
         pipe.trace = None
+        # forecast: a piece of p planes is ready at t and needs p * (bytes per plane and link) / B on every link; the links
+        # carry the pieces one after the other; then the axis-0 pass + binning and the all-reduces (0.1 ms assumed)
+        wire = pipe.wire_bytes()["transpose"] / (P - 1) / pipe.nloc / 1e6          # MB per plane and link
+        tail = (prof.get("fft_tile.c2c_power", (0, 0))[1] + prof.get("fft_tile.shell_reduce", (0, 0))[1]) / reps + 0.1
+        pieces = [(t0.elapsed_time(e), entry[2]) for entry, e in pipe_trace if entry[0] == "fft"]
+        single = float(os.environ.get("SINGLE_GPU_MS", "13.13"))
+        for B in (40, 50, 60, 70, 1e9):
+            done = 0.0
+            for ready, planes in sorted(pieces):
+                done = max(done, ready) + planes * wire / B
+            step = done + tail
+            print(f"    forecast B = {B if B < 1e8 else 'inf':>4} GB/s per link and direction: exchange done {done:.3f} ms, step {step:.3f} ms, "
+                  f"{single / step:.2f}x of the single GPU's {single} ms")
     del pipe
     torch.cuda.empty_cache()
 
 
 run("bulk")
-for streams in (1, 2):
-    for rps in (None, 2, 3, 5):
-        run("staged", rps, streams)
+run("staged", parts=1)               # everything grouped first (first stage half as long)
+run("staged", parts=4)               # grouping in four parts, the last one first (the default for x-ordered input)
+run("staged", parts=8)
+run("staged", rps=5, parts=1)
 dist.destroy_process_group()

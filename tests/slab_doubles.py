@@ -84,6 +84,7 @@ class StagedPaintDouble:
         self.periodic = nx_alloc == n and x_start == 0
         self.walked, self.folded, self.full = set(), set(), None
         self.lost = False
+        self.parts_grouped, self.parts_total = None, None
 
     def fold_needs(self, row):
         rows = [row - 1, row] + ([row + 1] if self.window == "tsc" else [])
@@ -91,7 +92,33 @@ class StagedPaintDouble:
             return sorted({r % self.nrows_total for r in rows})
         return [r for r in rows if 0 <= r < self.nrows_total]
 
+    def _key_rows(self):
+        """Tile row (of the buffer) of every particle's base cell, -1 outside the buffer."""
+        sgrid = self.pos.numpy()[:, 0] * (self.n / self.L)
+        base = np.floor(sgrid if self.window == "cic" else sgrid + 0.5)
+        plane = np.mod(base - self.x_start, self.n).astype(np.int64)
+        return np.where(plane < self.nx, plane // self.row_planes, -1)
+
+    def reset(self):
+        self.group()
+        self.parts_grouped = set()
+        self.parts_total = None
+
+    def group_part(self, k, parts, closed_row0=0, closed_nrows=0):
+        """Part k of `parts` (x-ordered input): no particle of it may belong to a row that has been walked - the closed
+        range handed over must be exactly the rows walked so far."""
+        assert self.parts_total in (None, parts) and k not in self.parts_grouped
+        self.parts_total = parts
+        closed = {(closed_row0 + i) % self.nrows_total for i in range(closed_nrows)}
+        assert closed == self.walked, (closed, self.walked)
+        npart = self.pos.shape[0]
+        rows = self._key_rows()[k * npart // parts:(k + 1) * npart // parts]
+        if np.isin(rows, list(closed)).any():
+            self.lost = True                       # what the kernel counts as dropped
+        self.parts_grouped.add(k)
+
     def group(self):
+        self.parts_grouped, self.parts_total = None, None
         full = omesh.paint(self.pos.numpy(), None if self.mass is None else self.mass.numpy(), self.n, self.L, self.window)
         planes = (self.x_start + np.arange(self.nx)) % self.n
         self.lost = not np.isclose(full.sum(), full[planes].sum(), rtol=1e-12)
@@ -106,6 +133,13 @@ class StagedPaintDouble:
         assert self.full is not None, "walk before group"
         for r in range(row0, row0 + nrows):
             assert r not in self.walked, "row walked twice"
+            if self.parts_grouped is not None:     # grouping in parts: every particle of this row must have been grouped
+                npart, rows = self.pos.shape[0], self._key_rows()
+                owners = {int(i * self.parts_total // npart) for i in np.nonzero(rows == r)[0]} if self.parts_total else set()
+                # (particle i belongs to part k iff k npart // K <= i < (k + 1) npart // K)
+                owners = {k for k in range(self.parts_total or 0)
+                          if (rows[k * npart // self.parts_total:(k + 1) * npart // self.parts_total] == r).any()}
+                assert owners <= self.parts_grouped, f"row {r} walked before parts {owners - self.parts_grouped} were grouped"
             self.walked.add(r)
 
     def fold(self, row0, nrows):

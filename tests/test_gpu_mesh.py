@@ -621,3 +621,49 @@ def test_staged_paint_overflow_list_is_deposited_with_its_rows(dev):
     assert int(sp.dropped.item()) == 0
     np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-11 * ref.max())
     assert got.sum(dtype=np.float64) == pytest.approx(pos.shape[0], rel=1e-12)
+
+
+@pytest.mark.parametrize("window", ["cic", "tsc"])
+def test_staged_paint_grouped_in_parts(dev, window):
+    """ast_paint_tiled_stage GROUP_PART: x-ordered particles of a slab buffer grouped in four parts - the last part first
+    (it completes the top rows), rows walked as soon as every part that can hold their particles is in, closed rows handed
+    to the later parts - give the grid of the one-call paint bit for bit and nothing is counted as dropped; on SHUFFLED
+    particles the promise is broken: particles turn up for rows already walked and are counted (check() raises)."""
+    n, L = 256, 1000.0
+    nx, x_start, gl, ghost = 72, 60, 4, 3                        # owned planes 64 .. 127 of the box, ghost zone 4
+    pos = dev.synth_lattice_particles(n, n, L, dtype=torch.float32)
+    idx = torch.arange(n ** 3, device="cuda") // (n * n)
+    mine = pos[(idx >= x_start + gl) & (idx < x_start + nx - gl)].contiguous()           # lattice planes 64 .. 127: x-ordered, jitter < ghost
+    ref = dev.paint(mine, None, n, L, window, method="tiled", accumulate=False, x_start=x_start, nx_alloc=nx, offset=0.5,
+                    offset_planes=(gl, nx - 2 * gl), check_dropped=True)
+    K, PR = 4, 8
+    nloc = nx - 2 * gl
+
+    def key_rows(k):
+        return range((gl - ghost + k * nloc // K) // PR, (gl + ghost + (k + 1) * nloc // K - 1) // PR + 1)
+
+    for particles, expect_loss in ((mine, False), (mine[torch.randperm(mine.shape[0], device="cuda")].contiguous(), True)):
+        out = torch.full((nx, n, n), float("nan"), dtype=torch.float32, device="cuda")
+        sp = dev.StagedPaint(particles, None, n, L, window, out, x_start=x_start, nx_alloc=nx, offset=0.5, offset_planes=(gl, nloc))
+        R = sp.nrows_total
+        sp.reset()
+        grouped, walked = set(), []
+        for k in [K - 1] + list(range(K - 1)):
+            high = [r for r in walked if all(q in walked for q in range(r, R))]
+            sp.group_part(k, K, min(high) if high else 0, len(walked))
+            grouped.add(k)
+            ready = [r for r in range(R) if r not in walked and all(j in grouped for j in range(K) if r in key_rows(j))]
+            top = sorted(r for r in ready if all(q in ready or q in walked for q in range(r, R)))
+            bottom = sorted(r for r in ready if r not in top)
+            for r in top + bottom:
+                sp.walk(r, 1)
+                walked.append(r)
+        assert sorted(walked) == list(range(R))
+        sp.fold(0, R)
+        if expect_loss:
+            assert int(sp.dropped.item()) > 0
+            with pytest.raises(Exception, match="walked already"):
+                sp.check()
+        else:
+            sp.check()
+            assert torch.equal(out, ref)

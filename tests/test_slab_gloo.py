@@ -26,7 +26,8 @@ def _particles(n=N, nps=NPS):
     return omesh.lattice_particles(nps, n, L, seed=7, sigma_cells=0.5)
 
 
-def _worker(rank, world, port, window, out_dir, chunks=2, n=N, nps=NPS, ghost=2, pipeline="bulk", rows_per_stage=None):
+def _worker(rank, world, port, window, out_dir, chunks=2, n=N, nps=NPS, ghost=2, pipeline="bulk", rows_per_stage=None,
+            group_chunks=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -37,13 +38,18 @@ def _worker(rank, world, port, window, out_dir, chunks=2, n=N, nps=NPS, ghost=2,
         mine = torch.from_numpy(np.ascontiguousarray(pos[rank * ppr:(rank + 1) * ppr]))
         pipe = slab.SlabPowerPipeline(n, L, nps, window=window, dtype=torch.float64, ghost=ghost,
                                       ops=NumpySlabOps(), pos=mine, chunks=chunks, pipeline=pipeline,
-                                      rows_per_stage=rows_per_stage)
-        assert pipe.pipeline == pipeline
+                                      rows_per_stage=rows_per_stage, xsorted=bool(group_chunks), group_chunks=group_chunks)
+        assert pipe.pipeline == pipeline and pipe.group_chunks == (group_chunks or 1)
         ks, ps, nm = pipe.step(check=True)
         ks, ps, nm = pipe.step(check=True)          # a second step reuses buffers, schedule and staged paint
         owned = (pipe.buf[pipe.gl: pipe.gl + pipe.nloc] if world > 1 else pipe.buf).clone()
         if pipeline == "staged" and world > 1:
             kinds = [e[0] for e in pipe.schedule]
+            if group_chunks:
+                # grouping in parts: planes are transformed (and sent) before the last part has been grouped
+                assert kinds.count("group_part") == group_chunks and "group" not in kinds
+                assert kinds.index("fft") < len(kinds) - 1 - kinds[::-1].index("group_part")
+                kinds = [k.replace("ghost_start_upper", "ghost_start") for k in kinds if k != "ghost_start_lower"]
             # the ghost exchange starts before the interior is walked, and planes leave before the ghosts are waited for
             assert kinds.index("ghost_start") < len(kinds) - 1 - kinds[::-1].index("walk")
             if pipe.nloc > pipe.gl + pipe.gh:
@@ -63,10 +69,16 @@ def _worker(rank, world, port, window, out_dir, chunks=2, n=N, nps=NPS, ghost=2,
     # the staged order (group, ghost rows first, then walk -> fold -> transform -> send per stage): the double poisons
     # every plane until its tile row has been folded
     ("cic", 1, 2, N, NPS, 2, "staged", None), ("tsc", 1, 2, N, NPS, 2, "staged", 1), ("cic", 1, 2, N, NPS, 3, "staged", 2),
-    ("cic", 1, 8, 64, 32, 3, "staged", None), ("tsc", 1, 8, 64, 32, 3, "staged", 1), ("tsc", 1, 4, 64, 32, 2, "staged", 3)])
+    ("cic", 1, 8, 64, 32, 3, "staged", None), ("tsc", 1, 8, 64, 32, 3, "staged", 1), ("tsc", 1, 4, 64, 32, 2, "staged", 3),
+    # ... with the particles grouped in parts (x-ordered input; rps column = number of parts, negative): the double checks
+    # that no row is walked before every part holding one of its particles is grouped, and that no part brings a
+    # particle for a row already walked
+    ("cic", 1, 2, 64, 64, 3, "staged", -4), ("tsc", 1, 2, 64, 64, 3, "staged", -2), ("cic", 1, 4, 128, 64, 3, "staged", -4)])
 def test_slab_pipeline_ranks_match_single_process_oracle(tmp_path, window, chunks, world, n, nps, ghost, pipeline, rps):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, window, str(tmp_path), chunks, n, nps, ghost, pipeline, rps), nprocs=world, join=True)
+    parts = -rps if rps is not None and rps < 0 else None
+    mp.spawn(_worker, args=(world, port, window, str(tmp_path), chunks, n, nps, ghost, pipeline, None if parts else rps, parts),
+             nprocs=world, join=True)
     pos = _particles(n, nps)
     full = omesh.paint(pos, None, n, L, window)
     ref = offt.fftpower_1d(full, L)
