@@ -481,9 +481,11 @@ def bench_kappa_pipeline(nplanes=64, npix=4096, steps=3, warmup=1, theta_deg=20.
 
     def step():
         if world > 1:
-            # the PDFs are collected by the caller after ALL maps have been queued: waiting for one here would hold
-            # back this rank's part of the next maps' collectives
-            return [p for p in (stream.push(planes, wnum, wden, tail) for _ in range(maps_per_step)) if p is not None]
+            # the PDFs are collected after ALL maps have been queued (run(), below): waiting for one here would hold back
+            # this rank's part of the next maps' collectives
+            for _ in range(maps_per_step):
+                stream.push(planes, wnum, wden, tail)
+            return []
         kappa_stack(planes, wnum, wden, out=out)
         convert_code_to_phy_units("kappa_2", out)
         sp.gaussian(out, sigma_px, "gaussianFFT")
@@ -509,7 +511,8 @@ def bench_kappa_pipeline(nplanes=64, npix=4096, steps=3, warmup=1, theta_deg=20.
             while world == 1 and len(pend) > 1:
                 collect(pend.pop(0))
         if world > 1:
-            stream.finish()
+            pend = list(stream.finish().values())
+            stream.results = {}
         for item in pend:
             collect(item)
 

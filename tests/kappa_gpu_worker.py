@@ -37,11 +37,9 @@ def main():
             pend = {}
             for m in range(nmaps):
                 scale = 1.0 + 0.25 * m                       # every map its own weights
-                p = stream.push(planes, wnum[ids] * scale, wden[ids], tail)
-                assert (p is not None) == (rank == m % world)
-                if p is not None:
-                    pend[m] = p
-            stream.finish()
+                stream.push(planes, wnum[ids] * scale, wden[ids], tail)
+            pend = dict(stream.finish())
+            assert set(pend) == {m for m in range(nmaps) if m % world == rank}
             torch.cuda.synchronize()
             np.savez(out + f".stream{rank}.npz", **{f"pdf{m}": p.result()[0] for m, p in pend.items()},
                      **{f"map{m}": v[0].cpu().numpy() for m, v in keep.items()},

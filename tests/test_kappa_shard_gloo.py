@@ -185,12 +185,15 @@ def _stream_worker(rank, world, port, nplanes, nmaps, out_dir):
             # every map of the stream has its own weights (the source plane moves): a mixed-up buffer would show
             wn = np.linspace(0.5, 1.5, nplanes) * (m + 1)
             wd = np.full(nplanes, 2.0)
-            res = stream.push([planes[i] for i in ids], wn[ids], wd[ids], tail=lambda mm, t: (mm, t.clone()))
-            assert (res is not None) == (rank == m % world) and stream.root_of(m) == m % world
-            if res is not None:
-                assert res[0] == m
-                got[m] = res[1].numpy()
-        stream.finish()
+            stream.push([planes[i] for i in ids], wn[ids], wd[ids], tail=lambda mm, t: (mm, t.clone()))
+            assert stream.root_of(m) == m % world
+            # a lag of one map: map m is finished by push(m + 1)
+            assert set(stream.results) == {q for q in range(m) if q % world == rank}
+        res = stream.finish()
+        assert set(res) == {q for q in range(nmaps) if q % world == rank}
+        for m, (mm, t) in res.items():
+            assert mm == m
+            got[m] = t.numpy()
         np.savez(os.path.join(out_dir, f"stream{rank}.npz"), **{str(k): v for k, v in got.items()})
     finally:
         dist.destroy_process_group()
