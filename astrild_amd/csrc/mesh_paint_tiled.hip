@@ -417,7 +417,7 @@ __device__ __noinline__ void place_late_slow(uint32_t p, uint32_t* __restrict__ 
 // GLOBAL particle ids).  Tiles closed_lo <= id < closed_lo + closed_n are closed: their particles go to the overflow list.
 template <typename T, int W, bool PLAINX>
 __global__ void __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 && PLAINX ? 5 : 1, sizeof(T) == 4 && PLAINX ? 5 : 8)))      // fp32, whole grid: 96 VGPRs, five workgroups per CU (what the 31 KB of LDS allow)
+__attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 5 : 1, sizeof(T) == 4 ? 5 : 8)))      // fp32: 96 VGPRs, five workgroups per CU (what the 31 KB of LDS allow); the slab variant spills 3 VGPRs for it and still gains (0.57 -> 0.52 ms for one rank of eight)
 tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t p_begin, size_t np, TileGeom g,
                   unsigned long long* __restrict__ fill64, GroupRec* __restrict__ recs, uint32_t rcap,
                   T* __restrict__ strays, uint32_t scap, uint32_t* __restrict__ ovf,
