@@ -628,55 +628,69 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
 // ------------------------------------------------------------------------------------
 // AST_PAINT_SCATTERED: particles WITHOUT spatial order in memory.  The grouping kernel above degenerates there
 // (every particle is a stray of a tile no neighbour shares: one returning global atomic and one 16-byte scattered
-// store per particle, 74 ms at 1024^3).  Two radix levels instead, every workgroup handling 4096 / 8192 records so that a
-// destination receives a run of records (4 at the first level, 16 at the second, at 1024^3) for ONE reservation atomic:
-//   level A   particle -> 16-byte record {x, y, z, m} in its coarse bucket's (SC_BUCKETS buckets of tpb consecutive tiles)
+// store per particle, 74 ms at 1024^3).  Two radix levels instead, every workgroup handling 4096 records so that a
+// destination receives a run of records (4 at the first level, 8 at the second, at 1024^3) for ONE reservation atomic:
+//   level A   particle -> 16-byte record {x, y, z, m} in its coarse bucket's (nb buckets of tpb consecutive tiles)
 //             fixed-capacity segment of a staging array (no counting pass, see scatter_level_a_kernel);
 //   level B   bucket by bucket, record -> the stray segment of its tile (the format the column walk reads), slots
 //             reserved per (workgroup, tile) from the tile's fill64 counter.
 // The walk then finds only stray copies (no group records) and reads them contiguously.  A record that does not fit
 // its tile's segment (strongly clustered input) is deposited on the spot with global atomics.
 // Workgroup shape per level (threads, records per thread).  A workgroup's phases - load, rank, reserve, scan, staged store -
-// run one after the other between barriers, so what is idle in one phase can only be used by ANOTHER workgroup of the CU.
-// Level A, 512 x 8: 68 KB of LDS, two workgroups per CU - 8.0 -> 6.8 ms at 1024^3 although its runs are half as long (4
-// records per bucket and workgroup).  Level B keeps 1024 x 8 (one workgroup per CU): with 512 x 8 its runs into the tile
-// segments (16 -> 8 records) cost more than the overlap gains, 8.9 -> 10.7 ms.  Measured and without effect (the loads
-// are not what the phases wait for): prefetching the next chunk's records during the staged store, in either level.
+// run one after the other between barriers, so what is idle in one phase can only be used by ANOTHER workgroup of the CU:
+// both levels run 512 x 8 with two workgroups per CU (<= 80 KB of LDS each).  Measured and without effect (the loads are
+// not what the phases wait for): prefetching the next chunk's records during the staged store, in either level; three
+// level-A workgroups per CU (80 VGPRs, 8 spilled).
+// Level B used to run 1024 x 8, one workgroup per CU, because halving its runs into the tile segments cost more than the
+// overlap gained (8.9 -> 10.7 ms at 1024^3).  That was a symptom: the workgroups of one bucket were spread over the whole
+// launch (grid (bucket, 32)), so the lines a run left partly written met their other pieces long after they had left L2.
+// With a bucket's workgroups running at the SAME time on ONE XCD (round 4) those pieces meet in L2: 9.2 -> 6.4 ms as it
+// was, 5.7 ms with 512 x 8.
 #ifndef SCA_NT
 #define SCA_NT 512
 #endif
 #ifndef SCB_NT
-#define SCB_NT 1024
+#define SCB_NT 512
 #endif
 constexpr int SC_PER_THREAD = 8;                                 // (16 per thread spills at the 128 VGPRs either shape allows)
 constexpr int SCA_THREADS = SCA_NT, SCB_THREADS = SCB_NT;
-constexpr uint32_t SC_BUCKETS = 1024, SC_TPB_MAX = 2048;        // buckets; most tiles per bucket (LDS counters of level B)
+// Most buckets (level A's LDS tables) and most tiles per bucket (level B's; its scan takes 4 entries per thread).  The
+// number of buckets is chosen per call (scatter_buckets): about the square root of the number of tiles, so that both
+// levels write runs of similar length.
+constexpr uint32_t SC_BUCKETS_MAX = 1024, SC_TPB_MAX = 4 * SCB_NT;
 // Every bucket's range of the staging array is cut into SC_GROUPS sub-ranges, and chunk c writes into sub-range
 // c mod 8.  Blocks b and b + 8 share an XCD (observed placement; nothing here depends on it for correctness: the
 // sub-ranges are fixed segments, one per (bucket, label)), so the 96-byte runs that complete a 128-byte line come
 // from workgroups behind ONE L2 and the line leaves it whole.  With one cursor per bucket the pieces of a line sat in
 // different XCDs' L2s and went to HBM as partial writes: level A's stores ran at 2 TB/s.
 constexpr uint32_t SC_GROUPS = 8;
+// Level B: workgroups per bucket.  They take consecutive slots of ONE XCD (see the kernel), 2 per CU x 32 CUs.
+#ifndef SCB_WGS
+#define SCB_WGS 64
+#endif
 
 // records staged per round: four (float) or two (double) per thread - 96 KB of LDS per 1024 threads
 template <typename T, int NT> constexpr uint32_t sc_round() { return (sizeof(T) == 4 ? 4u : 2u) * (uint32_t)NT; }
 
-// Exclusive scan of cnt[0 .. table) into lstart[] by the whole workgroup (NT threads, table <= 2 * NT);
-// returns the total.  wsum: 16 words of LDS.
+// Exclusive scan of cnt[0 .. table) into lstart[] by the whole workgroup (NT threads, table <= 4 * NT: thread t takes
+// the entries [K t, K t + K), K = 2 or 4); returns the total.  wsum: 16 words of LDS.
 template <int NT>
 __device__ inline uint32_t block_exclusive_scan(const uint32_t* cnt, uint32_t* lstart, uint32_t table, uint32_t* wsum) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t i0 = 2u * tid, a = i0 < table ? cnt[i0] : 0u, b = i0 + 1 < table ? cnt[i0 + 1] : 0u;
-    uint32_t inc = a + b;
+    const uint32_t K = table > 2u * NT ? 4u : 2u, i0 = K * tid;
+    uint32_t v[4], own = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) { v[k] = (k < K && i0 + k < table) ? cnt[i0 + k] : 0u; own += v[k]; }
+    uint32_t inc = own;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
     uint32_t woff = 0, total = 0;
     for (int k = 0; k < NT / 64; ++k) { if (k < wave) woff += wsum[k]; total += wsum[k]; }
-    const uint32_t ex = woff + inc - (a + b);
-    if (i0 < table) lstart[i0] = ex;
-    if (i0 + 1 < table) lstart[i0 + 1] = ex + a;
+    uint32_t ex = woff + inc - own;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) { if (k < K && i0 + k < table) lstart[i0 + k] = ex; ex += v[k]; }
     __syncthreads();
     return total;
 }
@@ -728,19 +742,19 @@ __device__ inline void staged_store(const T (&rx)[SC_PER_THREAD], const T (&ry)[
 // stray segment in level B, and is deposited with global atomics; device.paint sees the count and repaints two-pass.
 template <typename T, int W, bool PLAINX, int SW>
 __global__ void __launch_bounds__(SCA_THREADS)
-scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t np, TileGeom g, uint32_t tpb,
+scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t np, TileGeom g, uint32_t tpb, uint32_t nb,
                        unsigned long long* __restrict__ cursor, T* __restrict__ staging, uint32_t cap_bg,
                        uint32_t* __restrict__ col_flags, T* __restrict__ late_list, unsigned long long late_cap,
                        unsigned long long* __restrict__ late, unsigned long long* dropped) {
-    __shared__ uint32_t cnt[SC_BUCKETS], lstart[SC_BUCKETS], room[SC_BUCKETS], wsum[16];
-    __shared__ unsigned long long base[SC_BUCKETS];
+    __shared__ uint32_t cnt[SC_BUCKETS_MAX], lstart[SC_BUCKETS_MAX], room[SC_BUCKETS_MAX], wsum[16];
+    __shared__ unsigned long long base[SC_BUCKETS_MAX];
     extern __shared__ unsigned long long dyn[];          // stage: 4096 records, then their 4096 destinations
     T* stage = reinterpret_cast<T*>(dyn);
     constexpr int NT = SCA_THREADS, SC_CHUNK = NT * SC_PER_THREAD;
-    unsigned long long* sidx = dyn + sc_round<T, NT>() * 4 * sizeof(T) / sizeof(unsigned long long);
+    unsigned long long* sidx = dyn + sc_round<T, NT>() * SW * sizeof(T) / sizeof(unsigned long long);
     typedef T vec4_t __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x;
-    for (uint32_t b = tid; b < SC_BUCKETS; b += NT) cnt[b] = 0;
+    for (uint32_t b = tid; b < nb; b += NT) cnt[b] = 0;
     __syncthreads();
     const size_t p0 = (size_t)blockIdx.x * SC_CHUNK;
     T x[SC_PER_THREAD], y[SC_PER_THREAD], z[SC_PER_THREAD], m[SC_PER_THREAD];
@@ -774,15 +788,15 @@ scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, si
     __shared__ int any_full;
     if (tid == 0) any_full = 0;
     __syncthreads();
-    for (uint32_t b = tid; b < SC_BUCKETS; b += NT) {
+    for (uint32_t b = tid; b < nb; b += NT) {
         if (!cnt[b]) continue;
-        const unsigned long long old = atomicAdd(&cursor[grp * SC_BUCKETS + b], (unsigned long long)cnt[b]);
+        const unsigned long long old = atomicAdd(&cursor[grp * nb + b], (unsigned long long)cnt[b]);
         const uint32_t bs = (uint32_t)min(old, (unsigned long long)cap_bg);
         base[b] = ((unsigned long long)b * SC_GROUPS + grp) * cap_bg + bs;
         room[b] = cap_bg - bs;
         if (cnt[b] > cap_bg - bs) any_full = 1;
     }
-    const uint32_t total = block_exclusive_scan<NT>(cnt, lstart, SC_BUCKETS, wsum);          // (barriers inside: any_full is settled)
+    const uint32_t total = block_exclusive_scan<NT>(cnt, lstart, nb, wsum);          // (barriers inside: any_full is settled)
     const bool full = any_full != 0;                      // uniform; a full segment is rare (strongly clustered input)
     if (full) {
 #pragma unroll
@@ -836,25 +850,33 @@ late_deposit_kernel(const T* __restrict__ late_list, const unsigned long long* _
                                     grid, dropped, x_lo, x_hi);
 }
 
+// Level B's grid is one-dimensional: workgroup L runs on XCD L mod 8 (round-robin dispatch; observed placement, nothing
+// depends on it for correctness), and the SCB_WGS workgroups of a bucket take consecutive slots of ONE XCD - so they run
+// at the same time behind one L2, where the lines one workgroup's run leaves partly written are completed by the next
+// run into the same tile segment before they are written back.  (nb is a multiple of 8.)
 template <typename T, int W, bool PLAINX, int SW>
 __global__ void __launch_bounds__(SCB_THREADS)
 scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* __restrict__ cursor, uint32_t cap_bg, TileGeom g, uint32_t tpb,
-                       unsigned long long* __restrict__ fill64, T* __restrict__ strays, uint32_t scap,
+                       uint32_t nb, unsigned long long* __restrict__ fill64, T* __restrict__ strays, uint32_t scap,
                        T* __restrict__ late_list, unsigned long long late_cap, unsigned long long* __restrict__ late,
                        unsigned long long* dropped) {
-    __shared__ uint32_t cnt[SC_TPB_MAX], room[SC_TPB_MAX], lstart[SC_TPB_MAX], wsum[16];
-    __shared__ unsigned long long base[SC_TPB_MAX];
-    extern __shared__ unsigned long long dyn[];
-    T* stage = reinterpret_cast<T*>(dyn);
+    __shared__ uint32_t wsum[16];
+    extern __shared__ unsigned long long dyn[];          // base[tpb] | stage | sidx | cnt[tpb] room[tpb] lstart[tpb]
     constexpr int NT = SCB_THREADS, SC_CHUNK = NT * SC_PER_THREAD;
-    unsigned long long* sidx = dyn + sc_round<T, NT>() * 4 * sizeof(T) / sizeof(unsigned long long);
+    const uint32_t tp = (tpb + 1u) & ~1u;                // (the staged records stay 16-byte aligned)
+    unsigned long long* base = dyn;
+    T* stage = reinterpret_cast<T*>(dyn + tp);
+    unsigned long long* sidx = dyn + tp + sc_round<T, NT>() * SW * sizeof(T) / sizeof(unsigned long long);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(sidx + sc_round<T, NT>());
+    uint32_t* room = cnt + tp;
+    uint32_t* lstart = room + tp;
     const int tid = threadIdx.x;
-    const uint32_t bucket = blockIdx.x;
-    // the bucket's SC_GROUPS segments of the staging array, gridDim.y / SC_GROUPS workgroups each (blocks with equal
-    // blockIdx.x - one bucket - share an XCD like the groups that wrote the segments)
-    const uint32_t grp = blockIdx.y % SC_GROUPS, sub = blockIdx.y / SC_GROUPS, nsub = gridDim.y / SC_GROUPS;
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t bucket = ((slot / SCB_WGS) << 3) | xcd, by = slot % SCB_WGS;
+    // the bucket's SC_GROUPS segments of the staging array, SCB_WGS / SC_GROUPS workgroups each
+    const uint32_t grp = by % SC_GROUPS, sub = by / SC_GROUPS, nsub = SCB_WGS / SC_GROUPS;
     const size_t b0 = ((size_t)bucket * SC_GROUPS + grp) * cap_bg;
-    const size_t b1 = b0 + (size_t)min(cursor[grp * SC_BUCKETS + bucket], (unsigned long long)cap_bg);
+    const size_t b1 = b0 + (size_t)min(cursor[grp * nb + bucket], (unsigned long long)cap_bg);
     typedef T vec4_t __attribute__((ext_vector_type(4)));
     struct Rec3 { T x, y, z; };
     for (size_t c0 = b0 + (size_t)sub * SC_CHUNK; c0 < b1; c0 += (size_t)nsub * SC_CHUNK) {
@@ -1796,11 +1818,12 @@ struct Workspace {
     void* strays;                    // [tile][scap] x {x, y, z, m}
     uint32_t rcap, scap;
     // AST_PAINT_SCATTERED: two-level bucket scatter
-    unsigned long long* bcursor;     // [SC_GROUPS][SC_BUCKETS] level A write cursors = records per (chunk label, coarse bucket)
+    unsigned long long* bcursor;     // [SC_GROUPS][nb] level A write cursors = records per (chunk label, coarse bucket)
     uint32_t cap_bg;                 // records per (bucket, label) segment of the staging array
     unsigned long long* late;        // records that found their tile's segment full (deposited on the spot)
     void* staging;                   // [np] x {x, y, z, m}, bucket-major
     uint32_t tpb;                    // tiles per bucket (0: the scatter path does not apply)
+    uint32_t nb;                     // buckets (scatter_buckets)
     size_t bytes;
 };
 
@@ -1818,6 +1841,18 @@ inline uint32_t tile_capacity(size_t np, uint32_t ntiles) {
 // (with AST_PAINT_OVERWRITE) the compact group / stray lists.  A tile's group segment holds cap / MINPOP records
 // (enough for `cap` particles however they are grouped), its stray segment cap / 4 copies - or `cap` with
 // AST_PAINT_SCATTERED, for input without spatial order where every particle is a stray.
+// Buckets of the two-level scatter: the power of two nearest to sqrt(ntiles) from above, in [64, SC_BUCKETS_MAX] - both
+// levels then split into about equally many destinations (1024^3: 524288 tiles -> 1024 buckets of 512 tiles; 512 buckets of
+// 1024 measure the same within 1 %) - and enough of them that a bucket's tiles fit level B's tables.
+// AST_PAINT_SC_BUCKETS overrides (experiments; a multiple of 8).
+uint32_t scatter_buckets(uint32_t ntiles) {
+    static const uint32_t forced = [] { const char* v = getenv("AST_PAINT_SC_BUCKETS"); return v ? (uint32_t)atoi(v) : 0u; }();
+    if (forced >= 8 && forced <= SC_BUCKETS_MAX && forced % 8 == 0) return forced;
+    uint32_t nb = 64;
+    while (nb < SC_BUCKETS_MAX && ((unsigned long long)nb * nb < ntiles || (ntiles + nb - 1) / nb > SC_TPB_MAX)) nb <<= 1;
+    return nb;
+}
+
 Workspace carve(void* base, size_t np, uint32_t ntiles, uint32_t ncols, int flags, size_t esz, size_t rec_bytes, size_t zrec_bytes = 0) {
     const bool two_pass = (flags & AST_PAINT_TWO_PASS) != 0;
     const bool compact = !two_pass && (flags & AST_PAINT_OVERWRITE);
@@ -1830,11 +1865,12 @@ Workspace carve(void* base, size_t np, uint32_t ntiles, uint32_t ncols, int flag
     w.tile_fill = (uint32_t*)take((size_t)ntiles * 4);
     w.fill64 = (unsigned long long*)take(compact ? (size_t)ntiles * 8 : 0);
     const bool scattered = compact && (flags & AST_PAINT_SCATTERED);
-    w.tpb = scattered ? (ntiles + SC_BUCKETS - 1) / SC_BUCKETS : 0;
-    if (w.tpb > SC_TPB_MAX || np < (size_t)(SCB_THREADS * SC_PER_THREAD)) w.tpb = 0;      // huge grids / tiny inputs: the grouping kernel does it
-    w.bcursor = (unsigned long long*)take(w.tpb ? SC_BUCKETS * SC_GROUPS * 8 : 0);      // (inside the part run_tiled zeroes)
+    w.nb = scatter_buckets(ntiles);
+    w.tpb = scattered ? (ntiles + w.nb - 1) / w.nb : 0;
+    if (w.tpb > SC_TPB_MAX || np < (size_t)8192) w.tpb = 0;      // huge grids / tiny inputs: the grouping kernel does it
+    w.bcursor = (unsigned long long*)take(w.tpb ? (size_t)w.nb * SC_GROUPS * 8 : 0);      // (inside the part run_tiled zeroes)
     // a (bucket, label) segment holds twice its mean share of the particles
-    w.cap_bg = w.tpb ? (uint32_t)((2 * ((np + SC_BUCKETS * SC_GROUPS - 1) / (SC_BUCKETS * SC_GROUPS)) + 1024 + 63) / 64 * 64) : 0;
+    w.cap_bg = w.tpb ? (uint32_t)((2 * ((np + (size_t)w.nb * SC_GROUPS - 1) / ((size_t)w.nb * SC_GROUPS)) + 1024 + 63) / 64 * 64) : 0;
     w.late = (unsigned long long*)take(w.tpb ? 8 : 0);
     w.tile_off = (uint32_t*)take((size_t)ntiles * 4);
     w.block_sums = (uint32_t*)take((size_t)((ntiles + 1023) / 1024 + 1) * 4);
@@ -1844,7 +1880,7 @@ Workspace carve(void* base, size_t np, uint32_t ntiles, uint32_t ncols, int flag
     w.index = (uint32_t*)take(two_pass ? np * 4 : compact ? 0 : (size_t)ntiles * w.cap * 4);
     w.recs = (GroupRec*)take((size_t)ntiles * w.rcap * sizeof(GroupRec));
     w.strays = take((size_t)ntiles * w.scap * 4 * esz);
-    w.staging = take(w.tpb ? (size_t)SC_BUCKETS * SC_GROUPS * w.cap_bg * 4 * esz : 0);
+    w.staging = take(w.tpb ? (size_t)w.nb * SC_GROUPS * w.cap_bg * 4 * esz : 0);
     w.ovf = (uint32_t*)take(two_pass ? 0 : np * 4);
     w.rec = take(rec_bytes);
     w.zrec = (unsigned long long*)take(zrec_bytes);
@@ -1956,25 +1992,26 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
         auto run = [&](auto px, auto sw) -> int {
             constexpr bool PX = decltype(px)::value;
             constexpr int SW = decltype(sw)::value;
-            const size_t lds_a = sc_round<T, SCA_THREADS>() * (4 * sizeof(T) + sizeof(unsigned long long));
-            const size_t lds_b = sc_round<T, SCB_THREADS>() * (4 * sizeof(T) + sizeof(unsigned long long));
+            const size_t lds_a = sc_round<T, SCA_THREADS>() * (SW * sizeof(T) + sizeof(unsigned long long));
+            const size_t lds_b = sc_round<T, SCB_THREADS>() * (SW * sizeof(T) + sizeof(unsigned long long)) + (size_t)((w.tpb + 1u) & ~1u) * 20;
+            const size_t lds_b_max = sc_round<T, SCB_THREADS>() * (SW * sizeof(T) + sizeof(unsigned long long)) + (size_t)SC_TPB_MAX * 20;
             static ast::PerDeviceOnce attr_once;
             if (attr_once.need()) {
                 AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_level_a_kernel<T, W, PX, SW>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
                 AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_level_b_kernel<T, W, PX, SW>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b_max));
                 attr_once.mark();
             }
             const unsigned long long late_cap = np / 4 * sizeof(uint32_t) / sizeof(T);       // the overflow list's room
             {
                 AST_PROF("paint_tiled.level_a", s);
                 scatter_level_a_kernel<T, W, PX, SW><<<nchunks, SCA_THREADS, lds_a, s>>>(
-                    pos, mass, np, g, w.tpb, w.bcursor, (T*)w.staging, w.cap_bg, w.col_flags, (T*)w.ovf, late_cap, w.late, dropped);
+                    pos, mass, np, g, w.tpb, w.nb, w.bcursor, (T*)w.staging, w.cap_bg, w.col_flags, (T*)w.ovf, late_cap, w.late, dropped);
             }
             AST_PROF("paint_tiled.level_b", s);
-            scatter_level_b_kernel<T, W, PX, SW><<<dim3(SC_BUCKETS, 32), SCB_THREADS, lds_b, s>>>(
-                (const T*)w.staging, w.bcursor, w.cap_bg, g, w.tpb, w.fill64, (T*)w.strays, w.scap, (T*)w.ovf, late_cap, w.late, dropped);
+            scatter_level_b_kernel<T, W, PX, SW><<<w.nb * SCB_WGS, SCB_THREADS, lds_b, s>>>(
+                (const T*)w.staging, w.bcursor, w.cap_bg, g, w.tpb, w.nb, w.fill64, (T*)w.strays, w.scap, (T*)w.ovf, late_cap, w.late, dropped);
             return AST_OK;
         };
         using S3 = std::integral_constant<int, 3>;

@@ -26,5 +26,6 @@ for order in orders:
         prof = dev.profile_report()
         dev.profile_enable(False)
         ms = {k: round(v[1] / reps, 3) for k, v in prof.items()}
-        print(f"n={n} {order:8s} {w}: total {sum(ms.values()):7.3f} ms  {ms}  lists {st}", flush=True)
+        chk = (float(grid.double().sum()), float((grid.double() ** 2).sum()))      # fixed-point sums: equal between variants
+        print(f"n={n} {order:8s} {w}: total {sum(ms.values()):7.3f} ms  {ms}  lists {st}  check {chk}", flush=True)
     del pos
