@@ -68,7 +68,7 @@ SIGNATURES = {
     "ast_lowk_work_bytes": (_sz, [_sz, _sz]),
     "ast_lowk_mode_count": (_i, []),
     "ast_lowk_shell_count": (_i, []),
-    "ast_fft_tile_c2r_3d_batch": (_i, [_vp, ct.POINTER(_vp), ct.POINTER(_vp), _i, _sz, ct.POINTER(_i), ct.POINTER(_i), _i, _d, _i, _vp]),
+    "ast_fft_tile_c2r_3d_batch": (_i, [_vp, ct.POINTER(_vp), ct.POINTER(_vp), _i, _sz, ct.POINTER(_i), ct.POINTER(_i), _i, _d, _i, _sz, _vp]),
     "ast_fft_tile_rows_r2c_lowz": (_i, [_vp, _vp, _i, _sz, _sz, _sz, _sz, _d, _vp, _vp]),
     "ast_lowk_modes_from_z": (_i, [_sz, _sz, _sz, _i, _vp, _vp, _sz, _vp]),
     "ast_lowk_modes": (_i, [_vp, _i, _sz, _sz, _sz, _i, _vp, _vp, _sz, _vp]),

@@ -132,7 +132,8 @@ __global__ void tile_isqrt_table_kernel(int* out, int count) {
 //          with k_y^2 + k_z0^2 >= hi2 (the very tiles pass 0 left unwritten: both passes cut k_z into the same tiles);
 //   the z pass (rows_c2r_kernel) reads k_z < m_hi only.
 // A shell of radius N/4 moves 40 % of the full transform's bytes.
-struct ShellMask { const float2* src; long long lo2, hi2; int ky0 = 0; int pass = 0; };     // ky0 (POWER): global k_y index of batch 0 (slab blocks)
+struct ShellMask { const float2* src; long long lo2, hi2; int ky0 = 0; int pass = 0;       // ky0 (POWER): global k_y index of batch 0 (slab blocks)
+                   size_t src_elem_stride = 0, src_batch_stride = 0; };                    // strides of `src` when they differ from the destination's (0: the same)
 
 // PACK: the stores go to `pack.out` in the layout the slab transpose sends (what ast_slab_pack makes of the array): row
 // k_y of batch (plane) b lands in part k_y / c1 at ((part * nbatch + b) * c1 + k_y % c1) * pitch + column.
@@ -141,6 +142,9 @@ struct ShellMask { const float2* src; long long lo2, hi2; int ky0 = 0; int pass 
 // work array and radii.  Thirty-one shells used to be 93 launches of 0.06-0.4 ms each, most of them far too small to fill
 // the chip to the end; batched, the shells of a launch fill each other's tails.
 constexpr int SHELL_BATCH = 8;
+#ifndef C2C_XCD_MODE
+#define C2C_XCD_MODE 2              // batch rows -> XCDs in strided_c2c_kernel: 0 never, 1 inverse passes, 2 all passes
+#endif
 struct ShellBatch { int count = 0; float2* work[SHELL_BATCH]; long long lo2[SHELL_BATCH], hi2[SHELL_BATCH]; };
 struct C2RBatch { int count = 0; const float2* in[SHELL_BATCH]; float* out[SHELL_BATCH]; int kmax[SHELL_BATCH]; };
 
@@ -167,7 +171,20 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
     float2* Y = lds;                 // [n2][k1][c]  (SPLIT: [n2 mod R2/2][k1][c])
     float2* tw = lds + YN * C;       // exp(-2 pi i m / N)
     double* shell = reinterpret_cast<double*>(lds + YN * C + N);    // [NB + 1] when POWER
-    const unsigned tile = blockIdx.x % tiles_per_batch, b = blockIdx.x / tiles_per_batch;
+    unsigned tile = blockIdx.x % tiles_per_batch, b = blockIdx.x / tiles_per_batch;
+#if C2C_XCD_MODE
+    // A 16-column tile row is 128 bytes at an 8-byte-aligned address (row pitch N / 2 + 1): every line it touches is shared
+    // with the neighbouring column tile.  Consecutive workgroups go to consecutive XCDs (observed round-robin placement;
+    // a matter of speed only), so neighbouring tiles sat behind different L2s and each fetched the shared lines - the
+    // masked inverse passes read 1.94 x their bytes (scripts/pmc_per_launch.py).  Here the tiles of one batch row follow each
+    // other on ONE XCD: batch b runs on XCD b mod 8.  512^3 bispectrum: x / y inverse passes 6.9 -> 5.9 ms; forward passes
+    // 512^3 0.52 -> 0.46 ms, 256^3 0.069 -> 0.050 ms, 1024^3 (32-column tiles) -0.05 ms per step.
+    if ((INV || C2C_XCD_MODE == 2) && (gridDim.x / tiles_per_batch) % 8u == 0u) {
+        const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        b = (slot / tiles_per_batch) * 8u + xcd;
+        tile = slot % tiles_per_batch;
+    }
+#endif
     const size_t c0 = (size_t)tile * C;
     if (INV && sb.count > 0) {                        // this workgroup's shell of the batch (uniform)
         data = sb.work[blockIdx.y];
@@ -195,9 +212,12 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
         // last row block): predicated loads compile to a branch each
         // address = UNIFORM base (batch and row block: scalar registers) + one 32-bit per-lane offset shared by all
         // R1 loads (global_load ... v_off, s[base]): per-load 64-bit lane addresses cost two VGPRs each while in flight
-        const float2* ubase = (INV && mask.src ? mask.src : data) + (size_t)b * batch_stride;
+        // (the masked first inverse pass may read a source of another row pitch than the array it writes)
+        const bool own = INV && mask.src != nullptr && mask.src_elem_stride != 0;
+        const size_t es_in = own ? mask.src_elem_stride : elem_stride;
+        const float2* ubase = (INV && mask.src ? mask.src : data) + (size_t)b * (own ? mask.src_batch_stride : batch_stride);
         const int lsub = task1 ? sub : R2 - 1;
-        const uint32_t voff = (uint32_t)lsub * (uint32_t)elem_stride + min((uint32_t)c0 + (uint32_t)c, (uint32_t)ncols - 1u);     // host checks: < 2^29
+        const uint32_t voff = (uint32_t)lsub * (uint32_t)es_in + min((uint32_t)c0 + (uint32_t)c, (uint32_t)ncols - 1u);     // host checks: < 2^29
         if (INV && mask.hi2 > 0 && mask.pass == 1) {
             const long long c02 = (long long)(c0 * c0);
 #pragma unroll
@@ -205,11 +225,11 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
                 const int row = n1 * R2 + lsub;
                 const long long ky = row > N / 2 ? row - N : row;
                 v[n1] = make_float2(0.f, 0.f);
-                if (ky * ky + c02 < mask.hi2) v[n1] = (ubase + (size_t)(n1 * R2) * elem_stride)[voff];
+                if (ky * ky + c02 < mask.hi2) v[n1] = (ubase + (size_t)(n1 * R2) * es_in)[voff];
             }
         } else {
 #pragma unroll
-            for (int n1 = 0; n1 < R1; ++n1) v[n1] = ld_stream<(!INV && N >= 1024)>(ubase + (size_t)(n1 * R2) * elem_stride + voff);
+            for (int n1 = 0; n1 < R1; ++n1) v[n1] = ld_stream<(!INV && N >= 1024)>(ubase + (size_t)(n1 * R2) * es_in + voff);
         }
         if (INV) {
             if (mask.hi2 > 0 && mask.pass == 0) {
@@ -300,7 +320,7 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
         // (the word is fetched HERE, not at the top: nothing of this epilogue may stay live across the two register
         // FFTs - the kernel is held to 128 VGPRs and every long-lived value there turned into scratch traffic)
         unsigned fallmask = 0;
-        if (edge_fall) fallmask = edge_fall[(size_t)blockIdx.x * NT + threadIdx.x];
+        if (edge_fall) fallmask = edge_fall[((size_t)b * tiles_per_batch + tile) * NT + threadIdx.x];
         const int kz = (int)c0 + tid_e % C;
         const int kyi = (int)b + mask.ky0;
         const int ky = kyi > N / 2 ? kyi - N : kyi;
@@ -322,7 +342,7 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
     if (POWER) {
         __syncthreads();
         const double s2 = (double)scale * (double)scale;
-        for (int i = threadIdx.x; i < NB; i += NT) partial[(size_t)blockIdx.x * NB + i] = shell[i + 1] * s2;
+        for (int i = threadIdx.x; i < NB; i += NT) partial[((size_t)b * tiles_per_batch + tile) * NB + i] = shell[i + 1] * s2;
     }
 }
 
@@ -1468,17 +1488,21 @@ extern "C" int ast_fft_tile_c2r_3d(const void* spec, void* work, void* out, int 
 
 // ast_fft_tile_c2r_3d for up to SHELL_BATCH shells of ONE spectrum in three launches (x, y, z with blockIdx.y = shell):
 // works[i] / outs[i] are shell i's scratch spectrum and real output (host arrays of device pointers), m_lo[i] < m_hi[i] its
-// radii.  Same arithmetic per shell as the single call (bit-identical outputs).
+// radii.  Same arithmetic per shell as the single call (bit-identical outputs).  work_pitch: row pitch of the scratch spectra
+// in complex elements (0: n / 2 + 1).  A multiple of 16 makes the 128-byte row pieces of the x / y passes' column tiles whole
+// lines - at the natural pitch every piece straddles two, both shared with the neighbouring tiles.
 extern "C" int ast_fft_tile_c2r_3d_batch(const void* spec, void* const* works, void* const* outs, int dtype, size_t n,
-                                         const int* m_lo, const int* m_hi, int count, double scale, int passes, void* stream) {
+                                         const int* m_lo, const int* m_hi, int count, double scale, int passes, size_t work_pitch,
+                                         void* stream) {
     AST_CHECK_ARG(spec != nullptr && works != nullptr && outs != nullptr && m_lo != nullptr && m_hi != nullptr);
     AST_CHECK_ARG(passes >= 1 && passes <= 3);
+    AST_CHECK_ARG(work_pitch == 0 || work_pitch >= n / 2 + 1);
     AST_CHECK_ARG(count >= 1 && count <= SHELL_BATCH);
     AST_CHECK_ARG(ast_fft_tile_supported(dtype, n));
     const float2* tw = g_tw.get((int)n);
     if (!tw) { ast::set_error("ast_fft_tile_c2r_3d_batch: twiddle table allocation failed"); return AST_ERR_HIP; }
     hipStream_t s = ast::as_stream(stream);
-    const size_t nz = n / 2 + 1;
+    const size_t nz = n / 2 + 1, wp = work_pitch ? work_pitch : nz;      // row pitch of the scratch spectra
     ShellBatch sb;
     C2RBatch cb;
     sb.count = cb.count = count;
@@ -1497,18 +1521,18 @@ extern "C" int ast_fft_tile_c2r_3d_batch(const void* spec, void* const* works, v
         for (int k = 0; k < i; ++k) AST_CHECK_ARG(works[i] != works[k] && outs[i] != outs[k]);
     if (passes & 1) {
         AST_PROF("fft_tile.c2c_inv", s);
-        ShellMask mx{(const float2*)spec, 0, 1};                 // radii come from the batch; hi2 > 0 switches the pruning on
-        int rc = dispatch_c2c_inv(n, sb.work[0], tw, n * nz, nz, n, nz, 1.0f, mx, s, sb);
+        ShellMask mx{(const float2*)spec, 0, 1, 0, 0, n * nz, nz};      // radii come from the batch; hi2 > 0 switches the pruning on
+        int rc = dispatch_c2c_inv(n, sb.work[0], tw, n * wp, nz, n, wp, 1.0f, mx, s, sb);
         if (rc != AST_OK) return rc;
         ShellMask my{nullptr, 0, 1, 0, 1};
-        rc = dispatch_c2c_inv(n, sb.work[0], tw, nz, nz, n, n * nz, 1.0f, my, s, sb);
+        rc = dispatch_c2c_inv(n, sb.work[0], tw, wp, nz, n, n * wp, 1.0f, my, s, sb);
         if (rc != AST_OK) return rc;
     }
     if (!(passes & 2)) return AST_OK;
     AST_PROF("fft_tile.rows_c2r", s);
-    if (n == 1024) return launch_c2r<16, 32, 16>(cb.in[0], cb.out[0], tw, n * n, nz, n, (float)scale, cb.kmax[0], s, cb);
-    if (n == 512) return launch_c2r<16, 16, 16>(cb.in[0], cb.out[0], tw, n * n, nz, n, (float)scale, cb.kmax[0], s, cb);
-    return launch_c2r<8, 16, 16>(cb.in[0], cb.out[0], tw, n * n, nz, n, (float)scale, cb.kmax[0], s, cb);
+    if (n == 1024) return launch_c2r<16, 32, 16>(cb.in[0], cb.out[0], tw, n * n, wp, n, (float)scale, cb.kmax[0], s, cb);
+    if (n == 512) return launch_c2r<16, 16, 16>(cb.in[0], cb.out[0], tw, n * n, wp, n, (float)scale, cb.kmax[0], s, cb);
+    return launch_c2r<8, 16, 16>(cb.in[0], cb.out[0], tw, n * n, wp, n, (float)scale, cb.kmax[0], s, cb);
 }
 
 // The last pass of a slab-decomposed transform fused with the shell binning: `block_d` is a rank's (n, nloc, pitch)

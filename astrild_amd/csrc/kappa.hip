@@ -295,6 +295,7 @@ struct ast_lens_plan {
     // LINEAR convolution with K(d) = +-f((|d| + 1/2) dx), cut at r > nc dx - which any periodic grid of >= 2 nc - 1 points
     // computes as well.  kappa is copied into the corner of a zeroed ncf x ncf array, the kernels are sampled on the
     // (2 ncf)^2 grid with the MAP's dx and cut-off, and the nc x nc corner of the result is copied out.
+    size_t pitch = 0;             // row pitch (complex elements) of spec / prod / kspec: lens_plan_pitch
     double* kin = nullptr;        // ncf x ncf staging input (zero outside the nc x nc corner, for the plan's lifetime)
     double* kout[2] = {nullptr, nullptr};
     ast_fft_plan* r2c = nullptr;
@@ -383,6 +384,17 @@ copy2d_kernel(const double* __restrict__ in, size_t in_pitch, double* __restrict
     }
 }
 
+// Row pitch of the plan's half spectra.  With the hand-written rows and columns it is a whole number of 128-byte lines: a
+// column tile's row piece (16 columns, 256 bytes) then covers two lines of its own.  At the natural pitch nc + 1 the piece
+// starts 16 bytes further in every row and shares its first and last line with the neighbouring tiles - which run on other
+// XCDs, behind other L2s, so those lines were fetched twice.  (AST_LENS_PITCH_ALIGN: elements, 1 = natural pitch.)
+static size_t lens_plan_pitch(bool hand_rows, size_t nh) {
+    if (!hand_rows) return nh;                         // (the rocFFT row plans are made for the natural pitch)
+    const char* v = getenv("AST_LENS_PITCH_ALIGN");
+    const size_t a = v ? (size_t)atoll(v) : 8;
+    return a > 1 ? (nh + a - 1) / a * a : nh;
+}
+
 extern "C" int ast_lens_plan_create(ast_lens_plan** out, int nc, double bsz) {
     AST_CHECK_ARG(out != nullptr && nc >= 1 && nc <= 16384 && bsz > 0.0);
     auto* p = new ast_lens_plan();
@@ -404,6 +416,7 @@ extern "C" int ast_lens_plan_create(ast_lens_plan** out, int nc, double bsz) {
     p->cols = ast_lens_cols_supported(n2) != 0 && !getenv("AST_LENS_ROCFFT_2D");
     p->rows = p->cols && ast_lens_rows_supported((size_t)p->ncf) != 0 && !getenv("AST_LENS_ROCFFT_ROWS");
     p->split_cols = getenv("AST_LENS_SPLIT_COLS") != nullptr;
+    p->pitch = lens_plan_pitch(p->rows, nh);
     if (p->rows) {
         // hand-written rows and columns: no rocFFT plan at all
     } else if (p->cols) {
@@ -419,8 +432,8 @@ extern "C" int ast_lens_plan_create(ast_lens_plan** out, int nc, double bsz) {
     hipError_t e = hipMalloc(&p->pad, n2 * n2 * sizeof(double));
     if (e == hipSuccess && !p->rows) e = hipMalloc(&p->pad_in, n2 * n2 * sizeof(double));      // (the row kernels read kappa unpadded)
     if (e == hipSuccess && !p->rows) e = hipMemset(p->pad_in, 0, n2 * n2 * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&p->spec, n2 * nh * sizeof(double2));
-    if (e == hipSuccess) e = hipMalloc(&p->prod, n2 * nh * sizeof(double2));
+    if (e == hipSuccess) e = hipMalloc(&p->spec, n2 * p->pitch * sizeof(double2));
+    if (e == hipSuccess) e = hipMalloc(&p->prod, n2 * p->pitch * sizeof(double2));
     if (e == hipSuccess && embedded) {
         const size_t sq = (size_t)p->ncf * p->ncf * sizeof(double);
         e = hipMalloc(&p->kin, sq);
@@ -441,15 +454,15 @@ extern "C" int ast_lens_plan_create(ast_lens_plan** out, int nc, double bsz) {
 static int lens_kernel_spectrum(ast_lens_plan* p, int which, hipStream_t s) {
     if (p->kready[which]) return AST_OK;
     const size_t n2 = 2 * (size_t)p->ncf, nh = n2 / 2 + 1;
-    if (!p->kspec[which]) AST_CHECK_HIP(hipMalloc(&p->kspec[which], n2 * nh * sizeof(double2)));
+    if (!p->kspec[which]) AST_CHECK_HIP(hipMalloc(&p->kspec[which], n2 * p->pitch * sizeof(double2)));
     const double dsx = p->bsz / (double)p->nc;
     // sampled with the MAP's pixel size and cut at the map's side nc dx (= Dcell * Ncc / 2 of lensing_funcs.c:58) - for an
     // embedded plan on the larger grid
     iso_kernel_build<<<ast::stream_grid(n2 * n2, 256), 256, 0, s>>>((int)n2, dsx, which, p->pad, dsx * (double)p->nc);
     AST_CHECK_LAUNCH();
     if (p->rows) {
-        AST_FWD(ast_lens_rows_forward_full(p->pad, (size_t)p->ncf, n2, p->kspec[which], nh, s));
-        AST_FWD(ast_lens_cols_forward(p->kspec[which], n2, nh, nh, n2, s));
+        AST_FWD(ast_lens_rows_forward_full(p->pad, (size_t)p->ncf, n2, p->kspec[which], p->pitch, s));
+        AST_FWD(ast_lens_cols_forward(p->kspec[which], n2, p->pitch, nh, n2, s));
     } else if (p->cols) {
         AST_FWD(ast_fft_exec(p->rows_fwd_all, p->pad, p->kspec[which], s));
         AST_FWD(ast_lens_cols_forward(p->kspec[which], n2, nh, nh, n2, s));
@@ -462,8 +475,7 @@ static int lens_kernel_spectrum(ast_lens_plan* p, int which, hipStream_t s) {
 
 // rows of the padded kappa -> p->spec (nc rows of nc + 1 complex; the column transform is the caller's)
 static int lens_rows_forward(ast_lens_plan* p, const double* kappa, hipStream_t s) {
-    const size_t n2 = 2 * (size_t)p->ncf, nh = n2 / 2 + 1;
-    if (p->rows) return ast_lens_rows_forward(kappa, (size_t)p->ncf, p->spec, nh, s);
+    if (p->rows) return ast_lens_rows_forward(kappa, (size_t)p->ncf, p->spec, p->pitch, s);
     {
         AST_PROF("lens.zero_pad", s);
         pad_corner_kernel<<<ast::stream_grid((size_t)p->nc * p->nc, 256), 256, 0, s>>>(kappa, p->nc, p->pad_in);
@@ -474,10 +486,10 @@ static int lens_rows_forward(ast_lens_plan* p, const double* kappa, hipStream_t 
 
 // the row part after the columns: out = corner of the inverse row transforms of prod, scaled
 static int lens_rows_inverse(ast_lens_plan* p, double2* prod, double* out, hipStream_t s) {
-    const size_t n2 = 2 * (size_t)p->ncf, nh = n2 / 2 + 1;
+    const size_t n2 = 2 * (size_t)p->ncf;
     if (p->rows) {                                                          // corner_matrix and out / (nx ny) * dx dy in the store
         const double dsx = p->bsz / (double)p->nc;
-        return ast_lens_rows_inverse(prod, nh, (size_t)p->ncf, dsx * dsx / (double)(n2 * n2), out, s);
+        return ast_lens_rows_inverse(prod, p->pitch, (size_t)p->ncf, dsx * dsx / (double)(n2 * n2), out, s);
     }
     AST_FWD(ast_fft_exec(p->rows_inv, prod, p->pad, s));                    // nc rows of 2nc reals
     AST_PROF("lens.crop_scale", s);
@@ -516,17 +528,17 @@ static int lens_convolve_cols(ast_lens_plan* p, const double* kappa_in, const in
     } crop{p, outs_in, nmul, s, embedded};
     AST_FWD(lens_rows_forward(p, kappa, s));
     if (p->split_cols) {
-        AST_FWD(ast_lens_cols_forward(p->spec, n2, nh, nh, (size_t)p->ncf, s));
+        AST_FWD(ast_lens_cols_forward(p->spec, n2, p->pitch, nh, (size_t)p->ncf, s));
         for (int m = 0; m < nmul; ++m) {
-            AST_FWD(ast_lens_cols_inverse(p->spec, p->kspec[which[m]], p->prod, n2, nh, nh, (size_t)p->ncf, s));
+            AST_FWD(ast_lens_cols_inverse(p->spec, p->kspec[which[m]], p->prod, n2, p->pitch, nh, (size_t)p->ncf, s));
             AST_FWD(lens_rows_inverse(p, p->prod, outs[m], s));
         }
         return crop.run();
     }
-    if (nmul == 2 && !p->prod2) AST_CHECK_HIP(hipMalloc(&p->prod2, n2 * nh * sizeof(double2)));
+    if (nmul == 2 && !p->prod2) AST_CHECK_HIP(hipMalloc(&p->prod2, n2 * p->pitch * sizeof(double2)));
     const void* muls[2] = {p->kspec[which[0]], p->kspec[which[nmul - 1]]};
     void* prods[2] = {p->prod, nmul == 2 ? (void*)p->prod2 : (void*)p->prod};
-    AST_FWD(ast_lens_cols_convolve(p->spec, n2, nh, nh, (size_t)p->ncf, muls, prods, nmul, (size_t)p->ncf, s));
+    AST_FWD(ast_lens_cols_convolve(p->spec, n2, p->pitch, nh, (size_t)p->ncf, muls, prods, nmul, (size_t)p->ncf, s));
     for (int m = 0; m < nmul; ++m) AST_FWD(lens_rows_inverse(p, (double2*)prods[m], outs[m], s));
     return crop.run();
 }

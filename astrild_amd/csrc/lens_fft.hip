@@ -766,7 +766,9 @@ col3_kernel(double2* __restrict__ data, const double2* __restrict__ twM, size_t 
     // C * 16 B < 128 B (N = 1024: four columns): a workgroup touches HALF of every 128-byte line, the workgroup of the next
     // tile the other half.  Workgroups go to the 8 XCDs round robin, so those two ran behind different L2s and every line
     // crossed HBM twice (x pass: 8.6 GB read in 3.3 ms = 2.6 TB/s apparent).  COL3_XCD_PAIR: consecutive tiles are mapped
-    // to consecutive launch slots of ONE XCD, so the second one finds the line in that L2.
+    // to consecutive launch slots of ONE XCD, so the second one finds the line in that L2.  (All tiles of a batch row on one
+    // XCD, as fft_tile.hip's strided passes do for arrays of the natural pitch, measured the same here: the pitch of the
+    // power pipeline's scratch spectrum is a whole number of lines, only the two halves of a line are shared.)
 #ifndef COL3_XCD_PAIR
 #define COL3_XCD_PAIR 1
 #endif
@@ -824,7 +826,7 @@ col3_kernel(double2* __restrict__ data, const double2* __restrict__ twM, size_t 
     if (POWER) {
         __syncthreads();
         const double s2 = scale * scale;
-        for (int i = threadIdx.x; i < NB; i += C * G::NT) partial[(size_t)blockIdx.x * NB + i] = shell[i + 1] * s2;
+        for (int i = threadIdx.x; i < NB; i += C * G::NT) partial[(size_t)bid * NB + i] = shell[i + 1] * s2;
     }
 }
 

@@ -661,15 +661,26 @@ def c2r_tile(spec, work=None, out=None, m_lo=0, m_hi=0, scale=1.0):
     return out
 
 
+def tile_work_pitch(n):
+    """Row pitch (complex elements) of the scratch spectra of :func:`c2r_tile_batch`: n/2+1 rounded up to 16 elements, so
+    that the 128-byte row pieces of the x / y passes' 16-column tiles are whole lines (at n/2+1 every piece straddles two
+    lines, both shared with the neighbouring tiles: 19 % more bytes written and re-read, profiles/r04_bispec_pruning.txt)."""
+    return (int(n) // 2 + 1 + 15) // 16 * 16
+
+
 def c2r_tile_batch(spec, shells, works, outs=None, scale=1.0, xy_batch=None):
     """:func:`c2r_tile` for up to 8 shells ``[(m_lo, m_hi), ...]`` of one spectrum (the shell is the launches' second grid
-    dimension).  ``works``: one scratch spectrum per shell.  xy_batch: shells per launch of the x and y passes (default 1:
+    dimension).  ``works``: one scratch spectrum per shell, shaped like ``spec`` or (n, n, pitch) with any pitch >= n/2+1
+    (:func:`tile_work_pitch`).  xy_batch: shells per launch of the x and y passes (default 1:
     shell by shell, so that a shell's y pass reads its x pass's output out of the Infinity Cache; measured at 512^3:
     eight per launch 8.4 ms for the 31 shells' x / y passes against 6.7); the z passes always go in one launch.
     Returns the real fields."""
     n = spec.shape[0]
     k = len(shells)
     assert 1 <= k <= 8 and len(works) >= k
+    pitch = int(works[0].shape[-1])
+    for w in works[:k]:
+        assert w.is_cuda and w.is_contiguous() and w.dtype == torch.complex64 and tuple(w.shape) == (n, n, pitch) and pitch >= n // 2 + 1
     assert spec.is_cuda and spec.is_contiguous() and spec.dtype == torch.complex64 and tuple(spec.shape) == (n, n, n // 2 + 1)
     if outs is None:
         outs = [torch.empty((n, n, n), dtype=torch.float32, device=spec.device) for _ in range(k)]
@@ -683,14 +694,14 @@ def c2r_tile_batch(spec, shells, works, outs=None, scale=1.0, xy_batch=None):
         xy_batch = int(os.environ.get("ASTRILD_BISPEC_XY_BATCH", "1"))
     xy_batch = max(1, min(int(xy_batch), k))
     if xy_batch >= k:
-        check(L.ast_fft_tile_c2r_3d_batch(ptr(spec), wp, op, F32, n, lo, hi, k, float(scale), 3, stream()), "ast_fft_tile_c2r_3d_batch")
+        check(L.ast_fft_tile_c2r_3d_batch(ptr(spec), wp, op, F32, n, lo, hi, k, float(scale), 3, pitch, stream()), "ast_fft_tile_c2r_3d_batch")
         return list(outs[:k])
     for b0 in range(0, k, xy_batch):
         kb = min(xy_batch, k - b0)
         sub = lambda arr, typ: (typ * kb)(*arr[b0:b0 + kb])
         check(L.ast_fft_tile_c2r_3d_batch(ptr(spec), sub(wp, ct.c_void_p), sub(op, ct.c_void_p), F32, n, sub(lo, ct.c_int),
-                                          sub(hi, ct.c_int), kb, float(scale), 1, stream()), "ast_fft_tile_c2r_3d_batch")
-    check(L.ast_fft_tile_c2r_3d_batch(ptr(spec), wp, op, F32, n, lo, hi, k, float(scale), 2, stream()), "ast_fft_tile_c2r_3d_batch")
+                                          sub(hi, ct.c_int), kb, float(scale), 1, pitch, stream()), "ast_fft_tile_c2r_3d_batch")
+    check(L.ast_fft_tile_c2r_3d_batch(ptr(spec), wp, op, F32, n, lo, hi, k, float(scale), 2, pitch, stream()), "ast_fft_tile_c2r_3d_batch")
     return list(outs[:k])
 
 
@@ -758,7 +769,9 @@ def bispectrum(field, boxsize, edges, triangles):
     triangles = [tuple(int(v) for v in t) for t in triangles]
     used = sorted({s for t in triangles for s in t})
     spec = r2c(field)
-    scratch = torch.empty_like(spec)
+    tile = spec.dtype == torch.complex64 and bool(_lib.lib().ast_fft_tile_supported(F32, n))
+    # (the tile passes' scratch spectrum has line-aligned rows)
+    scratch = torch.empty((n, n, tile_work_pitch(n)), dtype=spec.dtype, device=spec.device) if tile else torch.empty_like(spec)
     key = (torch.cuda.current_device(), n, tuple(edges), tuple(triangles))
     ntri = _tri_cache.get(key)
     if ntri is None:
@@ -791,7 +804,6 @@ def bispectrum(field, boxsize, edges, triangles):
         _tri_cache[key] = ntri
         _tri_cache[key + ("residual",)] = worst
     dfields = {}
-    tile = spec.dtype == torch.complex64 and bool(_lib.lib().ast_fft_tile_supported(F32, n))
     if tile:
         # the masked, pruned inverse tile passes (shell mask fused into the first pass's loads), shell by shell through ONE
         # scratch spectrum.  ASTRILD_BISPEC_BATCH=k runs k shells per launch (ast_fft_tile_c2r_3d_batch) - measured at
@@ -799,7 +811,7 @@ def bispectrum(field, boxsize, edges, triangles):
         # passes lose more (6.9 -> 8.0 ms: k scratch spectra instead of one that stays in the Infinity Cache)
         import os
         batch = max(1, min(8, int(os.environ.get("ASTRILD_BISPEC_BATCH", "1")))) if len(used) > 1 else 1
-        works = [scratch] + [torch.empty_like(spec) for _ in range(min(batch, len(used)) - 1)]
+        works = [scratch] + [torch.empty_like(scratch) for _ in range(min(batch, len(used)) - 1)]
         for b0 in range(0, len(used), batch):
             group = used[b0:b0 + batch]
             fields = c2r_tile_batch(spec, [(edges[s], edges[s + 1]) for s in group], works)

@@ -311,9 +311,12 @@ int ast_fft_tile_c2r_3d(const void* spec_d, void* work_d, void* out_d, int dtype
  * shell i's scratch spectrum and real output, m_lo[i] < m_hi[i] (host ints) its radii.  Outputs bit-identical to the
  * single call's.  passes: 1 = the x and y passes only (works[i] then hold what the z pass reads), 2 = the z pass only, 3 = all -
  * so that a caller can run x / y shell by shell (the y pass finds the x pass's output in the Infinity Cache) and the z
- * passes of several shells in one launch (small shells fill the tails of large ones). */
+ * passes of several shells in one launch (small shells fill the tails of large ones).
+ * work_pitch: row pitch of the scratch spectra in complex elements, 0 or >= n/2+1 (0 = n/2+1; works[i] then hold
+ * n * n * work_pitch elements).  A multiple of 16 keeps the 128-byte row pieces of the x / y passes on whole lines. */
 int ast_fft_tile_c2r_3d_batch(const void* spec_d, void* const* works, void* const* outs, int dtype, size_t n,
-                              const int* m_lo, const int* m_hi, int count, double scale, int passes, void* stream);
+                              const int* m_lo, const int* m_hi, int count, double scale, int passes, size_t work_pitch,
+                              void* stream);
 /* a-4 + a-5 fused: FFTPower's shell sums of an (n, n, n) real grid.  z and y passes
  * go through scratch_d (line-aligned row pitch); the x pass adds w |delta_k|^2 of its
  * modes to per-workgroup shell tables instead of storing delta_k, and a fixed-order

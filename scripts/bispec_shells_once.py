@@ -1,0 +1,19 @@
+"""The 31 masked inverse transforms of the 512^3 bispectrum leg, once, shell by shell (for rocprofv3 --pmc: per-dispatch
+traffic of the x, y and z passes against the pruning model printed by scripts/pmc_per_launch.py).
+usage: python scripts/bispec_shells_once.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from astrild_amd import device as dev
+n, L, width = 512, 1000.0, 8
+pos = dev.synth_lattice_particles(n, n, L, seed=20240601, dtype=torch.float32)
+grid = dev.paint(pos, None, n, L, "cic")
+del pos
+spec = dev.r2c(grid, engine="tile")
+edges = list(range(1, n // 2 + 1, width))
+work = torch.empty_like(spec)
+out = torch.empty((n, n, n), dtype=torch.float32, device=spec.device)
+for lo, hi in zip(edges[:-1], edges[1:]):
+    dev.c2r_tile(spec, work, out, lo, hi)
+torch.cuda.synchronize()
+print("shells", len(edges) - 1, float(out.double().sum()))

@@ -248,13 +248,22 @@ def test_batched_inverse_passes_equal_the_single_shell_calls(hip, n):
         assert torch.isfinite(field).all() and torch.equal(field, ref), (lo, hi)
     one = dev.c2r_tile_batch(spec, shells[3:4], works)
     assert torch.equal(one[0], got[3])
+    # scratch spectra with line-aligned rows (what device.bispectrum uses): the same fields, bit for bit
+    pitch = dev.tile_work_pitch(n)
+    assert pitch % 16 == 0 and n // 2 + 1 <= pitch < n // 2 + 17
+    worksp = [torch.full((n, n, pitch), float("nan"), dtype=spec.dtype, device="cuda") for _ in shells]
+    for xy in (1, 8):
+        gotp = dev.c2r_tile_batch(spec, shells, worksp, xy_batch=xy)
+        assert all(torch.equal(a, b) for a, b in zip(got, gotp)), xy
+    del worksp, gotp
     import ctypes as ct
     wp = (ct.c_void_p * 2)(works[0].data_ptr(), works[0].data_ptr())        # the same work array twice
     op = (ct.c_void_p * 2)(got[0].data_ptr(), got[1].data_ptr())
     lo, hi = (ct.c_int * 2)(1, 9), (ct.c_int * 2)(9, 17)
-    assert hip.ast_fft_tile_c2r_3d_batch(dev.ptr(spec), wp, op, 0, n, lo, hi, 2, 1.0, 3, dev.stream()) < 0
-    assert hip.ast_fft_tile_c2r_3d_batch(dev.ptr(spec), wp, op, 0, n, lo, hi, 9, 1.0, 3, dev.stream()) < 0
-    assert hip.ast_fft_tile_c2r_3d_batch(dev.ptr(spec), wp, op, 0, n, lo, hi, 1, 1.0, 0, dev.stream()) < 0
+    assert hip.ast_fft_tile_c2r_3d_batch(dev.ptr(spec), wp, op, 0, n, lo, hi, 2, 1.0, 3, 0, dev.stream()) < 0
+    assert hip.ast_fft_tile_c2r_3d_batch(dev.ptr(spec), wp, op, 0, n, lo, hi, 9, 1.0, 3, 0, dev.stream()) < 0
+    assert hip.ast_fft_tile_c2r_3d_batch(dev.ptr(spec), wp, op, 0, n, lo, hi, 1, 1.0, 0, 0, dev.stream()) < 0
+    assert hip.ast_fft_tile_c2r_3d_batch(dev.ptr(spec), wp, op, 0, n, lo, hi, 1, 1.0, 3, n // 2, dev.stream()) < 0      # pitch < n/2+1
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
