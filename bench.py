@@ -154,21 +154,32 @@ def bispectrum_leg(dev, n=512, width=8):
                    "file": os.path.relpath(tf[-1], ROOT), "measured_in_this_run": False, "matches_this_run": same,
                    "profiled": {"config": doc.get("config"), "src_sha256_16": doc.get("src_sha256_16")},
                    "current": {"config": want, "src_sha256_16": now}}
-    # per shell: the three passes of an UNPRUNED inverse transform (read + write of the half spectrum twice, read of it
-    # and write of the real cube once = 24 B per cell) + one read of the cube by the triangle sums.  The transform
-    # skips the parts of the spectrum that a shell leaves zero, so the bytes really moved are fewer.
-    alg = nsh * 24 * ng + nsh * 4 * ng
+    # Algorithmic bytes of the numerator: the forward transform of the grid (24 B per cell), per shell the three PRUNED
+    # inverse passes - what a shell of outer radius m leaves nonzero, at the passes' 16-column tile granularity: the x pass
+    # reads the rows |k_x| < m of the (k_y, k_z tile) pairs inside the disc and writes those pairs' columns, the y pass reads
+    # them and writes the k_z tiles below m for every (x, k_y), the z pass reads k_z < m and writes the real cube - and one
+    # read of the 31 cubes by the triangle sums.  (scripts/pmc_per_launch.py prints the same model beside the counters.)
+    nz = n // 2 + 1
+    alg = 24 * ng + nsh * 4 * ng
+    ky2 = np.minimum(np.arange(n), n - np.arange(n)).astype(np.int64) ** 2
+    for sh in range(nsh):
+        m = edges[sh + 1]
+        cols16 = sum(int(np.count_nonzero(ky2 + c0 * c0 < m * m)) * min(16, nz - c0) for c0 in range(0, nz, 16))
+        kz_t = sum(min(16, nz - c0) for c0 in range(0, nz, 16) if c0 < m)
+        alg += 8 * (cols16 * min(n, 2 * m) + 2 * cols16 * n + n * n * kz_t + n * n * min(m, nz)) + 4 * ng
+    unpruned = nsh * 24 * ng + nsh * 4 * ng
     return {"metric": f"bispectrum on {n}^3 grid: {nsh} shells of width {width} k_F, {len(tri)} triangle bins, fp32",
             "value": len(tri) / dt, "unit": "triangle bins/s", "ms_total": dt * 1e3,
             "alg_GB": round(alg / 1e9, 2), "GBps": round(alg / dt / 1e9, 1), "frac": round(alg / dt / 1e9 / HBM_PEAK_GBS, 4),
+            "unpruned_GB": round(unpruned / 1e9, 2),
             "traffic": traffic,
             "frac_of_peak_on_bytes_moved": (round(traffic["GB_per_call"] / dt / HBM_PEAK_GBS, 4)
                                             if traffic and traffic["GB_per_call"] else None),
             "ntri_total": int(np.sum(res["ntri"])), "ntri_residual": res["ntri_residual"],
             "first_call_ms_with_triangle_counts": round(first_ms, 1),
             "note": "value / ms_total time the estimator's numerator (31 masked, pruned inverse FFTs + all 75 cube sums in one "
-                    "pass over the 31 fields); alg_GB / frac price UNPRUNED three-pass transforms (the kernels skip what a shell "
-                    "leaves zero), frac_of_peak_on_bytes_moved uses the bytes the PMC counters saw; the triangle counts (31 "
+                    "pass over the 31 fields); alg_GB / frac price the PRUNED passes (what a shell leaves nonzero; unpruned_GB: three "
+                    "full passes per shell), frac_of_peak_on_bytes_moved uses the bytes the PMC counters saw; the triangle counts (31 "
                     "forward float64 transforms of the shell indicators + the sums) are geometry, computed on the first call "
                     "and cached - first_call_ms includes them",
             "kernels_ms": {k: round(v[1], 3) for k, v in prof.items()}}

@@ -11,9 +11,11 @@ grid = dev.paint(pos, None, n, L, "cic")
 del pos
 spec = dev.r2c(grid, engine="tile")
 edges = list(range(1, n // 2 + 1, width))
-work = torch.empty_like(spec)
+# scratch spectrum as device.bispectrum allocates it (NATURAL_PITCH=1: rows of n/2+1 elements, as before round 4)
+pitch = n // 2 + 1 if os.environ.get("NATURAL_PITCH") else dev.tile_work_pitch(n)
+work = torch.empty((n, n, pitch), dtype=spec.dtype, device=spec.device)
 out = torch.empty((n, n, n), dtype=torch.float32, device=spec.device)
 for lo, hi in zip(edges[:-1], edges[1:]):
-    dev.c2r_tile(spec, work, out, lo, hi)
+    dev.c2r_tile_batch(spec, [(lo, hi)], [work], [out])
 torch.cuda.synchronize()
 print("shells", len(edges) - 1, float(out.double().sum()))

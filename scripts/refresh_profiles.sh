@@ -22,7 +22,11 @@ rocprofv3 --pmc WRITE_SIZE -d $out/pmc_bwrite -o w --output-format csv -- python
 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_sfetch -o f --output-format csv -- python3 $R/bench.py $lean --order shuffled --steps 2 --warmup 1 > /dev/null 2> $out/pmc_sfetch.stderr
 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_swrite -o w --output-format csv -- python3 $R/bench.py $lean --order shuffled --steps 2 --warmup 1 > /dev/null 2> $out/pmc_swrite.stderr
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $out/pmc_sq -o q --output-format csv -- python3 $R/scripts/perf_paint.py 1024 cic,tsc natural 1 > $out/pmc_sq.stdout 2> $out/pmc_sq.stderr
+# per-dispatch traffic of the bispectrum's masked inverse passes against the pruning model
+rocprofv3 --pmc FETCH_SIZE -d $out/pmc_shf -o f --output-format csv -- python3 $R/scripts/bispec_shells_once.py > /dev/null 2> $out/pmc_shf.stderr
+rocprofv3 --pmc WRITE_SIZE -d $out/pmc_shw -o w --output-format csv -- python3 $R/scripts/bispec_shells_once.py > /dev/null 2> $out/pmc_shw.stderr
 cd $R
+python3 scripts/pmc_per_launch.py $out/pmc_shf $out/pmc_shw > $out/${tag}_bispec_pruning.txt
 python3 scripts/pmc_summary.py $out/pmc_sq > $out/${tag}_paint_sq_counters.txt
 python3 scripts/pmc_bispec_json.py $out/pmc_bfetch $out/pmc_bwrite $out/${tag}_pmc_bispectrum.json
 mkdir -p profiles && cp $out/${tag}_pmc_bispectrum.json profiles/${tag}_pmc_bispectrum.json
@@ -35,5 +39,5 @@ python3 bench.py > $out/${tag}_bench_1gpu.json 2> $out/bench.stderr
 find $out/stats -name "*kernel_stats.csv" -exec cp {} $out/${tag}_bench_kernel_stats.csv \;
 find $out/stats_legs -name "*kernel_stats.csv" -exec cp {} $out/${tag}_legs_kernel_stats.csv \;
 # the raw traces are large: keep only the summaries
-rm -rf $out/stats $out/stats_legs $out/pmc_fetch $out/pmc_write $out/pmc_bfetch $out/pmc_bwrite $out/pmc_sq $out/pmc_sfetch $out/pmc_swrite
+rm -rf $out/stats $out/stats_legs $out/pmc_fetch $out/pmc_write $out/pmc_bfetch $out/pmc_bwrite $out/pmc_sq $out/pmc_sfetch $out/pmc_swrite $out/pmc_shf $out/pmc_shw
 ls -la $out
