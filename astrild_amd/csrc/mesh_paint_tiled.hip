@@ -668,6 +668,7 @@ constexpr uint32_t SC_GROUPS = 8;
 #ifndef SCB_WGS
 #define SCB_WGS 64
 #endif
+static_assert(SCB_WGS % SC_GROUPS == 0 && SCB_WGS >= SC_GROUPS, "level B: every (bucket, label) segment gets SCB_WGS / SC_GROUPS workgroups");
 
 // records staged per round: four (float) or two (double) per thread - 96 KB of LDS per 1024 threads
 template <typename T, int NT> constexpr uint32_t sc_round() { return (sizeof(T) == 4 ? 4u : 2u) * (uint32_t)NT; }
