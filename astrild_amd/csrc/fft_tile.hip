@@ -227,6 +227,19 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
                 v[n1] = make_float2(0.f, 0.f);
                 if (ky * ky + c02 < mask.hi2) v[n1] = (ubase + (size_t)(n1 * R2) * es_in)[voff];
             }
+        } else if (INV && mask.hi2 > 0) {
+            // pass 0: the R2 rows n1 R2 .. n1 R2 + R2 - 1 (one per row of threads) lie outside the sphere together when the
+            // smallest |k_x| among them does - a test on scalars, the same for the whole workgroup: no load (the x pass read
+            // all N rows of every column inside the disc before, 5.2 GB for 3.4 GB of nonzero rows over the 31 shells)
+            const long long kyb = (long long)((int)b > N / 2 ? (int)b - N : (int)b);
+            const long long r2yz = kyb * kyb + (long long)(c0 * c0);
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) {
+                const int lo = n1 * R2, hi = lo + R2 - 1;
+                const long long kxmin = hi <= N / 2 ? lo : (lo >= N / 2 ? N - hi : 0);
+                v[n1] = make_float2(0.f, 0.f);
+                if (kxmin * kxmin + r2yz < mask.hi2) v[n1] = (ubase + (size_t)(n1 * R2) * es_in)[voff];
+            }
         } else {
 #pragma unroll
             for (int n1 = 0; n1 < R1; ++n1) v[n1] = ld_stream<(!INV && N >= 1024)>(ubase + (size_t)(n1 * R2) * es_in + voff);

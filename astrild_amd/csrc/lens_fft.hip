@@ -773,7 +773,14 @@ col3_kernel(double2* __restrict__ data, const double2* __restrict__ twM, size_t 
 #define COL3_XCD_PAIR 1
 #endif
     unsigned bid = blockIdx.x;
-    if (COL3_XCD_PAIR && C * sizeof(double2) < 128) {
+    const size_t row_pitch = elem_stride < batch_stride ? elem_stride : batch_stride;
+    if ((row_pitch & 7) != 0 && (gridDim.x / tiles_per_batch) % 8u == 0u) {
+        // rows that are NOT a whole number of lines (ast_fft64_r2c_3d's contiguous n / 2 + 1): a tile's pieces straddle into
+        // the lines of the tiles on either side, so all tiles of a batch row follow each other on one XCD (batch b on XCD
+        // b mod 8), as in fft_tile.hip's strided passes
+        const unsigned xcd = bid % 8, slot = bid / 8;
+        bid = ((slot / tiles_per_batch) * 8 + xcd) * tiles_per_batch + slot % tiles_per_batch;
+    } else if (COL3_XCD_PAIR && C * sizeof(double2) < 128) {
         const unsigned full = gridDim.x / 16 * 16;
         if (bid < full) {
             const unsigned xcd = bid % 8, slot = bid / 8;
