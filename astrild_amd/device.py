@@ -151,6 +151,25 @@ class PaintHalo:
         self.workspace, self.rec_ptr, self.window_code = workspace, rec_ptr, window_code
 
 
+def sample_is_unordered(pos, nmesh, boxsize, shift=0.0, windows=256):
+    """Looks at ``windows`` runs of 32 consecutive particles spread over ``pos``: in input with spatial order in memory
+    (lattice order, cell- or curve-sorted snapshots, halo by halo) at least 8 particles of a run share the 8 x 8 x 32-cell
+    tile of the run's middle particle - that is what the grouping kernel of the tiled paint turns into group records; in
+    shuffled input next to none do and the paint belongs on the two-level bucket scatter from the start.  True when fewer
+    than a quarter of the runs are groupable.  One small gather, a dozen elementwise launches and ONE host sync."""
+    npart = int(pos.shape[0])
+    if npart < 64:
+        return False
+    n = int(nmesh)
+    starts = (torch.linspace(0, npart - 32, int(windows), device=pos.device).long() // 32) * 32
+    idx = (starts[:, None] + torch.arange(32, device=pos.device)[None, :]).reshape(-1)
+    cell = torch.floor(pos[idx].double() * (n / float(boxsize)) + float(shift)).long() % n
+    tile = ((cell[:, 0] // 8) * n + cell[:, 1] // 8) * n + cell[:, 2] // 32
+    tile = tile.view(-1, 32)
+    groupable = ((tile == tile[:, 15:16]).sum(dim=1) >= 8).double().mean()
+    return bool(groupable.item() < 0.25)
+
+
 def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="auto",
           x_start=0, nx_alloc=None, check_dropped=True, accumulate=None, defer_fold=False, offset=0.0,
           hint=None, stats=None, shift=0.0, offset_planes=None):
@@ -168,7 +187,9 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     before the one rounding to the grid dtype; ``offset="mean"`` uses total mass * scale / nmesh^3,
     i.e. the grid holds rho - mean (only the DC mode changes, which FFTPower discards).
     hint: "scattered" sizes the tiled overwrite paint's workspace for particles without spatial order in memory
-    (AST_PAINT_SCATTERED); "xsorted" says they come in ascending x (lattice order, slab-ordered files): grouping and
+    (AST_PAINT_SCATTERED; without a hint, a paint of >= 2^20 particles that checks its result anyway first looks at a
+    sample - :func:`sample_is_unordered` - instead of finding out from the overflow list of a wasted first attempt);
+    "xsorted" says they come in ascending x (lattice order, slab-ordered files): grouping and
     column walk then overlap chunk by chunk (AST_PAINT_XSORTED; a wrong hint costs time, never correctness).  stats: a dict that receives the list statistics of the tiled overwrite paint.
     shift: added to every coordinate in grid units (0.5 paints the second mesh of an interlaced pair).
     offset_planes: (first, count) of the buffer planes the offset applies to (default: all) - a slab buffer's
@@ -219,6 +240,9 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
         offset = total_mass(mass, npart) * float(scale) / float(n) ** 3
     off_planes = (0, -1) if offset_planes is None else offset_planes      # (first buffer plane, count) that get the offset
     compact = use_tiled and not accumulate and method != "tiled2"       # single pass + overwrite: group / stray lists
+    if compact and hint is None and check_dropped and npart >= (1 << 20) and sample_is_unordered(pos, n, boxsize, shift):
+        tflags |= 8                                                     # (a wrong guess costs time, never correctness)
+        ws_bytes = int(L.ast_paint_tiled_workspace_bytes(win, code, npart, n, nx, tflags))
     if use_tiled:
         mass_bound = 1.0
         if mass is not None and not accumulate and npart:

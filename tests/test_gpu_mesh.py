@@ -449,6 +449,33 @@ def test_scattered_path_two_level_bucket_scatter(dev, window, dtype):
     np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * ref.max())
 
 
+def test_paint_without_hint_samples_the_order_first(hip):
+    """hint=None on >= 2^20 particles: device.paint looks at 256 runs of 32 consecutive particles before it picks the path.
+    Lattice order (also halo-like order: compact clumps, unordered inside) goes to the grouping kernel, shuffled input to
+    the two-level scatter IN THE FIRST ATTEMPT (no grouping launch at all) - and both give the grid of the explicit hint."""
+    from astrild_amd import device as dev
+    torch.cuda.set_device(0)
+    n, L = 128, 500.0
+    nat = dev.synth_lattice_particles(n, n, L, seed=5, dtype=torch.float32)
+    shuf = nat[torch.randperm(nat.shape[0], device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))].contiguous()
+    assert not dev.sample_is_unordered(nat, n, L) and dev.sample_is_unordered(shuf, n, L)
+    # clumps of 64 neighbours in lattice order, shuffled INSIDE each clump: still groupable
+    clumps = nat.view(-1, 64, 3)[:, torch.randperm(64, device="cuda"), :].reshape(-1, 3).contiguous()
+    assert not dev.sample_is_unordered(clumps, n, L)
+    for pos, want_scattered in ((nat, False), (shuf, True)):
+        st = {}
+        dev.profile_enable(True)
+        got = dev.paint(pos, None, n, L, "cic", method="tiled", accumulate=False, stats=st)
+        torch.cuda.synchronize()
+        sites = set(dev.profile_report())
+        dev.profile_enable(False)
+        assert st["scattered"] == want_scattered and st["overflow"] == 0
+        assert ("paint_tiled.level_a" in sites) == want_scattered and ("paint_tiled.fill" in sites) == (not want_scattered), sites
+        ref = dev.paint(pos, None, n, L, "cic", method="tiled", accumulate=False, hint="scattered" if want_scattered else None,
+                        check_dropped=False)
+        assert torch.equal(got, ref)
+
+
 def test_repeated_fused_pipeline_calls_are_bit_identical(hip):
     """paint -> FFT -> shells with the low-k channel on its side stream: 30 back-to-back calls (no host sync in between
     except the result fetch) give bit-identical spectra - the event ordering between the two streams holds and every
