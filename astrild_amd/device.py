@@ -151,6 +151,14 @@ class PaintHalo:
         self.workspace, self.rec_ptr, self.window_code = workspace, rec_ptr, window_code
 
 
+def sample_run_starts(npart, windows=256):
+    """First particles of ``windows`` runs of 32 spread evenly over ``npart`` particles, each a multiple of 32 and at most
+    npart - 32.  Host integers: a float32 ``linspace`` rounds 2^30 - 32 UP and the last run would start past the end."""
+    npart, windows = int(npart), max(2, int(windows))
+    assert npart >= 32
+    return [min(i * (npart - 32) // (windows - 1) // 32 * 32, npart - 32) for i in range(windows)]
+
+
 def sample_is_unordered(pos, nmesh, boxsize, shift=0.0, windows=256):
     """Looks at ``windows`` runs of 32 consecutive particles spread over ``pos``: in input with spatial order in memory
     (lattice order, cell- or curve-sorted snapshots, halo by halo) at least 8 particles of a run share the 8 x 8 x 32-cell
@@ -161,7 +169,7 @@ def sample_is_unordered(pos, nmesh, boxsize, shift=0.0, windows=256):
     if npart < 64:
         return False
     n = int(nmesh)
-    starts = (torch.linspace(0, npart - 32, int(windows), device=pos.device).long() // 32) * 32
+    starts = torch.tensor(sample_run_starts(npart, windows), dtype=torch.int64, device=pos.device)
     idx = (starts[:, None] + torch.arange(32, device=pos.device)[None, :]).reshape(-1)
     cell = torch.floor(pos[idx].double() * (n / float(boxsize)) + float(shift)).long() % n
     tile = ((cell[:, 0] // 8) * n + cell[:, 1] // 8) * n + cell[:, 2] // 32

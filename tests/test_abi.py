@@ -65,3 +65,22 @@ def test_no_gpu_means_error_not_fallback():
     from astrild_amd import device, _lib
     with pytest.raises(_lib.AstrildHipError):
         device.device()
+
+
+def test_order_probe_sample_stays_inside_the_particle_array():
+    """device.sample_is_unordered reads 32 particles from each start: every start is a multiple of 32 and leaves room for
+    its run at every particle count - in particular at 2^30, where a float32 linspace of the starts rounds past the end -
+    and on CPU tensors the probe tells lattice order from shuffled order."""
+    import numpy as np
+    import torch
+    from astrild_amd import device as dev
+    for npart in (32, 33, 64, 65, 1000, 1 << 20, (1 << 30) - 1, 1 << 30, (1 << 30) + 31, (1 << 32) - 66):
+        st = dev.sample_run_starts(npart)
+        assert len(st) == 256 and st[0] == 0 and all(s % 32 == 0 or s == npart - 32 for s in st)
+        assert all(0 <= s <= npart - 32 for s in st) and st == sorted(st)
+    n, L = 64, 100.0
+    ijk = np.stack(np.meshgrid(*(np.arange(n),) * 3, indexing="ij"), axis=-1).reshape(-1, 3)
+    rng = np.random.default_rng(3)
+    nat = torch.from_numpy((((ijk + 0.5 + 0.5 * rng.standard_normal(ijk.shape)) * (L / n)) % L).astype(np.float32))
+    assert not dev.sample_is_unordered(nat, n, L)
+    assert dev.sample_is_unordered(nat[torch.from_numpy(rng.permutation(len(nat)))].contiguous(), n, L)
