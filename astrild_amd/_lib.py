@@ -43,6 +43,7 @@ SIGNATURES = {
     "ast_paint_tile_rows": (_i, [_i]),
     "ast_paint_tile_row_planes": (_i, []),
     "ast_paint_tiled_list_stats": (_i, [_vp, _i, _i, _sz, _i, _i, _i, _vp, _vp]),
+    "ast_paint_order_probe": (_i, [_vp, _i, _sz, _i, _d, _d, _i, _vp, _vp]),
     "ast_route_count": (_i, [_vp, _i, _sz, _i, _d, _i, _i, _vp, _vp]),
     "ast_route_scatter": (_i, [_vp, _vp, _i, _sz, _i, _d, _i, _i, _vp, _vp, _vp, _vp]),
     "ast_accumulate": (_i, [_vp, _vp, _i, _sz, _vp]),

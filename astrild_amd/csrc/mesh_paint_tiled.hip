@@ -2281,6 +2281,52 @@ extern "C" int ast_paint_tiled_list_stats(void* workspace, int window, int dtype
     return AST_OK;
 }
 
+// ---- order probe: does the input have spatial order in memory? ----
+// One 64-lane workgroup per run of 32 consecutive particles (lanes 32-63 idle): the tile (TX x TY x TZ cells) of every
+// particle's cell, a ballot against the tile of the run's 16th particle; a run with >= 8 takers is what the grouping
+// kernel turns into a group record.  *groupable += 1 for such a run.  (A heuristic on plain floor(x n / L + shift): the
+// window only shifts the base cell by one.)
+template <typename T>
+__global__ void __launch_bounds__(64)
+order_probe_kernel(const T* __restrict__ pos, size_t np, int n, double inv_dx, double shift, int windows,
+                   unsigned* __restrict__ groupable) {
+    const size_t w = blockIdx.x;
+    // run starts as device.sample_run_starts: evenly spread, multiples of 32, at most np - 32 (64-bit integers)
+    size_t start = (w * (np - 32) / (size_t)(windows - 1)) / 32 * 32;
+    if (start > np - 32) start = np - 32;
+    const int lane = threadIdx.x;
+    unsigned long long key = ~0ull;
+    if (lane < 32) {
+        const T* p = pos + 3 * (start + lane);
+        long long c[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double sc = floor(__fma_rn((double)p[a], inv_dx, shift));
+            long long ci = (long long)fmod(sc, (double)n);       // (|sc| < 2^53: exact)
+            if (ci < 0) ci += n;
+            c[a] = ci;
+        }
+        key = ((unsigned long long)(c[0] / ast::TX) * (unsigned long long)n + (unsigned long long)(c[1] / ast::TY)) * (unsigned long long)n +
+              (unsigned long long)(c[2] / ast::TZ);
+    }
+    const unsigned long long k15 = __shfl(key, 15, 64);
+    const unsigned long long same = __ballot(lane < 32 && key == k15);
+    if (lane == 0 && __popcll(same) >= 8) atomicAdd(groupable, 1u);
+}
+
+extern "C" int ast_paint_order_probe(const void* pos, int dtype, size_t np, int nmesh, double boxsize, double shift_cells,
+                                     int windows, unsigned* groupable, void* stream) {
+    AST_CHECK_ARG(pos != nullptr && groupable != nullptr && (dtype == AST_F32 || dtype == AST_F64));
+    AST_CHECK_ARG(np >= 32 && nmesh > 0 && boxsize > 0.0 && windows >= 2 && windows <= 65536);
+    hipStream_t s = ast::as_stream(stream);
+    AST_CHECK_HIP(hipMemsetAsync(groupable, 0, sizeof(unsigned), s));
+    const double inv_dx = (double)nmesh / boxsize;
+    if (dtype == AST_F32) order_probe_kernel<float><<<windows, 64, 0, s>>>((const float*)pos, np, nmesh, inv_dx, shift_cells, windows, groupable);
+    else order_probe_kernel<double><<<windows, 64, 0, s>>>((const double*)pos, np, nmesh, inv_dx, shift_cells, windows, groupable);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
 static int paint_tiled_impl(int window, int dtype, const void* pos, const void* mass, size_t np, int nmesh,
                             double boxsize, double scale, int x_start, int nx_alloc, void* grid,
                             void* workspace, size_t workspace_bytes, unsigned long long* dropped,

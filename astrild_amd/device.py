@@ -159,23 +159,30 @@ def sample_run_starts(npart, windows=256):
     return [min(i * (npart - 32) // (windows - 1) // 32 * 32, npart - 32) for i in range(windows)]
 
 
-def sample_is_unordered(pos, nmesh, boxsize, shift=0.0, windows=256):
+def sample_is_unordered(pos, nmesh, boxsize, shift=0.0, windows=256, fraction=False):
     """Looks at ``windows`` runs of 32 consecutive particles spread over ``pos``: in input with spatial order in memory
     (lattice order, cell- or curve-sorted snapshots, halo by halo) at least 8 particles of a run share the 8 x 8 x 32-cell
     tile of the run's middle particle - that is what the grouping kernel of the tiled paint turns into group records; in
     shuffled input next to none do and the paint belongs on the two-level bucket scatter from the start.  True when fewer
-    than a quarter of the runs are groupable.  One small gather, a dozen elementwise launches and ONE host sync."""
+    than a quarter of the runs are groupable (``fraction=True``: that fraction itself).  On the device: ``ast_paint_order_probe`` and ONE 4-byte fetch; CPU tensors
+    (tests) go through the same arithmetic in torch."""
     npart = int(pos.shape[0])
     if npart < 64:
         return False
     n = int(nmesh)
+    if pos.is_cuda:                                    # one small kernel + a 4-byte fetch (the torch ops below: 0.25 ms)
+        cnt = torch.empty(1, dtype=torch.int32, device=pos.device)
+        check(_lib.lib().ast_paint_order_probe(ptr(pos), real_code(pos), npart, n, float(boxsize), float(shift), int(windows),
+                                               ptr(cnt), stream()), "ast_paint_order_probe")
+        frac = int(cnt.item()) / max(2, int(windows))
+        return frac if fraction else frac < 0.25
     starts = torch.tensor(sample_run_starts(npart, windows), dtype=torch.int64, device=pos.device)
     idx = (starts[:, None] + torch.arange(32, device=pos.device)[None, :]).reshape(-1)
     cell = torch.floor(pos[idx].double() * (n / float(boxsize)) + float(shift)).long() % n
     tile = ((cell[:, 0] // 8) * n + cell[:, 1] // 8) * n + cell[:, 2] // 32
     tile = tile.view(-1, 32)
-    groupable = ((tile == tile[:, 15:16]).sum(dim=1) >= 8).double().mean()
-    return bool(groupable.item() < 0.25)
+    groupable = float(((tile == tile[:, 15:16]).sum(dim=1) >= 8).double().mean().item())
+    return groupable if fraction else groupable < 0.25
 
 
 def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="auto",

@@ -215,6 +215,14 @@ int ast_paint_tiled_halo(void* workspace_d, int window, int dtype, size_t np, in
  * AST_PAINT_SCATTERED or AST_PAINT_TWO_PASS. */
 int ast_paint_tiled_list_stats(void* workspace_d, int window, int dtype, size_t np, int nmesh, int nx_alloc, int flags,
                                unsigned long long* out_d, void* stream);
+/* Does the input have spatial order in memory?  `windows` (2 .. 65536) runs of 32 consecutive particles, evenly spread over
+ * pos_d; *groupable_d (device, 4 bytes; zeroed by the call) = the number of runs in which at least 8 particles share the
+ * 8 x 8 x 32-cell tile of the run's 16th particle - what the tiled paint's grouping kernel turns into group records.
+ * Lattice-, cell- or curve-ordered input: nearly all runs; shuffled input: none, and the paint belongs on
+ * AST_PAINT_SCATTERED from the start (device.paint decides so below a quarter).  np >= 32.  No reference counterpart:
+ * pmesh's paint (stats_subfind.py:130-131) does not care about order. */
+int ast_paint_order_probe(const void* pos_d, int dtype, size_t np, int nmesh, double boxsize, double shift_cells,
+                          int windows, unsigned* groupable_d, void* stream);
 
 /* Interlacing and window compensation of a catalogue-painted mesh in Fourier space - what nbodykit's
  * CatalogMesh does for the parameters astrild writes at power_spectra/power_spectrum_3d.py:197-212

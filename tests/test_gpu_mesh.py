@@ -462,6 +462,8 @@ def test_paint_without_hint_samples_the_order_first(hip):
     # clumps of 64 neighbours in lattice order, shuffled INSIDE each clump: still groupable
     clumps = nat.view(-1, 64, 3)[:, torch.randperm(64, device="cuda"), :].reshape(-1, 3).contiguous()
     assert not dev.sample_is_unordered(clumps, n, L)
+    for pos in (nat, shuf, clumps, nat.double(), nat[:1000003].contiguous()):      # the kernel against the same arithmetic in torch
+        assert dev.sample_is_unordered(pos, n, L, 0.5, fraction=True) == dev.sample_is_unordered(pos.cpu(), n, L, 0.5, fraction=True)
     for pos, want_scattered in ((nat, False), (shuf, True)):
         st = {}
         dev.profile_enable(True)
