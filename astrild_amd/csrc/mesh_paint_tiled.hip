@@ -2051,14 +2051,16 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
         if (sel.stage == AST_PAINT_STAGE_GROUP_PART) {
             // part row0 of nrows equal parts of the particle array (boundaries on whole grouping intervals, as in the
             // x-sorted pipeline); tile rows [closed_row0, closed_row0 + closed_nrows) (mod ntx) have been walked already
-            const int k = sel.row0, K = sel.nrows;
-            if (w.tpb || plainx || K < 1 || k < 0 || k >= K || sel.closed_nrows < 0 || sel.closed_nrows > g.ntx ||
+            // (nrows = parts | (span - 1) << 16: `span` CONSECUTIVE parts, row0 .. row0 + span - 1, in one launch - stages of
+            // unequal size out of equal parts)
+            const int k = sel.row0, K = sel.nrows & 0xffff, span = (sel.nrows >> 16) + 1;
+            if (w.tpb || plainx || K < 1 || k < 0 || span < 1 || k + span > K || sel.closed_nrows < 0 || sel.closed_nrows > g.ntx ||
                 sel.closed_row0 < 0 || sel.closed_row0 >= g.ntx) {
-                ast::set_error("ast_paint_tiled_stage: GROUP_PART needs a slab buffer (not the scattered path), 0 <= part < parts and closed rows inside the buffer");
+                ast::set_error("ast_paint_tiled_stage: GROUP_PART needs a slab buffer (not the scattered path), 0 <= part, part + span <= parts and closed rows inside the buffer");
                 return AST_ERR_ARG;
             }
             const size_t pb = (size_t)((double)k / K * (double)np) / per_interval * per_interval;
-            const size_t pe = k + 1 == K ? np : (size_t)((double)(k + 1) / K * (double)np) / per_interval * per_interval;
+            const size_t pe = k + span == K ? np : (size_t)((double)(k + span) / K * (double)np) / per_interval * per_interval;
             const uint32_t rs = (uint32_t)(g.nty * g.ntz);             // tiles per row
             if (pe > pb) group_pass(pb, pe, (uint32_t)sel.closed_row0 * rs, (uint32_t)sel.closed_nrows * rs, ntiles);
             AST_CHECK_LAUNCH();

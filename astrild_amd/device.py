@@ -373,11 +373,12 @@ class StagedPaint:
         self.dropped.zero_()
         self._stage(4, 0, 0)
 
-    def group_part(self, k, parts, closed_row0=0, closed_nrows=0):
-        """The lists of part k of `parts` equal parts of the particle array (x-ordered input, slab buffers).  closed_*: the
-        tile rows walked so far, one range modulo the buffer's rows; a particle that turns up for one of them is counted
-        as dropped (check() raises): the order that was promised did not hold."""
-        self._stage(3, k, parts, closed_row0, closed_nrows)
+    def group_part(self, k, parts, closed_row0=0, closed_nrows=0, span=1):
+        """The lists of parts k .. k + span - 1 of `parts` equal parts of the particle array, in one launch (x-ordered input,
+        slab buffers).  closed_*: the tile rows walked so far, one range modulo the buffer's rows; a particle that turns up
+        for one of them is counted as dropped (check() raises): the order that was promised did not hold."""
+        assert 1 <= parts <= 65535 and span >= 1 and 0 <= k and k + span <= parts
+        self._stage(3, k, parts | ((span - 1) << 16), closed_row0, closed_nrows)
 
     def walk(self, row0, nrows):
         self._stage(1, row0, nrows)

@@ -458,10 +458,22 @@ class SlabPowerPipeline:
         # particles and step(check=True) raises).  ASTRILD_SLAB_GROUP_CHUNKS=1 groups everything first, as in the bulk order.
         if xsorted is None:
             xsorted = pos is None and not shuffle and not route
-        want = int(group_chunks or os.environ.get("ASTRILD_SLAB_GROUP_CHUNKS") or (4 if xsorted else 1))
-        ok = pipeline == "staged" and P > 1 and xsorted and not self.rows_per_stage and want > 1 and self.nloc % want == 0 \
-            and self.nloc // want >= 2 * (ghost + 1) and hasattr(o, "staged_paint")
-        self.group_chunks = want if ok else 1
+        def parts_ok(want):
+            return pipeline == "staged" and P > 1 and xsorted and not self.rows_per_stage and want > 1 and self.nloc % want == 0 \
+                and self.nloc // want >= 2 * (ghost + 1) and hasattr(o, "staged_paint")
+        asked = int(group_chunks or os.environ.get("ASTRILD_SLAB_GROUP_CHUNKS") or 0)
+        if asked:
+            self.group_chunks = asked if parts_ok(asked) else 1
+        else:
+            # the finest of 16 / 8 / 4 equal parts the slab allows (a part must be deeper than the particles' reach); the
+            # stages then take unequal numbers of them (_make_schedule)
+            self.group_chunks = next((k for k in (16, 8, 4) if xsorted and parts_ok(k)), 1)
+        # ASTRILD_SLAB_STAGES="7|0,1,2,3|4,5|6": which of the group_chunks equal parts each stage groups (consecutive parts of
+        # a stage go in one launch) - stages of unequal size; default: see _make_schedule
+        self.group_stages = None
+        spec = os.environ.get("ASTRILD_SLAB_STAGES")
+        if spec and self.group_chunks > 1:
+            self.group_stages = [[int(v) for v in st.split(",")] for st in spec.split("|")]
         self.send_planes = max(1, int(os.environ.get("ASTRILD_SLAB_SEND_PLANES") or 24))
         self.staged = None
         self.schedule = None
@@ -493,7 +505,7 @@ class SlabPowerPipeline:
     def _make_schedule(self, sp):
         """The static order of a staged step - the same on every rank (it depends on the geometry only), which is what
         lets the ranks' point-to-point operations match up.  Entries: ("group",) or ("reset",) and ("group_part", k, K,
-        closed_row0, closed_nrows); ("walk", row0, nrows); ("fold", row0, nrows); ("ghost_start",) or ("ghost_start_upper",) /
+        closed_row0, closed_nrows, span); ("walk", row0, nrows); ("fold", row0, nrows); ("ghost_start",) or ("ghost_start_upper",) /
         ("ghost_start_lower",); ("ghost_finish",); ("fft", p0, npl) with p0 counted in OWNED planes."""
         R, PR = sp.nrows_total, sp.row_planes
         gl, gh, nloc = self.gl, self.gh, self.nloc
@@ -555,12 +567,13 @@ class SlabPowerPipeline:
 
             grouped = set()
 
-            def group(k):
-                # the walked rows form one range modulo R: a block that ends at R - 1 (walked first) and a block that starts at 0
+            def group(k, span=1):
+                # parts k .. k + span - 1 in ONE launch.  The walked rows form one range modulo R: a block that ends at
+                # R - 1 (walked first) and a block that starts at 0
                 high = sorted(r for r in walked if all(q in walked for q in range(r, R)))
                 row0 = high[0] if high else 0
-                sched.append(("group_part", k, K, row0 if walked else 0, len(walked)))
-                grouped.add(k)
+                sched.append(("group_part", k, K, row0 if walked else 0, len(walked), span))
+                grouped.update(range(k, k + span))
                 assert not walked or set((row0 + i) % R for i in range(len(walked))) == walked, "walked rows must stay one cyclic range"
 
             def walk_complete():
@@ -584,14 +597,23 @@ class SlabPowerPipeline:
             started = {"upper": False, "lower": False}
             # parts per stage: the last part alone (the rows of the upper ghost planes), then two at a time, and the
             # LAST stage one part again - what is still to be transformed and sent after the last walk is then small
-            order = list(range(K - 1))
-            stages = [[K - 1]]
-            while len(order) > 2:
-                stages.append([order.pop(0), order.pop(0)])
-            stages += [[k] for k in order]
+            stages = self.group_stages
+            if stages is None:
+                # the last part alone (the rows of the upper ghost planes: their exchange starts, the first planes leave),
+                # the parts 0 .. K - 3 in ceil((K - 2) / 5) stages of about equal size - one launch each; a stage's planes
+                # travel while the next stage is grouped and walked -, and part K - 2 alone: what is still to be
+                # transformed and sent after the last walk is small.  K = 4: 3 | 0 1 | 2;  8: 7 | 0 1 2 | 3 4 5 | 6;
+                # 16: 15 | 0-4 | 5-9 | 10-13 | 14 - at 1024^3 on 8 ranks (scripts/perf_slab_staged.py, STAGE_SPECS=...) the
+                # forecast at 60 GB/s per link: 5.24-5.31x, 5.41-5.44x, 5.50x; ten other splits of 8 or 16 parts: 5.25-5.47x
+                middle = list(range(K - 2))
+                ng = max(1, -(-(K - 2) // 5))
+                cut = [-(-i * len(middle) // ng) for i in range(ng + 1)]          # (the larger stages first)
+                stages = [[K - 1]] + [middle[cut[i]:cut[i + 1]] for i in range(ng)] + [[K - 2]]
+                stages = [st for st in stages if st]
+            assert sorted(k for st in stages for k in st) == list(range(K)), "every part in exactly one stage"
             for stage in stages:
-                for k in stage:
-                    group(k)
+                for k0, span in runs(stage):          # consecutive parts of a stage: one grouping launch
+                    group(k0, span)
                 walk_complete()
                 fold_ready()
                 if not started["upper"] and upper_rows <= folded:
@@ -728,7 +750,7 @@ class SlabPowerPipeline:
             elif kind == "reset":
                 sp.reset()
             elif kind == "group_part":
-                sp.group_part(entry[1], entry[2], entry[3], entry[4])
+                sp.group_part(entry[1], entry[2], entry[3], entry[4], entry[5])
             elif kind == "ghost_start":
                 self.ghosts.start()
             elif kind == "ghost_start_upper":

@@ -187,7 +187,8 @@ int ast_paint_tiled(int window, int dtype, const void* pos_d, const void* mass_d
 /* Grouping in PARTS, for particles that come in ascending x (slab-ordered input; slab buffers only, not AST_PAINT_SCATTERED):
  *   AST_PAINT_STAGE_RESET          once, instead of GROUP: clears the lists' counters;
  *   AST_PAINT_STAGE_GROUP_PART k K the lists of part k of K equal parts of the particle array (row0 = k, nrows = K), in any
- *                                  order of parts.  closed_row0 / closed_nrows name the tile rows that have been WALKED
+ *                                  order of parts; nrows = K | (span - 1) << 16 (K <= 65535) takes the `span` consecutive
+ *                                  parts k .. k + span - 1 in ONE launch (stages of unequal size).  closed_row0 / closed_nrows name the tile rows that have been WALKED
  *                                  already - one range, taken modulo the buffer's rows (the rows of the top ghost planes
  *                                  first, then 0, 1, ...).  A particle of a later part whose tile lies in a closed row
  *                                  cannot be painted any more (the row may have been transformed and sent): it is counted

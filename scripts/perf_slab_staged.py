@@ -96,12 +96,20 @@ def run(pipeline, rps=None, streams=1, reps=7, parts=None):
 
 
 if os.environ.get("ONLY_DEFAULT"):
-    run("staged", parts=4)
+    run("staged", parts=None)
+    dist.destroy_process_group()
+    sys.exit(0)
+if os.environ.get("STAGE_SPECS"):         # e.g. STAGE_SPECS="8:7|0,1,2,3|4,5|6;4:3|0,1|2": parts:stages, one run each
+    for item in os.environ["STAGE_SPECS"].split(";"):
+        k, spec = item.split(":")
+        os.environ["ASTRILD_SLAB_STAGES"] = spec
+        print(f"=== parts {k}, stages {spec}", flush=True)
+        run("staged", parts=int(k), reps=5)
     dist.destroy_process_group()
     sys.exit(0)
 run("bulk")
 run("staged", parts=1)               # everything grouped first (first stage half as long)
-run("staged", parts=4)               # grouping in four parts, the last one first (the default for x-ordered input)
-run("staged", parts=8)
-run("staged", rps=5, parts=1)
+run("staged", parts=4)               # grouping in four equal parts, the last one first: 3 | 0 1 | 2
+run("staged", parts=8)               # 7 | 0 1 2 | 3 4 5 | 6
+run("staged", parts=None)            # the default for x-ordered input: sixteen parts in five stages, 15 | 0-4 | 5-9 | 10-13 | 14
 dist.destroy_process_group()

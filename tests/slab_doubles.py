@@ -104,18 +104,19 @@ class StagedPaintDouble:
         self.parts_grouped = set()
         self.parts_total = None
 
-    def group_part(self, k, parts, closed_row0=0, closed_nrows=0):
-        """Part k of `parts` (x-ordered input): no particle of it may belong to a row that has been walked - the closed
-        range handed over must be exactly the rows walked so far."""
-        assert self.parts_total in (None, parts) and k not in self.parts_grouped
+    def group_part(self, k, parts, closed_row0=0, closed_nrows=0, span=1):
+        """Parts k .. k + span - 1 of `parts` (x-ordered input): no particle of them may belong to a row that has been
+        walked - the closed range handed over must be exactly the rows walked so far."""
+        assert span >= 1 and 0 <= k and k + span <= parts
+        assert self.parts_total in (None, parts) and not (set(range(k, k + span)) & self.parts_grouped)
         self.parts_total = parts
         closed = {(closed_row0 + i) % self.nrows_total for i in range(closed_nrows)}
         assert closed == self.walked, (closed, self.walked)
         npart = self.pos.shape[0]
-        rows = self._key_rows()[k * npart // parts:(k + 1) * npart // parts]
+        rows = self._key_rows()[k * npart // parts:(k + span) * npart // parts]
         if np.isin(rows, list(closed)).any():
             self.lost = True                       # what the kernel counts as dropped
-        self.parts_grouped.add(k)
+        self.parts_grouped.update(range(k, k + span))
 
     def group(self):
         self.parts_grouped, self.parts_total = None, None

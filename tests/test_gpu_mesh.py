@@ -665,22 +665,25 @@ def test_staged_paint_grouped_in_parts(dev, window):
     mine = pos[(idx >= x_start + gl) & (idx < x_start + nx - gl)].contiguous()           # lattice planes 64 .. 127: x-ordered, jitter < ghost
     ref = dev.paint(mine, None, n, L, window, method="tiled", accumulate=False, x_start=x_start, nx_alloc=nx, offset=0.5,
                     offset_planes=(gl, nx - 2 * gl), check_dropped=True)
-    K, PR = 4, 8
+    PR = 8
     nloc = nx - 2 * gl
+    shuffled = mine[torch.randperm(mine.shape[0], device="cuda")].contiguous()
+    # equal parts one by one, and stages of unequal size: several consecutive parts of 8 in one launch
+    plans = ((4, [(3, 1), (0, 1), (1, 1), (2, 1)]), (8, [(7, 1), (0, 4), (4, 2), (6, 1)]))
 
-    def key_rows(k):
-        return range((gl - ghost + k * nloc // K) // PR, (gl + ghost + (k + 1) * nloc // K - 1) // PR + 1)
+    for (K, launches), (particles, expect_loss) in [(pl, case) for pl in plans for case in ((mine, False), (shuffled, True))]:
+        def key_rows(k):
+            return range((gl - ghost + k * nloc // K) // PR, (gl + ghost + (k + 1) * nloc // K - 1) // PR + 1)
 
-    for particles, expect_loss in ((mine, False), (mine[torch.randperm(mine.shape[0], device="cuda")].contiguous(), True)):
         out = torch.full((nx, n, n), float("nan"), dtype=torch.float32, device="cuda")
         sp = dev.StagedPaint(particles, None, n, L, window, out, x_start=x_start, nx_alloc=nx, offset=0.5, offset_planes=(gl, nloc))
         R = sp.nrows_total
         sp.reset()
         grouped, walked = set(), []
-        for k in [K - 1] + list(range(K - 1)):
+        for k, span in launches:
             high = [r for r in walked if all(q in walked for q in range(r, R))]
-            sp.group_part(k, K, min(high) if high else 0, len(walked))
-            grouped.add(k)
+            sp.group_part(k, K, min(high) if high else 0, len(walked), span)
+            grouped.update(range(k, k + span))
             ready = [r for r in range(R) if r not in walked and all(j in grouped for j in range(K) if r in key_rows(j))]
             top = sorted(r for r in ready if all(q in ready or q in walked for q in range(r, R)))
             bottom = sorted(r for r in ready if r not in top)

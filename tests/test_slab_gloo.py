@@ -29,6 +29,8 @@ def _particles(n=N, nps=NPS):
 def _worker(rank, world, port, window, out_dir, chunks=2, n=N, nps=NPS, ghost=2, pipeline="bulk", rows_per_stage=None,
             group_chunks=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if group_chunks == 8:                 # stages of unequal size: consecutive parts of a stage are grouped in one launch
+        os.environ["ASTRILD_SLAB_STAGES"] = "7|0,1,2,3|4,5|6"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from astrild_amd import slab
@@ -47,7 +49,10 @@ def _worker(rank, world, port, window, out_dir, chunks=2, n=N, nps=NPS, ghost=2,
             kinds = [e[0] for e in pipe.schedule]
             if group_chunks:
                 # grouping in parts: planes are transformed (and sent) before the last part has been grouped
-                assert kinds.count("group_part") == group_chunks and "group" not in kinds
+                spans = [e[5] for e in pipe.schedule if e[0] == "group_part"]          # (consecutive parts of a stage: one launch)
+                assert sum(spans) == group_chunks and len(spans) <= group_chunks and "group" not in kinds
+                if group_chunks == 8:
+                    assert spans == [1, 4, 2, 1]
                 assert kinds.index("fft") < len(kinds) - 1 - kinds[::-1].index("group_part")
                 kinds = [k.replace("ghost_start_upper", "ghost_start") for k in kinds if k != "ghost_start_lower"]
             # the ghost exchange starts before the interior is walked, and planes leave before the ghosts are waited for
@@ -73,7 +78,8 @@ def _worker(rank, world, port, window, out_dir, chunks=2, n=N, nps=NPS, ghost=2,
     # ... with the particles grouped in parts (x-ordered input; rps column = number of parts, negative): the double checks
     # that no row is walked before every part holding one of its particles is grouped, and that no part brings a
     # particle for a row already walked
-    ("cic", 1, 2, 64, 64, 3, "staged", -4), ("tsc", 1, 2, 64, 64, 3, "staged", -2), ("cic", 1, 4, 128, 64, 3, "staged", -4)])
+    ("cic", 1, 2, 64, 64, 3, "staged", -4), ("tsc", 1, 2, 64, 64, 3, "staged", -2), ("cic", 1, 4, 128, 64, 3, "staged", -4),
+    ("tsc", 1, 2, 128, 64, 3, "staged", -8)])
 def test_slab_pipeline_ranks_match_single_process_oracle(tmp_path, window, chunks, world, n, nps, ghost, pipeline, rps):
     port = _free_port()
     parts = -rps if rps is not None and rps < 0 else None
