@@ -465,9 +465,9 @@ class SlabPowerPipeline:
         if asked:
             self.group_chunks = asked if parts_ok(asked) else 1
         else:
-            # the finest of 16 / 8 / 4 equal parts the slab allows (a part must be deeper than the particles' reach); the
-            # stages then take unequal numbers of them (_make_schedule)
-            self.group_chunks = next((k for k in (16, 8, 4) if xsorted and parts_ok(k)), 1)
+            # 8 equal parts (else 4) where the slab allows it - a part must be deeper than the particles' reach; the stages
+            # take unequal numbers of them (_make_schedule).  16 parts forecast the same within the box-to-box spread
+            self.group_chunks = next((k for k in (8, 4) if xsorted and parts_ok(k)), 1)
         # ASTRILD_SLAB_STAGES="7|0,1,2,3|4,5|6": which of the group_chunks equal parts each stage groups (consecutive parts of
         # a stage go in one launch) - stages of unequal size; default: see _make_schedule
         self.group_stages = None
@@ -599,16 +599,32 @@ class SlabPowerPipeline:
             # LAST stage one part again - what is still to be transformed and sent after the last walk is then small
             stages = self.group_stages
             if stages is None:
-                # the last part alone (the rows of the upper ghost planes: their exchange starts, the first planes leave),
-                # the parts 0 .. K - 3 in ceil((K - 2) / 5) stages of about equal size - one launch each; a stage's planes
-                # travel while the next stage is grouped and walked -, and part K - 2 alone: what is still to be
-                # transformed and sent after the last walk is small.  K = 4: 3 | 0 1 | 2;  8: 7 | 0 1 2 | 3 4 5 | 6;
-                # 16: 15 | 0-4 | 5-9 | 10-13 | 14 - at 1024^3 on 8 ranks (scripts/perf_slab_staged.py, STAGE_SPECS=...) the
-                # forecast at 60 GB/s per link: 5.24-5.31x, 5.41-5.44x, 5.50x; ten other splits of 8 or 16 parts: 5.25-5.47x
-                middle = list(range(K - 2))
-                ng = max(1, -(-(K - 2) // 5))
-                cut = [-(-i * len(middle) // ng) for i in range(ng + 1)]          # (the larger stages first)
-                stages = [[K - 1]] + [middle[cut[i]:cut[i + 1]] for i in range(ng)] + [[K - 2]]
+                # FIRST the top parts that complete the tile rows of the upper ghost planes (their exchange starts, the first
+                # planes leave; the ghost planes share the two links to the ring neighbours with a seventh of the spectrum and
+                # must be in before the last planes can be transformed).  Then the parts 0, 1, ... in stages of DECREASING
+                # size, one grouping launch each: a stage's planes travel while the next stage is grouped and walked, and what
+                # is still to be transformed and sent after the last walk is small.
+                # 1024^3 on 8 ranks (scripts/perf_slab_staged.py with STAGE_SPECS=..., forecast at 60 / 50 GB/s per link
+                # with the ghost planes on the neighbour links, two boxes): 4 parts 3 | 0 1 | 2: 5.21-5.22x / 4.73x;  8 parts (the
+                # default) 7 | 0 1 2 | 3 4 5 | 6: 5.35-5.45x / 4.99-5.03x;  16 parts 14 15 | 0-5 | 6-10 | 11 12 | 13: 5.32-5.40x /
+                # 5.03-5.05x (14 15 | 0-4 | 5-8 | 9-12 | 13: 5.26x / 5.09x; 15 | 0-4 | 5-9 | 10-13 | 14, whose upper ghost planes
+                # leave last: 4.91x / 4.63x);  everything grouped first: 5.16x / 4.94x.
+                need = set()
+                for r in upper_rows:
+                    need.update(sp.fold_needs(r))
+                first = [K - 1]
+                while first[0] > 1 and need & set(key_rows(first[0] - 1)):
+                    first.insert(0, first[0] - 1)
+                m = first[0]                                            # parts 0 .. m - 1 remain
+                sizes = {(16, 14): [6, 5, 2, 1], (8, 7): [3, 3, 1], (4, 3): [2, 1]}.get((K, m))
+                if sizes is None:                                       # other geometries: stages of <= 5 parts, the last part alone
+                    ng = max(1, -(-(m - 1) // 5))
+                    cut = [-(-i * (m - 1) // ng) for i in range(ng + 1)]
+                    sizes = [cut[i + 1] - cut[i] for i in range(ng) if cut[i + 1] > cut[i]] + [1]
+                stages, k0 = [first], 0
+                for sz in sizes:
+                    stages.append(list(range(k0, k0 + sz)))
+                    k0 += sz
                 stages = [st for st in stages if st]
             assert sorted(k for st in stages for k in st) == list(range(K)), "every part in exactly one stage"
             for stage in stages:

@@ -78,19 +78,45 @@ def run(pipeline, rps=None, streams=1, reps=7, parts=None):
                 tag = f"   -> {sent}/{pipe.nloc} planes ready to send"
             print(f"    {t0.elapsed_time(e):7.3f} ms  {entry}{tag}")
         pipe.trace = None
-        # forecast: a piece of p planes is ready at t and needs p * (bytes per plane and link) / B on every link; the links
-        # carry the pieces one after the other; then the axis-0 pass + binning and the all-reduces (0.1 ms assumed)
-        wire = pipe.wire_bytes()["transpose"] / (P - 1) / pipe.nloc / 1e6          # MB per plane and link
+        # forecast: a piece of p planes is ready at t and needs p * (bytes per plane and link) / B on every link; a link
+        # carries its messages one after the other in the order they were enqueued; then the axis-0 pass + binning and the
+        # all-reduces (0.1 ms assumed).  The two links to the ring neighbours ALSO carry the ghost planes (upper ghosts to
+        # rank + 1 when ghost_start_upper / ghost_start is enqueued, lower ghosts to rank - 1): every rank runs the same
+        # schedule, so what this rank waits for at ghost_finish arrives when its own ghost message would; a late arrival
+        # delays everything enqueued after ghost_finish.
+        wb = pipe.wire_bytes()
+        wire = wb["transpose"] / (P - 1) / pipe.nloc / 1e6          # MB per plane and link
+        ghost_mb = wb["ghost"] / 2 / 1e6                            # MB of ghost planes per neighbour
         tail = (prof.get("fft_tile.c2c_power", (0, 0))[1] + prof.get("fft_tile.shell_reduce", (0, 0))[1]) / reps + 0.1
-        pieces = [(t0.elapsed_time(e), entry[2]) for entry, e in pipe_trace if entry[0] == "fft"]
+        times = [(t0.elapsed_time(e), entry) for entry, e in pipe_trace[1:]]
+        t_finish = next(t for t, en in times if en[0] == "ghost_finish")
         single = float(os.environ.get("SINGLE_GPU_MS", "13.13"))
         for B in (40, 50, 60, 70, 1e9):
-            done = 0.0
-            for ready, planes in sorted(pieces):
-                done = max(done, ready) + planes * wire / B
+            def link(ghost_kinds, delay):
+                """Completion of all messages on one link direction and of its ghost message: FIFO by enqueue time."""
+                msgs = []
+                for t, en in times:
+                    t += delay if t > t_finish else 0.0
+                    if en[0] == "fft":
+                        msgs.append((t, en[2] * wire))
+                    elif en[0] in ghost_kinds:
+                        msgs.append((t, -ghost_mb))
+                done, ghost_done = 0.0, 0.0
+                for t, mb in sorted(msgs, key=lambda m: m[0]):
+                    done = max(done, t) + abs(mb) / B
+                    if mb < 0:
+                        ghost_done = done
+                return done, ghost_done
+            delay = 0.0
+            for _ in range(3):                                      # (the delay moves the last pieces, which moves nothing before them)
+                _, g_up = link(("ghost_start", "ghost_start_upper"), delay)
+                _, g_lo = link(("ghost_start", "ghost_start_lower"), delay)
+                delay = max(0.0, max(g_up, g_lo) - t_finish)
+            done = max(link((), delay)[0], link(("ghost_start", "ghost_start_upper"), delay)[0],
+                       link(("ghost_start", "ghost_start_lower"), delay)[0])
             step = done + tail
-            print(f"    forecast B = {B if B < 1e8 else 'inf':>4} GB/s per link and direction: exchange done {done:.3f} ms, step {step:.3f} ms, "
-                  f"{single / step:.2f}x of the single GPU's {single} ms")
+            print(f"    forecast B = {B if B < 1e8 else 'inf':>4} GB/s per link and direction: ghosts in {max(g_up, g_lo):.3f} ms (waited for at {t_finish:.3f}), "
+                  f"exchange done {done:.3f} ms, step {step:.3f} ms, {single / step:.2f}x of the single GPU's {single} ms")
     del pipe
     torch.cuda.empty_cache()
 
@@ -110,6 +136,6 @@ if os.environ.get("STAGE_SPECS"):         # e.g. STAGE_SPECS="8:7|0,1,2,3|4,5|6;
 run("bulk")
 run("staged", parts=1)               # everything grouped first (first stage half as long)
 run("staged", parts=4)               # grouping in four equal parts, the last one first: 3 | 0 1 | 2
-run("staged", parts=8)               # 7 | 0 1 2 | 3 4 5 | 6
-run("staged", parts=None)            # the default for x-ordered input: sixteen parts in five stages, 15 | 0-4 | 5-9 | 10-13 | 14
+run("staged", parts=None)            # the default for x-ordered input: eight parts in four stages, 7 | 0 1 2 | 3 4 5 | 6
+run("staged", parts=16)              # 14 15 | 0-5 | 6-10 | 11 12 | 13
 dist.destroy_process_group()

@@ -277,8 +277,8 @@ def test_one_rank_of_eight_at_1024_local_pieces(hip, ghost):
 
 @pytest.mark.parametrize("rank", [0, 3, 7])
 def test_one_rank_of_eight_staged_step_with_grouping_in_parts(hip, monkeypatch, rank):
-    """The driver's 8-GPU geometry (1024^3, 128 planes per rank, ghost 3 -> 136-plane buffer, particles grouped in sixteen
-    parts over five stages, the last part first) for ONE rank in one process: the exchanges are stubbed out, everything the rank computes is real.
+    """The driver's 8-GPU geometry (1024^3, 128 planes per rank, ghost 3 -> 136-plane buffer, particles grouped in eight
+    parts over four stages, the last part first) for ONE rank in one process: the exchanges are stubbed out, everything the rank computes is real.
     No particle may turn up for a tile row that was walked already (check=True: the dropped counter stays zero, also for
     the ranks that hold the periodic wrap), and the slab buffer must equal the one-call paint of the same particles."""
     import torch.distributed as dist
@@ -294,10 +294,10 @@ def test_one_rank_of_eight_staged_step_with_grouping_in_parts(hip, monkeypatch, 
         monkeypatch.setattr(slab.GhostExchange, name, lambda self: None)
     monkeypatch.setattr(slab.GhostExchange, "finish", lambda self: None)          # (no neighbours: nothing is added)
     pipe = slab.SlabPowerPipeline(n, L, n, window="cic", dtype=torch.float32, ghost=3, seed=20240601)
-    assert pipe.pipeline == "staged" and pipe.group_chunks == 16 and pipe.nx_alloc == 136
+    assert pipe.pipeline == "staged" and pipe.group_chunks == 8 and pipe.nx_alloc == 136
     sched = pipe._make_schedule(pipe.ops.staged_paint(pipe.pos, None, n, L, "cic", pipe.buf, pipe.x_start, pipe.nx_alloc))
     kinds = [e[0] for e in sched]
-    assert [e[5] for e in sched if e[0] == "group_part"] == [1, 5, 5, 4, 1] and kinds.index("fft") < len(kinds) - 1 - kinds[::-1].index("group_part")
+    assert [e[5] for e in sched if e[0] == "group_part"] == [1, 3, 3, 1] and kinds.index("fft") < len(kinds) - 1 - kinds[::-1].index("group_part")
     pipe.step(check=True)                       # raises if a deposit left the buffer or a particle arrived late
     assert int(pipe.staged.dropped.item()) == 0
     staged = pipe.buf.clone()
