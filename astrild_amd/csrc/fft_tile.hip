@@ -196,6 +196,18 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
         const long long r2 = (long long)(c0 * c0) + (mask.pass == 0 ? kb * kb : 0);
         if (r2 >= mask.hi2) return;
     }
+    // FORWARD PRUNING (mask.hi2 = (N/2)^2 on the two strided passes of the power pipeline): FFTPower keeps |m| < N/2 only
+    // (power_spectrum_3d.py:189-195; a vector of norm exactly N/2 may fall into the last shell under the float64 rule, so the
+    // edge itself stays).  After the y pass a row (k_y, 16-column tile from k_z0) with k_y^2 + k_z0^2 > (N/2)^2 holds no mode
+    // any shell takes, whatever k_x: the y pass does not store it (below), and the binning pass leaves that tile out - 21.5 %
+    // of the half plane, neither written nor read again.  The skipped workgroup still owns a row of `partial`: zeros.
+    if (!INV && POWER && mask.hi2 > 0) {
+        const long long kyi = (long long)b + mask.ky0, ky = kyi > N / 2 ? kyi - N : kyi;
+        if (ky * ky + (long long)(c0 * c0) > mask.hi2) {
+            for (int i = threadIdx.x; i < NB; i += NT) partial[((size_t)b * tiles_per_batch + tile) * NB + i] = 0.0;
+            return;
+        }
+    }
     for (int i = threadIdx.x; i < N; i += NT) tw[i] = tw_g[i];
     if (POWER)
         for (int i = threadIdx.x; i <= NB; i += NT) shell[i] = 0.0;
@@ -306,11 +318,20 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
         const bool ok_s = C > 16 ? (unsigned)c0 + (unsigned)cs < (unsigned)ncols : col_ok;
         if (ok_s && !POWER) {
             float2* const base = data + (size_t)b * batch_stride + c0 + cs;
+            // forward pruning: rows are k_y, the tile starts at k_z0 = c0; keep k_y^2 <= room.  Decided per WAVE on scalars (the
+            // wave's smallest |k_y| of the row block; a wave holds 64 / C consecutive `sub`): a per-lane test cost 16 VGPRs
+            // in a kernel held to 128, and the one to three rows a wave stores beyond the disc are never read.
+            const int room = (!INV && mask.hi2 > 0) ? (int)mask.hi2 - (int)(c0 * c0) : 0x7fffffff;
+            const int wsub0 = __builtin_amdgcn_readfirstlane((int)threadIdx.x) / C, wsub1 = wsub0 + 64 / C - 1;
 #pragma unroll
             for (int k2 = 0; k2 < R2; ++k2) {
                 float2 x = u[bitrev(k2, ilog2(R2))];
                 x.x *= scale;
                 x.y *= INV ? -scale : scale;
+                if (!INV) {
+                    const int aky = R1 * k2 >= N / 2 ? N - (wsub1 + R1 * k2) : wsub0 + R1 * k2;    // smallest |k_y| in the wave
+                    if (aky * aky > room) continue;
+                }
                 if (PACK) {
                     // c1 = rows per part >= R1 (host-checked): the part of row sub + R1 k2 and its row block inside the
                     // part do not depend on the lane - a uniform base per k2 plus ONE 32-bit lane offset for all stores
@@ -985,7 +1006,7 @@ struct TwiddleCache {
 
 template <int R1, int R2, int C, bool POWER>
 int launch_c2c(float2* data, const float2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride,
-               float scale, double* partial, hipStream_t s, const unsigned* edge_fall = nullptr, int ky0 = 0) {
+               float scale, double* partial, hipStream_t s, const unsigned* edge_fall = nullptr, int ky0 = 0, long long prune2 = 0) {
     constexpr int N = R1 * R2, NT = C * (R1 > R2 ? R1 : R2);
     constexpr bool SPLIT = (POWER || C > 16) && R1 == R2 && N * C * sizeof(float2) > 64 * 1024;       // as in the kernel
     const size_t lds = (size_t)((SPLIT ? N / 2 : N) * C + N) * sizeof(float2) + (POWER ? (N / 2) * sizeof(double) : 0);
@@ -1000,7 +1021,7 @@ int launch_c2c(float2* data, const float2* tw, size_t elem_stride, size_t ncols,
     AST_CHECK_ARG((size_t)(R2 - 1) * elem_stride + ncols < (1ull << 29));      // the kernel's 32-bit lane offsets
     strided_c2c_kernel<R1, R2, C, POWER><<<(unsigned)(tiles * batch), NT, lds, s>>>(data, tw, elem_stride, ncols,
                                                                                    batch_stride, (unsigned)tiles, scale,
-                                                                                   partial, edge_fall, ShellMask{nullptr, 0, 0, ky0});
+                                                                                   partial, edge_fall, ShellMask{nullptr, 0, prune2, ky0});
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
@@ -1055,15 +1076,16 @@ int dispatch_c2c_inv(size_t n, float2* d, const float2* tw, size_t elem_stride, 
 
 template <bool POWER>
 int dispatch_c2c(size_t n, float2* d, const float2* tw, size_t elem_stride, size_t ncols, size_t batch,
-                 size_t batch_stride, float scale, double* partial, hipStream_t s, const unsigned* edge_fall = nullptr, int ky0 = 0) {
+                 size_t batch_stride, float scale, double* partial, hipStream_t s, const unsigned* edge_fall = nullptr, int ky0 = 0,
+                 long long prune2 = 0) {
 #ifndef FWD_C
 #define FWD_C 32                    // columns per workgroup of the plain forward pass at N = 1024: 32 = 256-byte row pieces, one 1024-thread
                                     // workgroup per CU with the split exchange (y pass 2.02 -> 1.91 ms); 16 = as in rounds 1-2
 #endif
-    if constexpr (!POWER) { if (n == 1024) return launch_c2c<32, 32, FWD_C, false>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0); }
-    if (n == 1024) return launch_c2c<32, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0);
-    if (n == 512) return launch_c2c<16, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0);
-    return launch_c2c<16, 16, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0);
+    if constexpr (!POWER) { if (n == 1024) return launch_c2c<32, 32, FWD_C, false>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0, prune2); }
+    if (n == 1024) return launch_c2c<32, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0, prune2);
+    if (n == 512) return launch_c2c<16, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0, prune2);
+    return launch_c2c<16, 16, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0, prune2);
 }
 
 template <int R1, int R2, int C, int FOLDW = 0, bool LOWK = false>
@@ -1403,8 +1425,13 @@ static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, 
                            z_fused ? reinterpret_cast<double*>(work) : nullptr);                       // z
     if (rc != AST_OK) return rc;
     if (z_fused) { rc = lowk_rest(); if (rc != AST_OK) return rc; }
-    rc = ast_fft_tile_c2c(spec, dtype, n, nzp, nz, n, n * nzp, 1.0, stream);                          // y, per x-plane
-    if (rc != AST_OK) return rc;
+    // both strided passes leave out what FFTPower drops: rows / tiles with k_y^2 + k_z0^2 > (n/2)^2 (AST_FFT_NO_PRUNE: A/B runs)
+    const long long prune2 = getenv("AST_FFT_NO_PRUNE") ? 0 : (long long)(n / 2) * (long long)(n / 2);
+    {
+        AST_PROF("fft_tile.c2c", s);
+        rc = dispatch_c2c<false>(n, spec, tw, nzp, nz, n, n * nzp, 1.0f, nullptr, s, nullptr, 0, prune2);       // y, per x-plane
+        if (rc != AST_OK) return rc;
+    }
     const double inv_ng = 1.0 / ((double)n * (double)n * (double)n);
     {
         AST_PROF("fft_tile.c2c_power", s);
@@ -1413,7 +1440,7 @@ static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, 
             edge_fall = g_edge.get(n, boxsize, s);
             if (!edge_fall) { ast::set_error("ast_fft_tile_power_3d: edge table allocation failed"); return AST_ERR_HIP; }
         }
-        rc = dispatch_c2c<true>(n, spec, tw, n * nzp, nz, n, nzp, (float)inv_ng, partial, s, edge_fall);   // x + binning
+        rc = dispatch_c2c<true>(n, spec, tw, n * nzp, nz, n, nzp, (float)inv_ng, partial, s, edge_fall, 0, prune2);   // x + binning
         if (rc != AST_OK) return rc;
     }
     AST_PROF("fft_tile.shell_reduce", s);

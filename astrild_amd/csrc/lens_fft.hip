@@ -757,7 +757,7 @@ extern "C" int ast_lens_rows_inverse(const void* spec, size_t pitch, size_t nc, 
 template <int RA, int RB, int RC, int C, bool POWER>
 __global__ void __launch_bounds__((C * RowGeo<RA, RB, RC>::NT))
 col3_kernel(double2* __restrict__ data, const double2* __restrict__ twM, size_t elem_stride, size_t ncols, size_t batch_stride,
-            unsigned tiles_per_batch, double scale, double* __restrict__ partial, double kf_rule) {
+            unsigned tiles_per_batch, double scale, double* __restrict__ partial, double kf_rule, int prune2 = 0) {
     using G = RowGeo<RA, RB, RC>;
     constexpr int N = G::M, NB = N / 2 - 1, LINE = N + N / 8;
     extern __shared__ double2 lds64[];
@@ -790,6 +790,17 @@ col3_kernel(double2* __restrict__ data, const double2* __restrict__ twM, size_t 
     const unsigned tile = bid % tiles_per_batch, b = bid / tiles_per_batch;
     const size_t c0 = (size_t)tile * C;
     const bool col_ok = c0 + c < ncols;
+    // FORWARD PRUNING (prune2 = (N/2)^2 on the power pipeline's two strided passes, as in fft_tile.hip): FFTPower keeps
+    // |m| < N/2 (power_spectrum_3d.py:189-195; the edge itself stays for the float64 rule), so a row (k_y, tile from k_z0)
+    // with k_y^2 + k_z0^2 > (N/2)^2 is not stored by the y pass and its tile is left out by the binning pass (its row of
+    // `partial` is zeros) - 21.5 % of the half plane, with C = 4 or 8 columns cut close to the circle.
+    if (POWER && prune2 > 0) {
+        const int ky = (int)b > N / 2 ? (int)b - N : (int)b;
+        if (ky * ky + (int)(c0 * c0) > prune2) {                            // block-uniform, before any barrier
+            for (int i = threadIdx.x; i < NB; i += C * G::NT) partial[(size_t)bid * NB + i] = 0.0;
+            return;
+        }
+    }
     double2* base = data + (size_t)b * batch_stride + min(c0 + c, ncols - 1);
     double2* Y = lds64 + c * LINE;
     if (POWER)
@@ -803,12 +814,14 @@ col3_kernel(double2* __restrict__ data, const double2* __restrict__ twM, size_t 
     if (t < G::T3 && col_ok) {
         const int al = t / RB, be = t % RB;
         if (!POWER) {
+            const int room = prune2 > 0 ? prune2 - (int)(c0 * c0) : 0x7fffffff;        // rows are k_y: keep k_y^2 <= room
 #pragma unroll
             for (int ga = 0; ga < RC; ++ga) {
                 double2 x = vc[bitrev(ga, ilog2(RC))];
                 x.x *= scale;
                 x.y *= scale;
-                base[(size_t)(al + RA * be + RA * RB * ga) * elem_stride] = x;
+                const int row = al + RA * be + RA * RB * ga, aky = RA * RB * ga >= N / 2 ? N - row : row;
+                if (aky * aky <= room) base[(size_t)row * elem_stride] = x;
             }
         } else {
             const int kz = (int)(c0 + c);
@@ -865,7 +878,7 @@ namespace {
 constexpr int col3_columns(size_t n) { return n == 1024 ? 4 : 8; }
 template <int RA, int RB, int RC, bool POWER>
 int col3_launch(double2* data, const double2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride, double scale,
-                double* partial, double kf_rule, hipStream_t s) {
+                double* partial, double kf_rule, hipStream_t s, int prune2 = 0) {
     using G = RowGeo<RA, RB, RC>;
     constexpr int C = col3_columns(G::M), LINE = G::M + G::M / 8;
     const size_t lds = (size_t)C * LINE * sizeof(double2) + (POWER ? (G::M / 2) * sizeof(double) : 0);
@@ -878,16 +891,16 @@ int col3_launch(double2* data, const double2* tw, size_t elem_stride, size_t nco
     const size_t tiles = (ncols + C - 1) / C;
     AST_CHECK_ARG(tiles * batch < 0x7fffffffull);
     col3_kernel<RA, RB, RC, C, POWER><<<(unsigned)(tiles * batch), C * G::NT, lds, s>>>(data, tw, elem_stride, ncols, batch_stride,
-                                                                                        (unsigned)tiles, scale, partial, kf_rule);
+                                                                                        (unsigned)tiles, scale, partial, kf_rule, prune2);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
 template <bool POWER>
 int col3_dispatch(size_t n, double2* data, const double2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride,
-                  double scale, double* partial, double kf_rule, hipStream_t s) {
-    if (n == 1024) return col3_launch<16, 8, 8, POWER>(data, tw, elem_stride, ncols, batch, batch_stride, scale, partial, kf_rule, s);
-    if (n == 512) return col3_launch<8, 8, 8, POWER>(data, tw, elem_stride, ncols, batch, batch_stride, scale, partial, kf_rule, s);
-    return col3_launch<8, 8, 4, POWER>(data, tw, elem_stride, ncols, batch, batch_stride, scale, partial, kf_rule, s);
+                  double scale, double* partial, double kf_rule, hipStream_t s, int prune2 = 0) {
+    if (n == 1024) return col3_launch<16, 8, 8, POWER>(data, tw, elem_stride, ncols, batch, batch_stride, scale, partial, kf_rule, s, prune2);
+    if (n == 512) return col3_launch<8, 8, 8, POWER>(data, tw, elem_stride, ncols, batch, batch_stride, scale, partial, kf_rule, s, prune2);
+    return col3_launch<8, 8, 4, POWER>(data, tw, elem_stride, ncols, batch, batch_stride, scale, partial, kf_rule, s, prune2);
 }
 }  // namespace
 
@@ -930,6 +943,7 @@ static int fft64_power_impl(const double* grid, const double* rec, int window, v
     const double2* twH = g_tw.get((int)(n / 2), s);       // the rows' half-length transform
     const double2* twN = g_tw.get((int)n, s);
     if (!twH || !twN) { ast::set_error("ast_fft64_power_3d: twiddle table allocation failed"); return AST_ERR_HIP; }
+    const int prune2 = getenv("AST_FFT_NO_PRUNE") ? 0 : (int)((n / 2) * (n / 2));      // what FFTPower drops is neither stored nor binned
     int rc;
     {
         AST_PROF("fft64.rows_r2c", s);
@@ -948,13 +962,13 @@ static int fft64_power_impl(const double* grid, const double* rec, int window, v
     }
     {
         AST_PROF("fft64.cols", s);
-        rc = col3_dispatch<false>(n, spec, twN, nzp, nz, n, n * nzp, 1.0, nullptr, 0.0, s);               // y, per x plane
+        rc = col3_dispatch<false>(n, spec, twN, nzp, nz, n, n * nzp, 1.0, nullptr, 0.0, s, prune2);       // y, per x plane
         if (rc != AST_OK) return rc;
     }
     const double kf_rule = binning == AST_BIN_FLOAT64 ? 2.0 * M_PI / boxsize : 0.0;
     {
         AST_PROF("fft64.cols_power", s);
-        rc = col3_dispatch<true>(n, spec, twN, n * nzp, nz, n, nzp, 1.0 / ((double)n * (double)n * (double)n), partial, kf_rule, s);
+        rc = col3_dispatch<true>(n, spec, twN, n * nzp, nz, n, nzp, 1.0 / ((double)n * (double)n * (double)n), partial, kf_rule, s, prune2);
         if (rc != AST_OK) return rc;
     }
     AST_PROF("fft64.shell_reduce", s);

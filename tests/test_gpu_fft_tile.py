@@ -98,6 +98,31 @@ def test_fused_fft_power_matches_unfused_and_oracle(dev, n):
         np.testing.assert_allclose(fused["power"], ref["power"].real, rtol=1e-6)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("n", [256, 512])
+def test_forward_pruning_to_the_nyquist_disc_changes_no_bit(dev, n, dtype):
+    """FFTPower(mode="1d", kmin=k_F) drops |m| >= N/2 (power_spectrum_3d.py:189-195): the y pass does not store the rows with
+    k_y^2 + k_z0^2 > (N/2)^2 and the binning pass leaves their tiles out.  Same shell sums as the unpruned passes
+    (AST_FFT_NO_PRUNE) - bit for bit in fp32 - under both edge rules (a vector of norm exactly N/2 may fall into the last shell)."""
+    import os
+    g = torch.Generator(device="cuda").manual_seed(n + 5)
+    t = torch.randn((n, n, n), dtype=torch.float32 if dtype == "f32" else torch.float64, device="cuda", generator=g)
+    fn = dev.power_sums_fused if dtype == "f32" else dev.power_sums_fused64
+    for L in (1000.0, 750.0):                          # the float64 rule's edge falls depend on L
+        for rule in ("float64", "integer"):
+            _, pruned, _ = fn(t, L, binning=rule)
+            os.environ["AST_FFT_NO_PRUNE"] = "1"
+            try:
+                _, full, _ = fn(t, L, binning=rule)
+            finally:
+                del os.environ["AST_FFT_NO_PRUNE"]
+            if dtype == "f32":
+                assert torch.equal(pruned, full), (L, rule)
+            else:      # double products added by LDS atomics in arrival order: the last bits move from run to run either way
+                np.testing.assert_allclose(pruned.cpu().numpy(), full.cpu().numpy(), rtol=1e-12)
+            assert float(pruned[-1]) > 0.0
+
+
 def test_mean_subtraction_recovers_cold_low_k_shells_in_fp32(dev):
     # lattice + small jitter: low-k power is ~1e-5 of the peak; the fp32 FFT round-off of the
     # O(1) mean density swamps it unless the mean is removed on load
