@@ -66,6 +66,11 @@ SIGNATURES = {
     "ast_fft_tile_power_3d_halo": (_i, [_vp, _vp, _i, _vp, _sz, _i, _sz, _d, _d, _i, _i, _vp, _vp]),
     "ast_fft_tile_block_power_scratch_bytes": (_sz, [_sz, _sz]),
     "ast_fft_tile_block_power": (_i, [_vp, _vp, _sz, _i, _sz, _sz, _sz, _sz, _d, _d, _i, _i, _vp, _vp]),
+    "ast_fft_tile_disc_layout": (_i, [_sz, _i, ct.POINTER(ct.c_uint), ct.POINTER(ct.c_ubyte), ct.POINTER(_i)]),
+    "ast_fft_tile_disc_table": (_i, [_sz, _i, ct.POINTER(_i), _sz]),
+    "ast_fft_tile_c2c_disc": (_i, [_vp, _vp, _i, _sz, _sz, _sz, _i, _i, _vp, _d, _vp]),
+    "ast_fft_tile_disc_power_scratch_bytes": (_sz, [_sz, _i]),
+    "ast_fft_tile_disc_block_power": (_i, [_vp, _vp, _sz, _i, _sz, _i, _i, _d, _d, _i, _i, _vp, _vp]),
     "ast_lowk_work_bytes": (_sz, [_sz, _sz]),
     "ast_lowk_mode_count": (_i, []),
     "ast_lowk_shell_count": (_i, []),

@@ -19,6 +19,7 @@
 #include "paint_tile_geom.h"
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -148,9 +149,18 @@ constexpr int SHELL_BATCH = 8;
 struct ShellBatch { int count = 0; float2* work[SHELL_BATCH]; long long lo2[SHELL_BATCH], hi2[SHELL_BATCH]; };
 struct C2RBatch { int count = 0; const float2* in[SHELL_BATCH]; float* out[SHELL_BATCH]; int kmax[SHELL_BATCH]; };
 
-struct PackDst { float2* out = nullptr; unsigned c1_log2 = 0; unsigned nbatch = 0; float2* self_out = nullptr; unsigned self_part = ~0u; unsigned pitch = 0; };
+// DISC layout (PACK = 2 stores, POWER loads): what is left of the half spectrum after the k_y pass once everything FFTPower
+// drops is cut away, laid out for the slab transpose and for the last pass.  The k_y rows are dealt to `parts` owners in BLOCKS
+// of R1 rows (the rows a workgroup of the k_y pass stores with one value of k2), balanced by the area of the Nyquist disc they
+// cover; a part's plane is tile-major - for every 16-column k_z tile the part's rows that reach into the disc, in row order,
+// 16 complex each - so the k_y pass stores whole 4-KB runs (R1 rows x 128 B) and every 128-byte piece sits on one line.
+// One table entry per (k_z tile, row block): where sub-row 0 of the block would land in its part's plane (offb, in complex
+// elements; sub-rows lo <= sub < hi exist), the part's plane size S, the sum of the lower parts' plane sizes, the part.
+struct DiscEntry { int offb; unsigned S, cumS, lohi; };                   // lohi = lo | hi << 8 | part << 16
+struct PackDst { float2* out = nullptr; unsigned c1_log2 = 0; unsigned nbatch = 0; float2* self_out = nullptr; unsigned self_part = ~0u; unsigned pitch = 0;
+                 const DiscEntry* disc = nullptr; const unsigned short* gk = nullptr; unsigned part = 0; };
 
-template <int R1, int R2, int C, bool POWER, bool INV = false, bool PACK = false>
+template <int R1, int R2, int C, bool POWER, bool INV = false, int PACK = 0>
 __global__ void __launch_bounds__(C * (R1 > R2 ? R1 : R2))
 // N = 1024 with binning: 128 VGPRs, so that two 8-wave workgroups fit a CU (see SPLIT below)
 __attribute__((amdgpu_waves_per_eu((POWER || C > 16) && R1 * R2 >= 1024 ? 4 : 1, (POWER || C > 16) && R1 * R2 >= 1024 ? 4 : 8)))
@@ -201,7 +211,24 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
     // edge itself stays).  After the y pass a row (k_y, 16-column tile from k_z0) with k_y^2 + k_z0^2 > (N/2)^2 holds no mode
     // any shell takes, whatever k_x: the y pass does not store it (below), and the binning pass leaves that tile out - 21.5 %
     // of the half plane, neither written nor read again.  The skipped workgroup still owns a row of `partial`: zeros.
-    if (!INV && POWER && mask.hi2 > 0) {
+    // DISC source (binning pass over a part's block in the disc layout): batch b is the part's local row, block b / R1 of the
+    // part is row block gk of the lattice; the table says where the tile's rows of that block start - or that this row
+    // lies outside the disc for this tile: nothing stored, nothing to bin
+    const float2* disc_base = nullptr;
+    unsigned disc_S = 0;
+    int disc_ky = 0;
+    if (!INV && POWER && pack.disc != nullptr) {
+        const unsigned subb = b % R1, gk = pack.gk[pack.part * (pack.nbatch / R1) + b / R1];
+        const DiscEntry e = pack.disc[(size_t)tile * R2 + gk];
+        const unsigned lo = e.lohi & 255u, hi = (e.lohi >> 8) & 255u;
+        if (subb - lo >= hi - lo) {
+            for (int i = threadIdx.x; i < NB; i += NT) partial[((size_t)b * tiles_per_batch + tile) * NB + i] = 0.0;
+            return;
+        }
+        disc_ky = (int)(gk * R1 + subb);
+        disc_base = data + ((long long)e.offb + (long long)(subb * 16u));
+        disc_S = e.S;
+    } else if (!INV && POWER && mask.hi2 > 0) {
         const long long kyi = (long long)b + mask.ky0, ky = kyi > N / 2 ? kyi - N : kyi;
         if (ky * ky + (long long)(c0 * c0) > mask.hi2) {
             for (int i = threadIdx.x; i < NB; i += NT) partial[((size_t)b * tiles_per_batch + tile) * NB + i] = 0.0;
@@ -226,10 +253,15 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
         // R1 loads (global_load ... v_off, s[base]): per-load 64-bit lane addresses cost two VGPRs each while in flight
         // (the masked first inverse pass may read a source of another row pitch than the array it writes)
         const bool own = INV && mask.src != nullptr && mask.src_elem_stride != 0;
-        const size_t es_in = own ? mask.src_elem_stride : elem_stride;
+        size_t es_in = own ? mask.src_elem_stride : elem_stride;
         const float2* ubase = (INV && mask.src ? mask.src : data) + (size_t)b * (own ? mask.src_batch_stride : batch_stride);
         const int lsub = task1 ? sub : R2 - 1;
-        const uint32_t voff = (uint32_t)lsub * (uint32_t)es_in + min((uint32_t)c0 + (uint32_t)c, (uint32_t)ncols - 1u);     // host checks: < 2^29
+        uint32_t voff = (uint32_t)lsub * (uint32_t)es_in + min((uint32_t)c0 + (uint32_t)c, (uint32_t)ncols - 1u);     // host checks: < 2^29
+        if (POWER && !INV && disc_base != nullptr) {      // rows = planes, S apart; the tile's 16 columns are contiguous
+            es_in = disc_S;
+            ubase = disc_base;
+            voff = (uint32_t)lsub * disc_S + (uint32_t)c;
+        }
         if (INV && mask.hi2 > 0 && mask.pass == 1) {
             const long long c02 = (long long)(c0 * c0);
 #pragma unroll
@@ -316,7 +348,27 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
         if (C > 16) asm volatile("" : "+v"(tid_s));
         const int cs = C > 16 ? tid_s % C : c;
         const bool ok_s = C > 16 ? (unsigned)c0 + (unsigned)cs < (unsigned)ncols : col_ok;
-        if (ok_s && !POWER) {
+        if (PACK == 2 && !POWER) {
+            // DISC stores: per k2 one table entry (scalar loads), a uniform base and the thread id as the lane offset - the
+            // R1 x 16 values of a row block land in one contiguous run.  Columns past ncols hold copies of the last one.
+            static_assert(PACK != 2 || C == 16, "the disc layout's tiles are 16 columns");
+            // the tile's R2 entries in ONE vector load - lane l holds entry l mod R2 - and v_readlane per k2 (32 scalar loads,
+            // each waited for in turn, cost the pass a quarter of its time)
+            const int4 ev = reinterpret_cast<const int4*>(pack.disc + (size_t)tile * R2)[threadIdx.x % R2];
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) {
+                float2 x = u[bitrev(k2, ilog2(R2))];
+                x.x *= scale;
+                x.y *= scale;
+                const int offb = __builtin_amdgcn_readlane(ev.x, k2);
+                const unsigned S = (unsigned)__builtin_amdgcn_readlane(ev.y, k2), cumS = (unsigned)__builtin_amdgcn_readlane(ev.z, k2);
+                const unsigned lohi = (unsigned)__builtin_amdgcn_readlane(ev.w, k2);
+                const unsigned lo = lohi & 255u, hi = (lohi >> 8) & 255u, part = lohi >> 16;
+                float2* const ub = (part == pack.self_part ? pack.self_out : pack.out + (size_t)pack.nbatch * cumS)
+                                   + ((size_t)b * S + (long long)offb);
+                if ((unsigned)sub - lo < hi - lo) st_stream<(N >= 1024)>(ub + threadIdx.x, x);
+            }
+        } else if (ok_s && !POWER) {
             float2* const base = data + (size_t)b * batch_stride + c0 + cs;
             // forward pruning: rows are k_y, the tile starts at k_z0 = c0; keep k_y^2 <= room.  Decided per WAVE on scalars (the
             // wave's smallest |k_y| of the row block; a wave holds 64 / C consecutive `sub`): a per-lane test cost 16 VGPRs
@@ -354,9 +406,9 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
         // (the word is fetched HERE, not at the top: nothing of this epilogue may stay live across the two register
         // FFTs - the kernel is held to 128 VGPRs and every long-lived value there turned into scratch traffic)
         unsigned fallmask = 0;
-        if (edge_fall) fallmask = edge_fall[((size_t)b * tiles_per_batch + tile) * NT + threadIdx.x];
+        const int kyi = disc_base != nullptr ? disc_ky : (int)b + mask.ky0;
+        if (edge_fall) fallmask = edge_fall[((size_t)(disc_base != nullptr ? (unsigned)disc_ky : b) * tiles_per_batch + tile) * NT + threadIdx.x];
         const int kz = (int)c0 + tid_e % C;
-        const int kyi = (int)b + mask.ky0;
         const int ky = kyi > N / 2 ? kyi - N : kyi;
         const int m2yz = ky * ky + kz * kz;
         const float w = (kz > 0 && kz < N / 2) ? 2.0f : 1.0f;
@@ -1006,7 +1058,8 @@ struct TwiddleCache {
 
 template <int R1, int R2, int C, bool POWER>
 int launch_c2c(float2* data, const float2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride,
-               float scale, double* partial, hipStream_t s, const unsigned* edge_fall = nullptr, int ky0 = 0, long long prune2 = 0) {
+               float scale, double* partial, hipStream_t s, const unsigned* edge_fall = nullptr, int ky0 = 0, long long prune2 = 0,
+               PackDst disc = PackDst{}) {
     constexpr int N = R1 * R2, NT = C * (R1 > R2 ? R1 : R2);
     constexpr bool SPLIT = (POWER || C > 16) && R1 == R2 && N * C * sizeof(float2) > 64 * 1024;       // as in the kernel
     const size_t lds = (size_t)((SPLIT ? N / 2 : N) * C + N) * sizeof(float2) + (POWER ? (N / 2) * sizeof(double) : 0);
@@ -1021,7 +1074,7 @@ int launch_c2c(float2* data, const float2* tw, size_t elem_stride, size_t ncols,
     AST_CHECK_ARG((size_t)(R2 - 1) * elem_stride + ncols < (1ull << 29));      // the kernel's 32-bit lane offsets
     strided_c2c_kernel<R1, R2, C, POWER><<<(unsigned)(tiles * batch), NT, lds, s>>>(data, tw, elem_stride, ncols,
                                                                                    batch_stride, (unsigned)tiles, scale,
-                                                                                   partial, edge_fall, ShellMask{nullptr, 0, prune2, ky0});
+                                                                                   partial, edge_fall, ShellMask{nullptr, 0, prune2, ky0}, disc);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
@@ -1046,7 +1099,7 @@ int launch_c2c_inv(float2* data, const float2* tw, size_t elem_stride, size_t nc
     return AST_OK;
 }
 
-template <int R1, int R2, int C>
+template <int R1, int R2, int C, int PACKM = 1>
 int launch_c2c_pack(float2* data, const float2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride,
                     float scale, PackDst pack, hipStream_t s) {
     constexpr int N = R1 * R2, NT = C * (R1 > R2 ? R1 : R2);
@@ -1054,14 +1107,14 @@ int launch_c2c_pack(float2* data, const float2* tw, size_t elem_stride, size_t n
     const size_t lds = (size_t)((SPLIT ? N / 2 : N) * C + N) * sizeof(float2);
     static ast::PerDeviceOnce attr_once;
     if (attr_once.need()) {
-        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&strided_c2c_kernel<R1, R2, C, false, false, true>),
+        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&strided_c2c_kernel<R1, R2, C, false, false, PACKM>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_once.mark();
     }
     const size_t tiles = (ncols + C - 1) / C;
     AST_CHECK_ARG(tiles * batch < 0x7fffffffull);
     AST_CHECK_ARG((size_t)(R2 - 1) * elem_stride + ncols < (1ull << 29));      // the kernel's 32-bit lane offsets
-    strided_c2c_kernel<R1, R2, C, false, false, true><<<(unsigned)(tiles * batch), NT, lds, s>>>(
+    strided_c2c_kernel<R1, R2, C, false, false, PACKM><<<(unsigned)(tiles * batch), NT, lds, s>>>(
         data, tw, elem_stride, ncols, batch_stride, (unsigned)tiles, scale, nullptr, nullptr, ShellMask{nullptr, 0, 0}, pack);
     AST_CHECK_LAUNCH();
     return AST_OK;
@@ -1077,15 +1130,15 @@ int dispatch_c2c_inv(size_t n, float2* d, const float2* tw, size_t elem_stride, 
 template <bool POWER>
 int dispatch_c2c(size_t n, float2* d, const float2* tw, size_t elem_stride, size_t ncols, size_t batch,
                  size_t batch_stride, float scale, double* partial, hipStream_t s, const unsigned* edge_fall = nullptr, int ky0 = 0,
-                 long long prune2 = 0) {
+                 long long prune2 = 0, PackDst disc = PackDst{}) {
 #ifndef FWD_C
 #define FWD_C 32                    // columns per workgroup of the plain forward pass at N = 1024: 32 = 256-byte row pieces, one 1024-thread
                                     // workgroup per CU with the split exchange (y pass 2.02 -> 1.91 ms); 16 = as in rounds 1-2
 #endif
     if constexpr (!POWER) { if (n == 1024) return launch_c2c<32, 32, FWD_C, false>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0, prune2); }
-    if (n == 1024) return launch_c2c<32, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0, prune2);
-    if (n == 512) return launch_c2c<16, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0, prune2);
-    return launch_c2c<16, 16, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0, prune2);
+    if (n == 1024) return launch_c2c<32, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0, prune2, disc);
+    if (n == 512) return launch_c2c<16, 32, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0, prune2, disc);
+    return launch_c2c<16, 16, 16, POWER>(d, tw, elem_stride, ncols, batch, batch_stride, scale, partial, s, edge_fall, ky0, prune2, disc);
 }
 
 template <int R1, int R2, int C, int FOLDW = 0, bool LOWK = false>
@@ -1127,6 +1180,109 @@ int launch_c2r(const float2* in, float* out, const float2* tw, size_t nrows, siz
                                                                                                         scale, kmax, cb);
     AST_CHECK_LAUNCH();
     return AST_OK;
+}
+
+// ------------------------------------------------------------------ disc layout (host side)
+// Built from (n, parts) alone - every rank computes the same table.  astrild_amd/slab.py restates it in Python (disc_layout)
+// for the buffer sizes of the CPU doubles; tests compare the two.
+constexpr int tile_r1(size_t n) { return n == 1024 ? 32 : 16; }           // rows per block = the first radix of the passes
+struct DiscLayout {
+    size_t n = 0;
+    int parts = 0, r1 = 0;
+    unsigned nblk = 0, tiles = 0;
+    std::vector<unsigned> S, cumS;                 // plane size of each part (complex elements), sum of the lower parts'
+    std::vector<unsigned short> gk;                // [part][j]: the part's row blocks in ascending order
+    std::vector<unsigned char> part_of;            // [row block]
+    std::vector<DiscEntry> tab;                    // [tile][row block]
+    struct Dev { int dev; DiscEntry* tab; unsigned short* gk; };
+    std::vector<Dev> devs;
+    unsigned total() const { return cumS.back() + S.back(); }
+};
+
+static bool disc_row_in(size_t n, int row, unsigned tile) {
+    const long long ky = row > (int)(n / 2) ? row - (long long)n : row, kz0 = 16ll * tile, h = (long long)(n / 2);
+    return ky * ky + kz0 * kz0 <= h * h;           // the edge itself stays (float64 shell rule)
+}
+
+static void disc_build(DiscLayout& L, size_t n, int parts) {
+    L.n = n; L.parts = parts; L.r1 = tile_r1(n);
+    L.nblk = (unsigned)(n / L.r1); L.tiles = (unsigned)((n / 2 + 1 + 15) / 16);
+    const unsigned nb = L.nblk / parts;
+    std::vector<unsigned> area(L.nblk, 0);
+    for (unsigned k = 0; k < L.nblk; ++k)
+        for (int sub = 0; sub < L.r1; ++sub)
+            for (unsigned t = 0; t < L.tiles; ++t) area[k] += disc_row_in(n, (int)(k * L.r1 + sub), t) ? 1u : 0u;
+    // blocks in order of decreasing area (ties: ascending index), each to the part with the smallest sum so far among those
+    // that still take blocks (ties: the lowest part): within 4 % of the mean at 8 parts, where contiguous ranges of rows
+    // would leave the parts around k_y = 0 with 97 % of a full plane - and their links with as many bytes as before
+    std::vector<unsigned> order(L.nblk);
+    for (unsigned k = 0; k < L.nblk; ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](unsigned a, unsigned b) { return area[a] > area[b]; });
+    std::vector<unsigned long long> sum(parts, 0);
+    std::vector<unsigned> cnt(parts, 0);
+    L.part_of.assign(L.nblk, 0);
+    for (unsigned k : order) {
+        int best = -1;
+        for (int r = 0; r < parts; ++r)
+            if (cnt[r] < nb && (best < 0 || sum[r] < sum[best])) best = r;
+        L.part_of[k] = (unsigned char)best;
+        sum[best] += area[k];
+        ++cnt[best];
+    }
+    L.gk.clear();
+    for (int r = 0; r < parts; ++r)
+        for (unsigned k = 0; k < L.nblk; ++k)
+            if (L.part_of[k] == r) L.gk.push_back((unsigned short)k);
+    L.tab.assign((size_t)L.tiles * L.nblk, DiscEntry{0, 0, 0, 0});
+    L.S.assign(parts, 0);
+    L.cumS.assign(parts, 0);
+    for (int r = 0; r < parts; ++r) {
+        unsigned rows = 0;                          // valid (tile, row) pairs of the part so far, tile-major
+        for (unsigned t = 0; t < L.tiles; ++t)
+            for (unsigned j = 0; j < nb; ++j) {
+                const unsigned k = L.gk[(size_t)r * nb + j];
+                int lo = -1, hi = -1;
+                for (int sub = 0; sub < L.r1; ++sub)
+                    if (disc_row_in(n, (int)(k * L.r1 + sub), t)) { if (lo < 0) lo = sub; hi = sub + 1; }
+                DiscEntry& e = L.tab[(size_t)t * L.nblk + k];
+                if (lo < 0) { e.lohi = (unsigned)r << 16; continue; }
+                e.offb = 16 * ((int)rows - lo);
+                e.lohi = (unsigned)lo | (unsigned)hi << 8 | (unsigned)r << 16;
+                rows += (unsigned)(hi - lo);        // (the rows of a block inside the disc are one range: n / 2 is a block boundary)
+            }
+        L.S[r] = 16 * rows;
+    }
+    for (int r = 1; r < parts; ++r) L.cumS[r] = L.cumS[r - 1] + L.S[r - 1];
+    for (auto& e : L.tab) { const unsigned r = e.lohi >> 16; e.S = L.S[r]; e.cumS = L.cumS[r]; }
+}
+
+struct DiscCache {
+    std::mutex m;
+    std::vector<DiscLayout*> all;
+    // host table (and, with `device`, its copy on the current device)
+    const DiscLayout* get(size_t n, int parts, bool device, const DiscLayout::Dev** dv) {
+        std::lock_guard<std::mutex> lock(m);
+        DiscLayout* L = nullptr;
+        for (auto* x : all) if (x->n == n && x->parts == parts) L = x;
+        if (!L) { L = new DiscLayout; disc_build(*L, n, parts); all.push_back(L); }
+        if (!device) return L;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+        for (auto& d : L->devs) if (d.dev == dev) { *dv = &d; return L; }
+        DiscLayout::Dev d{dev, nullptr, nullptr};
+        if (hipMalloc(&d.tab, L->tab.size() * sizeof(DiscEntry)) != hipSuccess) return nullptr;
+        if (hipMalloc(&d.gk, L->gk.size() * sizeof(unsigned short)) != hipSuccess) return nullptr;
+        if (hipMemcpy(d.tab, L->tab.data(), L->tab.size() * sizeof(DiscEntry), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        if (hipMemcpy(d.gk, L->gk.data(), L->gk.size() * sizeof(unsigned short), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        L->devs.reserve(64);
+        L->devs.push_back(d);
+        *dv = &L->devs.back();
+        return L;
+    }
+} g_disc;
+
+static bool disc_geometry_ok(size_t n, int parts) {
+    return (n == 256 || n == 512 || n == 1024) && parts >= 1 && parts <= 256 && (n / tile_r1(n)) % (size_t)parts == 0;
 }
 
 }  // namespace
@@ -1295,10 +1451,14 @@ extern "C" int ast_fft_tile_r2c_3d(const void* in, void* out, int dtype, size_t 
 // Row pitch (in complex elements) of the scratch spectrum used by ast_fft_tile_power_3d:
 // n/2+1 rounded up to a multiple of 16 so every 128-byte tile row is line-aligned.
 extern "C" size_t ast_lowk_work_bytes(size_t n, size_t nx);
+static size_t power_disc_bytes(size_t n) {          // the k_y pass's output in the disc layout (one part): 78 % of a spectrum
+    const DiscLayout* L = disc_geometry_ok(n, 1) ? g_disc.get(n, 1, false, nullptr) : nullptr;
+    return L ? ((size_t)n * L->S[0] * sizeof(float2) + 255) / 256 * 256 : 0;
+}
 static size_t power_core_bytes(size_t n) {
     const size_t nzp = ((n / 2 + 1) + 15) / 16 * 16;
     const size_t tiles = (n / 2 + 1 + 15) / 16;
-    return n * n * nzp * sizeof(float2) + n * tiles * (n / 2 - 1) * sizeof(double) + 64 * sizeof(double);     // + low-k sums
+    return n * n * nzp * sizeof(float2) + power_disc_bytes(n) + n * tiles * (n / 2 - 1) * sizeof(double) + 64 * sizeof(double);     // + low-k sums
 }
 static size_t lowk_area_bytes(size_t n);
 extern "C" size_t ast_fft_tile_power_scratch_bytes(size_t n) {
@@ -1391,7 +1551,8 @@ static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, 
     AST_CHECK_ARG(scratch_bytes >= ast_fft_tile_power_scratch_bytes(n));
     const size_t nz = n / 2 + 1, nzp = (nz + 15) / 16 * 16, tiles = (nz + 15) / 16;
     float2* spec = (float2*)scratch;
-    double* partial = (double*)((char*)scratch + n * n * nzp * sizeof(float2));
+    float2* disc = (float2*)((char*)scratch + n * n * nzp * sizeof(float2));
+    double* partial = (double*)((char*)disc + power_disc_bytes(n));
     const float2* tw = g_tw.get((int)n);
     if (!tw) { ast::set_error("ast_fft_tile_power_3d: twiddle table allocation failed"); return AST_ERR_HIP; }
     hipStream_t s = ast::as_stream(stream);
@@ -1427,13 +1588,34 @@ static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, 
     if (z_fused) { rc = lowk_rest(); if (rc != AST_OK) return rc; }
     // both strided passes leave out what FFTPower drops: rows / tiles with k_y^2 + k_z0^2 > (n/2)^2 (AST_FFT_NO_PRUNE: A/B runs)
     const long long prune2 = getenv("AST_FFT_NO_PRUNE") ? 0 : (long long)(n / 2) * (long long)(n / 2);
-    {
-        AST_PROF("fft_tile.c2c", s);
-        rc = dispatch_c2c<false>(n, spec, tw, nzp, nz, n, n * nzp, 1.0f, nullptr, s, nullptr, 0, prune2);       // y, per x-plane
-        if (rc != AST_OK) return rc;
-    }
     const double inv_ng = 1.0 / ((double)n * (double)n * (double)n);
-    {
+    // AST_FFT_DISC=1 (A/B runs): the k_y pass stores in the disc layout (one part) and the last pass reads it from there;
+    // default: in place on the pitched rows, rows / tiles outside the disc skipped
+    const bool use_disc = prune2 != 0 && getenv("AST_FFT_DISC") != nullptr && getenv("AST_FFT_DISC")[0] == '1';
+    if (use_disc) {
+        rc = ast_fft_tile_c2c_disc(spec, nullptr, dtype, n, nzp, n, 1, 0, disc, 1.0, stream);                     // y, per x-plane
+        if (rc != AST_OK) return rc;
+        const DiscLayout::Dev* dv = nullptr;
+        const DiscLayout* L = g_disc.get(n, 1, true, &dv);
+        if (!L) { ast::set_error("ast_fft_tile_power_3d: disc table allocation failed"); return AST_ERR_HIP; }
+        AST_PROF("fft_tile.c2c_power", s);
+        const unsigned* edge_fall = nullptr;
+        if (kf_rule != 0.0) {
+            edge_fall = g_edge.get(n, boxsize, s);
+            if (!edge_fall) { ast::set_error("ast_fft_tile_power_3d: edge table allocation failed"); return AST_ERR_HIP; }
+        }
+        PackDst src;
+        src.disc = dv->tab;
+        src.gk = dv->gk;
+        src.nbatch = (unsigned)n;
+        rc = dispatch_c2c<true>(n, disc, tw, L->S[0], nz, n, 16, (float)inv_ng, partial, s, edge_fall, 0, 0, src);   // x + binning
+        if (rc != AST_OK) return rc;
+    } else {
+        {
+            AST_PROF("fft_tile.c2c", s);
+            rc = dispatch_c2c<false>(n, spec, tw, nzp, nz, n, n * nzp, 1.0f, nullptr, s, nullptr, 0, prune2);       // y, per x-plane
+            if (rc != AST_OK) return rc;
+        }
         AST_PROF("fft_tile.c2c_power", s);
         const unsigned* edge_fall = nullptr;
         if (kf_rule != 0.0) {
@@ -1610,6 +1792,105 @@ extern "C" int ast_fft_tile_block_power(void* block, void* scratch, size_t scrat
     {
         AST_PROF("fft_tile.c2c_power", s);
         int rc = dispatch_c2c<true>(n, (float2*)block, tw, nloc * pitch, nz, nloc, pitch, (float)scale, partial, s, edge_fall, (int)ky0);
+        if (rc != AST_OK) return rc;
+    }
+    AST_PROF("fft_tile.shell_reduce", s);
+    shell_partials_stage1_kernel<<<REDUCE_ROWS, 256, 0, s>>>(partial, nloc * tiles, nb, partial2);
+    shell_partials_stage2_kernel<<<(nb + 7) / 8, 256, 0, s>>>(partial2, nb, boxsize * boxsize * boxsize, first_bin, psum);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
+// ------------------------------------------------------------------ disc layout: C-ABI
+// plane_elems[parts]: complex elements of one plane of each part; block_part[n / r1]: owner of every row block (may be NULL);
+// r1_out: rows per block.  Pure host arithmetic (no GPU needed).
+extern "C" int ast_fft_tile_disc_layout(size_t n, int parts, unsigned* plane_elems, unsigned char* block_part, int* r1_out) {
+    AST_CHECK_ARG(disc_geometry_ok(n, parts) && plane_elems != nullptr);
+    const DiscLayout* L = g_disc.get(n, parts, false, nullptr);
+    if (!L) { ast::set_error("ast_fft_tile_disc_layout: table construction failed"); return AST_ERR_HIP; }
+    for (int r = 0; r < parts; ++r) plane_elems[r] = L->S[r];
+    if (block_part) for (unsigned k = 0; k < L->nblk; ++k) block_part[k] = L->part_of[k];
+    if (r1_out) *r1_out = L->r1;
+    return AST_OK;
+}
+
+// The table itself, [tile][row block] x (offb, S, cumS, lohi) as 4 x int32 (tests; host memory).
+extern "C" int ast_fft_tile_disc_table(size_t n, int parts, int* out, size_t out_ints) {
+    AST_CHECK_ARG(disc_geometry_ok(n, parts) && out != nullptr);
+    const DiscLayout* L = g_disc.get(n, parts, false, nullptr);
+    if (!L) { ast::set_error("ast_fft_tile_disc_table: table construction failed"); return AST_ERR_HIP; }
+    AST_CHECK_ARG(out_ints >= L->tab.size() * 4);
+    memcpy(out, L->tab.data(), L->tab.size() * sizeof(DiscEntry));
+    return AST_OK;
+}
+
+// The k_y pass of `nplanes` local planes (planes_d: (nplanes, n, pitch) complex, the z pass's output; left intact) storing in
+// the disc layout: part q's rows of plane b go to packed_d + nplanes * cumS[q] + b * S[q] (what is sent to rank q: nplanes
+// contiguous planes of S[q] elements), the part `self_part` to self_out_d + b * S[self_part] instead (the rank's own piece,
+// straight into its receive block; self_part < 0: none).  Rows outside the Nyquist disc are not stored anywhere.
+extern "C" int ast_fft_tile_c2c_disc(const void* planes, void* packed, int dtype, size_t n, size_t pitch, size_t nplanes,
+                                     int parts, int self_part, void* self_out, double scale, void* stream) {
+    AST_CHECK_ARG(planes != nullptr && planes != packed && planes != self_out && nplanes >= 1 && pitch >= n / 2 + 1);
+    AST_CHECK_ARG(dtype == AST_F32 && disc_geometry_ok(n, parts));
+    AST_CHECK_ARG((self_out == nullptr) == (self_part < 0) && self_part < parts);
+    AST_CHECK_ARG(packed != nullptr || (self_out != nullptr && parts == 1));
+    AST_CHECK_ARG(pitch < (1u << 24));
+    const DiscLayout::Dev* dv = nullptr;
+    const DiscLayout* L = g_disc.get(n, parts, true, &dv);
+    const float2* tw = g_tw.get((int)n);
+    if (!L || !tw) { ast::set_error("ast_fft_tile_c2c_disc: table allocation failed"); return AST_ERR_HIP; }
+    hipStream_t s = ast::as_stream(stream);
+    PackDst pack;
+    pack.out = (float2*)packed;
+    pack.nbatch = (unsigned)nplanes;
+    pack.disc = dv->tab;
+    if (self_out) { pack.self_out = (float2*)self_out; pack.self_part = (unsigned)self_part; }
+    AST_PROF("fft_tile.c2c", s);
+    float2* d = (float2*)const_cast<void*>(planes);
+    const size_t ncols = n / 2 + 1;
+    if (n == 1024) return launch_c2c_pack<32, 32, 16, 2>(d, tw, pitch, ncols, nplanes, n * pitch, (float)scale, pack, s);
+    if (n == 512) return launch_c2c_pack<16, 32, 16, 2>(d, tw, pitch, ncols, nplanes, n * pitch, (float)scale, pack, s);
+    return launch_c2c_pack<16, 16, 16, 2>(d, tw, pitch, ncols, nplanes, n * pitch, (float)scale, pack, s);
+}
+
+// The last pass of a slab-decomposed transform over a part's block in the disc layout ((n planes, S[part]) complex, what
+// ast_fft_tile_c2c_disc wrote / the transpose delivered), fused with the shell binning: psum_d += L^3 sum w |delta_k|^2 of the
+// part's modes (delta_k scaled by `scale`).  scratch_d: ast_fft_tile_disc_power_scratch_bytes(n, parts).
+extern "C" size_t ast_fft_tile_disc_power_scratch_bytes(size_t n, int parts) {
+    if (!disc_geometry_ok(n, parts)) return 0;
+    return ast_fft_tile_block_power_scratch_bytes(n, n / (size_t)parts);
+}
+
+extern "C" int ast_fft_tile_disc_block_power(void* block, void* scratch, size_t scratch_bytes, int dtype, size_t n, int parts,
+                                             int part, double scale, double boxsize, int first_bin, int binning, double* psum,
+                                             void* stream) {
+    AST_CHECK_ARG(block != nullptr && scratch != nullptr && psum != nullptr && boxsize > 0.0 && first_bin >= 0);
+    AST_CHECK_ARG(dtype == AST_F32 && disc_geometry_ok(n, parts) && part >= 0 && part < parts);
+    AST_CHECK_ARG(binning == AST_BIN_INTEGER || binning == AST_BIN_FLOAT64);
+    AST_CHECK_ARG(scratch_bytes >= ast_fft_tile_disc_power_scratch_bytes(n, parts));
+    const size_t nz = n / 2 + 1, tiles = (nz + 15) / 16, nloc = n / (size_t)parts;
+    const int nb = (int)(n / 2 - 1);
+    const DiscLayout::Dev* dv = nullptr;
+    const DiscLayout* L = g_disc.get(n, parts, true, &dv);
+    const float2* tw = g_tw.get((int)n);
+    if (!L || !tw) { ast::set_error("ast_fft_tile_disc_block_power: table allocation failed"); return AST_ERR_HIP; }
+    hipStream_t s = ast::as_stream(stream);
+    const unsigned* edge_fall = nullptr;
+    if (binning == AST_BIN_FLOAT64) {
+        edge_fall = g_edge.get(n, boxsize, s);                       // [k_y][tile][thread]: indexed by the lattice row
+        if (!edge_fall) { ast::set_error("ast_fft_tile_disc_block_power: edge table allocation failed"); return AST_ERR_HIP; }
+    }
+    PackDst src;
+    src.disc = dv->tab;
+    src.gk = dv->gk;
+    src.part = (unsigned)part;
+    src.nbatch = (unsigned)nloc;
+    double* partial = (double*)scratch;
+    double* partial2 = partial + nloc * tiles * nb;
+    {
+        AST_PROF("fft_tile.c2c_power", s);
+        // (elem_stride / batch_stride only feed the host's range check here: the kernel takes both from the table)
+        int rc = dispatch_c2c<true>(n, (float2*)block, tw, L->S[part], nz, nloc, 16, (float)scale, partial, s, edge_fall, 0, 0, src);
         if (rc != AST_OK) return rc;
     }
     AST_PROF("fft_tile.shell_reduce", s);

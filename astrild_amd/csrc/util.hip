@@ -287,15 +287,41 @@ __device__ inline uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
     return z ^ (z >> 31);
 }
 
+// A pseudo-random PERMUTATION of [0, count): a four-round Feistel network on 2 * half bits (the smallest even width that
+// covers count), round function = the splitmix64 finaliser keyed by (key, round), walked along its cycle until the value
+// falls below count (a bijection of [0, 2^bits) restricted this way is a bijection of [0, count); < 4 steps on average).
+// "shuffled = a fixed permutation from seed + 1".
+__device__ inline uint64_t feistel_perm(uint64_t t, uint64_t count, int half, uint64_t key) {
+    const uint64_t mask = (1ull << half) - 1ull;
+    uint64_t v = t;
+    do {
+        uint64_t l = v >> half, r = v & mask;
+#pragma unroll
+        for (int round = 0; round < 4; ++round) {
+            const uint64_t f = mix64(r ^ mix64(key + (uint64_t)round)) & mask;
+            const uint64_t nl = r;
+            r = l ^ f;
+            l = nl;
+        }
+        v = (l << half) | r;
+    } while (v >= count);
+    return v;
+}
+
+constexpr uint64_t SYNTH_SHUFFLE_PRNG = ~0ull;      // shuffle_stride value that selects the Feistel permutation
+
 template <typename T>
 __global__ void synth_kernel(T* pos, size_t first, size_t count, int npside, double boxsize,
                              double sigma, uint64_t seed, uint64_t shuffle_stride) {
     const double h = boxsize / npside;
     size_t stride = (size_t)gridDim.x * blockDim.x;
+    int half = 1;
+    while ((1ull << (2 * half)) < count) ++half;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += stride) {
         // shuffled order permutes the particles INSIDE [first, first + count), so a rank's
         // range keeps holding its own lattice planes
-        uint64_t id = first + (shuffle_stride ? (uint64_t)(((unsigned __int128)t * shuffle_stride) % count) : t);
+        uint64_t id = first + (shuffle_stride == SYNTH_SHUFFLE_PRNG ? feistel_perm(t, count, half, seed + 1)
+                               : shuffle_stride ? (uint64_t)(((unsigned __int128)t * shuffle_stride) % count) : t);
         uint64_t k = id % npside, j = (id / npside) % npside, i = id / ((uint64_t)npside * npside);
         double q[3] = {(i + 0.5) * h, (j + 0.5) * h, (k + 0.5) * h};
         // two Box-Muller pairs give three normals

@@ -396,15 +396,19 @@ class StagedPaint:
 
 def synth_lattice_particles(npside, nmesh, boxsize, seed=20240601, sigma_cells=0.5, shuffle=False,
                             dtype=torch.float32, first=0, count=None):
-    """Synthetic particle set of SURVEY.md §8(d), generated directly in HBM."""
+    """Synthetic particle set of SURVEY.md §8(d), generated directly in HBM.  shuffle=True: the particles of the range in
+    a pseudo-random order (a fixed permutation keyed by seed + 1); shuffle="stride": t -> t * stride mod count, the
+    low-discrepancy order of rounds 1-4 (every chunk of the array feeds every tile almost evenly: a friendlier input)."""
     n3 = int(npside) ** 3
     count = n3 - first if count is None else int(count)
     pos = torch.empty((count, 3), dtype=dtype, device=device())
     stride = 0
-    if shuffle and count > 1:
+    if shuffle == "stride" and count > 1:
         stride = 2654435761 % count or 1
         while np.gcd(stride, count) != 1:
             stride += 1
+    elif shuffle and count > 1:
+        stride = 2 ** 64 - 1
     check(_lib.lib().ast_synth_lattice_particles(ptr(pos), real_code(pos), int(first), count, int(npside),
                                                  float(boxsize), float(sigma_cells) * boxsize / nmesh,
                                                  int(seed), int(stride), stream()), "ast_synth_lattice_particles")
@@ -843,6 +847,16 @@ def bispectrum(field, boxsize, edges, triangles):
             raise _lib.AstrildHipError(f"triangle counts are not integers to 0.05 (worst {worst:.3g})")
         _tri_cache[key] = ntri
         _tri_cache[key + ("residual",)] = worst
+    # The triangle sums form f_i f_j f_l of fp32 fields in fp32 (only the running sums are double): a field in physical units
+    # (a mass-weighted grid in Msun/h per cell) would overflow the product above |D| ~ 7e12.  The shell fields are therefore
+    # built from the spectrum divided by A = max |field| - values of order one - and the sums multiplied back by A^3.
+    amp = 1.0
+    if field.dtype == torch.float32 and field.numel():
+        lo_hi = torch.empty(2, dtype=torch.float64, device=field.device)
+        check(_lib.lib().ast_minmax(ptr(field), real_code(field), field.numel(), ptr(lo_hi), stream()), "ast_minmax")
+        amp = float(lo_hi.abs().max()) or 1.0
+        if not np.isfinite(amp):
+            raise _lib.AstrildHipError("bispectrum: the field holds inf / NaN")
     dfields = {}
     if tile:
         # the masked, pruned inverse tile passes (shell mask fused into the first pass's loads), shell by shell through ONE
@@ -854,13 +868,16 @@ def bispectrum(field, boxsize, edges, triangles):
         works = [scratch] + [torch.empty_like(scratch) for _ in range(min(batch, len(used)) - 1)]
         for b0 in range(0, len(used), batch):
             group = used[b0:b0 + batch]
-            fields = c2r_tile_batch(spec, [(edges[s], edges[s + 1]) for s in group], works)
+            fields = c2r_tile_batch(spec, [(edges[s], edges[s + 1]) for s in group], works, scale=1.0 / amp)
             dfields.update(zip(group, fields))
         del works
+    if not tile and amp != 1.0:
+        sr = torch.view_as_real(spec)
+        check(_lib.lib().ast_divide(ptr(sr), real_code(sr), sr.numel(), amp, stream()), "ast_divide")
     for s in ([] if tile else used):
         shell_filter(spec, n, edges[s], edges[s + 1], out=scratch)
         dfields[s] = c2r(scratch, (n, n, n))
-    num = triple_product_sums(dfields, triangles).cpu().numpy()
+    num = triple_product_sums(dfields, triangles).cpu().numpy() * amp ** 3
     kf = 2.0 * np.pi / boxsize
     kmid = np.array([[kf * 0.5 * (edges[s] + edges[s + 1]) for s in t] for t in triangles])
     with np.errstate(invalid="ignore", divide="ignore"):

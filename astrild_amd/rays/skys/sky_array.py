@@ -4,7 +4,7 @@ crop / division / merge.  ``self.data`` holds numpy arrays like the reference;
 the arithmetic runs on the GPU through libastrild_hip.so.
 
 Not carried over (out of scope): create_cmb (broken in the reference,
-sky_array.py:735-739), resize (skimage)."""
+sky_array.py:735-739)."""
 import copy
 from typing import Dict, List, Optional, Tuple, Union
 
@@ -92,6 +92,27 @@ class SkyArray:
         map_array = SkyUtils.analytic_Halo_signal_to_SkyArray(
             np.arange(len(halo_dict["m200"])), halo_dict, extent, direction, suppress, suppression_R, npix, to)
         map_array = np.nan_to_num(map_array, copy=False, nan=0.0, posinf=0.0, neginf=0.0)
+        return cls(map_array, opening_angle, quantity, dirs=None, map_file=None)
+
+    @classmethod
+    def from_halo_catalogue_to_temperature_perturbation_map(cls, halo_cat: pd.DataFrame, extent: float = 1,
+                                                            direction: List[int] = [0, 1], suppress: bool = False,
+                                                            suppression_R: float = 1, npix: int = 8192,
+                                                            opening_angle: float = 20.0, ncpus: int = 1) -> "SkyArray":
+        """Rees-Sciama / Birkinshaw-Gull / moving-cluster temperature perturbation map dT / T_CMB of a halo catalogue
+        (sky_array.py:341-400): the NFW stamps of ``from_halo_dataframe(..., to="dT")`` under the quantity label
+        ``isw_rs[_x|_y]``, infinities zeroed.  ``ncpus`` is accepted for compatibility (one GPU launch paints all halos)."""
+        keys = ["r200_deg", "r200_pix", "m200", "c_NFW", "Dc", "theta1_pix", "theta2_pix", "theta1_tv", "theta2_tv"]
+        halo_dict = {k: np.asarray(halo_cat[k]) for k in keys}
+        map_array = SkyUtils.analytic_Halo_signal_to_SkyArray(
+            np.arange(len(halo_dict["m200"])), halo_dict, extent, direction, suppress, suppression_R, npix)
+        map_array[np.isinf(map_array)] = 0.0
+        if 1 in direction and 0 in direction:
+            quantity = "isw_rs"
+        elif 0 in direction:
+            quantity = "isw_rs_x"
+        else:
+            quantity = "isw_rs_y"
         return cls(map_array, opening_angle, quantity, dirs=None, map_file=None)
 
     @property

@@ -150,6 +150,31 @@ class Filters:
         return res
 
     @staticmethod
+    def tophat_compensated(rad_obj, obj_posx, obj_posy, mapp, alpha, Nbins: int = 10):
+        """Compensated top-hat of ONE object on a flat-sky map (filters.py:461-524; best alpha 0.6-0.7): the pixels within
+        sqrt(2) alpha rad_obj of (obj_posx, obj_posy) are summed in ``Nbins`` annuli of the scaled radius; the mean of the
+        annulus sums inside the filter radius minus the mean of those between it and sqrt(2) times it.  The reference reads
+        the number of annuli from an undefined global ``args["Nbins"]``; here it is an argument.  A few hundred pixels
+        around one object, evaluated on the host like the reference (not part of the per-map pipeline)."""
+        rad_filter = alpha * rad_obj
+        extend = np.sqrt(2)
+        rad_filter_sqrt2 = int(np.ceil(extend * rad_filter))
+        delta_eta = extend / Nbins                       # annulus thickness in units of the filter radius
+        pix = np.arange(-rad_filter_sqrt2, rad_filter_sqrt2)
+        pix_xx, pix_yy = np.meshgrid(pix, pix)
+        pix_dist = np.sqrt(pix_xx ** 2 + pix_yy ** 2) / rad_filter
+        eta = (pix_dist / delta_eta).astype(int)
+        keep = eta < Nbins
+        pix_xx, pix_yy, eta = pix_xx[keep], pix_yy[keep], eta[keep]
+        annulus_value = np.zeros(Nbins)
+        # (the reference indexes the map with the meshgrid's x offsets on axis 0 and its y offsets on axis 1)
+        np.add.at(annulus_value, eta, np.asarray(mapp)[obj_posy + pix_xx, obj_posx + pix_yy])
+        middle = int(np.ceil(1 / delta_eta))
+        white_hat = np.mean(annulus_value[:middle])      # 0 -> rad_filter
+        black_hat = np.mean(annulus_value[middle:])      # rad_filter -> sqrt(2) rad_filter
+        return white_hat - black_hat
+
+    @staticmethod
     def sigma_to_fwhm(sigma: float) -> float:
         return sigma * (2 * np.sqrt(2 * np.log(2)))
 

@@ -26,6 +26,62 @@ import torch
 import torch.distributed as dist
 
 
+def disc_layout(n, parts, r1, tile=16):
+    """The DISC layout of the half spectrum between the k_y pass and the last pass (include/astrild_hip.h,
+    ast_fft_tile_disc_layout; csrc/fft_tile.hip builds the same table - tests compare them): FFTPower(mode="1d", kmin=k_F)
+    drops |m| >= n/2 (power_spectrum_3d.py:189-195), so a row (k_y, k_z tile from k_z0) with k_y^2 + k_z0^2 > (n/2)^2 is neither
+    stored nor sent.  The k_y rows go to `parts` owners in blocks of `r1` rows, balanced by disc area; a part's plane is
+    tile-major: for every tile of `tile` columns the part's rows inside the disc, in row order.
+
+    Returns a dict: r1, tile, nblk, tiles, part_of[row block], gk[part] (its row blocks, ascending), S[part] (complex elements
+    per plane), cumS[part], total, lo / hi / offb [tile][row block] (sub-rows lo <= sub < hi of the block exist; sub-row 0
+    would land at element offb of the part's plane) and rows[part] / cols[part]: for every element of a part's plane the
+    (k_y row, k_z column) it holds (columns past n/2 are padding)."""
+    n, parts, r1, tile = int(n), int(parts), int(r1), int(tile)
+    nblk, tiles, half = n // r1, (n // 2 + 1 + tile - 1) // tile, n // 2
+    if nblk * r1 != n or nblk % parts or half % r1:
+        raise ValueError(f"{n} rows in blocks of {r1} do not deal out to {parts} parts")
+    nb = nblk // parts
+
+    def inside(row, t):
+        ky = row - n if row > half else row
+        return ky * ky + (tile * t) ** 2 <= half * half
+
+    area = [sum(inside(k * r1 + sub, t) for sub in range(r1) for t in range(tiles)) for k in range(nblk)]
+    order = sorted(range(nblk), key=lambda k: (-area[k], k))
+    sums, cnt, part_of = [0] * parts, [0] * parts, [0] * nblk
+    for k in order:
+        best = min((r for r in range(parts) if cnt[r] < nb), key=lambda r: (sums[r], r))
+        part_of[k] = best
+        sums[best] += area[k]
+        cnt[best] += 1
+    gk = [[k for k in range(nblk) if part_of[k] == r] for r in range(parts)]
+    lo = np.zeros((tiles, nblk), dtype=np.int64)
+    hi = np.zeros((tiles, nblk), dtype=np.int64)
+    offb = np.zeros((tiles, nblk), dtype=np.int64)
+    S, rows, cols = [], [], []
+    for r in range(parts):
+        count, prow, pcol = 0, [], []
+        for t in range(tiles):
+            for k in gk[r]:
+                valid = [sub for sub in range(r1) if inside(k * r1 + sub, t)]
+                if not valid:
+                    continue
+                assert valid == list(range(valid[0], valid[-1] + 1)), "the rows of a block inside the disc are one range"
+                lo[t, k], hi[t, k] = valid[0], valid[-1] + 1
+                offb[t, k] = tile * (count - valid[0])
+                for sub in valid:
+                    prow += [k * r1 + sub] * tile
+                    pcol += list(range(tile * t, tile * t + tile))
+                count += len(valid)
+        S.append(tile * count)
+        rows.append(np.array(prow, dtype=np.int64))
+        cols.append(np.array(pcol, dtype=np.int64))
+    cumS = [sum(S[:r]) for r in range(parts)]
+    return dict(n=n, parts=parts, r1=r1, tile=tile, nblk=nblk, tiles=tiles, part_of=part_of, gk=gk, S=S, cumS=cumS,
+                total=sum(S), lo=lo, hi=hi, offb=offb, rows=rows, cols=cols)
+
+
 class HipSlabOps:
     """Local arithmetic on the GPU through the C-ABI."""
 
@@ -136,6 +192,62 @@ class HipSlabOps:
         check(lib().ast_fft_tile_c2c_packed(self.dev.ptr(spec), self.dev.ptr(packed), code, n1, nz, pitch, nloc, parts,
                                             self_part, self.dev.ptr(self_dst), 1.0, self.dev.stream()),
               "ast_fft_tile_c2c_packed")
+
+    def disc_layout(self, n, parts):
+        """The disc layout of the slab transpose for (n, parts) from the library (plane sizes, owners of the row blocks),
+        or None where the hand-written passes or the geometry do not allow it (ASTRILD_SLAB_DISC=0: never)."""
+        import ctypes as ct
+        import os
+        from ._lib import check, lib
+        if os.environ.get("ASTRILD_SLAB_DISC", "1") == "0" or self.dtype != torch.float32 or not self._tile_ok(0, n):
+            return None
+        r1 = 32 if n == 1024 else 16
+        if (n // r1) % parts:
+            return None
+        S = (ct.c_uint * parts)()
+        owner = (ct.c_ubyte * (n // r1))()
+        r1_out = ct.c_int()
+        check(lib().ast_fft_tile_disc_layout(n, parts, S, owner, ct.byref(r1_out)), "ast_fft_tile_disc_layout")
+        S = [int(v) for v in S]
+        return dict(n=n, parts=parts, r1=int(r1_out.value), tile=16, S=S, cumS=[sum(S[:r]) for r in range(parts)], total=sum(S),
+                    part_of=[int(v) for v in owner])
+
+    def fft2d_planes_disc(self, planes, spec, packed, layout, self_part, self_dst, lowz=None):
+        """z rows of the planes into `spec`, then the k_y pass storing in the disc layout: part q's rows into
+        packed[npl * cumS[q] : npl * (cumS[q] + S[q])] (what goes to rank q), the rank's own part into self_dst."""
+        from ._lib import check, lib
+        nloc, n1, n2 = planes.shape
+        code = self.dev.real_code(planes)
+        pitch = spec.shape[-1]
+        assert spec.is_contiguous() and packed.is_contiguous() and self_dst.is_contiguous()
+        assert packed.numel() == nloc * layout["total"] and self_dst.numel() == nloc * layout["S"][self_part]
+        if lowz is not None:
+            assert lowz.is_contiguous() and lowz.dtype == torch.complex128 and lowz.numel() == nloc * n1 * 7
+            check(lib().ast_fft_tile_rows_r2c_lowz(self.dev.ptr(planes), self.dev.ptr(spec), code, n2, nloc * n1, n2, pitch,
+                                                   1.0, self.dev.ptr(lowz), self.dev.stream()), "ast_fft_tile_rows_r2c_lowz")
+        else:
+            check(lib().ast_fft_tile_rows_r2c(self.dev.ptr(planes), self.dev.ptr(spec), code, n2, nloc * n1, n2, pitch,
+                                              1.0, self.dev.stream()), "ast_fft_tile_rows_r2c")
+        check(lib().ast_fft_tile_c2c_disc(self.dev.ptr(spec), self.dev.ptr(packed), code, n1, pitch, nloc, layout["parts"],
+                                          int(self_part), self.dev.ptr(self_dst), 1.0, self.dev.stream()), "ast_fft_tile_c2c_disc")
+
+    def axis0_power_disc(self, block, scale, n, boxsize, layout, part, psum, first_bin):
+        """The last pass over the rank's block in the disc layout fused with its shell binning (ast_fft_tile_disc_block_power);
+        psum is overwritten (shells below first_bin left at zero)."""
+        from ._lib import check, lib
+        parts = layout["parts"]
+        key = (n, parts, "disc")
+        if getattr(self, "_bp_key", None) != key:
+            self._bp_key = key
+            self._bp_scratch = torch.empty(int(lib().ast_fft_tile_disc_power_scratch_bytes(n, parts)), dtype=torch.uint8,
+                                           device=self.device)
+        assert block.is_contiguous() and block.numel() == n * layout["S"][part]
+        psum.zero_()
+        check(lib().ast_fft_tile_disc_block_power(self.dev.ptr(block), self.dev.ptr(self._bp_scratch), self._bp_scratch.numel(), 0,
+                                                  n, parts, int(part), float(scale), float(boxsize), int(first_bin),
+                                                  self.dev._bin_code(None), self.dev.ptr(psum), self.dev.stream()),
+              "ast_fft_tile_disc_block_power")
+        return psum
 
     def pack(self, spec, out, parts):
         from ._lib import check, lib
@@ -301,6 +413,26 @@ def exchange_planes(packed_c, block, p0, npl, nloc, group=None, self_done=False)
     return dist.batch_isend_irecv(ops_list) if ops_list else []
 
 
+def exchange_planes_disc(packed, block, p0, npl, nloc, layout, group=None):
+    """Step 4 in the disc layout for the local planes [p0, p0 + npl).  packed: flat, npl * total elements - the piece for
+    rank s is packed[npl * cumS[s] : npl * (cumS[s] + S[s])] (npl planes of S[s]); it lands in planes s_src * nloc + p0 ... of
+    the receiver's block (n, S[receiver]).  The rank's own piece was written into the block by the producer."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    S, cumS = layout["S"], layout["cumS"]
+    ops_list = []
+    if world > 1:
+        comm_ready(group)
+    for s in range(world):
+        if s == rank:
+            continue
+        piece = packed[npl * cumS[s]: npl * (cumS[s] + S[s])]
+        dst = block[s * nloc + p0: s * nloc + p0 + npl]
+        ops_list.append(dist.P2POp(dist.isend, torch.view_as_real(piece), _peer(group, s), group))
+        ops_list.append(dist.P2POp(dist.irecv, torch.view_as_real(dst), _peer(group, s), group))
+    return dist.batch_isend_irecv(ops_list) if ops_list else []
+
+
 def exchange_chunk(packed_c, block, chunk, pc, nloc, group=None, self_done=False):
     """exchange_planes for chunk `chunk` of `pc` local planes."""
     return exchange_planes(packed_c, block, chunk * pc, pc, nloc, group, self_done)
@@ -426,8 +558,16 @@ class SlabPowerPipeline:
             raise ValueError(f"{self.nloc} local planes do not split into {chunks} chunks")
         self.chunks = chunks
         self.pc = self.nloc // chunks
-        self.packed = o.empty((chunks, P, self.pc, self.nloc, self.nzp), o.cdtype)
-        self.block = o.empty((n, self.nloc, self.nzp), o.cdtype)
+        # the transpose's wire format: the disc layout (only what FFTPower keeps, owners balanced by disc area) where the
+        # ops offer it, else `parts` blocks of whole pitched rows
+        disc_fn = getattr(o, "disc_layout", None)
+        self.disc = disc_fn(n, P) if disc_fn else None
+        if self.disc is not None:
+            self.packed = o.empty((self.nloc * self.disc["total"],), o.cdtype)
+            self.block = o.empty((n, self.disc["S"][self.rank]), o.cdtype)
+        else:
+            self.packed = o.empty((chunks, P, self.pc, self.nloc, self.nzp), o.cdtype)
+            self.block = o.empty((n, self.nloc, self.nzp), o.cdtype)
         self.psum = o.zeros((n // 2 - 1,), torch.float64)
         self._side = None
         self._stage_s = {}
@@ -737,6 +877,13 @@ class SlabPowerPipeline:
         def transform(p0, npl):
             planes = owned[p0:p0 + npl]
             spec = self.spec2d[p0:p0 + npl]
+            if self.disc is not None:
+                tot = self.disc["total"]
+                packed = self.packed_flat[p0 * tot:(p0 + npl) * tot]
+                mine = self.block[self.rank * nloc + p0: self.rank * nloc + p0 + npl]
+                o.fft2d_planes_disc(planes, spec, packed, self.disc, self.rank, mine,
+                                    lowz=self._lowz_rows(p0, npl) if self.lowz is not None else None)
+                return exchange_planes_disc(packed, self.block, p0, npl, nloc, self.disc, self.group)
             nly = self.n // P
             packed = self.packed_flat[P * p0 * nly * nz: P * (p0 + npl) * nly * nz].view(P, npl, nly, nz)
             if packed_fn and packed_fn(planes, P):
@@ -838,7 +985,10 @@ class SlabPowerPipeline:
         """Axis-0 pass + shell binning of the received block, all-reduces, low-k patch."""
         import time
         fused_fn = getattr(self.ops, "axis0_power_supported", None)
-        if fused_fn and fused_fn(self.n):
+        if self.disc is not None:
+            self.ops.axis0_power_disc(self.block, 1.0 / float(self.n) ** 3, self.n, self.L, self.disc, self.rank, self.psum,
+                                      5 if self.lowk else 0)
+        elif fused_fn and fused_fn(self.n):
             # axis-0 pass and shell binning in one kernel (the spectrum block is not written back)
             self.ops.fft1d_axis0_power(self.block, 1.0 / float(self.n) ** 3, self.n, self.L, self.rank * self.nloc, self.psum,
                                        5 if self.lowk else 0)
@@ -867,8 +1017,13 @@ class SlabPowerPipeline:
         if self.world == 1:
             return {"ghost": 0, "transpose": 0, "allreduce": 0}
         esz = torch.empty((), dtype=self.ops.dtype).element_size() if hasattr(self.ops, "dtype") else 4
+        if self.disc is not None:         # sent: the other parts' planes; received: the own part's planes from the others
+            sent = self.nloc * (self.disc["total"] - self.disc["S"][self.rank]) * 2 * esz
+            recv = (self.world - 1) * self.nloc * self.disc["S"][self.rank] * 2 * esz
+        else:
+            sent = recv = (self.world - 1) * self.nloc * self.nloc * self.nzp * 2 * esz
         return {"ghost": (self.gl + self.gh) * self.n * self.n * esz,
-                "transpose": (self.world - 1) * self.nloc * self.nloc * self.nzp * 2 * esz,
+                "transpose": sent, "transpose_received": recv,
                 "allreduce": (self.n // 2 - 1) * 8 + (1183 * 16 if self.lowk else 0)}
 
     def stage_ms(self, steps):
@@ -912,6 +1067,14 @@ class SlabPowerPipeline:
                 before_edge()
             planes = owned[c * self.pc:(c + 1) * self.pc]
             spec = self.spec2d[c * self.pc:(c + 1) * self.pc]
+            if self.disc is not None:
+                tot, p0 = self.disc["total"], c * self.pc
+                packed = self.packed[p0 * tot:(p0 + self.pc) * tot]
+                mine = self.block[self.rank * self.nloc + p0: self.rank * self.nloc + p0 + self.pc]
+                o.fft2d_planes_disc(planes, spec, packed, self.disc, self.rank, mine,
+                                    lowz=self._lowz_rows(p0, self.pc) if self.lowz is not None else None)
+                pending += exchange_planes_disc(packed, self.block, p0, self.pc, self.nloc, self.disc, self.group)
+                continue
             packed_fn = getattr(o, "packed_supported", None)
             if packed_fn and packed_fn(planes, self.world):
                 # y pass stores in send order; the rank's own piece goes straight into the receive block

@@ -72,9 +72,11 @@ int ast_divide(void* buf_d, int dtype, size_t count, double divisor, void* strea
  * sigma * N(0,1) per component, wrapped into [0, L).  Counter-based
  * generator keyed by (seed, particle index, component); particles
  * [first, first+count) of the lattice are written to pos_d as (count, 3).
- * `shuffle_stride` != 0 writes them in the order
- * t -> first + (t * shuffle_stride) mod count (a fixed permutation of the range
- * when the stride is coprime with count): the scatter-unfriendly ordering.
+ * `shuffle_stride` = UINT64_MAX writes them in a pseudo-random order, a fixed
+ * permutation of the range keyed by seed + 1 (cycle-walked Feistel network over
+ * the splitmix64 finaliser): the scatter-unfriendly ordering of SURVEY.md S8(d).
+ * Any other non-zero value: t -> first + (t * shuffle_stride) mod count (a
+ * permutation when the stride is coprime with count; low-discrepancy, kept for A/B).
  * Bench / test plumbing, not part of the reference. */
 int ast_synth_lattice_particles(void* pos_d, int dtype, size_t first, size_t count,
                                 int npside, double boxsize, double sigma,
@@ -360,6 +362,31 @@ size_t ast_fft_tile_block_power_scratch_bytes(size_t n, size_t nloc);
 int ast_fft_tile_block_power(void* block_d, void* scratch_d, size_t scratch_bytes, int dtype, size_t n, size_t nloc,
                              size_t ky0, size_t pitch, double scale, double boxsize, int first_bin, int binning,
                              double* psum_d, void* stream);
+
+/* DISC LAYOUT of the half spectrum between the k_y pass and the last pass: only what FFTPower keeps.
+ * FFTPower(mode="1d", kmin=k_F) drops every mode with |m| >= N/2 (power_spectrum_3d.py:189-195), so after the k_y pass a row
+ * (k_y, 16-column k_z tile starting at k_z0) with k_y^2 + k_z0^2 > (N/2)^2 holds nothing any shell takes (the edge itself
+ * stays: under AST_BIN_FLOAT64 a vector of norm exactly N/2 may fall into the last shell) - 21.5 % of the half plane.
+ * The k_y rows are dealt to `parts` owners in blocks of r1 rows (32 at n = 1024, else 16), balanced by the area of the disc
+ * they cover (contiguous ranges would leave the owners of the rows around k_y = 0 with full planes); a part's plane holds,
+ * tile by tile, its rows that reach into the disc, 16 complex each.  The slab transpose sends these planes (pmesh transposes
+ * inside the reference's one FFTPower call; nothing in the reference corresponds to the layout).  fp32, n in {256, 512,
+ * 1024}, parts dividing n / r1.
+ *   ast_fft_tile_disc_layout: plane_elems[parts] = complex elements per plane of each part, block_part[n / r1] = owner of
+ *     every row block (or NULL), *r1_out = rows per block.  Host arithmetic only.
+ *   ast_fft_tile_disc_table: the table [tile][row block] x (offb, S, cumS, lo | hi << 8 | part << 16) as int32 (host).
+ *   ast_fft_tile_c2c_disc: the k_y pass of planes_d ((nplanes, n, pitch) complex, left intact) storing part q's rows of
+ *     plane b at packed_d + nplanes * cumS[q] + b * S[q], the part self_part at self_out_d + b * S[self_part] (its place in
+ *     the rank's own block; self_part < 0 and self_out_d NULL: none; packed_d may be NULL when parts == 1).
+ *   ast_fft_tile_disc_block_power: the last pass over part `part`'s block ((n, S[part]) complex) fused with the shell
+ *     binning, psum_d[shell] += L^3 sum w |scale * X|^2; shells below first_bin are skipped. */
+int ast_fft_tile_disc_layout(size_t n, int parts, unsigned* plane_elems, unsigned char* block_part, int* r1_out);
+int ast_fft_tile_disc_table(size_t n, int parts, int* out, size_t out_ints);
+int ast_fft_tile_c2c_disc(const void* planes_d, void* packed_d, int dtype, size_t n, size_t pitch, size_t nplanes, int parts,
+                          int self_part, void* self_out_d, double scale, void* stream);
+size_t ast_fft_tile_disc_power_scratch_bytes(size_t n, int parts);
+int ast_fft_tile_disc_block_power(void* block_d, void* scratch_d, size_t scratch_bytes, int dtype, size_t n, int parts, int part,
+                                  double scale, double boxsize, int first_bin, int binning, double* psum_d, void* stream);
 
 /* The low-k channel as separate calls, for slab-decomposed grids: every rank adds the contribution of its own
  * planes to the (2*6+1)^2 * 7 modes |m_i| <= 6, m_z >= 0 (complex128, [kx + 6][ky + 6][kz]); the modes are summed over

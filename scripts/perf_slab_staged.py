@@ -21,6 +21,7 @@ dist.get_world_size = lambda group=None: P
 dist.get_rank = lambda group=None: RANK
 dist.all_reduce = lambda t, *a, **k: None
 slab.exchange_planes = lambda *a, **k: []
+slab.exchange_planes_disc = lambda *a, **k: []
 slab.GhostExchange.start = lambda self: None
 slab.GhostExchange.start_upper = lambda self: None
 slab.GhostExchange.start_lower = lambda self: None
@@ -86,6 +87,12 @@ def run(pipeline, rps=None, streams=1, reps=7, parts=None):
         # delays everything enqueued after ghost_finish.
         wb = pipe.wire_bytes()
         wire = wb["transpose"] / (P - 1) / pipe.nloc / 1e6          # MB per plane and link
+        if pipe.disc is not None:
+            # disc layout: the link to rank s carries planes of S[s] elements - the fullest link sets the pace (the parts are
+            # balanced to a few per cent); every rank runs the same schedule, so this is also what the last receive waits for
+            wire = max(pipe.disc["S"]) * 8 / 1e6
+            print(f"    disc layout: plane sizes per part {pipe.disc['S']} (a full pitched plane: {pipe.nloc * pipe.nzp}); sent per step "
+                  f"{wb['transpose'] / 1e6:.1f} MB, received {wb['transpose_received'] / 1e6:.1f} MB; fullest link {wire * pipe.nloc:.1f} MB")
         ghost_mb = wb["ghost"] / 2 / 1e6                            # MB of ghost planes per neighbour
         tail = (prof.get("fft_tile.c2c_power", (0, 0))[1] + prof.get("fft_tile.shell_reduce", (0, 0))[1]) / reps + 0.1
         times = [(t0.elapsed_time(e), entry) for entry, e in pipe_trace[1:]]

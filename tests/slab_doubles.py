@@ -40,6 +40,42 @@ class NumpySlabOps:
         out.copy_(spec.reshape(n0, parts, n1 // parts, n2).permute(1, 0, 2, 3).contiguous().reshape(out.shape))
         return out
 
+    # ---- the disc wire format (slab.disc_layout): only what FFTPower keeps travels, owners balanced by disc area
+    disc_geometry = None               # (r1, tile) switches it on
+
+    def disc_layout(self, n, parts):
+        if self.disc_geometry is None:
+            return None
+        from astrild_amd import slab
+        r1, tile = self.disc_geometry
+        return slab.disc_layout(n, parts, r1, tile)
+
+    def fft2d_planes_disc(self, planes, spec, packed, layout, self_part, self_dst, lowz=None):
+        npl, n, _ = planes.shape
+        full = np.fft.rfft2(planes.numpy(), axes=(1, 2))
+        spec.copy_(torch.from_numpy(full))
+        tiles, tile = layout["tiles"], layout["tile"]
+        padded = np.zeros((npl, n, tiles * tile), dtype=full.dtype)
+        padded[:, :, :full.shape[2]] = full
+        # (what lies outside the disc is in no piece: it never reaches the other side)
+        for q in range(layout["parts"]):
+            piece = padded[:, layout["rows"][q], layout["cols"][q]]                 # (npl, S[q]) in the part's layout order
+            if q == self_part:
+                self_dst.copy_(torch.from_numpy(piece).reshape(self_dst.shape))
+            else:
+                a = npl * layout["cumS"][q]
+                packed[a:a + npl * layout["S"][q]] = torch.from_numpy(piece).reshape(-1)
+
+    def axis0_power_disc(self, block, scale, n, boxsize, layout, part, psum, first_bin):
+        tiles, tile = layout["tiles"], layout["tile"]
+        full = np.zeros((n, n, tiles * tile), dtype=np.complex128)                  # rows of other parts / outside the disc: zero
+        full[:, layout["rows"][part], layout["cols"][part]] = block.numpy().reshape(n, -1)
+        full = np.fft.fft(full[:, :, :n // 2 + 1], axis=0) * scale
+        p3d = (full * full.conj()).real * boxsize ** 3
+        _, ps, _ = offt.project_block(p3d, n, boxsize, 0, 0)
+        psum.copy_(torch.from_numpy(ps))
+        return psum
+
     def fft1d_axis0(self, block, scale):
         block.copy_(torch.from_numpy(np.fft.fft(block.numpy(), axis=0) * scale))
         return block

@@ -19,6 +19,8 @@ def main():
         from astrild_amd import device as dev, slab
         pipe = slab.SlabPowerPipeline(n, 1000.0, n, window=os.environ.get("SLAB_TEST_WINDOW", "cic"), dtype=dtype, seed=5, chunks=2)
         assert pipe.pipeline == os.environ.get("ASTRILD_SLAB_PIPELINE", "staged")
+        if dtype == torch.float32 and n in (256, 512, 1024) and (n // (32 if n == 1024 else 16)) % world == 0:
+            assert pipe.disc is not None          # the transpose travels in the disc layout (only what FFTPower keeps)
         ks, ps, nm = pipe.step(check=True)
         res = dev.finish_power(ks, ps, nm)
         if rank == 0:

@@ -140,6 +140,24 @@ def test_bispectrum_brute_force_tiny(tmp_path):
     npt.assert_allclose(res["B"][nb > 0], bb[nb > 0], rtol=1e-9)
 
 
+def test_bispectrum_of_a_field_in_physical_units_does_not_overflow():
+    """fp32 shell fields are multiplied in fp32 inside the triangle sums: a grid in Msun/h per cell (1e13) would overflow
+    |D|^3 - the estimator normalises the fields by max |field| and scales the sums back.  B is cubic in the amplitude."""
+    import torch
+    from astrild_amd import device as dev
+    torch.cuda.set_device(0)
+    n, L = 256, 500.0
+    g = torch.Generator(device="cuda").manual_seed(77)
+    f = torch.randn((n, n, n), dtype=torch.float32, device="cuda", generator=g)
+    f = f + 0.3 * f * f
+    edges = [1, 9, 17, 33, 65]
+    tri = [(0, 0, 0), (0, 1, 1), (1, 2, 2), (2, 3, 3), (1, 2, 3)]
+    base = dev.bispectrum(f, L, edges, tri)
+    big = dev.bispectrum(f * 1e13, L, edges, tri)
+    assert np.all(np.isfinite(big["B"])) and np.array_equal(big["ntri"], base["ntri"])
+    npt.assert_allclose(big["B"] / 1e39, base["B"], rtol=2e-5, atol=1e-6 * np.abs(base["B"]).max())
+
+
 def _kappa_frame(npix, seed=0):
     rng = np.random.default_rng(seed)
     c2, c3 = ok.C_LIGHT_KMS ** 2, ok.C_LIGHT_KMS ** 3

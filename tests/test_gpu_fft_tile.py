@@ -382,3 +382,82 @@ def test_double_precision_r2c_against_rocfft_and_numpy(hip, n):
     if n == 256:
         want = np.fft.rfftn(f) / n ** 3
         assert np.abs(got.cpu().numpy() - want).max() < 1e-13 * np.abs(want).max() * np.sqrt(n)
+
+
+# ------------------------------------------------------------------ disc layout (the slab transpose's wire format)
+def _disc(hip, n, parts):
+    from astrild_amd import slab
+    return slab.disc_layout(n, parts, 32 if n == 1024 else 16, 16)
+
+
+@pytest.mark.parametrize("n,parts,nplanes", [(256, 1, 3), (256, 4, 5), (512, 8, 2), (1024, 8, 2)])
+def test_ky_pass_storing_in_the_disc_layout(dev, hip, n, parts, nplanes):
+    """ast_fft_tile_c2c_disc against numpy: every element of every part's planes (only rows inside the Nyquist disc exist),
+    the rank's own part written to its own place, the rest of the send buffer left alone."""
+    from astrild_amd import _lib
+    lay = _disc(hip, n, parts)
+    nz, pitch = n // 2 + 1, (n // 2 + 1 + 15) // 16 * 16
+    rng = np.random.default_rng(n + parts)
+    a = (rng.standard_normal((nplanes, n, pitch)) + 1j * rng.standard_normal((nplanes, n, pitch))).astype(np.complex64)
+    t = dev.as_device(a.copy())
+    me = parts - 1
+    packed = torch.full((nplanes * lay["total"],), float("nan"), dtype=torch.complex64, device="cuda")
+    mine = torch.full((nplanes, lay["S"][me]), float("nan"), dtype=torch.complex64, device="cuda")
+    _lib.check(hip.ast_fft_tile_c2c_disc(dev.ptr(t), dev.ptr(packed), 0, n, pitch, nplanes, parts, me, dev.ptr(mine), 0.5, dev.stream()))
+    ref = 0.5 * np.fft.fft(a.astype(np.complex128), axis=1)
+    rms = np.sqrt(np.mean(np.abs(ref[:, :, :nz]) ** 2))
+    got_all = packed.cpu().numpy()
+    for q in range(parts):
+        rows, cols = lay["rows"][q], lay["cols"][q]
+        if q == me:
+            got = mine.cpu().numpy()
+            assert np.isnan(got_all[nplanes * lay["cumS"][q]: nplanes * (lay["cumS"][q] + lay["S"][q])].real).all()      # its slot in the send buffer stays unwritten
+        else:
+            got = got_all[nplanes * lay["cumS"][q]: nplanes * (lay["cumS"][q] + lay["S"][q])].reshape(nplanes, -1)
+        ok = cols < nz                                     # (columns past n/2 of the last tile: copies, never read)
+        np.testing.assert_allclose(got[:, ok], ref[:, rows[ok], cols[ok]], rtol=0, atol=2e-6 * rms)
+    assert torch.equal(t.cpu(), torch.from_numpy(a))       # the planes are left intact
+
+
+@pytest.mark.parametrize("n,parts", [(256, 4), (512, 8)])
+def test_last_pass_over_disc_blocks_adds_up_to_the_single_gpu_sums(dev, hip, n, parts):
+    """One GPU plays every rank: z rows + k_y pass of ALL planes in the disc layout gives each part's whole block; the
+    last pass + binning of the parts' blocks adds up to the shell sums of the single-GPU pipeline (same modes, same
+    arithmetic per mode; the order of the additions differs)."""
+    from astrild_amd import _lib
+    lay = _disc(hip, n, parts)
+    g = torch.Generator(device="cuda").manual_seed(n + 11)
+    grid = torch.randn((n, n, n), dtype=torch.float32, device="cuda", generator=g)
+    nz, pitch = n // 2 + 1, (n // 2 + 1 + 15) // 16 * 16
+    spec = torch.empty((n, n, pitch), dtype=torch.complex64, device="cuda")
+    _lib.check(hip.ast_fft_tile_rows_r2c(dev.ptr(grid), dev.ptr(spec), 0, n, n * n, n, pitch, 1.0, dev.stream()))
+    packed = torch.empty((n * lay["total"],), dtype=torch.complex64, device="cuda")
+    _lib.check(hip.ast_fft_tile_c2c_disc(dev.ptr(spec), dev.ptr(packed), 0, n, pitch, n, parts, -1, None, 1.0, dev.stream()))
+    scratch = torch.empty(int(hip.ast_fft_tile_disc_power_scratch_bytes(n, parts)), dtype=torch.uint8, device="cuda")
+    for rule in ("float64", "integer"):
+        total = torch.zeros(n // 2 - 1, dtype=torch.float64, device="cuda")
+        for q in range(parts):
+            block = packed[n * lay["cumS"][q]: n * (lay["cumS"][q] + lay["S"][q])].clone()
+            psum = torch.zeros(n // 2 - 1, dtype=torch.float64, device="cuda")
+            _lib.check(hip.ast_fft_tile_disc_block_power(dev.ptr(block), dev.ptr(scratch), scratch.numel(), 0, n, parts, q,
+                                                         1.0 / float(n) ** 3, 1000.0, 0, _lib.BIN[rule], dev.ptr(psum), dev.stream()))
+            assert float(psum.sum()) > 0.0
+            total += psum
+        _, ref, _ = dev.power_sums_fused(grid, 1000.0, lowk=False, binning=rule)
+        np.testing.assert_allclose(total.cpu().numpy(), ref.cpu().numpy(), rtol=1e-12)
+
+
+@pytest.mark.parametrize("n", [256, 512])
+def test_single_gpu_pipeline_through_the_disc_layout_changes_no_bit(dev, n):
+    """AST_FFT_DISC=1: the power pipeline's k_y pass stores in the disc layout (one part) and the binning pass reads it
+    from there - the same partial sums in the same order as the in-place passes."""
+    import os
+    g = torch.Generator(device="cuda").manual_seed(n + 13)
+    t = torch.randn((n, n, n), dtype=torch.float32, device="cuda", generator=g)
+    _, ref, _ = dev.power_sums_fused(t, 750.0)
+    os.environ["AST_FFT_DISC"] = "1"
+    try:
+        _, got, _ = dev.power_sums_fused(t, 750.0)
+    finally:
+        del os.environ["AST_FFT_DISC"]
+    assert torch.equal(got, ref)

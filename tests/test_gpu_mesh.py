@@ -238,6 +238,19 @@ def test_synthetic_generator_statistics(dev):
     # same multiset of particles, different order
     np.testing.assert_allclose(np.sort(sh[:, 0]), np.sort(pos[:, 0]), rtol=0, atol=0)
     assert not np.array_equal(sh, pos)
+    # the pseudo-random order (Feistel network keyed by seed + 1) is a PERMUTATION of any range - also of one whose length
+    # is no power of two - and a different one per seed; the stride order of rounds 1-4 stays available
+    first, count = 1000, 29791
+    sub = dev.synth_lattice_particles(n, n, L, seed=1, dtype=torch.float64, first=first, count=count).cpu().numpy()
+    for kind in (True, "stride"):
+        shs = dev.synth_lattice_particles(n, n, L, seed=1, shuffle=kind, dtype=torch.float64, first=first, count=count).cpu().numpy()
+        assert np.array_equal(shs[np.lexsort(shs.T)], sub[np.lexsort(sub.T)]) and not np.array_equal(shs, sub)
+    other = dev.synth_lattice_particles(n, n, L, seed=2, shuffle=True, dtype=torch.float64, first=first, count=count).cpu().numpy()
+    assert not np.array_equal(other[:, 0], shs[:, 0])
+    # random, not low-discrepancy: consecutive particles of the shuffled array are far apart in the lattice
+    idx = {tuple(r): i for i, r in enumerate(np.round(pos, 9).tolist())}
+    where = np.array([idx[tuple(r)] for r in np.round(sh[:4096], 9).tolist()])
+    assert len(set(np.diff(where).tolist())) > 4000          # (the stride order has ONE difference modulo the count)
 
 
 def test_single_pass_overflow_path_on_clustered_input(dev):

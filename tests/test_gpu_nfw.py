@@ -59,6 +59,14 @@ def test_catalogue_of_overlapping_and_clipped_halos():
         npt.assert_allclose(sky.data["orig"], ref, rtol=0, atol=1e-9 * abs(ref).max())
         assert sky.npix == npix and sky.opening_angle == 10.0
     assert SkyArray.from_halo_dataframe(cat, npix=npix, extent=3, direction=[0], to="alpha").quantity == "alpha_x"
+    # the Rees-Sciama map constructor (sky_array.py:341-400): the dT stamps under the isw_rs label
+    for direction, label in (([0, 1], "isw_rs"), ([0], "isw_rs_x"), ([1], "isw_rs_y")):
+        sky = SkyArray.from_halo_catalogue_to_temperature_perturbation_map(cat, extent=3, direction=direction, suppress=True,
+                                                                            suppression_R=2, npix=npix, opening_angle=10.0)
+        ref = ok.analytic_halo_signal_map({k: cat[k].values for k in cat.columns}, 3, direction, True, 2, npix, "dT")
+        ref[np.isinf(ref)] = 0.0
+        npt.assert_allclose(sky.data["orig"], ref, rtol=0, atol=1e-9 * abs(ref).max())
+        assert sky.quantity == label and sky.opening_angle == 10.0
 
 
 def test_single_stamp_maps_and_halo_series():

@@ -289,6 +289,7 @@ def test_one_rank_of_eight_staged_step_with_grouping_in_parts(hip, monkeypatch, 
     monkeypatch.setattr(dist, "get_rank", lambda group=None: rank)
     monkeypatch.setattr(dist, "all_reduce", lambda t, *a, **k: None)
     monkeypatch.setattr(slab, "exchange_planes", lambda *a, **k: [])
+    monkeypatch.setattr(slab, "exchange_planes_disc", lambda *a, **k: [])
     monkeypatch.setattr(slab, "comm_ready", lambda group=None: None)
     for name in ("start", "start_upper", "start_lower"):
         monkeypatch.setattr(slab.GhostExchange, name, lambda self: None)

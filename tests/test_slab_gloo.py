@@ -27,7 +27,7 @@ def _particles(n=N, nps=NPS):
 
 
 def _worker(rank, world, port, window, out_dir, chunks=2, n=N, nps=NPS, ghost=2, pipeline="bulk", rows_per_stage=None,
-            group_chunks=None):
+            group_chunks=None, disc=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if group_chunks == 8:                 # stages of unequal size: consecutive parts of a stage are grouped in one launch
         os.environ["ASTRILD_SLAB_STAGES"] = "7|0,1,2,3|4,5|6"
@@ -38,10 +38,13 @@ def _worker(rank, world, port, window, out_dir, chunks=2, n=N, nps=NPS, ghost=2,
         pos = _particles(n, nps)
         ppr = len(pos) // world
         mine = torch.from_numpy(np.ascontiguousarray(pos[rank * ppr:(rank + 1) * ppr]))
+        ops = NumpySlabOps()
+        ops.disc_geometry = disc              # (rows per block, columns per tile): the transpose in the disc layout
         pipe = slab.SlabPowerPipeline(n, L, nps, window=window, dtype=torch.float64, ghost=ghost,
-                                      ops=NumpySlabOps(), pos=mine, chunks=chunks, pipeline=pipeline,
+                                      ops=ops, pos=mine, chunks=chunks, pipeline=pipeline,
                                       rows_per_stage=rows_per_stage, xsorted=bool(group_chunks), group_chunks=group_chunks)
         assert pipe.pipeline == pipeline and pipe.group_chunks == (group_chunks or 1)
+        assert (pipe.disc is not None) == (disc is not None)
         ks, ps, nm = pipe.step(check=True)
         ks, ps, nm = pipe.step(check=True)          # a second step reuses buffers, schedule and staged paint
         owned = (pipe.buf[pipe.gl: pipe.gl + pipe.nloc] if world > 1 else pipe.buf).clone()
@@ -97,6 +100,49 @@ def test_slab_pipeline_ranks_match_single_process_oracle(tmp_path, window, chunk
         # transpose: rank r holds delta_k[:, r*nloc:(r+1)*nloc, :] for all kx
         np.testing.assert_allclose(res[r]["block"], spec[:, r * nloc:(r + 1) * nloc, :], rtol=1e-11, atol=1e-14)
     # all-reduced shell sums are identical on both ranks and match the oracle
+    assert np.array_equal(res[0]["nm"], res[-1]["nm"]) and np.array_equal(res[0]["nm"], ref["modes"])
+    np.testing.assert_allclose(res[0]["ps"], res[-1]["ps"], rtol=0, atol=0)
+    np.testing.assert_allclose(res[0]["ks"] / res[0]["nm"], ref["k"], rtol=1e-13)
+    np.testing.assert_allclose(res[0]["ps"] / res[0]["nm"], ref["power"].real, rtol=1e-10)
+
+
+# The transpose in the DISC layout (slab.disc_layout): only the rows of every k_z tile that reach into the Nyquist disc travel,
+# the k_y rows dealt to the ranks in blocks balanced by disc area.  What a rank receives is compared element by element with
+# the oracle's spectrum, the shell sums with the oracle's: nothing FFTPower keeps was cut away.
+@pytest.mark.parametrize("window,chunks,world,n,nps,ghost,pipeline,parts,disc", [
+    ("cic", 2, 2, N, NPS, 2, "bulk", None, (2, 2)), ("tsc", 1, 2, N, NPS, 2, "staged", None, (4, 2)),
+    ("cic", 4, 8, 64, 32, 3, "bulk", None, (2, 4)), ("tsc", 1, 8, 64, 32, 3, "staged", None, (2, 4)),
+    ("cic", 1, 4, 128, 64, 3, "staged", 4, (8, 16)), ("cic", 1, 1, N, NPS, 2, "bulk", None, (2, 2))])
+def test_slab_transpose_in_the_disc_layout(tmp_path, window, chunks, world, n, nps, ghost, pipeline, parts, disc):
+    from astrild_amd import slab
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, window, str(tmp_path), chunks, n, nps, ghost, pipeline, None, parts, disc),
+             nprocs=world, join=True)
+    pos = _particles(n, nps)
+    full = omesh.paint(pos, None, n, L, window)
+    ref = offt.fftpower_1d(full, L)
+    lay = slab.disc_layout(n, world, *disc)
+    # the layout itself: every (row, tile) inside the disc exactly once, nothing outside; owners balanced
+    half, tile = n // 2, disc[1]
+    seen = np.zeros((n, lay["tiles"]), dtype=np.int64)
+    for r in range(world):
+        rr, cc = lay["rows"][r], lay["cols"][r]
+        assert len(rr) == lay["S"][r] and np.all(cc % tile == np.arange(len(cc)) % tile)
+        np.add.at(seen, (rr[::tile], cc[::tile] // tile), 1)
+        assert sorted(set(rr // disc[0])) == lay["gk"][r]
+    ky = np.where(np.arange(n) > half, np.arange(n) - n, np.arange(n))
+    inside = ky[:, None] ** 2 + (tile * np.arange(lay["tiles"]))[None, :] ** 2 <= half * half
+    assert np.array_equal(seen, inside.astype(np.int64))
+    assert max(lay["S"]) <= 1.25 * np.mean(lay["S"]) and lay["total"] < 0.9 * n * lay["tiles"] * tile
+    spec = offt.r2c(full)
+    padded = np.zeros((n, n, lay["tiles"] * tile), dtype=spec.dtype)
+    padded[:, :, :spec.shape[2]] = spec
+    res = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for r in range(world):
+        # before the last pass a rank holds the k_y-transformed planes of ITS rows; the worker saved the block as the
+        # exchange left it (the double's last pass does not write back)
+        got = np.fft.fft(res[r]["block"].reshape(n, -1), axis=0) / float(n) ** 3
+        np.testing.assert_allclose(got, padded[:, lay["rows"][r], lay["cols"][r]], rtol=1e-11, atol=1e-14)
     assert np.array_equal(res[0]["nm"], res[-1]["nm"]) and np.array_equal(res[0]["nm"], ref["modes"])
     np.testing.assert_allclose(res[0]["ps"], res[-1]["ps"], rtol=0, atol=0)
     np.testing.assert_allclose(res[0]["ks"] / res[0]["nm"], ref["k"], rtol=1e-13)
