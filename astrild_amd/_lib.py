@@ -34,6 +34,9 @@ SIGNATURES = {
     "ast_fill": (_i, [_vp, _i, _sz, _d, _vp]),
     "ast_divide": (_i, [_vp, _i, _sz, _d, _vp]),
     "ast_synth_lattice_particles": (_i, [_vp, _i, _sz, _sz, _i, _d, _d, _u64, _u64, _vp]),
+    "ast_synth_clustered_particles": (_i, [_vp, _i, _sz, _i, _d, _d, _u64, _i, _d, _i, _vp]),
+    "ast_paint_occupancy_probe_bytes": (_sz, [_i]),
+    "ast_paint_occupancy_probe": (_i, [_vp, _i, _sz, _i, _d, _d, _sz, _vp, _sz, _vp, _vp]),
     "ast_ngp_assign": (_i, [_vp, _vp, _vp, _vp, _i, _sz, _i, _vp, _vp, _vp, _vp]),
     "ast_paint": (_i, [_i, _i, _vp, _vp, _sz, _i, _d, _d, _i, _i, _vp, _vp, _d, _vp]),
     "ast_paint_tiled_workspace_bytes": (_sz, [_i, _i, _sz, _i, _i, _i]),

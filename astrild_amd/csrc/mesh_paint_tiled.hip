@@ -2329,6 +2329,95 @@ extern "C" int ast_paint_order_probe(const void* pos, int dtype, size_t np, int 
     return AST_OK;
 }
 
+// ---- occupancy probe: will the single-pass paint's fixed tile segments overflow? ----
+// The single pass gives every tile room for max(2 mean, mean + 512) particles (tile_capacity); what does not fit goes through a
+// global-atomic list - fine for a few stragglers, a crawl for clustered input (evolved snapshots, halo catalogues:
+// stats_subfind.py:125-131 paints exactly such a set).  Finding that out from the overflow list costs a wasted paint, and only
+// callers that synchronise ever looked.  This probe estimates it from a SAMPLE before anything is painted: `samples`
+// particles, one from every stride of np / samples (position inside the stride from a hash of the stride's index, so that a
+// lattice-ordered file is not sampled on a sub-lattice), counted per tile (TX x TY x TZ cells of the periodic grid) in
+// counts_d (ntiles x 4 B, zeroed here); then per tile the sample count is scaled by np / samples and compared with the
+// capacity.  out_d[0] = estimated particles beyond capacity, out_d[1] = largest estimated tile occupancy.  With samples >= 8
+// per tile on average the Poisson noise of a uniform input stays below 0.1 % of np; callers compare with np / 64, the
+// level at which device.paint used to repeat the paint.
+__device__ inline uint64_t probe_mix(uint64_t z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+template <typename T>
+__global__ void __launch_bounds__(256)
+occupancy_sample_kernel(const T* __restrict__ pos, size_t np, int n, double inv_dx, double shift, size_t samples,
+                        unsigned* __restrict__ counts) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= samples) return;
+    const size_t lo = (size_t)(((unsigned __int128)i * np) / samples), hi = (size_t)(((unsigned __int128)(i + 1) * np) / samples);
+    const size_t j = lo + (hi > lo ? probe_mix(i) % (hi - lo) : 0);
+    const T* p = pos + 3 * j;
+    unsigned c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double sc = floor(__fma_rn((double)p[a], inv_dx, shift));
+        long long ci = (long long)fmod(sc, (double)n);
+        if (ci < 0) ci += n;
+        c[a] = (unsigned)ci;
+    }
+    const unsigned tile = ((c[0] / ast::TX) * (unsigned)(n / ast::TY) + c[1] / ast::TY) * (unsigned)(n / ast::TZ) + c[2] / ast::TZ;
+    atomicAdd(&counts[tile], 1u);
+}
+__global__ void __launch_bounds__(256)
+occupancy_excess_kernel(const unsigned* __restrict__ counts, unsigned ntiles, double per_sample, double cap,
+                        unsigned long long* __restrict__ out) {
+    __shared__ double ex[256];
+    __shared__ double mx[256];
+    double e = 0.0, m = 0.0;
+    for (unsigned t = blockIdx.x * 256 + threadIdx.x; t < ntiles; t += gridDim.x * 256) {
+        const double occ = (double)counts[t] * per_sample;
+        if (occ > cap) e += occ - cap;
+        m = occ > m ? occ : m;
+    }
+    ex[threadIdx.x] = e;
+    mx[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            ex[threadIdx.x] += ex[threadIdx.x + st];
+            mx[threadIdx.x] = mx[threadIdx.x + st] > mx[threadIdx.x] ? mx[threadIdx.x + st] : mx[threadIdx.x];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(&out[0], (unsigned long long)(ex[0] + 0.5));
+        atomicMax(&out[1], (unsigned long long)(mx[0] + 0.5));
+    }
+}
+
+extern "C" size_t ast_paint_occupancy_probe_bytes(int nmesh) {
+    if (nmesh <= 0 || nmesh % TY || nmesh % TZ || nmesh % TX) return 0;
+    return (size_t)(nmesh / TX) * (nmesh / TY) * (nmesh / TZ) * sizeof(unsigned);
+}
+
+extern "C" int ast_paint_occupancy_probe(const void* pos, int dtype, size_t np, int nmesh, double boxsize, double shift_cells,
+                                         size_t samples, void* counts, size_t counts_bytes, unsigned long long* out, void* stream) {
+    AST_CHECK_ARG(pos != nullptr && counts != nullptr && out != nullptr && (dtype == AST_F32 || dtype == AST_F64));
+    AST_CHECK_ARG(np >= 1 && boxsize > 0.0 && samples >= 1 && samples <= np && samples < (1ull << 40));
+    const size_t need = ast_paint_occupancy_probe_bytes(nmesh);
+    AST_CHECK_ARG(need != 0 && counts_bytes >= need);
+    const unsigned ntiles = (unsigned)(need / sizeof(unsigned));
+    hipStream_t s = ast::as_stream(stream);
+    AST_CHECK_HIP(hipMemsetAsync(counts, 0, need, s));
+    AST_CHECK_HIP(hipMemsetAsync(out, 0, 2 * sizeof(unsigned long long), s));
+    const double inv_dx = (double)nmesh / boxsize;
+    const unsigned blocks = (unsigned)((samples + 255) / 256);
+    if (dtype == AST_F32) occupancy_sample_kernel<float><<<blocks, 256, 0, s>>>((const float*)pos, np, nmesh, inv_dx, shift_cells, samples, (unsigned*)counts);
+    else occupancy_sample_kernel<double><<<blocks, 256, 0, s>>>((const double*)pos, np, nmesh, inv_dx, shift_cells, samples, (unsigned*)counts);
+    occupancy_excess_kernel<<<std::min(1024u, (ntiles + 255) / 256), 256, 0, s>>>((const unsigned*)counts, ntiles, (double)np / (double)samples,
+                                                                                 (double)tile_capacity(np, ntiles), out);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
 static int paint_tiled_impl(int window, int dtype, const void* pos, const void* mass, size_t np, int nmesh,
                             double boxsize, double scale, int x_start, int nx_alloc, void* grid,
                             void* workspace, size_t workspace_bytes, unsigned long long* dropped,

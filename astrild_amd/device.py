@@ -185,6 +185,44 @@ def sample_is_unordered(pos, nmesh, boxsize, shift=0.0, windows=256, fraction=Fa
     return groupable if fraction else groupable < 0.25
 
 
+def probe_input(pos, nmesh, boxsize, shift=0.0, windows=256):
+    """Looks at the particle array BEFORE a tiled paint (two small kernels, one 24-byte fetch): returns a dict with
+    ``groupable`` - the fraction of sampled runs of 32 consecutive particles the grouping kernel could turn into group records
+    (:func:`sample_is_unordered`; < 0.25: no spatial order in memory) -, ``overflow`` - the estimated number of particles beyond
+    the single pass's fixed tile segments (ast_paint_occupancy_probe: a sample of >= 8 particles per 8 x 8 x 32-cell tile) -
+    and ``max_tile`` - the largest estimated tile occupancy.  Evolved snapshots and halo catalogues
+    (stats_subfind.py:125-131) are clustered: their dense tiles overflow the segments, and the paint belongs on the exact
+    two-pass variant from the start."""
+    L = _lib.lib()
+    n, npart = int(nmesh), int(pos.shape[0])
+    cbytes = int(L.ast_paint_occupancy_probe_bytes(n))
+    if cbytes == 0 or npart < 64:
+        return None
+    ntiles = cbytes // 4
+    samples = min(npart, max(65536, 8 * ntiles))
+    counts = torch.empty(cbytes, dtype=torch.uint8, device=pos.device)
+    out = torch.zeros(3, dtype=torch.int64, device=pos.device)       # [overflow, max tile, groupable runs (low 4 bytes)]
+    check(L.ast_paint_occupancy_probe(ptr(pos), real_code(pos), npart, n, float(boxsize), float(shift), samples, ptr(counts),
+                                      cbytes, ptr(out), stream()), "ast_paint_occupancy_probe")
+    check(L.ast_paint_order_probe(ptr(pos), real_code(pos), npart, n, float(boxsize), float(shift), int(windows),
+                                  ct.c_void_p(out.data_ptr() + 16), stream()), "ast_paint_order_probe")
+    o = out.cpu().tolist()
+    return {"overflow": int(o[0]), "max_tile": int(o[1]), "groupable": (int(o[2]) & 0xffffffff) / max(2, int(windows)),
+            "mean_tile": npart / ntiles, "samples": samples}
+
+
+def synth_clustered_particles(npside, nmesh, boxsize, seed=20240601, sigma_cells=0.5, nattractors=256, amplitude=0.95,
+                              shuffle=False, dtype=torch.float32):
+    """A clustered synthetic set (ast_synth_clustered_particles): the lattice collapsing onto ``nattractors`` centres - tile
+    occupancies ~100 x the mean, like an evolved snapshot - in lattice order or (shuffle) in pseudo-random order."""
+    count = int(npside) ** 3
+    pos = torch.empty((count, 3), dtype=dtype, device=device())
+    check(_lib.lib().ast_synth_clustered_particles(ptr(pos), real_code(pos), count, int(npside), float(boxsize),
+                                                   float(sigma_cells) * boxsize / nmesh, int(seed), int(nattractors),
+                                                   float(amplitude), int(bool(shuffle)), stream()), "ast_synth_clustered_particles")
+    return pos
+
+
 def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="auto",
           x_start=0, nx_alloc=None, check_dropped=True, accumulate=None, defer_fold=False, offset=0.0,
           hint=None, stats=None, shift=0.0, offset_planes=None):
@@ -202,8 +240,10 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     before the one rounding to the grid dtype; ``offset="mean"`` uses total mass * scale / nmesh^3,
     i.e. the grid holds rho - mean (only the DC mode changes, which FFTPower discards).
     hint: "scattered" sizes the tiled overwrite paint's workspace for particles without spatial order in memory
-    (AST_PAINT_SCATTERED; without a hint, a paint of >= 2^20 particles that checks its result anyway first looks at a
-    sample - :func:`sample_is_unordered` - instead of finding out from the overflow list of a wasted first attempt);
+    (AST_PAINT_SCATTERED); "clustered" goes to the exact two-pass variant (no capacity limit per tile); "ordered" the
+    plain single pass.  Without a hint a paint of >= 2^20 particles onto the whole grid looks at the input first
+    (:func:`probe_input`: order in memory, tile occupancy tail) and picks single pass / scattered / two-pass up front -
+    also when ``check_dropped`` is False - instead of finding out from the overflow list of a wasted attempt;
     "xsorted" says they come in ascending x (lattice order, slab-ordered files): grouping and
     column walk then overlap chunk by chunk (AST_PAINT_XSORTED; a wrong hint costs time, never correctness).  stats: a dict that receives the list statistics of the tiled overwrite paint.
     shift: added to every coordinate in grid units (0.5 paints the second mesh of an interlaced pair).
@@ -224,8 +264,10 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     dropped = torch.zeros(1, dtype=torch.int64, device=pos.device)
     ws_bytes = 0
     # TWO_PASS | OVERWRITE | DEFER_FOLD | SCATTERED | XSORTED
-    if hint not in (None, "scattered", "xsorted"):
+    if hint not in (None, "scattered", "xsorted", "clustered", "ordered"):
         raise ValueError(hint)
+    if hint == "clustered" and method in ("auto", "tiled"):
+        method = "tiled2"
     tflags = (1 if method == "tiled2" else 0) | (0 if accumulate else 2) | (4 if defer_fold else 0) | \
              (8 if hint == "scattered" and not accumulate and method != "tiled2" else 0) | \
              (16 if hint == "xsorted" and not accumulate and method != "tiled2" else 0)
@@ -255,8 +297,17 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
         offset = total_mass(mass, npart) * float(scale) / float(n) ** 3
     off_planes = (0, -1) if offset_planes is None else offset_planes      # (first buffer plane, count) that get the offset
     compact = use_tiled and not accumulate and method != "tiled2"       # single pass + overwrite: group / stray lists
-    if compact and hint is None and check_dropped and npart >= (1 << 20) and sample_is_unordered(pos, n, boxsize, shift):
-        tflags |= 8                                                     # (a wrong guess costs time, never correctness)
+    attempts, probed = 0, None
+    if compact and hint is None and npart >= (1 << 20) and nx == n and int(x_start) == 0:
+        probed = probe_input(pos, n, boxsize, shift)                    # (a wrong guess costs time, never correctness)
+        if probed is not None and probed["overflow"] > npart // 64:
+            tflags = (tflags & ~(8 | 16)) | 1                           # clustered: the exact two-pass variant at once
+            compact = False
+        elif probed is not None and probed["groupable"] < 0.25:
+            tflags |= 8
+        ws_bytes = int(L.ast_paint_tiled_workspace_bytes(win, code, npart, n, nx, tflags))
+    elif compact and hint is None and check_dropped and npart >= (1 << 20) and sample_is_unordered(pos, n, boxsize, shift):
+        tflags |= 8                                                     # (slab buffers: the order probe alone)
         ws_bytes = int(L.ast_paint_tiled_workspace_bytes(win, code, npart, n, nx, tflags))
     if use_tiled:
         mass_bound = 1.0
@@ -265,6 +316,7 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
             check(L.ast_minmax(ptr(mass), code, npart, ptr(lo_hi), stream()), "ast_minmax")
             mass_bound = float(lo_hi.abs().max()) or 1.0
         while True:
+            attempts += 1
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pos.device)
             check(L.ast_paint_tiled(win, code, ptr(pos), ptr(mass), npart, n, float(boxsize), float(scale),
                                     int(x_start), nx, ptr(out), ptr(ws), ws_bytes, ptr(dropped), tflags,
@@ -290,8 +342,11 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
                     compact = False
                 ws_bytes = int(L.ast_paint_tiled_workspace_bytes(win, code, npart, n, nx, tflags))
                 continue
-            if stats is not None and st is not None:
-                stats.update(st, scattered=bool(tflags & 8))
+            if stats is not None:
+                stats.update(st or {}, scattered=bool(tflags & 8), attempts=attempts,
+                             path="two-pass" if tflags & 1 else "scattered" if tflags & 8 else "single-pass")
+                if probed is not None:
+                    stats["probe"] = probed
             break
     else:
         check(L.ast_paint(win, code, ptr(pos), ptr(mass), npart, n, float(boxsize), float(scale),

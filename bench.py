@@ -114,6 +114,43 @@ def cpu_baseline(sample, window, boxsize, dev=None):
     }
 
 
+def subfind_leg(dev, nobj=2_000_000, nbins=512, boxsize=500.0, reps=5):
+    """SubFind.power_spectrum's real shape (stats_subfind.py:109-153): 2e6 mass-weighted objects, TSC, nbins = 512,
+    float64, through the Python API from host arrays - H2D copies, mass bound, paint, /dx^3, FFTPower.  The catalogue:
+    positions drawn around 4096 centres (Gaussian clumps of 0.5-4 Mpc/h), masses log-uniform over three decades."""
+    import types
+    from astrild_amd.particles.hutils.stats_subfind import SubFind
+    rng = np.random.default_rng(20240601)
+    h = 0.6774
+    centres = rng.uniform(0.0, boxsize, size=(4096, 3))
+    which = rng.integers(0, 4096, size=nobj)
+    radius = rng.uniform(0.5, 4.0, size=4096)[which]
+    pos = np.mod(centres[which] + rng.standard_normal((nobj, 3)) * radius[:, None], boxsize)
+    mass = 10.0 ** rng.uniform(0.0, 3.0, size=nobj)
+    snap = types.SimpleNamespace(cat={"SubhaloPos": pos * 1e3 / h, "SubhaloMass": mass * 1e10 / h},
+                                 header=types.SimpleNamespace(hubble=h, boxsize=boxsize * 1e3))
+    k, pk = SubFind.power_spectrum(snap, nbins=nbins, boxsize=boxsize)           # warm-up: plans, scratch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        k, pk = SubFind.power_spectrum(snap, nbins=nbins, boxsize=boxsize)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    assert np.isfinite(pk).all()
+    dpos = dev.as_device(pos)
+    dmass = dev.as_device(mass)
+    st = {}
+    dev.paint(dpos, dmass, nbins, boxsize, "tsc", stats=st)
+    dense = nobj * 2048 >= 64 * nbins ** 3
+    return {"metric": f"SubFind.power_spectrum: {nobj} mass-weighted objects, TSC, nbins {nbins}, float64, host arrays in, (k, Pk) out",
+            "ms_per_call": round(dt * 1e3, 3), "objects_per_s": nobj / dt,
+            "h2d_MB": round((pos.nbytes + mass.nbytes) / 1e6, 1),
+            "paint_path": st.get("path") or ("direct global atomics (sparse catalogue: %.1f objects per 8x8x32-cell tile)" % (nobj * 2048 / nbins ** 3)
+                                             if not dense else "tiled"),
+            "paint_attempts": st.get("attempts", 1),
+            "note": "the whole API call from numpy arrays: two H2D copies, paint, /dx^3, fused float64 FFT + FFTPower shells, D2H of (k, Pk)"}
+
+
 def bispectrum_leg(dev, n=512, width=8):
     """Config E: matter bispectrum by FFT triangle counting on a 512^3 grid (equilateral +
     one squeezed and one isosceles family over shells of width 8 k_F), fp32, one GPU."""
@@ -298,12 +335,15 @@ def main():
                    "order_note": "natural = lattice order, the spatially coherent best case for the scatter; the "
                                  "shuffled (worst case), TSC and float64 figures are in `legs`",
                    "outside_timed_step": "FFT twiddles, per-shell geometry sums (sum w|k|, mode counts: data independent, "
-                                         "cached per (N, L) like an FFT plan), workspace allocation",
+                                         "cached per (N, L) like an FFT plan), workspace allocation, the input probe that "
+                                         "picks the paint path (once per particle array: config.paint_path.probe_ms)",
                    "parallelism": "single GPU" if not use_slab else f"axis-0 slabs x{world}, RCCL all-to-all transpose"},
         "roofline": roofline,
     }
     if "diag" in leg:
         out["multi_gpu"] = leg["diag"]
+    if "paint_path" in leg:
+        out["config"]["paint_path"] = leg["paint_path"]
     if rank == 0 and not use_slab:
         if args.legs:
             # the other orderings / windows of the same workload, a few steps each (same kernels, same accounting)
@@ -315,8 +355,19 @@ def main():
                     continue
                 lg = power_leg(dev, n, npside, L, win, order, args.dtype, args.method, steps=LEG_STEPS, warmup=LEG_WARMUP)
                 legs[name] = {"ms_per_step": round(lg["ms_per_step"], 3), "particles_per_s": npart_total / (lg["ms_per_step"] * 1e-3),
-                              "end_to_end_frac": lg["roofline"]["end_to_end"]["frac"],
+                              "end_to_end_frac": lg["roofline"]["end_to_end"]["frac"], "paint_path": lg["paint_path"],
                               "stages": {k: {"ms": v["ms"], "frac": v["frac"]} for k, v in lg["roofline"]["stages"].items()}}
+            # CLUSTERED input - what the reference's paint calls really see (evolved snapshots; stats_subfind.py:125-131): the
+            # lattice collapsing onto 256 attractors, tile occupancies ~100 x the mean, in file (lattice) order and in
+            # pseudo-random order; 512^3 particles on a 512^3 grid
+            nc = min(n, 512)
+            for name, order in (("clustered_natural_cic", "natural"), ("clustered_shuffled_cic", "shuffled")):
+                lg = power_leg(dev, nc, nc, L, "cic", order, args.dtype, args.method, steps=LEG_STEPS, warmup=LEG_WARMUP, clustered=True)
+                legs[name] = {"ngrid": nc, "nparticles": nc ** 3, "ms_per_step": round(lg["ms_per_step"], 3),
+                              "particles_per_s": nc ** 3 / (lg["ms_per_step"] * 1e-3), "paint_path": lg["paint_path"],
+                              "end_to_end_frac": lg["roofline"]["end_to_end"]["frac"],
+                              "stages": {k: {"ms": v["ms"], "frac": v["frac"], "kernels": v["kernels"]} for k, v in lg["roofline"]["stages"].items()}}
+            legs["subfind_power_spectrum"] = subfind_leg(dev)
             if args.dtype == "f32":
                 # the reference's own dtype: float64 particles and grid through the double-precision passes
                 lg = power_leg(dev, n, npside, L, "cic", "natural", "f64", args.method, steps=LEG_STEPS, warmup=LEG_WARMUP)
@@ -410,12 +461,16 @@ def _traffic_from_profiles():
     return gb * 1e9, source
 
 
-def power_leg(dev, n, npside, L, window, order, dtype, method, steps, warmup):
-    """One configuration of the 3D path on ONE GPU: paint -> 3D R2C -> shell binning, `steps` timed steps."""
+def power_leg(dev, n, npside, L, window, order, dtype, method, steps, warmup, clustered=False):
+    """One configuration of the 3D path on ONE GPU: paint -> 3D R2C -> shell binning, `steps` timed steps.
+    clustered: the lattice collapsing onto 256 attractors (tile occupancies ~100 x the mean) instead of the jittered lattice."""
     tdt = torch.float32 if dtype == "f32" else torch.float64
     esz = 4 if dtype == "f32" else 8
     npart_total = npside ** 3
-    pos = dev.synth_lattice_particles(npside, n, L, seed=20240601, shuffle=(order == "shuffled"), dtype=tdt)
+    if clustered:
+        pos = dev.synth_clustered_particles(npside, n, L, seed=20240601, shuffle=(order == "shuffled"), dtype=tdt)
+    else:
+        pos = dev.synth_lattice_particles(npside, n, L, seed=20240601, shuffle=(order == "shuffled"), dtype=tdt)
     grid = torch.empty((n, n, n), dtype=tdt, device="cuda")
     psum = torch.zeros(n // 2 - 1, dtype=torch.float64, device="cuda")
     dev.shell_geometry(n, L)          # data independent, cached like the FFT plan
@@ -425,7 +480,21 @@ def power_leg(dev, n, npside, L, window, order, dtype, method, steps, warmup):
     if not fused and not fused64:
         spec = torch.empty((n, n, n // 2 + 1), dtype=torch.complex64 if dtype == "f32" else torch.complex128, device="cuda")
     mean = npart_total / float(n) ** 3
-    hint = "scattered" if order == "shuffled" else None
+    # WHICH paint path: decided from the input by device.probe_input (order in memory + tile-occupancy tail of a sample:
+    # two small kernels and one 24-byte fetch), once per particle array - like an FFT plan, outside the timed steps (the
+    # fetch would otherwise serialise the host with the GPU every step); its cost is reported as `probe_ms`.  A caller of
+    # dev.paint without a hint gets the same probe inside the call.
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    probe = dev.probe_input(pos, n, L)
+    probe_ms = (time.perf_counter() - t0) * 1e3
+    if probe is not None and probe["overflow"] > npart_total // 64:
+        hint = "clustered"                 # exact two-pass lists: no capacity limit per tile
+    elif probe is not None and probe["groupable"] < 0.25:
+        hint = "scattered"                 # no spatial order in memory: two-level bucket scatter
+    else:
+        hint = "ordered"                   # single pass: group records straight from the array
+    pstats = {}
 
     def step():
         if fused and method in ("auto", "tiled"):
@@ -481,9 +550,17 @@ def power_leg(dev, n, npside, L, window, order, dtype, method, steps, warmup):
                        "frac": round(total / (ms_per_step * 1e6) / HBM_PEAK_GBS, 4)},
         "stages": stages,
     }
+    # what the timed paint left behind: which path ran, how often it was attempted (always once: the path is chosen up
+    # front), what went through the overflow list
+    dev.paint(pos, None, n, L, window, out=grid, method="tiled" if method == "auto" else method, check_dropped=False,
+              accumulate=False, hint=hint, stats=pstats)
+    path = {"hint": hint, "path": pstats.get("path"), "attempts": pstats.get("attempts"), "overflow_list": pstats.get("overflow"),
+            "probe_ms": round(probe_ms, 3),
+            "probe": None if probe is None else {"groupable_runs": round(probe["groupable"], 3), "est_overflow": probe["overflow"],
+                                                 "est_max_tile_over_mean": round(probe["max_tile"] / max(1.0, probe["mean_tile"]), 1)}}
     del pos, grid, spec
     torch.cuda.empty_cache()
-    return {"ms_per_step": ms_per_step, "roofline": roofline}
+    return {"ms_per_step": ms_per_step, "roofline": roofline, "paint_path": path}
 
 
 def slab_leg(dev, dist, n, npside, L, args, world, barrier, wd):

@@ -81,6 +81,14 @@ int ast_divide(void* buf_d, int dtype, size_t count, double divisor, void* strea
 int ast_synth_lattice_particles(void* pos_d, int dtype, size_t first, size_t count,
                                 int npside, double boxsize, double sigma,
                                 uint64_t seed, uint64_t shuffle_stride, void* stream);
+/* A CLUSTERED synthetic set (bench / test plumbing): the npside^3 lattice collapsing onto `nattractors` (<= 1024) centres,
+ * x = q - sum_h amplitude exp(-r^2 / 2 R_h^2) (q - c_h) + sigma N(0,1), R_h between 6 and 48 lattice spacings (many small,
+ * few large), centres and radii from hashes of seed.  amplitude 0.95: knots of several 10^5 particles in a few cells -
+ * tile occupancies ~100 x the mean, like the evolved snapshots and halo catalogues the reference paints
+ * (stats_subfind.py:125-131) - in lattice order (neighbours in memory stay neighbours in space outside the knots) or,
+ * with shuffle != 0, in the pseudo-random order of ast_synth_lattice_particles.  count must be npside^3. */
+int ast_synth_clustered_particles(void* pos_d, int dtype, size_t count, int npside, double boxsize, double sigma,
+                                  uint64_t seed, int nattractors, double amplitude, int shuffle, void* stream);
 
 /* ----------------------------------------------- a-1 / a-2: mass assignment */
 
@@ -226,6 +234,16 @@ int ast_paint_tiled_list_stats(void* workspace_d, int window, int dtype, size_t 
  * pmesh's paint (stats_subfind.py:130-131) does not care about order. */
 int ast_paint_order_probe(const void* pos_d, int dtype, size_t np, int nmesh, double boxsize, double shift_cells,
                           int windows, unsigned* groupable_d, void* stream);
+/* Will the single-pass paint's fixed tile segments (room for max(2 mean, mean + 512) particles per 8 x 8 x 32-cell tile)
+ * overflow?  `samples` particles, one from every stride of np / samples at a hashed offset, are counted per tile of the
+ * periodic grid in counts_d (ast_paint_occupancy_probe_bytes(nmesh) bytes, zeroed by the call); out_d[0] = the estimated
+ * number of particles beyond their tile's capacity, out_d[1] = the largest estimated tile occupancy (device uint64 x 2).
+ * With >= 8 samples per tile on average a uniform input reads < 0.1 % of np; clustered input (evolved snapshots, the halo
+ * catalogue of stats_subfind.py:125-131) reads what the overflow list would have held - before anything is painted, so
+ * the caller can go to AST_PAINT_TWO_PASS at once.  nmesh a multiple of 32. */
+size_t ast_paint_occupancy_probe_bytes(int nmesh);
+int ast_paint_occupancy_probe(const void* pos_d, int dtype, size_t np, int nmesh, double boxsize, double shift_cells,
+                              size_t samples, void* counts_d, size_t counts_bytes, unsigned long long* out_d, void* stream);
 
 /* Interlacing and window compensation of a catalogue-painted mesh in Fourier space - what nbodykit's
  * CatalogMesh does for the parameters astrild writes at power_spectra/power_spectrum_3d.py:197-212

@@ -712,3 +712,36 @@ def test_staged_paint_grouped_in_parts(dev, window):
         else:
             sp.check()
             assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_clustered_input_goes_to_the_two_pass_path_in_one_attempt(dev, shuffle):
+    """What the reference's paint calls really see (evolved snapshots, stats_subfind.py:125-131): a heavy tail of tile
+    occupancies.  256^3 particles collapsing onto 64 attractors: the probe reads the overflow from a sample BEFORE anything
+    is painted, the exact two-pass variant runs at once (also with check_dropped=False), and grid and spectrum match the
+    oracle on the same particles."""
+    n, L = 256, 1000.0
+    pos = dev.synth_clustered_particles(n, n, L, seed=11, nattractors=64, shuffle=shuffle, dtype=torch.float32)
+    probe = dev.probe_input(pos, n, L)
+    assert probe["overflow"] > pos.shape[0] // 64 and probe["max_tile"] > 20 * probe["mean_tile"]
+    assert (probe["groupable"] < 0.25) == shuffle
+    st = {}
+    grid = dev.paint(pos, None, n, L, "cic", method="tiled", check_dropped=False, stats=st)
+    assert st["path"] == "two-pass" and st["attempts"] == 1
+    host = pos.cpu().numpy().astype(np.float64)
+    ref = omesh.paint(host, None, n, L, "cic")
+    got = grid.cpu().numpy().astype(np.float64)
+    assert abs(got.sum() - ref.sum()) < 1e-6 * ref.sum()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=3e-6 * ref.max())
+    # the uniform lattice reads no overflow and stays on the single pass (scattered when it has no order in memory)
+    lat = dev.synth_lattice_particles(n, n, L, seed=11, dtype=torch.float32, shuffle=shuffle)
+    p2 = dev.probe_input(lat, n, L)
+    assert p2["overflow"] < lat.shape[0] // 1000
+    st2 = {}
+    dev.paint(lat, None, n, L, "cic", method="tiled", check_dropped=False, stats=st2)
+    assert st2["path"] == ("scattered" if shuffle else "single-pass") and st2["attempts"] == 1
+    # the whole pipeline on the clustered set: fp32 (deferred fold + rho - mean, two-pass lists) against the oracle's spectrum
+    res = dev.paint_power_1d(pos, None, n, L, "cic")
+    want = offt.fftpower_1d(ref, L)
+    assert np.array_equal(res["modes"], want["modes"])
+    np.testing.assert_allclose(res["power"], want["power"].real, rtol=2e-6)
