@@ -551,3 +551,65 @@ def bench_kappa_pipeline(nplanes=64, npix=4096, steps=3, warmup=1, theta_deg=20.
         "kernels_ms": {k: round(v[1] / (steps * maps_per_step), 4) for k, v in prof.items()},
     }
     return res
+
+
+def bench_kappa_api(nplanes=64, npix=4096, nz=8, one_by_one=2):
+    """The stack THROUGH THE REFERENCE-SHAPED API: SimulationCollection.sum_raytracing_snapshots over `nplanes` host arrays
+    (the .npy branch of simcoll.py:267-336; the loader hands over arrays already in host memory, so disk is not timed) for
+    `nz` source redshifts.  As a sequence (one call: every plane uploaded once, resident in HBM, one stacking pass per source
+    redshift) and, for `one_by_one` of them, as the reference's loop does it (one call per source redshift: every call
+    uploads all planes again).  maps/s = maps handed back as numpy arrays per second of wall time."""
+    import pandas as pd
+    from .simcoll import SimulationCollection
+    host = [p.cpu().numpy() for p in synth_kappa_planes(nplanes, npix)]
+    torch.cuda.empty_cache()
+    idx = pd.MultiIndex.from_tuples([(1, r + 1) for r in range(nplanes)], names=["box_nr", "snap_nr"])
+    table = pd.DataFrame({"redshift": [(r + 0.5) * (1.0 / nplanes) for r in range(nplanes)]}, index=idx)
+
+    class Flat:
+        def comoving_distance(self, z):
+            return 3000.0 * z
+
+    class MemCollection(SimulationCollection):
+        def _load_ray_map(self, ray_file):
+            return host[int(ray_file) - 1]
+
+    import types
+    sims = {"box1": types.SimpleNamespace(dirs={"sim": ""}, file_dsc={"root": "kappa", "extension": "npy"})}
+    import glob as _glob
+
+    def make():
+        sc = MemCollection(table.copy(), sims, cosmology=Flat())
+        return sc
+    # (the collection finds its files with glob: answered from memory here)
+    real_glob = _glob.glob
+    from . import simcoll as _sc
+    _sc.glob.glob = lambda pat: [pat.split("*")[1].split(".")[0]]
+    try:
+        zs = [0.55 + 0.05 * i for i in range(nz)]
+        rng = {"z": [], "box": [0], "ray": [0]}
+        make().sum_raytracing_snapshots(None, ["kappa_2"], ["kappa_2"], rng, z_src=1.1, z_src_shift=zs[:2], reweight=True)    # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        maps = make().sum_raytracing_snapshots(None, ["kappa_2"], ["kappa_2"], rng, z_src=1.1, z_src_shift=zs, reweight=True)
+        torch.cuda.synchronize()
+        t_many = time.perf_counter() - t0
+        assert len(maps) == nz and all(m.shape == (npix, npix) for m in maps)
+        t0 = time.perf_counter()
+        for z in zs[:one_by_one]:
+            one = make().sum_raytracing_snapshots(None, ["kappa_2"], ["kappa_2"], rng, z_src=1.1, z_src_shift=z, reweight=True)
+        torch.cuda.synchronize()
+        t_one = (time.perf_counter() - t0) / max(1, one_by_one)
+        same = bool(np.array_equal(one, maps[one_by_one - 1])) if one_by_one else None
+    finally:
+        _sc.glob.glob = real_glob
+    return {"metric": f"stacked kappa maps/s through SimulationCollection.sum_raytracing_snapshots: {nplanes} host planes x {npix}^2 fp64, "
+                      f"{nz} source redshifts", "value": nz / t_many, "unit": "maps/s",
+            "ms_total": round(t_many * 1e3, 2), "ms_per_map": round(t_many / nz * 1e3, 2),
+            "one_call_per_source_redshift": {"ms_per_map": round(t_one * 1e3, 2), "maps_per_s": round(1.0 / t_one, 2),
+                                             "note": "the reference's loop shape: every call uploads all planes again"},
+            "bit_identical_to_single_calls": same,
+            "h2d_GB_once": round(nplanes * npix * npix * 8 / 1e9, 2),
+            "note": "z_src_shift as a sequence: planes uploaded once and resident in HBM, one pass of ast_kappa_stack per "
+                    "source redshift, results copied back as numpy arrays; the loader returns arrays already in host memory"}
+

@@ -40,7 +40,10 @@ class SimulationCollection(PlaneStacker):
                                  z_src_shift: Optional[float] = None, rm_ray: Optional[dict] = None,
                                  reweight: bool = False, group=None):
         """simcoll.py:238-341.  Returns the summed DataFrame (``.h5`` planes) or
-        ndarray (``.npy`` planes).  ``reweight`` / ``group``: see rays/rayramses.py."""
+        ndarray (``.npy`` planes).  ``reweight`` / ``group``: see rays/rayramses.py.
+        ``z_src_shift`` may be a SEQUENCE of source redshifts: the planes are read and uploaded once, stay resident in
+        HBM and are re-weighted once per entry; a list comes back (one DataFrame / ndarray per source redshift; under a
+        process group map m is reduced onto rank m mod P and is None elsewhere)."""
         box_ray_nrs = self._get_box_and_ray_nrs_for_integration_range(integration_range, rm_ray)
         selection = []                                      # (sim, box_nr, ray_nr) in the reference's loop order
         for sim_name in self.sim.keys():
@@ -55,11 +58,31 @@ class SimulationCollection(PlaneStacker):
         if group is not None:
             import torch.distributed as dist
             rank, world = dist.get_rank(group), dist.get_world_size(group)
-        plane_w = [self._plane_weight(self.config, box_nr, ray_nr, z_src, z_src_shift, reweight,
-                                      SimulationCollectionWarning) for _, box_nr, ray_nr in selection]
-
         def ray_file_of(sim, ray_nr):
             return glob.glob(sim.dirs["sim"] + f"{sim.file_dsc['root']}_*{ray_nr}." + f"{sim.file_dsc['extension']}")[0]
+
+        if isinstance(z_src_shift, (list, tuple, np.ndarray)):
+            # several source redshifts over the same planes (the re-weighting loop of simcoll.py:302-320, once per source
+            # plane): every file is read and uploaded ONCE, the planes stay resident in HBM, one output map per entry
+            per_z = [[self._plane_weight(self.config, box_nr, ray_nr, z_src, float(zs), reweight, SimulationCollectionWarning)
+                      for _, box_nr, ray_nr in selection] for zs in z_src_shift]
+            mine = [ii for ii in range(len(selection)) if ii % world == rank]
+            maps = [self._load_ray_map(ray_file_of(selection[ii][0], selection[ii][2])) for ii in mine]
+            first = maps[0] if maps else self._load_ray_map(ray_file_of(selection[0][0], selection[0][2]))
+            is_frame = isinstance(first, pd.DataFrame)
+            weights_list = []
+            for pw in per_z:
+                if any(w is not None for w in pw):
+                    wn = [(pw[ii] or (1.0, 1.0))[0] for ii in mine]
+                    wd = [(pw[ii] or (1.0, 1.0))[1] for ii in mine]
+                    weights_list.append({c: (wn, wd) for c in (columns_z_shift or ["kappa_2"]) if c in columns} if is_frame else (wn, wd))
+                else:
+                    weights_list.append({} if is_frame else None)
+            if is_frame:
+                return self._stack_columns_many(maps, columns, weights_list, group, None if maps else first)
+            return self._stack_arrays_many(maps, weights_list, group, np.shape(first))
+        plane_w = [self._plane_weight(self.config, box_nr, ray_nr, z_src, z_src_shift, reweight,
+                                      SimulationCollectionWarning) for _, box_nr, ray_nr in selection]
 
         maps, wnum, wden = [], [], []
         for ii, (_sim, box_nr, ray_nr) in enumerate(selection):

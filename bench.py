@@ -114,6 +114,89 @@ def cpu_baseline(sample, window, boxsize, dev=None):
     }
 
 
+def _cpu_paint_chunk(pos, i0, planes, pad, n, boxsize, window, grid):
+    """oracle.mesh.paint's arithmetic for particles whose base planes lie in [i0 - pad, i0 + planes + pad): bincounts over
+    that slab of the grid only (a bincount over the whole 1024^3 grid per window corner would allocate 8.6 GB each)."""
+    from oracle import mesh as omesh
+    support = {"cic": 2, "tsc": 3}[window]
+    nloc = planes + 2 * pad
+    idx, wts = [], []
+    for d in range(3):
+        a, b = omesh.window_1d(pos[:, d] * (n / boxsize), window)
+        idx.append(a)
+        wts.append(b)
+    rel = np.mod(idx[0] - (i0 - pad), n)
+    assert int(rel.max()) + support <= nloc, "a particle left the chunk's slab"
+    local = np.zeros(nloc * n * n)
+    for a in range(support):
+        for b in range(support):
+            ib = np.mod(idx[1] + b, n)
+            wab = wts[0][a] * wts[1][b]
+            for c in range(support):
+                flat = ((rel + a) * n + ib) * n + np.mod(idx[2] + c, n)
+                local += np.bincount(flat, weights=wab * wts[2][c], minlength=nloc * n * n)
+    rows = np.mod(np.arange(i0 - pad, i0 + planes + pad), n)
+    grid[rows] += local.reshape(nloc, n, n)
+
+
+def cpu_baseline_chunked(sample, window, boxsize, planes=32, pad=6):
+    """The same CPU port at sizes whose temporaries do not fit the host in one piece ("one 1024^3 run if host
+    RAM >= 64 GB"): the particles are generated and painted `planes` lattice planes at a time (the oracle's window weights,
+    ONE numpy bincount per chunk over the chunk's slab of the grid; generation is not timed), the transform is one
+    scipy.fft.rfftn (single thread, then all cores), the shells are binned x-slab by x-slab with the oracle's
+    project_block.  Same arithmetic as cpu_baseline's port; float64 like the reference.  Opt-in: --cpu-sample >= 768."""
+    from oracle import mesh as omesh, fftpower as offt
+    import scipy.fft
+    n = int(sample)
+    ncpu = os.cpu_count() or 1
+    h = boxsize / n
+    g = (np.arange(n) + 0.5) * h
+    rng = np.random.Generator(np.random.PCG64(20240601))
+    grid = np.zeros((n, n, n))
+    t_paint = 0.0
+    for i0 in range(0, n, planes):
+        q = np.stack(np.meshgrid(g[i0:i0 + planes], g, g, indexing="ij"), axis=-1).reshape(-1, 3)
+        pos = np.mod(q + 0.5 * h * rng.standard_normal(q.shape), boxsize)
+        del q
+        t0 = time.perf_counter()
+        _cpu_paint_chunk(pos, i0, planes, pad, n, boxsize, window, grid)
+        t_paint += time.perf_counter() - t0
+        del pos
+    t0 = time.perf_counter()
+    spec = scipy.fft.rfftn(grid, workers=1)
+    t_fft1 = time.perf_counter() - t0
+    del spec
+    t0 = time.perf_counter()
+    spec = scipy.fft.rfftn(grid, workers=ncpu)
+    t_fftn = time.perf_counter() - t0
+    del grid
+    t0 = time.perf_counter()
+    nb = n // 2 - 1
+    ks, ps, nm = np.zeros(nb), np.zeros(nb), np.zeros(nb, dtype=np.int64)
+    ng = float(n) ** 3
+    for x0 in range(0, n, 8):
+        blk = spec[x0:x0 + 8]
+        p3d = (blk.real ** 2 + blk.imag ** 2) * (boxsize ** 3 / (ng * ng))
+        if x0 == 0:
+            p3d[0, 0, 0] = 0.0
+        a, b, c = offt.project_block(p3d, n, boxsize, x0, 0)
+        ks += a
+        ps += np.real(b)
+        nm += c
+    t_bin = time.perf_counter() - t0
+    npart = n ** 3
+    assert np.isfinite(ps / nm).all()
+    single = t_paint + t_fft1 + t_bin
+    return {"value": npart / single, "unit": "particles/s", "cores": 1, "kind": "port",
+            "sample": f"{n}^3 particles on a {n}^3 grid, float64: chunked numpy bincount paint {t_paint:.1f}s + scipy rfftn (1 thread) "
+                      f"{t_fft1:.1f}s + shell binning {t_bin:.1f}s (the benchmark's own configuration; particles generated and "
+                      f"painted {planes} lattice planes at a time)",
+            "threaded": {"value": npart / (t_paint + t_fftn + t_bin), "cores": ncpu, "fft_s": round(t_fftn, 2),
+                         "note": f"scipy.fft.rfftn(workers={ncpu}); paint and binning as in the single-thread leg"},
+            "seconds_single_thread": round(single, 1), "paint_s": round(t_paint, 1), "fft_s_single_thread": round(t_fft1, 1),
+            "binning_s": round(t_bin, 1), "cpu_model": _cpu_model(), "logical_cores": ncpu}
+
+
 def subfind_leg(dev, nobj=2_000_000, nbins=512, boxsize=500.0, reps=5):
     """SubFind.power_spectrum's real shape (stats_subfind.py:109-153): 2e6 mass-weighted objects, TSC, nbins = 512,
     float64, through the Python API from host arrays - H2D copies, mass bound, paint, /dx^3, FFTPower.  The catalogue:
@@ -376,7 +459,10 @@ def main():
                                            "end_to_end_frac": lg["roofline"]["end_to_end"]["frac"], "dtype": "f64",
                                            "stages": {k: {"ms": v["ms"], "frac": v["frac"]} for k, v in lg["roofline"]["stages"].items()}}
             out["legs"] = legs
-        if args.cpu_sample:
+        if args.cpu_sample >= 768:        # the benchmark's own size, chunked (minutes of CPU time: opt-in), beside the bounded sample
+            out["cpu_baseline"] = cpu_baseline(512, args.window, L, dev)
+            out["cpu_baseline"]["at_benchmark_size"] = cpu_baseline_chunked(args.cpu_sample, args.window, L)
+        elif args.cpu_sample:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.window, L, dev)
         torch.cuda.empty_cache()
         if args.bispec:
@@ -385,6 +471,9 @@ def main():
             torch.cuda.empty_cache()
         if args.kappa:
             out["kappa"] = kappa_leg(dev, args.steps, args.warmup)
+            torch.cuda.empty_cache()
+            from astrild_amd import lensing
+            out["kappa"]["api"] = lensing.bench_kappa_api()
     if use_slab and world > 1 and args.kappa:
         # config D on N GPUs: lens planes sharded over the ranks (every rank takes part)
         del leg
@@ -484,6 +573,7 @@ def power_leg(dev, n, npside, L, window, order, dtype, method, steps, warmup, cl
     # two small kernels and one 24-byte fetch), once per particle array - like an FFT plan, outside the timed steps (the
     # fetch would otherwise serialise the host with the GPU every step); its cost is reported as `probe_ms`.  A caller of
     # dev.paint without a hint gets the same probe inside the call.
+    dev.probe_input(pos, n, L)            # (first call: allocations)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     probe = dev.probe_input(pos, n, L)

@@ -44,6 +44,16 @@ def main():
             np.savez(out + f".stream{rank}.npz", **{f"pdf{m}": p.result()[0] for m, p in pend.items()},
                      **{f"map{m}": v[0].cpu().numpy() for m, v in keep.items()},
                      **{f"a1_{m}": v[1].cpu().numpy() for m, v in keep.items()})
+        if len(sys.argv) > 7 and sys.argv[7] == "api":
+            # what sum_snapshots / sum_raytracing_snapshots do with a SEQUENCE of source redshifts: the rank's planes stay
+            # resident, one weighted map per entry, map m lands on rank m mod P
+            from astrild_amd.rays.rayramses import PlaneStacker
+            nmaps = world + 2
+            flat = [p.reshape(-1) for p in planes]
+            wl = [None if m == 1 else (list(wnum[ids] * (1.0 + 0.5 * m)), list(wden[ids])) for m in range(nmaps)]
+            maps = PlaneStacker._stack_many(flat, wl, dist.group.WORLD)
+            assert [m for m, v in enumerate(maps) if v is not None] == [m for m in range(nmaps) if m % world == rank]
+            np.savez(out + f".api{rank}.npz", **{f"map{m}": v for m, v in enumerate(maps) if v is not None})
     finally:
         dist.destroy_process_group()
 

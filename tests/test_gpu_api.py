@@ -292,6 +292,52 @@ def test_simulation_collection_sum_npy_planes(tmp_path):
     assert np.array_equal(tot, ok.kappa_stack([planes[o] for o in order]))
 
 
+def test_several_source_redshifts_over_resident_planes(tmp_path):
+    """z_src_shift as a sequence (the re-weighting loops of rayramses.py:205-222 / simcoll.py:302-320 once per source
+    redshift): every plane is loaded once - the loader is counted - and each map equals the one-call result bit for bit."""
+    from astrild_amd.rays import RayRamses
+    from astrild_amd.simcoll import SimulationCollection
+    npix = 64
+    frames = {(b, r): _kappa_frame(npix, seed=10 * b + r) for (b, r) in _ray_table().index}
+    loads = []
+
+    class MemRay(RayRamses):
+        def _load_ray_map(self, ray_file):
+            loads.append(ray_file)
+            box = int(ray_file.split("box")[1].split("/")[0])
+            ray = int(ray_file.split("output")[1].split(".")[0])
+            return frames[(box, ray)].copy()
+
+    zs = [0.22, 0.12, 0.26, 0.22]
+    rng_all = {"z": [], "box": [0], "ray": [0]}
+    rr = MemRay({"lc": "/lc/"}, cosmology=FlatCosmology(), ray_info_df=_ray_table())
+    many = rr.sum_snapshots(None, ["kappa_2", "isw_rs"], ["kappa_2"], rng_all, z_src=0.4, z_src_shift=zs, reweight=True)
+    assert len(many) == len(zs) and len(loads) == 5                    # five planes, read once for four maps
+    for z, got in zip(zs, many):
+        one = MemRay({"lc": "/lc/"}, cosmology=FlatCosmology(), ray_info_df=_ray_table()).sum_snapshots(
+            None, ["kappa_2", "isw_rs"], ["kappa_2"], rng_all, z_src=0.4, z_src_shift=z, reweight=True)
+        assert np.array_equal(got["kappa_2"].values, one["kappa_2"].values)
+        assert np.array_equal(got["isw_rs"].values, one["isw_rs"].values)
+    assert not np.array_equal(many[0]["kappa_2"].values, many[1]["kappa_2"].values)
+    # .npy planes through the collection
+    rng = np.random.default_rng(8)
+    planes, sims = {}, {}
+    for box in (1, 2):
+        d = tmp_path / f"box{box}"
+        d.mkdir()
+        sims[f"box{box}"] = types.SimpleNamespace(dirs={"sim": str(d) + "/"},
+                                                  file_dsc={"root": "kappa2_maps", "extension": "npy"})
+        for ray in ((1, 2, 3) if box == 1 else (1, 2)):
+            planes[(box, ray)] = rng.standard_normal((48, 48))
+            np.save(d / f"kappa2_maps_output0000{ray}.npy", planes[(box, ray)])
+    sc = SimulationCollection(_ray_table(), sims, cosmology=FlatCosmology())
+    many = sc.sum_raytracing_snapshots(None, ["kappa_2"], ["kappa_2"], rng_all, z_src=0.4, z_src_shift=[0.22, 0.12], reweight=True)
+    for z, got in zip([0.22, 0.12], many):
+        one = SimulationCollection(_ray_table(), sims, cosmology=FlatCosmology()).sum_raytracing_snapshots(
+            None, ["kappa_2"], ["kappa_2"], rng_all, z_src=0.4, z_src_shift=z, reweight=True)
+        assert got.shape == (48, 48) and np.array_equal(got, one)
+
+
 def test_sharded_bispectrum_ranks_share_one_gpu(tmp_path):
     """SURVEY.md §8e row 2 rehearsal: 3 processes on cuda:0 over gloo, triangle bins split over the ranks, grid
     broadcast from rank 0; against the single-GPU estimator on the same grid (same kernels: identical numbers)."""

@@ -244,6 +244,23 @@ def test_map_stream_ranks_share_one_gpu(hip, tmp_path, world, nplanes, npix):
     _sharded_stack_ranks_share_one_gpu(tmp_path, world, nplanes, npix, True)
 
 
+def test_resident_planes_several_maps_sharded(hip, tmp_path):
+    """The sharded form of `z_src_shift` as a sequence (PlaneStacker._stack_many under a process group): 3 ranks on one GPU,
+    5 maps over the same resident planes, map m on rank m mod 3; each against the single-GPU stack with its weights."""
+    import torch
+    from astrild_amd import lensing
+    world, nplanes, npix = 3, 10, 512
+    _sharded_stack_ranks_share_one_gpu(tmp_path, world, nplanes, npix, "api")
+    out = str(tmp_path / "stack.npy")
+    planes = lensing.synth_kappa_planes(nplanes, npix)
+    wnum, wden = lensing.synth_plane_weights(nplanes)
+    res = [np.load(out + f".api{r}.npz") for r in range(world)]
+    for m in range(world + 2):
+        ref = lensing.kappa_stack(planes, None if m == 1 else wnum * (1.0 + 0.5 * m), None if m == 1 else wden).cpu().numpy()
+        got = res[m % world][f"map{m}"].reshape(npix, npix)
+        npt.assert_allclose(got, ref, rtol=0, atol=4e-15 * np.abs(ref).max())
+
+
 def _sharded_stack_ranks_share_one_gpu(tmp_path, world, nplanes, npix, stream):
     """Config D rehearsal: `world` processes on cuda:0 over gloo, plane p on rank p mod P, HipStackOps + the
     all-to-all chunk exchange of kappa_shard, against the single-GPU sequential stack (64 planes x 4096^2 fp64
@@ -260,7 +277,7 @@ def _sharded_stack_ranks_share_one_gpu(tmp_path, world, nplanes, npix, stream):
     out = str(tmp_path / "stack.npy")
     worker = os.path.join(os.path.dirname(__file__), "kappa_gpu_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(nplanes), str(npix), out] +
-                              (["stream"] if stream else [])) for r in range(world)]
+                              (["api"] if stream == "api" else ["stream"] if stream else [])) for r in range(world)]
     assert [p.wait(timeout=600) for p in procs] == [0] * world
     got = np.load(out).reshape(npix, npix)
     planes = lensing.synth_kappa_planes(nplanes, npix)
@@ -269,7 +286,7 @@ def _sharded_stack_ranks_share_one_gpu(tmp_path, world, nplanes, npix, stream):
     bound = sum(abs(float(wnum[p] / wden[p])) * float(planes[p].abs().max()) for p in range(nplanes))
     npt.assert_allclose(got, seq, rtol=0, atol=world * 2.0 ** -52 * bound)
     assert np.abs(got - seq).max() <= 1e-15 * np.abs(seq).max() * 4
-    if not stream:
+    if not stream or stream == "api":
         return
     lp, sp = lensing.lens_plan(npix, np.deg2rad(20.0)), lensing.smooth_plan(npix)
     res = [np.load(out + f".stream{r}.npz") for r in range(world)]
