@@ -349,17 +349,25 @@ __device__ inline void three_stage(double2 (&va)[RA], double2 (&vc)[RC], double2
 // FOLDW = 2 / 3 (CIC / TSC, grids only): the grid is what a deferred-fold paint left and `rec` its halo records; the up to
 // three record lines that end in a border row are added as the row is loaded - records first, then onto the row, the
 // order of the paint's own fold kernel (as in fft_tile.hip's float row pass).
-template <int RA, int RB, int RC, bool ZPAD, int FOLDW = 0>
+// TIN = float: the rows are read from a single-precision grid and widened on load (the double transform of an fp32 grid
+// without a 2x copy of it: cubes the fp32 tile passes do not cover - 128^3, 2048^3; no FOLDW).
+template <typename TIN> struct PairOf { typedef double2 type; };
+template <> struct PairOf<float> { typedef float2 type; };
+__device__ inline double2 widen(double2 v) { return v; }
+__device__ inline double2 widen(float2 v) { return make_double2((double)v.x, (double)v.y); }
+
+template <int RA, int RB, int RC, bool ZPAD, int FOLDW = 0, typename TIN = double>
 __global__ void __launch_bounds__((RowGeo<RA, RB, RC>::NT))
-lens_rows_forward_kernel(const double* __restrict__ kappa, size_t in_pitch, double2* __restrict__ spec, size_t pitch,
+lens_rows_forward_kernel(const TIN* __restrict__ kappa, size_t in_pitch, double2* __restrict__ spec, size_t pitch,
                          const double2* __restrict__ twM, const double2* __restrict__ twL, double scale,
                          const double* __restrict__ rec = nullptr) {
     using G = RowGeo<RA, RB, RC>;
     constexpr int M = G::M;
+    static_assert(FOLDW == 0 || sizeof(TIN) == 8, "halo records are folded in the grid's own precision: double rows only");
     extern __shared__ double2 Y[];
     const int t = threadIdx.x;
     const size_t row = blockIdx.x;
-    const double2* z = reinterpret_cast<const double2*>(kappa + row * in_pitch);        // packed pairs: M / 2 (ZPAD) or M
+    const typename PairOf<TIN>::type* z = reinterpret_cast<const typename PairOf<TIN>::type*>(kappa + row * in_pitch);        // packed pairs: M / 2 (ZPAD) or M
     double2 va[RA], vc[RC];
     // the halo sources of this row first (integer work, the same for the whole workgroup: one row per workgroup), so
     // that the row's loads and the records' loads are all in flight together
@@ -372,7 +380,7 @@ lens_rows_forward_kernel(const double* __restrict__ kappa, size_t in_pitch, doub
     }
     if (t < G::T1) {
 #pragma unroll
-        for (int a = 0; a < RA; ++a) va[a] = (!ZPAD || a < RA / 2) ? z[G::T1 * a + t] : make_double2(0.0, 0.0);
+        for (int a = 0; a < RA; ++a) va[a] = (!ZPAD || a < RA / 2) ? widen(z[G::T1 * a + t]) : make_double2(0.0, 0.0);
         if (FOLDW != 0 && ns > 0) {
             double2 h0[RA], h1[RA], h2[RA];
 #pragma unroll
@@ -649,20 +657,20 @@ extern "C" int ast_lens_rows_supported(size_t nc) {
 }
 
 namespace {
-template <int RA, int RB, int RC, bool ZPAD = true, int FOLDW = 0>
-int rows_forward_launch(const double* kappa, size_t nrows, double2* spec, size_t pitch, const double2* twM, const double2* twL, hipStream_t s,
+template <int RA, int RB, int RC, bool ZPAD = true, int FOLDW = 0, typename TIN = double>
+int rows_forward_launch(const TIN* kappa, size_t nrows, double2* spec, size_t pitch, const double2* twM, const double2* twL, hipStream_t s,
                         size_t in_pitch = 0, double scale = 1.0, const double* rec = nullptr) {
     using G = RowGeo<RA, RB, RC>;
     const size_t lds = (size_t)(G::M + G::M / 8) * sizeof(double2);
     static ast::PerDeviceOnce once;
     if (once.need() && lds > 48 * 1024) {
-        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lens_rows_forward_kernel<RA, RB, RC, ZPAD, FOLDW>),
+        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lens_rows_forward_kernel<RA, RB, RC, ZPAD, FOLDW, TIN>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         once.mark();
     }
     AST_CHECK_ARG(nrows < 0x7fffffffull);
-    lens_rows_forward_kernel<RA, RB, RC, ZPAD, FOLDW><<<(unsigned)nrows, G::NT, lds, s>>>(kappa, in_pitch ? in_pitch : (size_t)G::M, spec, pitch,
-                                                                                        twM, twL, scale, rec);
+    lens_rows_forward_kernel<RA, RB, RC, ZPAD, FOLDW, TIN><<<(unsigned)nrows, G::NT, lds, s>>>(kappa, in_pitch ? in_pitch : (size_t)G::M, spec, pitch,
+                                                                                             twM, twL, scale, rec);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
@@ -838,6 +846,10 @@ col3_kernel(double2* __restrict__ data, const double2* __restrict__ twM, size_t 
                 // tile_isqrt, checked exhaustively by test_gpu_fft_tile) - a double square root plus two repair loops per
                 // mode were a third of this pass
                 int r = (int)__builtin_amdgcn_sqrtf((float)m2 + 0.5f);
+                if (N > 1024) {                           // (beyond the range of the exhaustive check: one repair step either way)
+                    if (r * r > m2) --r;
+                    else if ((r + 1) * (r + 1) <= m2) ++r;
+                }
                 if (kf_rule != 0.0 && r > 0 && r * r == m2) r = ast::float64_edge_norm(r, kx, ky, kz, kf_rule);
                 if (r >= 1 && r <= NB) atomicAdd(&shell[r], (x.x * x.x + x.y * x.y) * w);      // shell = r - 1
             }
@@ -875,7 +887,8 @@ power64_stage2_kernel(const double* __restrict__ part, int nb, double pnorm, dou
 namespace {
 // columns per workgroup: 4 at N = 1024 (74 KB of LDS: two workgroups per CU; measured 4.5 + 4.0 ms for the y and x passes
 // against 5.4 + 4.5 with 8 columns and one workgroup per CU, 7.3 + 5.8 with 2), 8 below
-constexpr int col3_columns(size_t n) { return n == 1024 ? 4 : 8; }
+// (N = 2048: 4 columns = 147 KB, one 1024-thread workgroup per CU; N = 128: 8 columns, 18 KB)
+constexpr int col3_columns(size_t n) { return n >= 1024 ? 4 : 8; }
 template <int RA, int RB, int RC, bool POWER>
 int col3_launch(double2* data, const double2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride, double scale,
                 double* partial, double kf_rule, hipStream_t s, int prune2 = 0) {
@@ -898,13 +911,17 @@ int col3_launch(double2* data, const double2* tw, size_t elem_stride, size_t nco
 template <bool POWER>
 int col3_dispatch(size_t n, double2* data, const double2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride,
                   double scale, double* partial, double kf_rule, hipStream_t s, int prune2 = 0) {
+    if (n == 2048) return col3_launch<16, 16, 8, POWER>(data, tw, elem_stride, ncols, batch, batch_stride, scale, partial, kf_rule, s, prune2);
+    if (n == 128) return col3_launch<8, 4, 4, POWER>(data, tw, elem_stride, ncols, batch, batch_stride, scale, partial, kf_rule, s, prune2);
     if (n == 1024) return col3_launch<16, 8, 8, POWER>(data, tw, elem_stride, ncols, batch, batch_stride, scale, partial, kf_rule, s, prune2);
     if (n == 512) return col3_launch<8, 8, 8, POWER>(data, tw, elem_stride, ncols, batch, batch_stride, scale, partial, kf_rule, s, prune2);
     return col3_launch<8, 8, 4, POWER>(data, tw, elem_stride, ncols, batch, batch_stride, scale, partial, kf_rule, s, prune2);
 }
 }  // namespace
 
-extern "C" int ast_fft64_supported(size_t n) { return n == 256 || n == 512 || n == 1024; }
+// 128 (BASELINE config A's own size) ... 2048 (the largest cube whose float64 grid and scratch spectrum - 69 GB each - fit one
+// MI355X; domain_level is arbitrary in the reference, power_spectrum_3d.py:183-188)
+extern "C" int ast_fft64_supported(size_t n) { return n == 128 || n == 256 || n == 512 || n == 1024 || n == 2048; }
 
 // row pitch of the scratch spectrum (complex): n / 2 + 1 rounded up to 8 (128-byte pieces stay line aligned)
 static size_t fft64_pitch(size_t n) { return (n / 2 + 1 + 7) / 8 * 8; }
@@ -917,10 +934,17 @@ extern "C" size_t ast_fft64_power_scratch_bytes(size_t n) {
 // grid: FFTPower(ArrayMesh(grid), mode="1d", kmin = k_F)'s shell sums (power_spectrum_3d.py:183-224) without the
 // spectrum's last pass ever reaching HBM.  grid_d is not modified.
 static int fft64_power_impl(const double* grid, const double* rec, int window, void* scratch, size_t scratch_bytes, size_t n,
-                            double boxsize, int binning, double* psum, void* stream);
+                            double boxsize, int binning, double* psum, void* stream, const float* grid32 = nullptr);
 extern "C" int ast_fft64_power_3d(const double* grid, void* scratch, size_t scratch_bytes, size_t n, double boxsize, int binning,
                                   double* psum, void* stream) {
     return fft64_power_impl(grid, nullptr, 0, scratch, scratch_bytes, n, boxsize, binning, psum, stream);
+}
+// The same for a SINGLE-precision grid, transformed in double (widened as the z pass loads the rows): the route of fp32 cubes
+// the fp32 tile passes do not cover (128^3, 2048^3) - instead of a float64 copy of the grid in front of the passes.
+extern "C" int ast_fft64_power_3d_f32(const float* grid, void* scratch, size_t scratch_bytes, size_t n, double boxsize, int binning,
+                                      double* psum, void* stream) {
+    AST_CHECK_ARG(grid != nullptr);
+    return fft64_power_impl(nullptr, nullptr, 0, scratch, scratch_bytes, n, boxsize, binning, psum, stream, grid);
 }
 // The same for a grid painted with AST_PAINT_OVERWRITE | AST_PAINT_DEFER_FOLD: halo_rec_d (ast_paint_tiled_halo) is folded
 // into the border rows as the z pass loads them.
@@ -930,11 +954,11 @@ extern "C" int ast_fft64_power_3d_halo(const double* grid, const double* halo_re
     return fft64_power_impl(grid, halo_rec, window, scratch, scratch_bytes, n, boxsize, binning, psum, stream);
 }
 static int fft64_power_impl(const double* grid, const double* rec, int window, void* scratch, size_t scratch_bytes, size_t n,
-                            double boxsize, int binning, double* psum, void* stream) {
-    AST_CHECK_ARG(grid != nullptr && scratch != nullptr && psum != nullptr && boxsize > 0.0);
+                            double boxsize, int binning, double* psum, void* stream, const float* grid32) {
+    AST_CHECK_ARG((grid != nullptr || grid32 != nullptr) && scratch != nullptr && psum != nullptr && boxsize > 0.0);
     AST_CHECK_ARG(ast_fft64_supported(n) && scratch_bytes >= ast_fft64_power_scratch_bytes(n));
     AST_CHECK_ARG(binning == AST_BIN_INTEGER || binning == AST_BIN_FLOAT64);
-    AST_CHECK_ARG(((uintptr_t)grid & 15) == 0);
+    AST_CHECK_ARG(((uintptr_t)grid & 15) == 0 && ((uintptr_t)grid32 & 7) == 0 && (grid32 == nullptr || rec == nullptr));
     hipStream_t s = ast::as_stream(stream);
     const size_t nz = n / 2 + 1, nzp = fft64_pitch(n), cw = (size_t)col3_columns(n), tiles = (nz + cw - 1) / cw, nb = n / 2 - 1;
     double2* spec = (double2*)scratch;
@@ -949,13 +973,17 @@ static int fft64_power_impl(const double* grid, const double* rec, int window, v
         AST_PROF("fft64.rows_r2c", s);
         auto rows = [&](auto ra, auto rb, auto rcc) {
             constexpr int A = decltype(ra)::value, B = decltype(rb)::value, Cc = decltype(rcc)::value;
+            if (grid32 != nullptr) return rows_forward_launch<A, B, Cc, false, 0, float>(grid32, n * n, spec, nzp, twH, twN, s, n, 1.0);
             if (rec == nullptr) return rows_forward_launch<A, B, Cc, false, 0>(grid, n * n, spec, nzp, twH, twN, s, n, 1.0);
             if (window == AST_WIN_CIC) return rows_forward_launch<A, B, Cc, false, 2>(grid, n * n, spec, nzp, twH, twN, s, n, 1.0, rec);
             return rows_forward_launch<A, B, Cc, false, 3>(grid, n * n, spec, nzp, twH, twN, s, n, 1.0, rec);
         };
         using I4 = std::integral_constant<int, 4>;
         using I8 = std::integral_constant<int, 8>;
-        if (n == 1024) rc = rows(I8{}, I8{}, I8{});
+        using I16 = std::integral_constant<int, 16>;
+        if (n == 2048) rc = rows(I16{}, I8{}, I8{});
+        else if (n == 128) rc = rows(I4{}, I4{}, I4{});
+        else if (n == 1024) rc = rows(I8{}, I8{}, I8{});
         else if (n == 512) rc = rows(I8{}, I8{}, I4{});
         else rc = rows(I8{}, I4{}, I4{});
         if (rc != AST_OK) return rc;
@@ -992,7 +1020,9 @@ extern "C" int ast_fft64_r2c_3d(const double* grid, void* spec_out, size_t n, do
     int rc;
     {
         AST_PROF("fft64.rows_r2c", s);
-        if (n == 1024) rc = rows_forward_launch<8, 8, 8, false, 0>(grid, n * n, spec, nz, twH, twN, s, n, 1.0);
+        if (n == 2048) rc = rows_forward_launch<16, 8, 8, false, 0>(grid, n * n, spec, nz, twH, twN, s, n, 1.0);
+        else if (n == 128) rc = rows_forward_launch<4, 4, 4, false, 0>(grid, n * n, spec, nz, twH, twN, s, n, 1.0);
+        else if (n == 1024) rc = rows_forward_launch<8, 8, 8, false, 0>(grid, n * n, spec, nz, twH, twN, s, n, 1.0);
         else if (n == 512) rc = rows_forward_launch<8, 8, 4, false, 0>(grid, n * n, spec, nz, twH, twN, s, n, 1.0);
         else rc = rows_forward_launch<8, 4, 4, false, 0>(grid, n * n, spec, nz, twH, twN, s, n, 1.0);
         if (rc != AST_OK) return rc;

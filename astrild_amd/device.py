@@ -259,6 +259,21 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
         assert mass.is_cuda and mass.dtype == pos.dtype and mass.numel() == pos.shape[0] and mass.is_contiguous()
     if accumulate is None:
         accumulate = out is not None
+    # The tile lists hold 32-bit particle indices: more than 2^32 - 65 particles (2048^3 on the largest grid one GPU holds)
+    # are painted in chunks - the first one as asked for, the others accumulated onto it through the same LDS tiles.
+    # ASTRILD_PAINT_CHUNK (particles) forces chunking at smaller sizes (tests).
+    import os
+    chunk = int(os.environ.get("ASTRILD_PAINT_CHUNK", 0)) or (2 ** 31 if pos.shape[0] >= 2 ** 32 - 65 else 0)
+    if chunk and pos.shape[0] > chunk and method != "direct" and _lib.WIN[window.lower()] != 0:
+        if defer_fold:
+            raise _lib.AstrildHipError("defer_fold is not available for a paint in chunks (more than 2^32 - 65 particles)")
+        for a in range(0, pos.shape[0], chunk):
+            part = paint(pos[a:a + chunk], None if mass is None else mass[a:a + chunk], n, boxsize, window, scale=scale, out=out,
+                         method=method, x_start=x_start, nx_alloc=nx_alloc, check_dropped=check_dropped,
+                         accumulate=accumulate if a == 0 else True, offset=offset if a == 0 else 0.0, hint=hint if a == 0 else None,
+                         shift=shift, offset_planes=offset_planes)
+            out = part
+        return out
     win = _lib.WIN[window.lower()]
     npart = pos.shape[0]
     dropped = torch.zeros(1, dtype=torch.int64, device=pos.device)
@@ -474,7 +489,7 @@ def synth_lattice_particles(npside, nmesh, boxsize, seed=20240601, sigma_cells=0
 def r2c(field, out=None, engine="auto"):
     """pmesh-normalised forward transform: ``rfftn(field) / Ng``.
 
-    engine "tile": the hand-written three-pass LDS FFT (fp32 and fp64 cubes of side 256/512/1024);
+    engine "tile": the hand-written three-pass LDS FFT (fp32 cubes of side 256/512/1024, fp64 cubes of side 128 ... 2048);
     "rocfft": the rocFFT 3D R2C plan; "auto": tile when supported."""
     assert field.is_cuda and field.dim() == 3 and field.is_contiguous()
     n0, n1, n2 = field.shape
@@ -610,9 +625,11 @@ def lowk_shell_sums(modes, nmesh, boxsize, binning=None):
     return sums
 
 
-def fused_power64_supported(field):
+def fused_power64_supported(field, allow_f32=False):
+    """float64 cubes of side 128 ... 2048; with allow_f32 also float32 cubes (transformed in double, widened on load)."""
     n = field.shape[0]
-    return field.dim() == 3 and tuple(field.shape) == (n, n, n) and field.dtype == torch.float64 and field.is_contiguous() \
+    ok = (torch.float64, torch.float32) if allow_f32 else (torch.float64,)
+    return field.dim() == 3 and tuple(field.shape) == (n, n, n) and field.dtype in ok and field.is_contiguous() \
         and bool(_lib.lib().ast_fft64_supported(n))
 
 
@@ -629,6 +646,11 @@ def power_sums_fused64(field, boxsize, psum=None, binning=None, halo=None):
     if psum is None:
         psum = torch.zeros(n // 2 - 1, dtype=torch.float64, device=field.device)
     ksum, nmodes = shell_geometry(n, boxsize, binning=binning)
+    if field.dtype == torch.float32:          # an fp32 grid through the double passes (sizes without fp32 tile passes)
+        assert halo is None
+        check(L.ast_fft64_power_3d_f32(ptr(field), ptr(scratch), scratch.numel(), n, float(boxsize), _bin_code(binning), ptr(psum),
+                                       stream()), "ast_fft64_power_3d_f32")
+        return ksum, psum, nmodes
     if halo is not None:                      # grid from paint(..., defer_fold=True)
         check(L.ast_fft64_power_3d_halo(ptr(field), halo.rec_ptr, halo.window_code, ptr(scratch), scratch.numel(), n,
                                         float(boxsize), _bin_code(binning), ptr(psum), stream()), "ast_fft64_power_3d_halo")
@@ -655,6 +677,12 @@ def paint_power_1d(pos, mass, nmesh, boxsize, window="cic", scale=1.0, binning=N
         grid, halo = paint(pos, mass, n, boxsize, window, scale=scale, method="tiled", defer_fold=True,
                            offset="mean")
         return finish_power(*power_sums_fused(grid, boxsize, halo=halo, binning=binning))
+    if pos.dtype == torch.float32 and n % 32 == 0 and pos.shape[0] >= 65536 and pos.shape[0] * 2048 >= 64 * n ** 3 \
+            and bool(_lib.lib().ast_fft64_supported(n)):
+        # fp32 particles on a grid without fp32 tile passes (128^3, 2048^3): the grid holds rho - mean (only the discarded DC
+        # mode differs), the transform runs in double straight from the fp32 grid
+        grid = paint(pos, mass, n, boxsize, window, scale=scale, method="tiled", offset="mean")
+        return finish_power(*power_sums_fused64(grid, boxsize, binning=binning))
     fast64 = pos.dtype == torch.float64 and n % 32 == 0 and pos.shape[0] >= 65536 \
         and pos.shape[0] * 2048 >= 64 * n ** 3 and bool(_lib.lib().ast_fft64_supported(n))
     if fast64 and defer_fold64:               # float64: the halo fold inside the double z pass (26.2 vs 26.5 ms at 1024^3)
@@ -673,7 +701,9 @@ def fftpower_1d(field1, boxsize, field2=None, fused=True, binning=None):
         # transform of an O(1) mean would leave its round-off on every shell
         mean = total_mass(field1.reshape(-1), 0) / float(field1.numel())
         return finish_power(*power_sums_fused(field1, boxsize, mean=mean, binning=binning))
-    if fused and field2 is None and fused_power64_supported(field1):
+    if fused and field2 is None and fused_power64_supported(field1, allow_f32=True):
+        # float64 cubes of side 128 ... 2048 - and fp32 cubes of the sides the fp32 tile passes do not cover (128, 2048),
+        # transformed in double without a float64 copy of the grid
         return finish_power(*power_sums_fused64(field1, boxsize, binning=binning))
     if field1.dtype == torch.float32:
         # fp32 grids that do not take the fused path above - cross spectra, sizes the tile FFT does not cover: an fp32

@@ -565,8 +565,11 @@ def power_leg(dev, n, npside, L, window, order, dtype, method, steps, warmup, cl
     dev.shell_geometry(n, L)          # data independent, cached like the FFT plan
     fused = dev.fused_power_supported(grid)
     fused64 = dev.fused_power64_supported(grid) and not os.environ.get("ASTRILD_BENCH_ROCFFT64")
+    # fp32 grids of the sides the fp32 tile passes do not cover (128, 2048): painted as rho - mean, transformed in DOUBLE straight
+    # from the fp32 grid (ast_fft64_power_3d_f32) - the stage table still prices the FFT at the grid's 4 bytes per cell
+    f32_via_double = dtype == "f32" and not fused and dev.fused_power64_supported(grid, allow_f32=True)
     spec = None
-    if not fused and not fused64:
+    if not fused and not fused64 and not f32_via_double:
         spec = torch.empty((n, n, n // 2 + 1), dtype=torch.complex64 if dtype == "f32" else torch.complex128, device="cuda")
     mean = npart_total / float(n) ** 3
     # WHICH paint path: decided from the input by device.probe_input (order in memory + tile-occupancy tail of a sample:
@@ -594,6 +597,10 @@ def power_leg(dev, n, npside, L, window, order, dtype, method, steps, warmup, cl
                                 accumulate=False, defer_fold=True, offset=mean, hint=hint)
             psum.zero_()
             return dev.power_sums_fused(grid, L, psum=psum, halo=halo)
+        if f32_via_double and method in ("auto", "tiled"):
+            dev.paint(pos, None, n, L, window, out=grid, method="tiled", check_dropped=False, accumulate=False, offset=mean, hint=hint)
+            psum.zero_()
+            return dev.power_sums_fused64(grid, L, psum=psum)
         if fused64 and method in ("auto", "tiled"):     # float64: the halo fold rides on the double z pass too
             _, halo = dev.paint(pos, None, n, L, window, out=grid, method="tiled", check_dropped=False,
                                 accumulate=False, defer_fold=True, hint=hint)

@@ -522,13 +522,17 @@ typedef struct ast_lens_plan ast_lens_plan;
 int ast_lens_plan_create(ast_lens_plan** plan, int nc, double bsz);
 int ast_lens_plan_destroy(ast_lens_plan* plan);
 /* FFTPower of an in-memory float64 grid (the reference's dtype: power_spectrum_3d.py:183-224 on float64 arrays) for
- * n = 256 / 512 / 1024 through hand-written double-precision passes (z rows, then ONE strided pass per axis, the last
+ * n = 128 ... 2048 (powers of two) through hand-written double-precision passes (z rows, then ONE strided pass per axis, the last
  * one fused with the shell binning): psum_d[shell] += L^3 sum_modes w |delta_k|^2, delta_k = rfftn(grid) / n^3.
  * grid_d is not modified; scratch_d: ast_fft64_power_scratch_bytes(n) bytes. */
 int ast_fft64_supported(size_t n);
 size_t ast_fft64_power_scratch_bytes(size_t n);
 int ast_fft64_power_3d(const double* grid_d, void* scratch_d, size_t scratch_bytes, size_t n, double boxsize, int binning,
                        double* psum_d, void* stream);
+/* ast_fft64_power_3d of a SINGLE-precision grid, transformed in double (the z pass widens the rows as it loads them): fp32
+ * cubes the fp32 tile passes do not cover (n = 128, 2048) without a float64 copy of the grid.  Same scratch. */
+int ast_fft64_power_3d_f32(const float* grid_d, void* scratch_d, size_t scratch_bytes, size_t n, double boxsize, int binning,
+                           double* psum_d, void* stream);
 /* spec_d (n, n, n / 2 + 1) complex double, contiguous = rfftn(grid_d) * scale (pmesh's r2c with scale = 1 / n^3) through
  * the same passes; grid_d is not modified */
 int ast_fft64_r2c_3d(const double* grid_d, void* spec_d, size_t n, double scale, void* stream);

@@ -320,7 +320,7 @@ def test_triple_product_sums_one_pass(hip, dtype):
     assert abs(one - ref[-1]) <= tol * scale[-1]
 
 
-@pytest.mark.parametrize("n", [256, 512, 1024])
+@pytest.mark.parametrize("n", [128, 256, 512, 1024])
 def test_double_precision_fused_power_against_rocfft_route(hip, n):
     """ast_fft64_power_3d (hand-written double passes, binning fused into the x pass) against rocFFT R2C + ast_power_bin_1d
     on the same float64 grid, both shell rules; and against the numpy oracle at 256^3."""
@@ -338,16 +338,45 @@ def test_double_precision_fused_power_against_rocfft_route(hip, n):
     keep = t.clone()
     for rule in (("float64",) if n == 1024 else ("float64", "integer")):
         ks, ps, nm = dev.power_sums_fused64(t, 1000.0, binning=rule)
-        spec = dev.r2c(t)
+        spec = dev.r2c(t, engine="rocfft")
         ks2, ps2, nm2 = dev.power_bin_1d(spec, None, n, 1000.0, binning=rule)
         assert torch.equal(nm, nm2)
         np.testing.assert_allclose(ps.cpu().numpy(), ps2.cpu().numpy(), rtol=1e-11)
     assert torch.equal(t, keep)                                     # the grid is left intact
     res = dev.fftpower_1d(t, 1000.0)                                # default route for float64 cubes of this size
-    if n == 256:
+    if n <= 256:
         ref = offt.fftpower_1d(f, 1000.0)
         assert np.array_equal(res["modes"], ref["modes"])
         np.testing.assert_allclose(res["power"], ref["power"].real, rtol=1e-9)
+
+
+def test_config_a_size_runs_on_the_hand_written_passes(hip):
+    """128^3 (BASELINE config A's own size): float64 grids through ast_fft64_power_3d, fp32 grids through the same double
+    passes widened on load (ast_fft64_power_3d_f32) - both against the oracle; the fp32 pipeline (paint rho - mean, double
+    transform) within 1e-6 of the oracle on the same particles."""
+    from astrild_amd import device as dev
+    from oracle import fftpower as offt, mesh as omesh
+    torch.cuda.set_device(0)
+    n, L = 128, 1000.0
+    assert hip.ast_fft64_supported(128) and hip.ast_fft64_supported(2048) and not hip.ast_fft64_supported(4096)
+    rng = np.random.default_rng(128)
+    f32 = (rng.standard_normal((n, n, n)) + 3.0).astype(np.float32)
+    ref = offt.fftpower_1d(f32.astype(np.float64), L)
+    for rule in ("float64", "integer"):
+        got = dev.fftpower_1d(dev.as_device(f32), L, binning=rule)            # fp32 grid, transformed in double
+        want = ref if rule == "float64" else offt.fftpower_1d(f32.astype(np.float64), L, binning="integer")
+        assert np.array_equal(got["modes"], want["modes"])
+        np.testing.assert_allclose(got["power"], want["power"].real, rtol=1e-10)
+    pos = omesh.lattice_particles(n, n, L, seed=20240601)
+    oracle = offt.fftpower_1d(omesh.paint(pos, None, n, L, "cic"), L)
+    for dt, rtol in ((np.float64, 1e-9), (np.float32, 1e-6)):
+        res = dev.paint_power_1d(dev.as_device(pos.astype(dt)), None, n, L, "cic")
+        assert np.array_equal(res["modes"], oracle["modes"])
+        if dt == np.float32:        # the same fp32-rounded positions through the oracle
+            oracle32 = offt.fftpower_1d(omesh.paint(pos.astype(np.float32).astype(np.float64), None, n, L, "cic"), L)
+            np.testing.assert_allclose(res["power"], oracle32["power"].real, rtol=rtol)
+        else:
+            np.testing.assert_allclose(res["power"], oracle["power"].real, rtol=rtol)
 
 
 @pytest.mark.parametrize("window", ["cic", "tsc"])
@@ -367,7 +396,7 @@ def test_double_precision_pipeline_with_deferred_fold(hip, window):
     np.testing.assert_allclose(got["power"], ref["power"], rtol=1e-10)
 
 
-@pytest.mark.parametrize("n", [256, 512])
+@pytest.mark.parametrize("n", [128, 256, 512])
 def test_double_precision_r2c_against_rocfft_and_numpy(hip, n):
     """ast_fft64_r2c_3d (device.r2c's route for float64 cubes) against the rocFFT plan; against numpy at 256^3."""
     from astrild_amd import device as dev
@@ -379,7 +408,7 @@ def test_double_precision_r2c_against_rocfft_and_numpy(hip, n):
     ref = dev.r2c(t, engine="rocfft")
     scale = ref.abs().max().item()
     assert (got - ref).abs().max().item() < 1e-13 * scale * np.sqrt(n)
-    if n == 256:
+    if n <= 256:
         want = np.fft.rfftn(f) / n ** 3
         assert np.abs(got.cpu().numpy() - want).max() < 1e-13 * np.abs(want).max() * np.sqrt(n)
 

@@ -745,3 +745,19 @@ def test_clustered_input_goes_to_the_two_pass_path_in_one_attempt(dev, shuffle):
     want = offt.fftpower_1d(ref, L)
     assert np.array_equal(res["modes"], want["modes"])
     np.testing.assert_allclose(res["power"], want["power"].real, rtol=2e-6)
+
+
+@pytest.mark.parametrize("window,dtype", [("cic", torch.float32), ("tsc", torch.float64)])
+def test_paint_in_chunks_for_more_particles_than_32_bit_indices(dev, window, dtype, monkeypatch):
+    """More than 2^32 - 65 particles (2048^3) do not fit the tile lists' 32-bit indices: device.paint paints them in chunks
+    onto the same grid (first chunk as asked for - overwrite, rho - mean -, the rest accumulated).  Forced at 256^3 with
+    ASTRILD_PAINT_CHUNK; against the one-call paint."""
+    n, L = 256, 1000.0
+    pos = dev.synth_lattice_particles(n, n, L, seed=4, dtype=dtype)
+    whole = dev.paint(pos, None, n, L, window, method="tiled", offset="mean")
+    monkeypatch.setenv("ASTRILD_PAINT_CHUNK", str(5_000_000))
+    parts = dev.paint(pos, None, n, L, window, method="tiled", offset="mean")
+    monkeypatch.delenv("ASTRILD_PAINT_CHUNK")
+    tol = 2e-6 if dtype == torch.float32 else 1e-12
+    assert float((parts - whole).abs().max()) <= tol * max(1.0, float(whole.abs().max()))
+    assert abs(float(parts.double().sum())) < 1e-3 * n ** 3 * (1e-3 if dtype == torch.float64 else 1.0)     # rho - mean sums to ~0
