@@ -407,7 +407,9 @@ extern "C" int ast_lens_plan_create(ast_lens_plan** out, int nc, double bsz) {
         !getenv("AST_LENS_ROCFFT_2D") && !getenv("AST_LENS_ROCFFT_ROWS")) {
         int f = 128;
         while (f < nc) f *= 2;
-        p->ncf = f;
+        // ... unless the map is large AND just above a power of two (nc = 4100 -> 8192: 4 x the transform area and 15 GB of
+        // plan buffers instead of 4): then the exact-size rocFFT plans of rounds 1-3 stay (AST_LENS_EMBED_ALWAYS=1 overrides)
+        if (nc <= 2048 || 2 * (long long)f <= 3 * (long long)nc || getenv("AST_LENS_EMBED_ALWAYS")) p->ncf = f;
     }
     const bool embedded = p->ncf != nc;
     const size_t n2 = 2 * (size_t)p->ncf, nh = n2 / 2 + 1;

@@ -492,8 +492,12 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
                 uint32_t dkey = key - closed_lo;
                 if (!PLAINX && closed_mod && key < closed_lo) dkey += closed_mod;
                 if (dkey < closed_n && key != 0xffffffffu) {       // (closed_n = 0: never)
-                    place_late_slow(p, ovf, ovf_count);
+                    // x-sorted single-call paint: a late particle goes through the overflow list, deposited at the end of the
+                    // call (the result never depends on the order that was assumed).  STAGED paint: dropped cleanly - on the
+                    // overflow list a later FOLD would deposit the part of its window that falls into rows not yet folded,
+                    // a partial, order-dependent deposit; it is counted, and the caller's check() raises
                     if (!PLAINX && closed_mod) ++ndrop;
+                    else place_late_slow(p, ovf, ovf_count);
                     key = 0xffffffffu;
                 }
                 const bool live = key != 0xffffffffu;

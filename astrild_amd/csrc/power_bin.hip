@@ -514,7 +514,9 @@ extern "C" int ast_triple_product_sums(const void* const* fields, int nfields, i
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_once.mark();
         }
-        if (nfields <= TRI_PIPE_FIELDS && !getenv("AST_TRI_NO_PIPE"))
+        // the pipelined variant always issues TRI_PIPE_FIELDS loads per thread and chunk (slots past nfields re-read the last
+        // field): it pays for many fields (the bispectrum's 31 shells), not for the three fields of a single triangle
+        if (nfields > TRI_PIPE_FIELDS / 2 && nfields <= TRI_PIPE_FIELDS && !getenv("AST_TRI_NO_PIPE"))
             triple_sums_kernel<float, true><<<blocks, TRI_THREADS, lds, s>>>((const float* const*)fields, nfields, tri, ntri, parts, count,
                                                                              (double*)scratch);
         else

@@ -838,6 +838,7 @@ class SlabPowerPipeline:
             self.staged = o.staged_paint(self.pos, None, self.n, self.L, self.window, self.buf, self.x_start, self.nx_alloc,
                                          offset=self.mean_offset, owned=(self.gl, self.nloc) if self.mean_offset else None)
             self.schedule = self._make_schedule(self.staged)
+            self._schedule_checked = False
             self.packed_flat = self.packed.reshape(-1)
             # ASTRILD_SLAB_STREAMS=2: the paint stages (walk, fold) on the caller's stream, the transforms and the exchange
             # of finished plane ranges on a second one, so that a stage's transform runs beside the next stage's walk.
@@ -848,6 +849,18 @@ class SlabPowerPipeline:
             if self.buf.is_cuda and os.environ.get("ASTRILD_SLAB_STREAMS", "1") == "2":
                 self._fft_stream = torch.cuda.Stream()
         sp = self.staged
+        if check and not self._schedule_checked and self.world > 1:
+            # the ranks' point-to-point operations only match up if every rank runs the SAME schedule (and the same wire
+            # layout): before the first checked step posts any, a digest of both is compared across the ranks
+            import hashlib
+            text = repr(self.schedule) + repr(None if self.disc is None else (self.disc["S"], self.disc["part_of"]))
+            digest = int.from_bytes(hashlib.sha256(text.encode()).digest()[:7], "little")
+            both = torch.tensor([digest, -digest], dtype=torch.int64, device=self.psum.device)
+            comm_ready(self.group)
+            dist.all_reduce(both, op=dist.ReduceOp.MAX, group=self.group)
+            if int(both[0].item()) != digest or int(both[1].item()) != -digest:
+                raise RuntimeError(f"rank {self.rank}: the staged schedule differs between the ranks (digest {digest})")
+            self._schedule_checked = True
         owned = self.buf[self.gl: self.gl + self.nloc] if self.world > 1 else self.buf
         P, nloc, nz = self.world, self.nloc, self.nzp
         pending = []

@@ -621,3 +621,24 @@ def test_lens_plan_of_any_size_is_embedded_in_a_power_of_two(lens, dev, monkeypa
     a1b, _ = plan.alphas(kd)
     assert torch.equal(a1, a1b)
     del plan, ref
+
+
+def test_large_map_just_above_a_power_of_two_keeps_the_exact_size_plan(lens, dev, monkeypatch):
+    """nc = 2100 would embed in 4096 - 3.8 x the transform area and plan buffers: the exact-size rocFFT plan stays
+    (embedding only up to 1.5 x the side, or for maps <= 2048 px); same deflection field as the embedded plan."""
+    nc, bsz = 2100, np.deg2rad(5.0)
+    g = torch.Generator(device="cuda").manual_seed(nc)
+    kd = torch.randn((nc, nc), generator=g, device="cuda", dtype=torch.float64) * 0.01
+    plan = lens.LensPlan(nc, bsz)
+    dev.profile_enable(True)
+    a1, a2 = plan.alphas(kd)
+    torch.cuda.synchronize()
+    sites = set(dev.profile_report())
+    dev.profile_enable(False)
+    assert any(not k.startswith("lens.") for k in sites), sites        # a rocFFT plan ran
+    monkeypatch.setenv("AST_LENS_EMBED_ALWAYS", "1")
+    emb = lens.LensPlan(nc, bsz)
+    e1, e2 = emb.alphas(kd)
+    monkeypatch.delenv("AST_LENS_EMBED_ALWAYS")
+    for got, want in ((a1, e1), (a2, e2)):
+        assert float((got - want).abs().max()) <= 1e-11 * float(want.abs().max())
