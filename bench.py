@@ -730,7 +730,11 @@ def slab_leg(dev, dist, n, npside, L, args, world, barrier, wd):
                      "kernel_times_from": f"{prof_steps} steps run right after the timed region with the per-site events on "
                                           "(the timed steps run without them)",
                      "schedule": [list(e) for e in pipe.schedule] if pipe.schedule else None, "chunks": pipe.chunks,
-                     "spectrum_row_pitch": pipe.nzp, "nx_alloc": pipe.nx_alloc, "per_rank": per_rank}}
+                     "spectrum_row_pitch": pipe.nzp, "nx_alloc": pipe.nx_alloc,
+                     "transpose_layout": ("rows" if pipe.disc is None else
+                                          {"kind": "disc (only what FFTPower keeps; k_y row blocks dealt to the ranks by disc area)",
+                                           "plane_elems_per_part": pipe.disc["S"], "full_pitched_plane_elems": pipe.nloc * pipe.nzp}),
+                     "per_rank": per_rank}}
 
 
 if __name__ == "__main__":

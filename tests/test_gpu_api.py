@@ -59,6 +59,31 @@ def test_power_spectrum_3d_compute_auto_and_cross(tmp_path):
         ps._power_spectrum_3d(np.zeros((8, 8, 8)))
 
 
+def test_snapshot_loop_is_double_buffered_and_keeps_every_snapshot_apart(tmp_path):
+    """The snapshot loop (power_spectrum_3d.py:83-110) with a loader thread one snapshot ahead and rotating page-locked
+    staging buffers: five snapshots (more than buffers), auto and cross - every spectrum is its own snapshot's."""
+    from astrild_amd.power_spectra import PowerSpectrum3D
+    rng = np.random.default_rng(3)
+    n, L = 48, 250.0
+    grids = {nr: rng.standard_normal((n, n, n)) + 0.1 * nr for nr in (2, 4, 5, 8, 9)}
+    files = {}
+    for nr, g in grids.items():
+        files[nr] = str(tmp_path / f"grid_{nr:03d}.npy")
+        np.save(files[nr], g)
+    ps = PowerSpectrum3D("particles", FakeSimulation(tmp_path, n, L, files))
+    pk = ps.compute(["rho"], [{"path": "x", "root": "grid", "extension": "npy"}], save=False)
+    assert list(pk["P"]) == [f"snap_{nr}" for nr in sorted(grids)]
+    for nr, g in grids.items():
+        k, p = offt.power_spectrum_3d(g, L)
+        npt.assert_allclose(pk["P"][f"snap_{nr}"], p, rtol=1e-10)
+    nrs = sorted(grids)
+    other = nrs[1:] + nrs[:1]
+    cross = ps._cross_power_spectra(None, nrs, [files[a] for a in nrs], [files[b] for b in other])
+    for a, b in zip(nrs, other):
+        kr, pr = offt.power_spectrum_3d(grids[a], L, grids[b])
+        npt.assert_allclose(cross["P"][f"snap_{a}"], pr, rtol=1e-9, atol=1e-12 * abs(pr).max())
+
+
 def test_power_spectrum_3d_read_data_ngp_assign(tmp_path, monkeypatch):
     from astrild_amd.power_spectra import PowerSpectrum3D, power_spectrum_3d as mod
     rng = np.random.default_rng(1)
