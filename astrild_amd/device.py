@@ -267,6 +267,10 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     if chunk and pos.shape[0] > chunk and method != "direct" and _lib.WIN[window.lower()] != 0:
         if defer_fold:
             raise _lib.AstrildHipError("defer_fold is not available for a paint in chunks (more than 2^32 - 65 particles)")
+        if isinstance(offset, str):              # "mean" means the mean of ALL particles, not of the first chunk
+            if offset != "mean":
+                raise ValueError(offset)
+            offset = total_mass(mass, pos.shape[0]) * float(scale) / float(n) ** 3
         for a in range(0, pos.shape[0], chunk):
             part = paint(pos[a:a + chunk], None if mass is None else mass[a:a + chunk], n, boxsize, window, scale=scale, out=out,
                          method=method, x_start=x_start, nx_alloc=nx_alloc, check_dropped=check_dropped,

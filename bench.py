@@ -139,7 +139,7 @@ def _cpu_paint_chunk(pos, i0, planes, pad, n, boxsize, window, grid):
     grid[rows] += local.reshape(nloc, n, n)
 
 
-def cpu_baseline_chunked(sample, window, boxsize, planes=32, pad=6):
+def cpu_baseline_chunked(sample, window, boxsize, planes=32, pad=6, pos=None, dev=None):
     """The same CPU port at sizes whose temporaries do not fit the host in one piece ("one 1024^3 run if host
     RAM >= 64 GB"): the particles are generated and painted `planes` lattice planes at a time (the oracle's window weights,
     ONE numpy bincount per chunk over the chunk's slab of the grid; generation is not timed), the transform is one
@@ -154,14 +154,18 @@ def cpu_baseline_chunked(sample, window, boxsize, planes=32, pad=6):
     rng = np.random.Generator(np.random.PCG64(20240601))
     grid = np.zeros((n, n, n))
     t_paint = 0.0
+    given = pos                       # (n^3, 3) host array in lattice order (the device's own synthetic set), or None
     for i0 in range(0, n, planes):
-        q = np.stack(np.meshgrid(g[i0:i0 + planes], g, g, indexing="ij"), axis=-1).reshape(-1, 3)
-        pos = np.mod(q + 0.5 * h * rng.standard_normal(q.shape), boxsize)
-        del q
+        if given is not None:
+            chunk = np.asarray(given[i0 * n * n:(i0 + planes) * n * n], dtype=np.float64)
+        else:
+            q = np.stack(np.meshgrid(g[i0:i0 + planes], g, g, indexing="ij"), axis=-1).reshape(-1, 3)
+            chunk = np.mod(q + 0.5 * h * rng.standard_normal(q.shape), boxsize)
+            del q
         t0 = time.perf_counter()
-        _cpu_paint_chunk(pos, i0, planes, pad, n, boxsize, window, grid)
+        _cpu_paint_chunk(chunk, i0, planes, pad, n, boxsize, window, grid)
         t_paint += time.perf_counter() - t0
-        del pos
+        del chunk
     t0 = time.perf_counter()
     spec = scipy.fft.rfftn(grid, workers=1)
     t_fft1 = time.perf_counter() - t0
@@ -187,7 +191,21 @@ def cpu_baseline_chunked(sample, window, boxsize, planes=32, pad=6):
     npart = n ** 3
     assert np.isfinite(ps / nm).all()
     single = t_paint + t_fft1 + t_bin
-    return {"value": npart / single, "unit": "particles/s", "cores": 1, "kind": "port",
+    check = None
+    if given is not None and dev is not None:
+        # the CPU port's spectrum of the device's OWN particle set is the checker at the benchmark's size: the float64 device
+        # pipeline and the fp32 pipeline that `value` times, on the same (fp32-rounded) positions
+        p32 = dev.as_device(np.ascontiguousarray(given, dtype=np.float32))
+        d32 = dev.paint_power_1d(p32, None, n, boxsize, window)
+        d64 = dev.paint_power_1d(p32.double(), None, n, boxsize, window)
+        del p32
+        torch.cuda.empty_cache()
+        cpu_p = ps / nm
+        check = {"modes_equal": bool(np.array_equal(d64["modes"], nm) and np.array_equal(d32["modes"], nm)),
+                 "float64_pipeline_vs_cpu_max_rel": float(np.max(np.abs(d64["power"] / cpu_p - 1.0))),
+                 "fp32_pipeline_vs_cpu_max_rel": float(np.max(np.abs(d32["power"] / cpu_p - 1.0))),
+                 "note": "same particles (the device's synthetic set, fp32-rounded, copied to the host); north_star: 1e-6"}
+    return {"value": npart / single, "unit": "particles/s", "cores": 1, "kind": "port", "check": check,
             "sample": f"{n}^3 particles on a {n}^3 grid, float64: chunked numpy bincount paint {t_paint:.1f}s + scipy rfftn (1 thread) "
                       f"{t_fft1:.1f}s + shell binning {t_bin:.1f}s (the benchmark's own configuration; particles generated and "
                       f"painted {planes} lattice planes at a time)",
@@ -461,7 +479,10 @@ def main():
             out["legs"] = legs
         if args.cpu_sample >= 768:        # the benchmark's own size, chunked (minutes of CPU time: opt-in), beside the bounded sample
             out["cpu_baseline"] = cpu_baseline(512, args.window, L, dev)
-            out["cpu_baseline"]["at_benchmark_size"] = cpu_baseline_chunked(args.cpu_sample, args.window, L)
+            host_pos = dev.synth_lattice_particles(args.cpu_sample, args.cpu_sample, L, seed=20240601, dtype=torch.float32).cpu().numpy()
+            torch.cuda.empty_cache()
+            out["cpu_baseline"]["at_benchmark_size"] = cpu_baseline_chunked(args.cpu_sample, args.window, L, pos=host_pos, dev=dev)
+            del host_pos
         elif args.cpu_sample:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.window, L, dev)
         torch.cuda.empty_cache()
