@@ -74,6 +74,11 @@ SIGNATURES = {
     "ast_fft_tile_c2c_disc": (_i, [_vp, _vp, _i, _sz, _sz, _sz, _i, _i, _vp, _d, _vp]),
     "ast_fft_tile_disc_power_scratch_bytes": (_sz, [_sz, _i]),
     "ast_fft_tile_disc_block_power": (_i, [_vp, _vp, _sz, _i, _sz, _i, _i, _d, _d, _i, _i, _vp, _vp]),
+    "ast_comm_unique_id": (_i, [_vp, _sz]),
+    "ast_comm_init": (_i, [ct.POINTER(_vp), _i, _i, _vp, _sz]),
+    "ast_comm_destroy": (_i, [_vp]),
+    "ast_slab_transpose": (_i, [_vp, _vp, ct.POINTER(_sz), ct.POINTER(_sz), _vp, ct.POINTER(_sz), ct.POINTER(_sz), _i, _vp]),
+    "ast_comm_allreduce_sum": (_i, [_vp, _vp, _sz, _vp]),
     "ast_lowk_work_bytes": (_sz, [_sz, _sz]),
     "ast_lowk_mode_count": (_i, []),
     "ast_lowk_shell_count": (_i, []),

@@ -406,6 +406,27 @@ size_t ast_fft_tile_disc_power_scratch_bytes(size_t n, int parts);
 int ast_fft_tile_disc_block_power(void* block_d, void* scratch_d, size_t scratch_bytes, int dtype, size_t n, int parts, int part,
                                   double scale, double boxsize, int first_bin, int binning, double* psum_d, void* stream);
 
+/* ------------------------------------------------------------- communication (ast_comm_init, ast_slab_transpose)
+ * The multi-GPU exchange steps for a caller that binds this library alone: RCCL over xGMI, one process per GPU.  (The
+ * Python side of this repository reaches RCCL through torch.distributed and does not call these.)  RCCL is loaded lazily
+ * at the first call; the library has no link-time dependency on it.  The reference has no counterpart: pmesh / pfft
+ * transpose over MPI inside the one FFTPower call (power_spectrum_3d.py:189-195).
+ *   ast_comm_unique_id: 128 bytes from ncclGetUniqueId on ONE rank, to be handed to the others by the caller's own means.
+ *   ast_comm_init / ast_comm_destroy: a communicator of `nranks` ranks for the current device.
+ *   ast_slab_transpose: one group of point-to-point operations - to every peer q send_count[q] REAL elements of `dtype`
+ *     (a complex value is two) from send_d + send_offset[q], from every peer recv_count[q] into recv_d + recv_offset[q];
+ *     a piece addressed to the rank itself is copied on the stream.  With the disc layout of ast_fft_tile_c2c_disc for
+ *     `nplanes` local planes: send_offset[q] = 2 nplanes cumS[q], send_count[q] = 2 nplanes S[q]; recv_offset[q] =
+ *     2 (q nloc + p0) S[rank], recv_count[q] = 2 nplanes S[rank].  Asynchronous on `stream`.
+ *   ast_comm_allreduce_sum: in-place sum of float64 values over the ranks (shell sums, low-k modes). */
+typedef struct ast_comm ast_comm;
+int ast_comm_unique_id(void* id_out, size_t id_bytes);
+int ast_comm_init(ast_comm** out, int nranks, int rank, const void* id, size_t id_bytes);
+int ast_comm_destroy(ast_comm* comm);
+int ast_slab_transpose(ast_comm* comm, const void* send_d, const size_t* send_offset, const size_t* send_count, void* recv_d,
+                       const size_t* recv_offset, const size_t* recv_count, int dtype, void* stream);
+int ast_comm_allreduce_sum(ast_comm* comm, double* buf_d, size_t count, void* stream);
+
 /* The low-k channel as separate calls, for slab-decomposed grids: every rank adds the contribution of its own
  * planes to the (2*6+1)^2 * 7 modes |m_i| <= 6, m_z >= 0 (complex128, [kx + 6][ky + 6][kz]); the modes are summed over
  * ranks; the sums of the ast_lowk_shell_count() lowest shells are then taken from them.

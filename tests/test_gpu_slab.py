@@ -306,3 +306,32 @@ def test_one_rank_of_eight_staged_step_with_grouping_in_parts(hip, monkeypatch, 
     pipe.ops.paint(pipe.pos, None, n, L, "cic", ref, pipe.x_start, pipe.nx_alloc, check=True, offset=pipe.mean_offset,
                    owned=(pipe.gl, pipe.nloc))
     assert torch.equal(staged, ref)
+
+
+def test_c_abi_comm_entries_over_rccl_single_rank(hip):
+    """SURVEY.md S8(b)'s communication entries (ast_comm_init, ast_slab_transpose, ast_comm_allreduce_sum) for a caller that
+    binds the library alone: RCCL loaded lazily, a one-rank communicator on cuda:0 - the rank's own piece is copied, the sum
+    over one rank is the identity.  (More than one rank needs more than one GPU; the Python pipelines go through
+    torch.distributed.)"""
+    import ctypes as ct
+    from astrild_amd import _lib, device as dev
+    torch.cuda.set_device(0)
+    uid = (ct.c_char * 128)()
+    _lib.check(hip.ast_comm_unique_id(uid, 128), "ast_comm_unique_id")
+    comm = ct.c_void_p()
+    _lib.check(hip.ast_comm_init(ct.byref(comm), 1, 0, uid, 128), "ast_comm_init")
+    try:
+        send = torch.arange(1000, dtype=torch.float32, device="cuda")
+        recv = torch.zeros(1500, dtype=torch.float32, device="cuda")
+        sz = ct.c_size_t * 1
+        _lib.check(hip.ast_slab_transpose(comm, dev.ptr(send), sz(100), sz(600), dev.ptr(recv), sz(300), sz(600), 0, dev.stream()),
+                   "ast_slab_transpose")
+        torch.cuda.synchronize()
+        assert torch.equal(recv[300:900], send[100:700]) and float(recv[:300].abs().sum()) == 0.0 and float(recv[900:].abs().sum()) == 0.0
+        sums = torch.tensor([1.5, -2.0, 3.25], dtype=torch.float64, device="cuda")
+        _lib.check(hip.ast_comm_allreduce_sum(comm, dev.ptr(sums), 3, dev.stream()), "ast_comm_allreduce_sum")
+        torch.cuda.synchronize()
+        assert sums.tolist() == [1.5, -2.0, 3.25]
+        assert hip.ast_slab_transpose(comm, dev.ptr(send), sz(0), sz(10), dev.ptr(recv), sz(0), sz(20), 0, dev.stream()) != 0   # own piece: sizes differ
+    finally:
+        _lib.check(hip.ast_comm_destroy(comm), "ast_comm_destroy")
