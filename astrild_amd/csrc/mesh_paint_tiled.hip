@@ -745,6 +745,19 @@ __device__ inline void staged_store(const T (&rx)[SC_PER_THREAD], const T (&ry)[
 // read of all positions - 2.5 ms at 1024^3 - just to size the segments exactly was a tenth of the unordered paint).  A record
 // that does not fit its segment (strongly clustered input) goes to the late list like one that does not fit its tile's
 // stray segment in level B, and is deposited with global atomics; device.paint sees the count and repaints two-pass.
+// Append to a list with ONE returning global atomic per wave: every lane with `want` gets a slot of its own.  (Clustered
+// input sends millions of records to the late list; one atomic per record on the list's single counter serialised them:
+// level B took 48 ms at 1024^3 where the uniform set takes 5.7.)  Call in convergent control flow.
+__device__ inline unsigned long long wave_append(unsigned long long* __restrict__ counter, bool want) {
+    const unsigned long long m = __ballot(want);
+    if (m == 0ull) return 0ull;
+    const int lane = (int)(threadIdx.x & 63u), leader = __ffsll((long long)m) - 1;
+    unsigned long long base = 0ull;
+    if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(m));
+    base = __shfl(base, leader, 64);
+    return base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+}
+
 template <typename T, int W, bool PLAINX, int SW>
 __global__ void __launch_bounds__(SCA_THREADS)
 scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t np, TileGeom g, uint32_t tpb, uint32_t nb,
@@ -806,8 +819,9 @@ scatter_level_a_kernel(const T* __restrict__ pos, const T* __restrict__ mass, si
     if (full) {
 #pragma unroll
         for (int u = 0; u < SC_PER_THREAD; ++u) {         // the records that do not fit go to the late list
-            if (where[u] != 0xffffffffu && (where[u] & 0xffffu) >= room[where[u] >> 16]) {
-                const unsigned long long k = atomicAdd(late, 1ull);
+            const bool over = where[u] != 0xffffffffu && (where[u] & 0xffffu) >= room[where[u] >> 16];
+            const unsigned long long k = wave_append(late, over);
+            if (over) {
                 if (k < late_cap) reinterpret_cast<vec4_t*>(late_list)[k] = vec4_t{x[u], y[u], z[u], m[u]};
                 else ++ndrop;
             }
@@ -866,6 +880,8 @@ scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* 
                        T* __restrict__ late_list, unsigned long long late_cap, unsigned long long* __restrict__ late,
                        unsigned long long* dropped) {
     __shared__ uint32_t wsum[16];
+    __shared__ uint32_t late_n, any_full;
+    __shared__ unsigned long long late_base;
     extern __shared__ unsigned long long dyn[];          // base[tpb] | stage | sidx | cnt[tpb] room[tpb] lstart[tpb]
     constexpr int NT = SCB_THREADS, SC_CHUNK = NT * SC_PER_THREAD;
     const uint32_t tp = (tpb + 1u) & ~1u;                // (the staged records stay 16-byte aligned)
@@ -886,6 +902,7 @@ scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* 
     struct Rec3 { T x, y, z; };
     for (size_t c0 = b0 + (size_t)sub * SC_CHUNK; c0 < b1; c0 += (size_t)nsub * SC_CHUNK) {
         for (uint32_t t = tid; t < tpb; t += NT) cnt[t] = 0;
+        if (tid == 0) { late_n = 0u; any_full = 0u; }
         __syncthreads();
         T x[SC_PER_THREAD], y[SC_PER_THREAD], z[SC_PER_THREAD], m[SC_PER_THREAD];
         uint32_t where[SC_PER_THREAD];               // tile in bucket << 16 | rank (< 16384)
@@ -916,12 +933,27 @@ scatter_level_b_kernel(const T* __restrict__ staging, const unsigned long long* 
             const uint32_t bs = min(old, scap);
             base[t] = (unsigned long long)tile * scap + bs;
             room[t] = scap - bs;
+            if (cnt[t] > scap - bs) any_full = 1u;
         }
-        const uint32_t total = block_exclusive_scan<NT>(cnt, lstart, tpb, wsum);
+        const uint32_t total = block_exclusive_scan<NT>(cnt, lstart, tpb, wsum);         // (barriers inside: any_full is settled)
+        // a full tile segment: the record goes to the late list.  Rare for a uniform set; a clustered one sends millions -
+        // and the list has ONE counter, where same-address atomics are served one after the other (one per wave, as the
+        // compiler already arranges, still left level B at 48 ms for the clustered 1024^3 set against 5.7 for the uniform
+        // one): the workgroup counts its late records in LDS and reserves their slots with ONE global atomic per chunk
+        if (any_full != 0u) {                          // (uniform over the workgroup; never taken for a uniform particle set)
+            uint32_t lslot[SC_PER_THREAD];
 #pragma unroll
-        for (int u = 0; u < SC_PER_THREAD; ++u) {         // a full tile segment (rare): the record goes to the late list
-            if (where[u] != 0xffffffffu && (where[u] & 0xffffu) >= room[where[u] >> 16]) {
-                const unsigned long long k = atomicAdd(late, 1ull);
+            for (int u = 0; u < SC_PER_THREAD; ++u) {
+                const bool over = where[u] != 0xffffffffu && (where[u] & 0xffffu) >= room[where[u] >> 16];
+                lslot[u] = over ? atomicAdd(&late_n, 1u) : 0xffffffffu;
+            }
+            __syncthreads();
+            if (tid == 0 && late_n) late_base = atomicAdd(late, (unsigned long long)late_n);
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < SC_PER_THREAD; ++u) {
+                if (lslot[u] == 0xffffffffu) continue;
+                const unsigned long long k = late_base + lslot[u];
                 if (k < late_cap) reinterpret_cast<vec4_t*>(late_list)[k] = vec4_t{x[u], y[u], z[u], m[u]};
                 else if (dropped) atomicAdd(dropped, 1ull);            // more than a quarter of all particles: reported, not lost silently
             }

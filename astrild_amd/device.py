@@ -242,8 +242,9 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     hint: "scattered" sizes the tiled overwrite paint's workspace for particles without spatial order in memory
     (AST_PAINT_SCATTERED); "clustered" goes to the exact two-pass variant (no capacity limit per tile); "ordered" the
     plain single pass.  Without a hint a paint of >= 2^20 particles onto the whole grid looks at the input first
-    (:func:`probe_input`: order in memory, tile occupancy tail) and picks single pass / scattered / two-pass up front -
-    also when ``check_dropped`` is False - instead of finding out from the overflow list of a wasted attempt;
+    (:func:`probe_input`: order in memory, tile occupancy tail) and picks single pass / scattered (no order in memory,
+    clustered or not) / two-pass (ordered and clustered) up front - also when ``check_dropped`` is False - instead of
+    finding out from the overflow list of a wasted attempt;
     "xsorted" says they come in ascending x (lattice order, slab-ordered files): grouping and
     column walk then overlap chunk by chunk (AST_PAINT_XSORTED; a wrong hint costs time, never correctness).  stats: a dict that receives the list statistics of the tiled overwrite paint.
     shift: added to every coordinate in grid units (0.5 paints the second mesh of an interlaced pair).
@@ -319,11 +320,15 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
     attempts, probed = 0, None
     if compact and hint is None and npart >= (1 << 20) and nx == n and int(x_start) == 0:
         probed = probe_input(pos, n, boxsize, shift)                    # (a wrong guess costs time, never correctness)
-        if probed is not None and probed["overflow"] > npart // 64:
-            tflags = (tflags & ~(8 | 16)) | 1                           # clustered: the exact two-pass variant at once
-            compact = False
-        elif probed is not None and probed["groupable"] < 0.25:
+        if probed is not None and probed["groupable"] < 0.25 and probed["overflow"] <= npart // 5:
+            # no spatial order in memory: the bucket scatter, clustered or not - the two-pass variant makes two global
+            # atomics per particle on such input (1024^3 clustered + shuffled: 130 ms against 24); tiles that overflow
+            # their segments go through the late list, reserved once per workgroup and chunk (the list holds a quarter of
+            # the particles: beyond a fifth estimated, the two-pass variant below, slow but without any capacity)
             tflags |= 8
+        elif probed is not None and probed["overflow"] > npart // 64:
+            tflags = (tflags & ~(8 | 16)) | 1                           # clustered, in file order: the exact two-pass variant at once
+            compact = False
         ws_bytes = int(L.ast_paint_tiled_workspace_bytes(win, code, npart, n, nx, tflags))
     elif compact and hint is None and check_dropped and npart >= (1 << 20) and sample_is_unordered(pos, n, boxsize, shift):
         tflags |= 8                                                     # (slab buffers: the order probe alone)
@@ -351,7 +356,9 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
             # default stray segments: paint again with the two-level bucket scatter (AST_PAINT_SCATTERED).  If that
             # still overflows, the input is strongly CLUSTERED (tiles far above twice the mean occupancy): the exact
             # two-pass variant has no capacity limit.  (Callers that synchronise anyway.)
-            if st is not None and check_dropped and st["overflow"] > npart // 64:
+            if st is not None and check_dropped and st["overflow"] > npart // 64 and not (probed is not None and tflags & 8):
+                # (a scattered paint the probe chose knowingly - unordered AND clustered - keeps its late list: it is the
+                # fastest path for such input, and the result is complete either way)
                 dropped.zero_()
                 del ws
                 if not tflags & 8:

@@ -602,33 +602,35 @@ def power_leg(dev, n, npside, L, window, order, dtype, method, steps, warmup, cl
     t0 = time.perf_counter()
     probe = dev.probe_input(pos, n, L)
     probe_ms = (time.perf_counter() - t0) * 1e3
-    if probe is not None and probe["overflow"] > npart_total // 64:
-        hint = "clustered"                 # exact two-pass lists: no capacity limit per tile
-    elif probe is not None and probe["groupable"] < 0.25:
-        hint = "scattered"                 # no spatial order in memory: two-level bucket scatter
+    if probe is not None and probe["groupable"] < 0.25:
+        hint = "scattered"                 # no spatial order in memory (clustered or not): two-level bucket scatter
+    elif probe is not None and probe["overflow"] > npart_total // 64:
+        hint = "clustered"                 # file order, clustered: exact two-pass lists, no capacity limit per tile
     else:
         hint = "ordered"                   # single pass: group records straight from the array
     pstats = {}
+    collect = [None]                   # set to `pstats` for ONE untimed step after the timed ones: the same paint, with its list statistics
 
     def step():
         if fused and method in ("auto", "tiled"):
             # the paint stores rho - mean (subtracted in double before the fp32 rounding) and its halo fold rides
             # on the z pass of the FFT (one kernel and ~2 GB less)
             _, halo = dev.paint(pos, None, n, L, window, out=grid, method="tiled", check_dropped=False,
-                                accumulate=False, defer_fold=True, offset=mean, hint=hint)
+                                accumulate=False, defer_fold=True, offset=mean, hint=hint, stats=collect[0])
             psum.zero_()
             return dev.power_sums_fused(grid, L, psum=psum, halo=halo)
         if f32_via_double and method in ("auto", "tiled"):
-            dev.paint(pos, None, n, L, window, out=grid, method="tiled", check_dropped=False, accumulate=False, offset=mean, hint=hint)
+            dev.paint(pos, None, n, L, window, out=grid, method="tiled", check_dropped=False, accumulate=False, offset=mean, hint=hint,
+                      stats=collect[0])
             psum.zero_()
             return dev.power_sums_fused64(grid, L, psum=psum)
         if fused64 and method in ("auto", "tiled"):     # float64: the halo fold rides on the double z pass too
             _, halo = dev.paint(pos, None, n, L, window, out=grid, method="tiled", check_dropped=False,
-                                accumulate=False, defer_fold=True, hint=hint)
+                                accumulate=False, defer_fold=True, hint=hint, stats=collect[0])
             psum.zero_()
             return dev.power_sums_fused64(grid, L, psum=psum, halo=halo)
         dev.paint(pos, None, n, L, window, out=grid, method=method, check_dropped=False,
-                  accumulate=False, hint=hint)       # overwrite mode: no zero-fill pass
+                  accumulate=False, hint=hint, stats=collect[0])       # overwrite mode: no zero-fill pass
         psum.zero_()
         if fused:                         # tile FFT with the shell binning fused into the last pass
             return dev.power_sums_fused(grid, L, psum=psum, mean=mean)
@@ -668,10 +670,12 @@ def power_leg(dev, n, npside, L, window, order, dtype, method, steps, warmup, cl
                        "frac": round(total / (ms_per_step * 1e6) / HBM_PEAK_GBS, 4)},
         "stages": stages,
     }
-    # what the timed paint left behind: which path ran, how often it was attempted (always once: the path is chosen up
-    # front), what went through the overflow list
-    dev.paint(pos, None, n, L, window, out=grid, method="tiled" if method == "auto" else method, check_dropped=False,
-              accumulate=False, hint=hint, stats=pstats)
+    # which path the timed paint took, how often it was attempted (always once: the path is chosen up front), what went
+    # through the overflow list: ONE more step, untimed, identical but for the list statistics it fetches
+    collect[0] = pstats
+    step()
+    collect[0] = None
+    torch.cuda.synchronize()
     path = {"hint": hint, "path": pstats.get("path"), "attempts": pstats.get("attempts"), "overflow_list": pstats.get("overflow"),
             "probe_ms": round(probe_ms, 3),
             "probe": None if probe is None else {"groupable_runs": round(probe["groupable"], 3), "est_overflow": probe["overflow"],

@@ -727,7 +727,8 @@ def test_clustered_input_goes_to_the_two_pass_path_in_one_attempt(dev, shuffle):
     assert (probe["groupable"] < 0.25) == shuffle
     st = {}
     grid = dev.paint(pos, None, n, L, "cic", method="tiled", check_dropped=False, stats=st)
-    assert st["path"] == "two-pass" and st["attempts"] == 1
+    # file order: the exact two-pass lists; no order in memory: the bucket scatter (its late list reserved per workgroup)
+    assert st["path"] == ("scattered" if shuffle else "two-pass") and st["attempts"] == 1
     host = pos.cpu().numpy().astype(np.float64)
     ref = omesh.paint(host, None, n, L, "cic")
     got = grid.cpu().numpy().astype(np.float64)
