@@ -79,6 +79,8 @@ SIGNATURES = {
     "ast_comm_destroy": (_i, [_vp]),
     "ast_slab_transpose": (_i, [_vp, _vp, ct.POINTER(_sz), ct.POINTER(_sz), _vp, ct.POINTER(_sz), ct.POINTER(_sz), _i, _vp]),
     "ast_comm_allreduce_sum": (_i, [_vp, _vp, _sz, _vp]),
+    "ast_fft_tile_c2r_triangles_scratch_bytes": (_sz, []),
+    "ast_fft_tile_c2r_triangles": (_i, [ct.POINTER(_vp), ct.POINTER(_i), _i, _i, _sz, _sz, _d, _vp, _i, _vp, _vp, _vp]),
     "ast_lowk_work_bytes": (_sz, [_sz, _sz]),
     "ast_lowk_mode_count": (_i, []),
     "ast_lowk_shell_count": (_i, []),

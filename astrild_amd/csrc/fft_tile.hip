@@ -756,6 +756,172 @@ rows_c2r_kernel(const float2* __restrict__ in, float* __restrict__ out, const fl
     }
 }
 
+// ------------------------------------------- z pass of ALL shells fused with the triangle sums (bispectrum)
+// The estimator's last two steps used to be: per shell a z pass that WRITES the real cube (31 x 0.5 GB at 512^3), then one
+// kernel that READS the 31 cubes back and forms the triangle sums - 33 of the 65 GB the whole bispectrum moves.  Here one
+// workgroup takes ONE (x, y) row of EVERY shell: "row" r of the C2R transform below is shell r's row (its own scratch
+// spectrum, its own pruning radius), the C = 32 transformed rows stay in LDS as real values, and thread (triangle, part)
+// adds f_a f_b f_c over its part of the row's N cells before the workgroup moves to its next (x, y) position.  The real cubes
+// never exist.  Products of fp32 values in fp32, running sums in double, per-thread partials reduced in a fixed order
+// (deterministic).  Same transform as rows_c2r_kernel (Z[k] from the half spectrum, conj-FFT-conj in two register stages).
+constexpr int TRI_ROWS = 32;                 // shells per workgroup = rows of the batched C2R
+struct TriShells { const float2* work[TRI_ROWS]; int kmax[TRI_ROWS]; int count; };
+
+template <int R1, int R2>
+__global__ void __launch_bounds__(TRI_ROWS * R2)
+#ifndef TRI_OCC_FREE
+__attribute__((amdgpu_waves_per_eu(4, 4)))          // 128 VGPRs: two 512-thread workgroups per CU (74 KB of LDS each) up to n = 512
+#endif
+rows_c2r_triangles_kernel(TriShells sh, const float2* __restrict__ tw_g, size_t nrows, size_t in_pitch, const int* __restrict__ tri,
+                          int ntri, int parts, double* __restrict__ partial) {
+    constexpr int C = TRI_ROWS, M = R1 * R2, N = 2 * M, NT = C * R2, R2P = R2 + 1, MP = M + 1;
+    extern __shared__ float2 lds[];
+    float2* Y = lds;                     // X rows [r][k <= M], then the stage buffer, then the real rows [r][2 j, 2 j + 1]
+    float2* tw = lds + C * (R1 * R2P > MP ? R1 * R2P : MP);
+    __shared__ const float2* wsrc[C];
+    __shared__ int wkmax[C];
+    for (int i = threadIdx.x; i < N; i += NT) tw[i] = tw_g[i];
+    if (threadIdx.x < C) {
+        const int r = (int)threadIdx.x;
+        wsrc[r] = sh.work[r < sh.count ? r : sh.count - 1];
+        wkmax[r] = r < sh.count ? sh.kmax[r] : 0;             // rows past the last shell: zeros
+    }
+    // triangle (t, part) of this thread; fields as FLOAT offsets into Y (row pitch 2 MP floats)
+    const int t = threadIdx.x % ntri, part = threadIdx.x / ntri;
+    const bool worker = part < parts;
+    int ia = 0, ib = 0, ic = 0;
+    if (worker) {
+        ia = tri[3 * t] * (2 * MP); ib = tri[3 * t + 1] * (2 * MP); ic = tri[3 * t + 2] * (2 * MP);
+        if (ib == ic) { const int a = ia; ia = ib; ic = a; }          // a repeated field first: two LDS reads per term
+        else if (ia == ic) { const int b = ib; ib = ia; ic = b; }
+    }
+    const bool wave_pairs = __all((int)(!worker || ia == ib)) != 0;
+    // (an even number of cells per part: the products below read the rows two cells - one float2 - at a time)
+    const int per = (((N + parts - 1) / parts) + 1) & ~1, c_lo = min(part * per, N), c_hi = min(c_lo + per, N);
+    double acc = 0.0;
+    __syncthreads();
+    const int rr = threadIdx.x / R2, q = threadIdx.x % R2;        // load task: row rr, k = q + R2 i
+    const int kmax = wkmax[rr];
+    const float2* const wrow = wsrc[rr];
+    float2 tmp[R1 + 1];
+    auto fetch = [&](size_t pos) {
+        const float2* src = wrow + pos * in_pitch;
+        // (the clamped indices do not depend on the position either: hoisted, their 17 64-bit offsets cost 51 VGPRs)
+        int km = kmax > 0 ? kmax - 1 : 0;
+        asm volatile("" : "+v"(km));
+#pragma unroll
+        for (int i = 0; i <= R1; ++i) {
+            const unsigned k = (unsigned)min(q + R2 * i, km);     // unconditional load from inside the written part
+            tmp[i] = src[k];
+        }
+    };
+    constexpr bool PREFETCH = R2 == 16;        // (1024 threads at n = 1024 leave 128 VGPRs: no second row set in registers)
+    if (PREFETCH && (size_t)blockIdx.x < nrows) fetch(blockIdx.x);
+#pragma clang loop unroll(disable)
+    for (size_t pos = blockIdx.x; pos < nrows; pos += gridDim.x) {
+        if (!PREFETCH) fetch(pos);
+        int kmv = kmax;
+        asm volatile("" : "+v"(kmv));
+#pragma unroll
+        for (int i = 0; i <= R1; ++i) {
+            const int k = q + R2 * i;
+            if (k <= M) Y[rr * MP + k] = k < kmv ? tmp[i] : make_float2(0.f, 0.f);
+        }
+        __syncthreads();
+        // (the twiddles a thread uses do not depend on the position: left to itself the compiler keeps all 2 R1 of them in
+        // registers across the whole loop - 64 VGPRs, 104 spilled at the 128 this kernel may use; re-read from LDS instead)
+        int n2 = threadIdx.x % R2;
+        asm volatile("" : "+v"(n2));
+        const int r = threadIdx.x / R2;
+        float2 v[R1];
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) {
+            const int k = n1 * R2 + n2;
+            const float2 xk = Y[r * MP + k], xm = Y[r * MP + M - k];
+            const float2 e = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y - xm.y));
+            const float2 d = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y + xm.y));
+            const float2 w = tw[k];
+            const float2 tt = make_float2(d.x * w.x + d.y * w.y, d.y * w.x - d.x * w.y);
+            v[n1] = make_float2(e.x - tt.y, -(e.y + tt.x));
+        }
+        __syncthreads();
+        fft_reg<R1>(v);
+#pragma unroll
+        for (int k1 = 0; k1 < R1; ++k1) {
+            float2 y = v[bitrev(k1, ilog2(R1))];
+            if (k1 != 0) y = cmul(y, tw[2 * n2 * k1]);
+            Y[(r * R1 + k1) * R2P + n2] = y;
+        }
+        __syncthreads();
+        float2 u[R2];
+        const int k1 = threadIdx.x % R1, r2 = threadIdx.x / R1;
+        const bool task2 = r2 < C;
+        if (task2) {
+#pragma unroll
+            for (int j = 0; j < R2; ++j) u[j] = Y[(r2 * R1 + k1) * R2P + j];
+            fft_reg<R2>(u);
+        }
+        __syncthreads();
+        if (task2) {
+            // z[j] = conj(result[j]); x[2j] = 2 Re z, x[2j+1] = 2 Im z: the row's real values / 2, in place
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) {
+                const float2 zz = u[bitrev(k2, ilog2(R2))];
+                Y[r2 * MP + k1 + R1 * k2] = make_float2(zz.x, -zz.y);
+            }
+        }
+        __syncthreads();
+        // the next position's rows: in flight across the product loop (the longest phase, and the one with the fewest live
+        // registers - held across the two register FFTs the 34 extra VGPRs spilled)
+        if (PREFETCH && pos + gridDim.x < nrows) fetch(pos + gridDim.x);
+#ifndef TRI_FUSE_ABLATE
+#define TRI_FUSE_ABLATE 0           // perf experiments: 1 = no products, 2 = no global loads, 4 = no transform
+#endif
+        if (worker && !(TRI_FUSE_ABLATE & 1)) {
+            // two cells per LDS read; the part's <= N / parts products are summed in fp32 (each product carries 6e-8 already;
+            // ~90 terms add 6e-7 of the PART's sum, random from part to part), the parts and positions in double
+            const float* f = reinterpret_cast<const float*>(Y);
+            float s0 = 0.f, s1 = 0.f;
+            if (wave_pairs) {
+#pragma unroll 4
+                for (int c = c_lo; c < c_hi; c += 2) {
+                    const float2 x = *reinterpret_cast<const float2*>(f + ia + c), y = *reinterpret_cast<const float2*>(f + ic + c);
+                    s0 = fmaf(x.x * x.x, y.x, s0);
+                    s1 = fmaf(x.y * x.y, y.y, s1);
+                }
+            } else {
+#pragma unroll 4
+                for (int c = c_lo; c < c_hi; c += 2) {
+                    const float2 x = *reinterpret_cast<const float2*>(f + ia + c), y = *reinterpret_cast<const float2*>(f + ib + c);
+                    const float2 z = *reinterpret_cast<const float2*>(f + ic + c);
+                    s0 = fmaf(x.x * y.x, z.x, s0);
+                    s1 = fmaf(x.y * y.y, z.y, s1);
+                }
+            }
+            acc += (double)s0 + (double)s1;
+        }
+        __syncthreads();                                          // the rows are overwritten by the next position
+    }
+    partial[(size_t)blockIdx.x * NT + threadIdx.x] = worker ? acc : 0.0;
+}
+
+// out[t] = factor * sum over workgroups and parts of partial[block][part * ntri + t], fixed order
+__global__ void __launch_bounds__(256)
+triangles_reduce_kernel(const double* __restrict__ partial, int nblocks, int nthreads, int ntri, int parts, double factor,
+                        double* __restrict__ out) {
+    const int t = blockIdx.x;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblocks * parts; i += 256) {
+        const int blk = i / parts, part = i % parts;
+        acc += partial[(size_t)blk * nthreads + part * ntri + t];
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    __shared__ double w[4];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[t] = factor * ((w[0] + w[1]) + (w[2] + w[3]));
+}
+
 // -------------------------------------------------- low-k side channel in double
 // The fp32 transform leaves a white round-off floor of ~1e-7 of the field's rms amplitude on every mode.  A
 // spectrum with a large dynamic range (the cold lattice of the bench: the lowest shells hold 1e-5 of the peak
@@ -1730,7 +1896,8 @@ extern "C" int ast_fft_tile_c2r_3d_batch(const void* spec, void* const* works, v
     sb.count = cb.count = count;
     for (int i = 0; i < SHELL_BATCH; ++i) {
         const int j = i < count ? i : count - 1;                  // (unused slots repeat the last shell)
-        AST_CHECK_ARG(works[j] != nullptr && outs[j] != nullptr && works[j] != spec && works[j] != outs[j]);
+        AST_CHECK_ARG(works[j] != nullptr && works[j] != spec);
+        AST_CHECK_ARG(!(passes & 2) || (outs[j] != nullptr && works[j] != outs[j]));       // (no z pass: no output needed)
         AST_CHECK_ARG(m_lo[j] >= 0 && m_hi[j] > m_lo[j]);
         sb.work[i] = (float2*)works[j];
         sb.lo2[i] = (long long)m_lo[j] * m_lo[j];
@@ -1740,7 +1907,7 @@ extern "C" int ast_fft_tile_c2r_3d_batch(const void* spec, void* const* works, v
         cb.kmax[i] = (size_t)m_hi[j] < nz ? m_hi[j] : (int)nz;
     }
     for (int i = 0; i < count; ++i)
-        for (int k = 0; k < i; ++k) AST_CHECK_ARG(works[i] != works[k] && outs[i] != outs[k]);
+        for (int k = 0; k < i; ++k) AST_CHECK_ARG(works[i] != works[k] && (!(passes & 2) || outs[i] != outs[k]));
     if (passes & 1) {
         AST_PROF("fft_tile.c2c_inv", s);
         ShellMask mx{(const float2*)spec, 0, 1, 0, 0, n * nz, nz};      // radii come from the batch; hi2 > 0 switches the pruning on
@@ -1898,4 +2065,61 @@ extern "C" int ast_fft_tile_disc_block_power(void* block, void* scratch, size_t 
     shell_partials_stage2_kernel<<<(nb + 7) / 8, 256, 0, s>>>(partial2, nb, boxsize * boxsize * boxsize, first_bin, psum);
     AST_CHECK_LAUNCH();
     return AST_OK;
+}
+
+// ------------------------------------------------------------------ bispectrum: z passes of all shells + triangle sums in one kernel
+// works[s]: shell s's scratch spectrum after the masked x and y inverse passes (ast_fft_tile_c2r_3d_batch with passes = 1),
+// (n, n, work_pitch) complex64; m_hi[s] its outer radius (k_z < m_hi is all the passes wrote).  out_d[t] = sum over the n^3 cells of
+// f_a f_b f_c for triangle t = (a, b, c) (shell slots, device int array tri_d (ntri, 3)), f_s = scale * C2R_z(works[s]) - what
+// ast_fft_tile_c2r_3d_batch(passes = 2) followed by ast_triple_product_sums computes, without the real cubes ever reaching HBM.
+// nshells <= 32, ntri <= 512 (1024 at n = 1024).  scratch_d: ast_fft_tile_c2r_triangles_scratch_bytes().
+constexpr int TRI_GRID_MAX = 2048;
+extern "C" size_t ast_fft_tile_c2r_triangles_scratch_bytes(void) { return (size_t)TRI_GRID_MAX * 1024 * sizeof(double); }
+
+extern "C" int ast_fft_tile_c2r_triangles(void* const* works, const int* m_hi, int nshells, int dtype, size_t n, size_t work_pitch,
+                                          double scale, const int* tri, int ntri, void* scratch, double* out, void* stream) {
+    AST_CHECK_ARG(works != nullptr && m_hi != nullptr && tri != nullptr && scratch != nullptr && out != nullptr);
+    AST_CHECK_ARG(ast_fft_tile_supported(dtype, n) && nshells >= 1 && nshells <= TRI_ROWS);
+    const size_t nz = n / 2 + 1, wp = work_pitch ? work_pitch : nz;
+    AST_CHECK_ARG(wp >= nz);
+    const int nt = TRI_ROWS * (n == 1024 ? 32 : 16);
+    AST_CHECK_ARG(ntri >= 1 && ntri <= nt);
+    const float2* tw = g_tw.get((int)n);
+    if (!tw) { ast::set_error("ast_fft_tile_c2r_triangles: twiddle table allocation failed"); return AST_ERR_HIP; }
+    TriShells sh;
+    sh.count = nshells;
+    for (int i = 0; i < TRI_ROWS; ++i) {
+        const int j = i < nshells ? i : nshells - 1;
+        AST_CHECK_ARG(works[j] != nullptr && m_hi[j] > 0);
+        sh.work[i] = (const float2*)works[j];
+        sh.kmax[i] = (size_t)m_hi[j] < nz ? m_hi[j] : (int)nz;
+    }
+    hipStream_t s = ast::as_stream(stream);
+    const int parts = nt / ntri;
+    const size_t nrows = n * n;
+    AST_PROF("fft_tile.c2r_triangles", s);
+    auto go = [&](auto r1, auto r2) -> int {
+        constexpr int R1 = decltype(r1)::value, R2 = decltype(r2)::value, M = R1 * R2, NT = TRI_ROWS * R2;
+        constexpr int BUF = TRI_ROWS * (R1 * (R2 + 1) > M + 1 ? R1 * (R2 + 1) : M + 1);
+        const size_t lds = (size_t)(BUF + 2 * M) * sizeof(float2);
+        static ast::PerDeviceOnce attr_once;
+        if (attr_once.need()) {
+            AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rows_c2r_triangles_kernel<R1, R2>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_once.mark();
+        }
+        // persistent workgroups: as many as stay resident (LDS: two per CU up to n = 512, one at 1024), a few rounds each
+        const size_t resident = 256 * (lds <= 80 * 1024 ? 2 : 1);
+        const int blocks = (int)std::min<size_t>(std::min<size_t>(nrows, resident * 4), (size_t)TRI_GRID_MAX);
+        rows_c2r_triangles_kernel<R1, R2><<<blocks, NT, lds, s>>>(sh, tw, nrows, wp, tri, ntri, parts, (double*)scratch);
+        AST_CHECK_LAUNCH();
+        // every stored value is x / (2 scale'): the kernel keeps z, x = 2 z; three factors of 2 scale
+        const double f = 2.0 * scale;
+        triangles_reduce_kernel<<<ntri, 256, 0, s>>>((const double*)scratch, blocks, NT, ntri, parts, f * f * f, out);
+        AST_CHECK_LAUNCH();
+        return AST_OK;
+    };
+    if (n == 1024) return go(std::integral_constant<int, 16>{}, std::integral_constant<int, 32>{});
+    if (n == 512) return go(std::integral_constant<int, 16>{}, std::integral_constant<int, 16>{});
+    return go(std::integral_constant<int, 8>{}, std::integral_constant<int, 16>{});
 }

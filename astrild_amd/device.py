@@ -953,6 +953,38 @@ def bispectrum(field, boxsize, edges, triangles):
         amp = float(lo_hi.abs().max()) or 1.0
         if not np.isfinite(amp):
             raise _lib.AstrildHipError("bispectrum: the field holds inf / NaN")
+    # FUSED tail (default where it applies: fp32 tile sizes, <= 32 shells): every shell's masked x and y passes into its OWN
+    # scratch spectrum, then ONE kernel that runs the z passes of all shells row by row and forms the triangle sums from
+    # LDS (ast_fft_tile_c2r_triangles) - the 31 real cubes (0.5 GB each at 512^3, written once and read back once) never
+    # exist.  ASTRILD_BISPEC_FUSED=0: the cubes and ast_triple_product_sums, as before.
+    import os
+    if tile and len(used) <= 32 and os.environ.get("ASTRILD_BISPEC_FUSED", "1") != "0":
+        L = _lib.lib()
+        pitch = tile_work_pitch(n)
+        works = [scratch] + [torch.empty_like(scratch) for _ in range(len(used) - 1)]
+        wp = (ct.c_void_p * len(used))(*[w.data_ptr() for w in works])
+        hi = (ct.c_int * len(used))(*[edges[s + 1] for s in used])
+        for i, s_ in enumerate(used):           # shell by shell: a shell's y pass finds its x pass's output in the Infinity Cache
+            one_w = (ct.c_void_p * 1)(works[i].data_ptr())
+            one_o = (ct.c_void_p * 1)(None)                          # (no output: passes = 1 stops before the z pass)
+            check(L.ast_fft_tile_c2r_3d_batch(ptr(spec), one_w, one_o, F32, n, (ct.c_int * 1)(edges[s_]), (ct.c_int * 1)(edges[s_ + 1]),
+                                              1, 1.0, 1, pitch, stream()), "ast_fft_tile_c2r_3d_batch")
+        slot = {s_: i for i, s_ in enumerate(used)}
+        tri_d = torch.tensor([[slot[v] for v in t] for t in triangles], dtype=torch.int32).to(spec.device)
+        out = torch.empty(len(triangles), dtype=torch.float64, device=spec.device)
+        fscr = torch.empty(int(L.ast_fft_tile_c2r_triangles_scratch_bytes()) // 8, dtype=torch.float64, device=spec.device)
+        num = np.empty(len(triangles))
+        for b0 in range(0, len(triangles), 512):
+            nb_ = min(512, len(triangles) - b0)
+            check(L.ast_fft_tile_c2r_triangles(wp, hi, len(used), F32, n, pitch, 1.0 / amp, ptr(tri_d[b0:]), nb_, ptr(fscr), ptr(out[b0:]),
+                                               stream()), "ast_fft_tile_c2r_triangles")
+        num = out.cpu().numpy() * amp ** 3
+        del works
+        kf = 2.0 * np.pi / boxsize
+        kmid = np.array([[kf * 0.5 * (edges[s] + edges[s + 1]) for s in t] for t in triangles])
+        with np.errstate(invalid="ignore", divide="ignore"):
+            b = float(boxsize) ** 6 * num / (ntri * float(n) ** 3)
+        return {"B": b, "ntri": ntri, "k": kmid, "ntri_residual": _tri_cache[key + ("residual",)]}
     dfields = {}
     if tile:
         # the masked, pruned inverse tile passes (shell mask fused into the first pass's loads), shell by shell through ONE

@@ -298,13 +298,15 @@ def bispectrum_leg(dev, n=512, width=8):
     # them and writes the k_z tiles below m for every (x, k_y), the z pass reads k_z < m and writes the real cube - and one
     # read of the 31 cubes by the triangle sums.  (scripts/pmc_per_launch.py prints the same model beside the counters.)
     nz = n // 2 + 1
-    alg = 24 * ng + nsh * 4 * ng
+    # (round 5: the z passes of all shells and the triangle sums are ONE kernel - the real cubes are neither written nor read)
+    fused_tail = nsh <= 32 and os.environ.get("ASTRILD_BISPEC_FUSED", "1") != "0"
+    alg = 24 * ng + (0 if fused_tail else nsh * 4 * ng)
     ky2 = np.minimum(np.arange(n), n - np.arange(n)).astype(np.int64) ** 2
     for sh in range(nsh):
         m = edges[sh + 1]
         cols16 = sum(int(np.count_nonzero(ky2 + c0 * c0 < m * m)) * min(16, nz - c0) for c0 in range(0, nz, 16))
         kz_t = sum(min(16, nz - c0) for c0 in range(0, nz, 16) if c0 < m)
-        alg += 8 * (cols16 * min(n, 2 * m) + 2 * cols16 * n + n * n * kz_t + n * n * min(m, nz)) + 4 * ng
+        alg += 8 * (cols16 * min(n, 2 * m) + 2 * cols16 * n + n * n * kz_t + n * n * min(m, nz)) + (0 if fused_tail else 4 * ng)
     unpruned = nsh * 24 * ng + nsh * 4 * ng
     return {"metric": f"bispectrum on {n}^3 grid: {nsh} shells of width {width} k_F, {len(tri)} triangle bins, fp32",
             "value": len(tri) / dt, "unit": "triangle bins/s", "ms_total": dt * 1e3,
@@ -315,8 +317,10 @@ def bispectrum_leg(dev, n=512, width=8):
                                             if traffic and traffic["GB_per_call"] else None),
             "ntri_total": int(np.sum(res["ntri"])), "ntri_residual": res["ntri_residual"],
             "first_call_ms_with_triangle_counts": round(first_ms, 1),
-            "note": "value / ms_total time the estimator's numerator (31 masked, pruned inverse FFTs + all 75 cube sums in one "
-                    "pass over the 31 fields); alg_GB / frac price the PRUNED passes (what a shell leaves nonzero; unpruned_GB: three "
+            "fused_tail": fused_tail,
+            "note": "value / ms_total time the estimator's numerator (31 masked, pruned x / y inverse passes, then ONE kernel that runs "
+                    "the z passes of all shells row by row and forms the 75 triangle sums from LDS - no real cube reaches HBM; "
+                    "ASTRILD_BISPEC_FUSED=0: 31 cubes written and read back by the triangle kernel); alg_GB / frac price the PRUNED passes (what a shell leaves nonzero; unpruned_GB: three "
                     "full passes per shell), frac_of_peak_on_bytes_moved uses the bytes the PMC counters saw; the triangle counts (31 "
                     "forward float64 transforms of the shell indicators + the sums) are geometry, computed on the first call "
                     "and cached - first_call_ms includes them",

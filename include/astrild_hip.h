@@ -350,6 +350,15 @@ int ast_fft_tile_c2r_3d_batch(const void* spec_d, void* const* works, void* cons
  * go through scratch_d (line-aligned row pitch); the x pass adds w |delta_k|^2 of its
  * modes to per-workgroup shell tables instead of storing delta_k, and a fixed-order
  * reduction adds them into psum_d (same meaning as in ast_power_bin_1d; auto power). */
+/* The bispectrum estimator's last two steps in ONE kernel: the z passes (C2R) of all shells - works[s] = shell s's scratch
+ * spectrum after the masked x and y passes (ast_fft_tile_c2r_3d_batch, passes = 1), (n, n, work_pitch) complex64, m_hi[s] its
+ * outer radius - and the triangle sums out_d[t] = sum_x f_a f_b f_c, f_s = scale * C2R_z(works[s]), for the ntri triangles
+ * tri_d[(ntri, 3)] of shell slots.  One workgroup transforms one (x, y) row of EVERY shell and forms the sums from LDS: the
+ * real cubes (31 x 0.5 GB written and read back at 512^3) never reach HBM.  bispectrum_3d.py:165-215 holds no such
+ * arithmetic; this is the estimator its docstring cites.  nshells <= 32; ntri <= 512 (1024 at n = 1024). */
+size_t ast_fft_tile_c2r_triangles_scratch_bytes(void);
+int ast_fft_tile_c2r_triangles(void* const* works, const int* m_hi, int nshells, int dtype, size_t n, size_t work_pitch,
+                               double scale, const int* tri_d, int ntri, void* scratch_d, double* out_d, void* stream);
 size_t ast_fft_tile_power_scratch_bytes(size_t n);
 /* test hook: out_d[v] = the fused binning's floor(sqrt(v)) (one hardware sqrt, no repair), v < count */
 int ast_fft_tile_isqrt_table(int* out_d, int count, void* stream);

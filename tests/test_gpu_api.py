@@ -183,6 +183,38 @@ def test_bispectrum_of_a_field_in_physical_units_does_not_overflow():
     npt.assert_allclose(big["B"] / 1e39, base["B"], rtol=2e-5, atol=1e-6 * np.abs(base["B"]).max())
 
 
+def test_bispectrum_fused_z_passes_and_triangle_sums(monkeypatch):
+    """The estimator's tail in ONE kernel (ast_fft_tile_c2r_triangles: the z passes of all shells row by row, the triangle sums
+    from LDS, no real cube ever written) against the route through the cubes (ASTRILD_BISPEC_FUSED=0) and against the oracle
+    (float64 numpy) at 256^3: equilateral, squeezed, isosceles and scalene bins."""
+    import torch
+    from astrild_amd import device as dev
+    torch.cuda.set_device(0)
+    n, L = 256, 500.0
+    rng = np.random.default_rng(9)
+    f = rng.standard_normal((n, n, n))
+    f = (f + 0.3 * f * f).astype(np.float32)
+    edges = list(range(1, n // 2 + 1, 8))
+    nsh = len(edges) - 1
+    tri = [(i, i, i) for i in range(nsh)] + [(0, i, i) for i in range(1, nsh)] + [(1, 2, 3), (2, 5, 6), (0, 7, 7), (3, 4, 6)]
+    t = dev.as_device(f)
+    dev._tri_cache.clear()
+    fused = dev.bispectrum(t, L, edges, tri)
+    monkeypatch.setenv("ASTRILD_BISPEC_FUSED", "0")
+    cubes = dev.bispectrum(t, L, edges, tri)
+    monkeypatch.delenv("ASTRILD_BISPEC_FUSED")
+    assert np.array_equal(fused["ntri"], cubes["ntri"])
+    ok_ = fused["ntri"] > 0
+    scale = np.abs(cubes["B"][ok_]).max()
+    npt.assert_allclose(fused["B"][ok_], cubes["B"][ok_], rtol=1e-5, atol=1e-6 * scale)      # same fp32 fields, other summation order
+    b, ntri = ob.bispectrum_fft(f.astype(np.float64), L, edges, tri)
+    assert np.array_equal(fused["ntri"], np.rint(ntri).astype(np.int64))
+    npt.assert_allclose(fused["B"][ok_], b[ok_], rtol=2e-4, atol=1e-5 * scale)
+    again = dev.bispectrum(t, L, edges, tri)
+    assert np.array_equal(again["B"], fused["B"], equal_nan=True)                            # fixed summation order
+    dev._tri_cache.clear()
+
+
 def _kappa_frame(npix, seed=0):
     rng = np.random.default_rng(seed)
     c2, c3 = ok.C_LIGHT_KMS ** 2, ok.C_LIGHT_KMS ** 3
