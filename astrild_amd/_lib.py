@@ -61,6 +61,7 @@ SIGNATURES = {
     "ast_fft_tile_c2c": (_i, [_vp, _i, _sz, _sz, _sz, _sz, _sz, _d, _vp]),
     "ast_fft_tile_c2c_packed": (_i, [_vp, _vp, _i, _sz, _sz, _sz, _sz, _i, _i, _vp, _d, _vp]),
     "ast_fft_tile_rows_r2c": (_i, [_vp, _vp, _i, _sz, _sz, _sz, _sz, _d, _vp]),
+    "ast_fft_tile_rows_r2c_slab_halo": (_i, [_vp, _vp, _i, _sz, _sz, _sz, _d, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ast_fft_tile_r2c_3d": (_i, [_vp, _vp, _i, _sz, _d, _vp]),
     "ast_fft_tile_c2r_3d": (_i, [_vp, _vp, _vp, _i, _sz, _i, _i, _d, _vp]),
     "ast_fft_tile_power_scratch_bytes": (_sz, [_sz]),

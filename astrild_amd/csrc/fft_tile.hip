@@ -493,13 +493,19 @@ __device__ constexpr double kS16f[16] = {0.0, -0.38268343236508977, -0.707106781
 // its halo records; the up to three record lines that end in a border row are added as the row is
 // loaded — sum of the records first, then onto the row, the order of column_fold_kernel, so the
 // result is bit-identical to folding first.  Rows are (x, y) lines of the periodic n^3 grid.
+// SlabFold (FOLDW != 0, slab buffers): the rows are the (x, y) lines of the buffer planes xb0, xb0 + 1, ... of a slab buffer
+// of ntx tile rows (not periodic in x); only planes of the tile rows [row_lo, row_hi) are folded on load - the rows that hold
+// ghost planes were folded by the paint's own FOLD stage before their planes went to the neighbours.  ntx = 0: the whole
+// periodic grid, every row folded.
+struct SlabFold { int xb0 = 0, ntx = 0, row_lo = 0, row_hi = 0; bool ranges = false; };      // ranges: plane ranges of a buffer (ntx = 0: the periodic grid)
+
 template <int R1, int R2, int C, int FOLDW, bool LOWK = false>
 __global__ void __launch_bounds__(C * R2)
 __attribute__((amdgpu_waves_per_eu(LOWK ? 4 : 1, LOWK ? 4 : 8)))     // LOWK: keep two workgroups per CU (128 VGPRs)
 rows_r2c_kernel(const float* __restrict__ in, float2* __restrict__ out, const float2* __restrict__ tw_g,
                 size_t nrows, size_t in_pitch, size_t out_pitch, float scale, float mean,
                 const float* __restrict__ rec, const double2* __restrict__ lowk_lane = nullptr,
-                double* __restrict__ lowz = nullptr) {
+                double* __restrict__ lowz = nullptr, SlabFold sf = SlabFold{}) {
     constexpr int M = R1 * R2, N = 2 * M;
     constexpr int NT = C * R2;
     constexpr int R2P = R2 + 1;
@@ -522,7 +528,16 @@ rows_r2c_kernel(const float* __restrict__ in, float2* __restrict__ out, const fl
             const int ng = (int)(2 * M);
             const size_t row = min(row0 + r, nrows - 1);
             const float* src[3];
-            const int ns = ast::halo_sources<float, W>(rec, (int)(row / ng), (int)(row % ng), ng, ng / ast::TX, ng / ast::TY, src);
+            int ns;
+            if (sf.ntx == 0) {
+                const int xb = sf.xb0 + (int)(row / ng), trow = xb / ast::TX;
+                ns = !sf.ranges || (trow >= sf.row_lo && trow < sf.row_hi)
+                         ? ast::halo_sources<float, W>(rec, xb, (int)(row % ng), ng, ng / ast::TX, ng / ast::TY, src) : 0;
+            } else {
+                const int xb = sf.xb0 + (int)(row / ng), trow = xb / ast::TX;
+                ns = trow >= sf.row_lo && trow < sf.row_hi
+                         ? ast::halo_sources<float, W>(rec, xb, (int)(row % ng), ng, sf.ntx, ng / ast::TY, src, false) : 0;
+            }
             if (ns > 0) {                    // 15 of 64 rows (CIC); the loads and adds stay inside the branch
                 float2 h[R1];
 #pragma unroll
@@ -1310,7 +1325,7 @@ int dispatch_c2c(size_t n, float2* d, const float2* tw, size_t elem_stride, size
 template <int R1, int R2, int C, int FOLDW = 0, bool LOWK = false>
 int launch_r2c(const float* in, float2* out, const float2* tw, size_t nrows, size_t in_pitch, size_t out_pitch,
                float scale, float mean, hipStream_t s, const float* rec = nullptr, const double2* lowk_lane = nullptr,
-               double* lowz = nullptr) {
+               double* lowz = nullptr, SlabFold sf = SlabFold{}) {
     constexpr int M = R1 * R2, N = 2 * M, NT = C * R2;
     constexpr int BUF = C * (R1 * (R2 + 1) > M + 1 ? R1 * (R2 + 1) : M + 1);
     const size_t lds = (size_t)(BUF + N) * sizeof(float2);
@@ -1323,7 +1338,7 @@ int launch_r2c(const float* in, float2* out, const float2* tw, size_t nrows, siz
     const size_t blocks = (nrows + C - 1) / C;
     AST_CHECK_ARG(blocks < 0x7fffffffull);
     rows_r2c_kernel<R1, R2, C, FOLDW, LOWK><<<(unsigned)blocks, NT, lds, s>>>(in, out, tw, nrows, in_pitch, out_pitch, scale, mean, rec,
-                                                                             lowk_lane, lowz);
+                                                                             lowk_lane, lowz, sf);
     AST_CHECK_LAUNCH();
     return AST_OK;
 }
@@ -1536,7 +1551,7 @@ struct LowkLaneCache {
 
 static int rows_r2c_impl(const void* in, void* out, int dtype, size_t n, size_t nrows, size_t in_pitch,
                          size_t out_pitch, double scale, double mean, void* stream, const void* rec = nullptr,
-                         int window = 0, double* lowz = nullptr) {
+                         int window = 0, double* lowz = nullptr, SlabFold sf = SlabFold{}) {
     AST_CHECK_ARG(in != nullptr && out != nullptr && in != out && nrows >= 1);
     AST_CHECK_ARG(ast_fft_tile_supported(dtype, n));
     AST_CHECK_ARG(in_pitch >= n && in_pitch % 2 == 0 && out_pitch >= n / 2 + 1);
@@ -1551,29 +1566,29 @@ static int rows_r2c_impl(const void* in, void* out, int dtype, size_t n, size_t 
         if (!lane) { ast::set_error("ast_fft_tile_rows_r2c: low-k lane table allocation failed"); return AST_ERR_HIP; }
         const float* h = (const float*)rec;
         const float sc = (float)scale, mn = (float)mean;
-        AST_CHECK_ARG(rec == nullptr || (nrows == n * n && in_pitch == n && (window == AST_WIN_CIC || window == AST_WIN_TSC)));
+        AST_CHECK_ARG(rec == nullptr || ((nrows == n * n || sf.ranges) && in_pitch == n && (window == AST_WIN_CIC || window == AST_WIN_TSC)));
         auto go = [&](auto r1, auto r2) {
             constexpr int R1 = decltype(r1)::value, R2 = decltype(r2)::value;
             if (rec == nullptr) return launch_r2c<R1, R2, 16, 0, true>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, nullptr, lane, lowz);
-            if (window == AST_WIN_CIC) return launch_r2c<R1, R2, 16, 2, true>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h, lane, lowz);
-            return launch_r2c<R1, R2, 16, 3, true>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h, lane, lowz);
+            if (window == AST_WIN_CIC) return launch_r2c<R1, R2, 16, 2, true>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h, lane, lowz, sf);
+            return launch_r2c<R1, R2, 16, 3, true>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h, lane, lowz, sf);
         };
         if (n == 1024) return go(std::integral_constant<int, 16>{}, std::integral_constant<int, 32>{});
         if (n == 512) return go(std::integral_constant<int, 16>{}, std::integral_constant<int, 16>{});
         return go(std::integral_constant<int, 8>{}, std::integral_constant<int, 16>{});
     }
-    if (rec != nullptr) {                    // fold the paint's halo records while loading (whole periodic grid)
-        AST_CHECK_ARG(nrows == n * n && in_pitch == n && (window == AST_WIN_CIC || window == AST_WIN_TSC));
+    if (rec != nullptr) {                    // fold the paint's halo records while loading (whole periodic grid, or a slab buffer's planes)
+        AST_CHECK_ARG((nrows == n * n || sf.ranges) && in_pitch == n && (window == AST_WIN_CIC || window == AST_WIN_TSC));
         const float* h = (const float*)rec;
         const float sc = (float)scale, mn = (float)mean;
         if (window == AST_WIN_CIC) {
-            if (n == 1024) return launch_r2c<16, 32, 16, 2>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h);
-            if (n == 512) return launch_r2c<16, 16, 16, 2>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h);
-            return launch_r2c<8, 16, 16, 2>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h);
+            if (n == 1024) return launch_r2c<16, 32, 16, 2>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h, nullptr, nullptr, sf);
+            if (n == 512) return launch_r2c<16, 16, 16, 2>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h, nullptr, nullptr, sf);
+            return launch_r2c<8, 16, 16, 2>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h, nullptr, nullptr, sf);
         }
-        if (n == 1024) return launch_r2c<16, 32, 16, 3>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h);
-        if (n == 512) return launch_r2c<16, 16, 16, 3>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h);
-        return launch_r2c<8, 16, 16, 3>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h);
+        if (n == 1024) return launch_r2c<16, 32, 16, 3>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h, nullptr, nullptr, sf);
+        if (n == 512) return launch_r2c<16, 16, 16, 3>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h, nullptr, nullptr, sf);
+        return launch_r2c<8, 16, 16, 3>(i, o, tw, nrows, in_pitch, out_pitch, sc, mn, s, h, nullptr, nullptr, sf);
     }
     if (n == 1024) return launch_r2c<16, 32, 16>(i, o, tw, nrows, in_pitch, out_pitch, (float)scale, (float)mean, s);
     if (n == 512) return launch_r2c<16, 16, 16>(i, o, tw, nrows, in_pitch, out_pitch, (float)scale, (float)mean, s);
@@ -1599,6 +1614,25 @@ extern "C" int ast_fft_tile_rows_r2c_lowz(const void* in, void* out, int dtype, 
                                           size_t out_pitch, double scale, void* lowz, void* stream) {
     AST_CHECK_ARG(lowz != nullptr);
     return rows_r2c_impl(in, out, dtype, n, nrows, in_pitch, out_pitch, scale, 0.0, stream, nullptr, 0, (double*)lowz);
+}
+
+// The z pass of a plane range of a SLAB buffer painted by ast_paint_tiled_stage, folding the paint's halo records as the rows
+// are loaded (what AST_PAINT_STAGE_FOLD would have added, in the same order: bit-identical): in_d = buffer plane xb0 (nrows =
+// planes * n rows of n reals), halo_rec_d from ast_paint_tiled_halo for the same buffer of nx_alloc planes; only planes whose
+// tile row lies in [fold_row_lo, fold_row_hi) are folded here (the rows that hold ghost planes are folded by the paint, before
+// their planes travel).  lowz_d (optional): the low-k z sums of these rows, as ast_fft_tile_rows_r2c_lowz.
+extern "C" int ast_fft_tile_rows_r2c_slab_halo(const void* in, void* out, int dtype, size_t n, size_t nrows, size_t out_pitch,
+                                               double scale, const void* halo_rec, int window, int xb0, int nx_alloc,
+                                               int fold_row_lo, int fold_row_hi, void* lowz, void* stream) {
+    AST_CHECK_ARG(halo_rec != nullptr && nx_alloc >= 1 && xb0 >= 0 && nrows % n == 0 && xb0 + (int)(nrows / n) <= nx_alloc);
+    AST_CHECK_ARG(fold_row_lo >= 0 && fold_row_hi >= fold_row_lo);
+    SlabFold sf;
+    sf.xb0 = xb0;
+    sf.ntx = (size_t)nx_alloc == n ? 0 : (nx_alloc + ast::TX - 1) / ast::TX;        // a buffer of all n planes is the periodic grid
+    sf.row_lo = fold_row_lo;
+    sf.row_hi = fold_row_hi;
+    sf.ranges = true;
+    return rows_r2c_impl(in, out, dtype, n, nrows, n, out_pitch, scale, 0.0, stream, halo_rec, window, (double*)lowz, sf);
 }
 
 // The three passes of an (n, n, n) real -> (n, n, n/2+1) half-spectrum transform,

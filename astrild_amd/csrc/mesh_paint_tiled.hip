@@ -2115,8 +2115,8 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
                 z_seam_kernel<T, W><<<ncol, 256, 0, s>>>(w.zrec, g, scale, (uint32_t)std::min<unsigned long long>(5ull * w.cap, 0x3fffffffull),
                                                           mass ? mass_bound : 1.0, grid, (T*)w.rec, offset, dropped, col0, plan.nseg);
             }
-        } else if (sel.stage == AST_PAINT_STAGE_FOLD) {
-            {
+        } else if (sel.stage == AST_PAINT_STAGE_FOLD || sel.stage == AST_PAINT_STAGE_LATE) {
+            if (sel.stage == AST_PAINT_STAGE_FOLD) {
                 AST_PROF("paint_tiled.fold", s);
                 column_fold_kernel<T, W><<<ncol, 256, 0, s>>>((const T*)w.rec, g, grid, col0);
             }
@@ -2524,7 +2524,7 @@ extern "C" int ast_paint_tiled_stage(int window, int dtype, const void* pos, con
                                      double shift_cells, int stage, int row0, int nrows, int closed_row0, int closed_nrows,
                                      void* stream) {
     AST_CHECK_ARG(stage == AST_PAINT_STAGE_GROUP || stage == AST_PAINT_STAGE_WALK || stage == AST_PAINT_STAGE_FOLD ||
-                  stage == AST_PAINT_STAGE_GROUP_PART || stage == AST_PAINT_STAGE_RESET);
+                  stage == AST_PAINT_STAGE_GROUP_PART || stage == AST_PAINT_STAGE_RESET || stage == AST_PAINT_STAGE_LATE);
     StageSel sel;
     sel.stage = stage;
     sel.row0 = row0;

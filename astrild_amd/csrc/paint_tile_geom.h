@@ -28,8 +28,10 @@ template <int W> struct RingMap {
 
 // The record lines that end in the owned grid line (x, y) of a periodic (nx_alloc = n) grid: up to 3,
 // in the fixed order the fold adds them (dx outer, dy inner).  Returns their count.
+// x_periodic = false: a slab buffer of ntx tile rows (x = buffer plane): neighbours past either end of the buffer do not
+// exist (what they would have brought arrives with the ghost planes).
 template <typename T, int W>
-__device__ inline int halo_sources(const T* rec, int x, int y, int n, int ntx, int nty, const T* (&src)[3]) {
+__device__ inline int halo_sources(const T* rec, int x, int y, int n, int ntx, int nty, const T* (&src)[3], bool x_periodic = true) {
     constexpr int LO = Window<W>::LO;
     using RM = RingMap<W>;
     const int tx = x / TX, ao = x % TX, ty = y / TY, bo = y % TY;
@@ -44,7 +46,8 @@ __device__ inline int halo_sources(const T* rec, int x, int y, int n, int ntx, i
             if (dx == 0 && dy == 0) continue;
             const int a = ao + LO - dx * TX, b = bo + LO - dy * TY;   // this cell in the neighbour's LDS frame
             if (a < 0 || a >= RM::LX || b < 0 || b >= RM::LY) continue;
-            const int ntx_ = wrap1(tx + dx, ntx), nty_ = wrap1(ty + dy, nty);
+            if (!x_periodic && (tx + dx < 0 || tx + dx >= ntx)) continue;
+            const int ntx_ = x_periodic ? wrap1(tx + dx, ntx) : tx + dx, nty_ = wrap1(ty + dy, nty);
             const T* p = rec + ((size_t)(ntx_ * nty + nty_) * RM::COUNT + RM::cell(a, b)) * (size_t)n;
             s0 = ns == 0 ? p : s0;
             s1 = ns == 1 ? p : s1;

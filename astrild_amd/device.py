@@ -465,7 +465,41 @@ class StagedPaint:
         self._stage(1, row0, nrows)
 
     def fold(self, row0, nrows):
-        self._stage(2, row0, nrows)
+        """FOLD of the tile rows [row0, row0 + nrows).  After :meth:`defer_folds` only the rows named there get their records
+        added here; the others get their overflow-list deposits only (AST_PAINT_STAGE_LATE) and their records when the
+        consumer's z pass loads the planes (:meth:`halo_args`)."""
+        if self._explicit_rows is None:
+            self._stage(2, row0, nrows)
+            return
+        r = row0
+        while r < row0 + nrows:
+            kind = r in self._explicit_rows
+            e = r
+            while e < row0 + nrows and (e in self._explicit_rows) == kind:
+                e += 1
+            self._stage(2 if kind else 5, r, e - r)
+            r = e
+
+    _explicit_rows = None
+
+    def defer_folds(self, explicit_rows):
+        """From now on only ``explicit_rows`` (the tile rows that hold ghost planes: their planes travel before any transform)
+        are folded by fold(); every other row's halo records are added by the z pass that reads its planes
+        (ast_fft_tile_rows_r2c_slab_halo) - one kernel and one read-modify-write of the border lines less per row.  The rows
+        folded on load must form one range [lo, hi) of the buffer's rows."""
+        explicit = set(int(r) for r in explicit_rows)
+        rest = [r for r in range(self.nrows_total) if r not in explicit]
+        if rest and rest != list(range(rest[0], rest[-1] + 1)):
+            raise ValueError("the rows folded on load must be one contiguous range")
+        rec = ct.c_void_p()
+        check(_lib.lib().ast_paint_tiled_halo(ptr(self.ws), self.win, self.code, self.npart, self.n, self.nx, self.flags, ct.byref(rec)),
+              "ast_paint_tiled_halo")
+        self._explicit_rows = explicit
+        self._halo = (rec, self.win, rest[0] if rest else 0, rest[-1] + 1 if rest else 0)
+
+    def halo_args(self):
+        """(record pointer, window code, first tile row folded on load, one past the last) or None."""
+        return None if self._explicit_rows is None else self._halo
 
     def check(self):
         nd = int(self.dropped.item())

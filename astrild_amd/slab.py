@@ -212,7 +212,7 @@ class HipSlabOps:
         return dict(n=n, parts=parts, r1=int(r1_out.value), tile=16, S=S, cumS=[sum(S[:r]) for r in range(parts)], total=sum(S),
                     part_of=[int(v) for v in owner])
 
-    def fft2d_planes_disc(self, planes, spec, packed, layout, self_part, self_dst, lowz=None):
+    def fft2d_planes_disc(self, planes, spec, packed, layout, self_part, self_dst, lowz=None, halo=None):
         """z rows of the planes into `spec`, then the k_y pass storing in the disc layout: part q's rows into
         packed[npl * cumS[q] : npl * (cumS[q] + S[q])] (what goes to rank q), the rank's own part into self_dst."""
         from ._lib import check, lib
@@ -221,7 +221,14 @@ class HipSlabOps:
         pitch = spec.shape[-1]
         assert spec.is_contiguous() and packed.is_contiguous() and self_dst.is_contiguous()
         assert packed.numel() == nloc * layout["total"] and self_dst.numel() == nloc * layout["S"][self_part]
-        if lowz is not None:
+        if halo is not None:
+            # the staged paint left these planes' halo records unfolded: the z pass adds them as it loads the rows
+            rec, win, row_lo, row_hi, xb0, nx_alloc = halo
+            check(lib().ast_fft_tile_rows_r2c_slab_halo(self.dev.ptr(planes), self.dev.ptr(spec), code, n2, nloc * n1, pitch, 1.0, rec, win,
+                                                        int(xb0), int(nx_alloc), int(row_lo), int(row_hi),
+                                                        self.dev.ptr(lowz) if lowz is not None else None, self.dev.stream()),
+                  "ast_fft_tile_rows_r2c_slab_halo")
+        elif lowz is not None:
             assert lowz.is_contiguous() and lowz.dtype == torch.complex128 and lowz.numel() == nloc * n1 * 7
             check(lib().ast_fft_tile_rows_r2c_lowz(self.dev.ptr(planes), self.dev.ptr(spec), code, n2, nloc * n1, n2, pitch,
                                                    1.0, self.dev.ptr(lowz), self.dev.stream()), "ast_fft_tile_rows_r2c_lowz")
@@ -839,6 +846,17 @@ class SlabPowerPipeline:
                                          offset=self.mean_offset, owned=(self.gl, self.nloc) if self.mean_offset else None)
             self.schedule = self._make_schedule(self.staged)
             self._schedule_checked = False
+            # (HIP ops, disc layout) only the tile rows that hold ghost planes are folded by the paint - their planes travel
+            # before any transform; every other row's halo records are added by the z pass that loads its planes
+            # (ASTRILD_SLAB_DEFER_FOLD=0: every row folded by the paint's own kernel, as in round 4)
+            self._defer_fold = False
+            if self.disc is not None and hasattr(self.staged, "defer_folds") and os.environ.get("ASTRILD_SLAB_DEFER_FOLD", "1") != "0":
+                PR = self.staged.row_planes
+                ghost_rows = set()
+                if self.world > 1:
+                    ghost_rows = {p // PR for p in range(0, self.gl)} | {p // PR for p in range(self.gl + self.nloc, self.nx_alloc)}
+                self.staged.defer_folds(ghost_rows)
+                self._defer_fold = True
             self.packed_flat = self.packed.reshape(-1)
             # ASTRILD_SLAB_STREAMS=2: the paint stages (walk, fold) on the caller's stream, the transforms and the exchange
             # of finished plane ranges on a second one, so that a stage's transform runs beside the next stage's walk.
@@ -894,8 +912,12 @@ class SlabPowerPipeline:
                 tot = self.disc["total"]
                 packed = self.packed_flat[p0 * tot:(p0 + npl) * tot]
                 mine = self.block[self.rank * nloc + p0: self.rank * nloc + p0 + npl]
+                halo = None
+                if self._defer_fold:
+                    rec, win, row_lo, row_hi = sp.halo_args()
+                    halo = (rec, win, row_lo, row_hi, (self.gl if self.world > 1 else 0) + p0, self.nx_alloc)
                 o.fft2d_planes_disc(planes, spec, packed, self.disc, self.rank, mine,
-                                    lowz=self._lowz_rows(p0, npl) if self.lowz is not None else None)
+                                    lowz=self._lowz_rows(p0, npl) if self.lowz is not None else None, halo=halo)
                 return exchange_planes_disc(packed, self.block, p0, npl, nloc, self.disc, self.group)
             nly = self.n // P
             packed = self.packed_flat[P * p0 * nly * nz: P * (p0 + npl) * nly * nz].view(P, npl, nly, nz)

@@ -207,6 +207,10 @@ int ast_paint_tiled(int window, int dtype, const void* pos_d, const void* mass_d
  * are those of the one-part GROUP.  closed_row0 / closed_nrows are ignored by the other stages. */
 #define AST_PAINT_STAGE_GROUP_PART 3
 #define AST_PAINT_STAGE_RESET 4
+/*   AST_PAINT_STAGE_LATE  row0 n   FOLD without the record fold: only the overflow / late list's deposits into these rows'
+ *                                  planes - for rows whose halo records are added by the consumer instead
+ *                                  (ast_fft_tile_rows_r2c_slab_halo folds them as its z pass loads the rows). */
+#define AST_PAINT_STAGE_LATE 5
 int ast_paint_tiled_stage(int window, int dtype, const void* pos_d, const void* mass_d, size_t np,
                           int nmesh, double boxsize, double scale, int x_start, int nx_alloc,
                           void* grid_d, void* workspace_d, size_t workspace_bytes,
@@ -328,6 +332,14 @@ int ast_fft_tile_rows_r2c(const void* in_d, void* out_d, int dtype, size_t n, si
  * first stage of ast_lowk_modes without its second read of the planes.  fp32, n in {256, 512, 1024}. */
 int ast_fft_tile_rows_r2c_lowz(const void* in_d, void* out_d, int dtype, size_t n, size_t nrows, size_t in_pitch,
                                size_t out_pitch, double scale, void* lowz_d, void* stream);
+/* The z pass of a plane range of a SLAB buffer painted in stages (ast_paint_tiled_stage), folding the paint's halo records as
+ * the rows are loaded - what AST_PAINT_STAGE_FOLD adds, in the same order (bit-identical): in_d = buffer plane xb0, nrows =
+ * planes * n rows; halo_rec_d from ast_paint_tiled_halo for the same buffer (nx_alloc planes, not periodic in x); planes whose
+ * tile row lies in [fold_row_lo, fold_row_hi) are folded here, the others must have had their FOLD stage (the rows that hold
+ * ghost planes).  lowz_d: NULL, or the low-k z sums of these rows as ast_fft_tile_rows_r2c_lowz leaves them. */
+int ast_fft_tile_rows_r2c_slab_halo(const void* in_d, void* out_d, int dtype, size_t n, size_t nrows, size_t out_pitch,
+                                    double scale, const void* halo_rec_d, int window, int xb0, int nx_alloc, int fold_row_lo,
+                                    int fold_row_hi, void* lowz_d, void* stream);
 int ast_fft_tile_r2c_3d(const void* in_d, void* out_d, int dtype, size_t n, double scale, void* stream);
 /* The unnormalised inverse in three tile passes (x, y, z): out_d[x] = scale * sum_k spec_k e^{+ikx} for an (n, n, n/2+1)
  * half spectrum (fp32, n in {256, 512, 1024}).  spec_d is not modified; work_d (as large as spec_d) is scratch.

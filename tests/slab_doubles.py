@@ -50,7 +50,7 @@ class NumpySlabOps:
         r1, tile = self.disc_geometry
         return slab.disc_layout(n, parts, r1, tile)
 
-    def fft2d_planes_disc(self, planes, spec, packed, layout, self_part, self_dst, lowz=None):
+    def fft2d_planes_disc(self, planes, spec, packed, layout, self_part, self_dst, lowz=None, halo=None):
         npl, n, _ = planes.shape
         full = np.fft.rfft2(planes.numpy(), axes=(1, 2))
         spec.copy_(torch.from_numpy(full))

@@ -151,11 +151,22 @@ def test_slab_pipeline_object_on_one_gpu_over_nccl(hip):
         # the staged order on the whole periodic grid (no ghosts): same bits in the buffer, same spectrum
         assert pipe.pipeline == "bulk"
         keep = pipe.buf.clone()
-        pipe2 = slab.SlabPowerPipeline(n, L, n, window="cic", dtype=torch.float32, seed=5, pipeline="staged", rows_per_stage=5)
-        ks2, ps2, nm2 = pipe2.step(check=True)
+        os.environ["ASTRILD_SLAB_DEFER_FOLD"] = "0"           # every row folded by the paint: the buffer is the complete grid
+        try:
+            pipe2 = slab.SlabPowerPipeline(n, L, n, window="cic", dtype=torch.float32, seed=5, pipeline="staged", rows_per_stage=5)
+            ks2, ps2, nm2 = pipe2.step(check=True)
+        finally:
+            del os.environ["ASTRILD_SLAB_DEFER_FOLD"]
         assert torch.equal(pipe2.buf, keep)
         res2 = dev.finish_power(ks2, ps2, nm2)
         np.testing.assert_allclose(res2["power"], res["power"], rtol=1e-12)
+        # default: the halo records are folded by the z pass as it loads the planes (same additions in the same order): the
+        # buffer itself stays unfolded, the shell sums are the same bits
+        ps2 = ps2.clone()
+        pipe3 = slab.SlabPowerPipeline(n, L, n, window="cic", dtype=torch.float32, seed=5, pipeline="staged", rows_per_stage=5)
+        ks3, ps3, nm3 = pipe3.step(check=True)
+        assert pipe3._defer_fold and not torch.equal(pipe3.buf, keep)
+        assert torch.equal(ps3, ps2)
     finally:
         dist.destroy_process_group()
 
@@ -294,11 +305,13 @@ def test_one_rank_of_eight_staged_step_with_grouping_in_parts(hip, monkeypatch, 
     for name in ("start", "start_upper", "start_lower"):
         monkeypatch.setattr(slab.GhostExchange, name, lambda self: None)
     monkeypatch.setattr(slab.GhostExchange, "finish", lambda self: None)          # (no neighbours: nothing is added)
+    monkeypatch.setenv("ASTRILD_SLAB_DEFER_FOLD", "0")       # every tile row folded by the paint: the buffer is the complete slab
     pipe = slab.SlabPowerPipeline(n, L, n, window="cic", dtype=torch.float32, ghost=3, seed=20240601)
     assert pipe.pipeline == "staged" and pipe.group_chunks == 8 and pipe.nx_alloc == 136
     sched = pipe._make_schedule(pipe.ops.staged_paint(pipe.pos, None, n, L, "cic", pipe.buf, pipe.x_start, pipe.nx_alloc))
     kinds = [e[0] for e in sched]
     assert [e[5] for e in sched if e[0] == "group_part"] == [1, 3, 3, 1] and kinds.index("fft") < len(kinds) - 1 - kinds[::-1].index("group_part")
+    pipe.packed.zero_()                         # (the slot of the rank's own part in the send buffer is never written)
     pipe.step(check=True)                       # raises if a deposit left the buffer or a particle arrived late
     assert int(pipe.staged.dropped.item()) == 0
     staged = pipe.buf.clone()
@@ -306,6 +319,18 @@ def test_one_rank_of_eight_staged_step_with_grouping_in_parts(hip, monkeypatch, 
     pipe.ops.paint(pipe.pos, None, n, L, "cic", ref, pipe.x_start, pipe.nx_alloc, check=True, offset=pipe.mean_offset,
                    owned=(pipe.gl, pipe.nloc))
     assert torch.equal(staged, ref)
+    # default: only the tile rows that hold ghost planes (0 and 16) are folded by the paint, the others by the z pass as it
+    # loads their planes - same additions in the same order: the rank's own piece of the spectrum and its send buffer are
+    # the same bits, the buffer's interior rows stay unfolded
+    mine_ref, packed_ref = pipe.block.clone(), pipe.packed.clone()
+    monkeypatch.delenv("ASTRILD_SLAB_DEFER_FOLD")
+    pipe2 = slab.SlabPowerPipeline(n, L, n, window="cic", dtype=torch.float32, ghost=3, seed=20240601)
+    pipe2.packed.zero_()
+    pipe2.step(check=True)
+    assert pipe2._defer_fold and int(pipe2.staged.dropped.item()) == 0
+    assert torch.equal(pipe2.buf[:8], ref[:8]) and torch.equal(pipe2.buf[128:], ref[128:]) and not torch.equal(pipe2.buf[8:128], ref[8:128])
+    lo, hi = rank * pipe.nloc, (rank + 1) * pipe.nloc
+    assert torch.equal(pipe2.block[lo:hi], mine_ref[lo:hi]) and torch.equal(pipe2.packed, packed_ref)
 
 
 def test_c_abi_comm_entries_over_rccl_single_rank(hip):
