@@ -158,7 +158,8 @@ struct C2RBatch { int count = 0; const float2* in[SHELL_BATCH]; float* out[SHELL
 // elements; sub-rows lo <= sub < hi exist), the part's plane size S, the sum of the lower parts' plane sizes, the part.
 struct DiscEntry { int offb; unsigned S, cumS, lohi; };                   // lohi = lo | hi << 8 | part << 16
 struct PackDst { float2* out = nullptr; unsigned c1_log2 = 0; unsigned nbatch = 0; float2* self_out = nullptr; unsigned self_part = ~0u; unsigned pitch = 0;
-                 const DiscEntry* disc = nullptr; const unsigned short* gk = nullptr; unsigned part = 0; };
+                 const DiscEntry* disc = nullptr; const unsigned short* gk = nullptr; unsigned part = 0;
+                 unsigned xmajor = 0; };     // xmajor = N (one part only): element (x, row, col) of a tile at (row_pos * N + x) * 16 + col - the last pass reads N * 128 contiguous bytes
 
 template <int R1, int R2, int C, bool POWER, bool INV = false, int PACK = 0>
 __global__ void __launch_bounds__(C * (R1 > R2 ? R1 : R2))
@@ -226,8 +227,13 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
             return;
         }
         disc_ky = (int)(gk * R1 + subb);
-        disc_base = data + ((long long)e.offb + (long long)(subb * 16u));
-        disc_S = e.S;
+        if (pack.xmajor) {                            // x-major tiles: the N planes' pieces of this (row, tile) are contiguous
+            disc_base = data + ((long long)e.offb + (long long)(subb * 16u)) * (long long)pack.xmajor;
+            disc_S = 16u;
+        } else {
+            disc_base = data + ((long long)e.offb + (long long)(subb * 16u));
+            disc_S = e.S;
+        }
     } else if (!INV && POWER && mask.hi2 > 0) {
         const long long kyi = (long long)b + mask.ky0, ky = kyi > N / 2 ? kyi - N : kyi;
         if (ky * ky + (long long)(c0 * c0) > mask.hi2) {
@@ -364,6 +370,12 @@ strided_c2c_kernel(float2* __restrict__ data, const float2* __restrict__ tw_g, s
                 const unsigned S = (unsigned)__builtin_amdgcn_readlane(ev.y, k2), cumS = (unsigned)__builtin_amdgcn_readlane(ev.z, k2);
                 const unsigned lohi = (unsigned)__builtin_amdgcn_readlane(ev.w, k2);
                 const unsigned lo = lohi & 255u, hi = (lohi >> 8) & 255u, part = lohi >> 16;
+                if (pack.xmajor) {
+                    float2* const ub = pack.self_out + ((long long)offb * (long long)pack.xmajor + (long long)(b * 16u));
+                    if ((unsigned)sub - lo < hi - lo)
+                        st_stream<(N >= 1024)>(ub + ((uint32_t)sub * 16u * pack.xmajor + (uint32_t)(threadIdx.x & 15u)), x);
+                    continue;
+                }
                 float2* const ub = (part == pack.self_part ? pack.self_out : pack.out + (size_t)pack.nbatch * cumS)
                                    + ((size_t)b * S + (long long)offb);
                 if ((unsigned)sub - lo < hi - lo) st_stream<(N >= 1024)>(ub + threadIdx.x, x);
@@ -1791,13 +1803,26 @@ static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, 
     const double inv_ng = 1.0 / ((double)n * (double)n * (double)n);
     // AST_FFT_DISC=1 (A/B runs): the k_y pass stores in the disc layout (one part) and the last pass reads it from there;
     // default: in place on the pitched rows, rows / tiles outside the disc skipped
-    const bool use_disc = prune2 != 0 && getenv("AST_FFT_DISC") != nullptr && getenv("AST_FFT_DISC")[0] == '1';
+    const char* disc_env = getenv("AST_FFT_DISC");
+    const bool use_disc = prune2 != 0 && disc_env != nullptr && (disc_env[0] == '1' || disc_env[0] == '2');
+    const unsigned xmajor = use_disc && disc_env[0] == '2' ? (unsigned)n : 0u;      // 2: x-major tiles (experiment)
     if (use_disc) {
-        rc = ast_fft_tile_c2c_disc(spec, nullptr, dtype, n, nzp, n, 1, 0, disc, 1.0, stream);                     // y, per x-plane
-        if (rc != AST_OK) return rc;
         const DiscLayout::Dev* dv = nullptr;
         const DiscLayout* L = g_disc.get(n, 1, true, &dv);
         if (!L) { ast::set_error("ast_fft_tile_power_3d: disc table allocation failed"); return AST_ERR_HIP; }
+        {
+            AST_PROF("fft_tile.c2c", s);
+            PackDst pk;
+            pk.nbatch = (unsigned)n;
+            pk.disc = dv->tab;
+            pk.self_out = disc;
+            pk.self_part = 0;
+            pk.xmajor = xmajor;
+            if (n == 1024) rc = launch_c2c_pack<32, 32, 16, 2>(spec, tw, nzp, nz, n, n * nzp, 1.0f, pk, s);
+            else if (n == 512) rc = launch_c2c_pack<16, 32, 16, 2>(spec, tw, nzp, nz, n, n * nzp, 1.0f, pk, s);
+            else rc = launch_c2c_pack<16, 16, 16, 2>(spec, tw, nzp, nz, n, n * nzp, 1.0f, pk, s);       // y, per x-plane
+            if (rc != AST_OK) return rc;
+        }
         AST_PROF("fft_tile.c2c_power", s);
         const unsigned* edge_fall = nullptr;
         if (kf_rule != 0.0) {
@@ -1808,7 +1833,8 @@ static int power_3d_impl(const void* grid, void* scratch, size_t scratch_bytes, 
         src.disc = dv->tab;
         src.gk = dv->gk;
         src.nbatch = (unsigned)n;
-        rc = dispatch_c2c<true>(n, disc, tw, L->S[0], nz, n, 16, (float)inv_ng, partial, s, edge_fall, 0, 0, src);   // x + binning
+        src.xmajor = xmajor;
+        rc = dispatch_c2c<true>(n, disc, tw, xmajor ? 16 : L->S[0], nz, n, 16, (float)inv_ng, partial, s, edge_fall, 0, 0, src);   // x + binning
         if (rc != AST_OK) return rc;
     } else {
         {

@@ -1007,7 +1007,6 @@ def bispectrum(field, boxsize, edges, triangles):
         tri_d = torch.tensor([[slot[v] for v in t] for t in triangles], dtype=torch.int32).to(spec.device)
         out = torch.empty(len(triangles), dtype=torch.float64, device=spec.device)
         fscr = torch.empty(int(L.ast_fft_tile_c2r_triangles_scratch_bytes()) // 8, dtype=torch.float64, device=spec.device)
-        num = np.empty(len(triangles))
         for b0 in range(0, len(triangles), 512):
             nb_ = min(512, len(triangles) - b0)
             check(L.ast_fft_tile_c2r_triangles(wp, hi, len(used), F32, n, pitch, 1.0 / amp, ptr(tri_d[b0:]), nb_, ptr(fscr), ptr(out[b0:]),

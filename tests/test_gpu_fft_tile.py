@@ -484,9 +484,10 @@ def test_single_gpu_pipeline_through_the_disc_layout_changes_no_bit(dev, n):
     g = torch.Generator(device="cuda").manual_seed(n + 13)
     t = torch.randn((n, n, n), dtype=torch.float32, device="cuda", generator=g)
     _, ref, _ = dev.power_sums_fused(t, 750.0)
-    os.environ["AST_FFT_DISC"] = "1"
-    try:
-        _, got, _ = dev.power_sums_fused(t, 750.0)
-    finally:
-        del os.environ["AST_FFT_DISC"]
-    assert torch.equal(got, ref)
+    for mode in ("1", "2"):                  # 2: x-major tiles (the last pass reads N * 128 contiguous bytes per workgroup)
+        os.environ["AST_FFT_DISC"] = mode
+        try:
+            _, got, _ = dev.power_sums_fused(t, 750.0)
+        finally:
+            del os.environ["AST_FFT_DISC"]
+        assert torch.equal(got, ref), mode
