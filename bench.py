@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--bispec", type=int, default=1, help="also time the 512^3 bispectrum (1/0)")
     ap.add_argument("--legs", type=int, default=1, help="also time the shuffled-order and TSC legs (1/0)")
     ap.add_argument("--slab", type=int, default=0, help="run the slab-decomposed pipeline even on one GPU (rehearsal)")
+    ap.add_argument("--cpu-paint-child", type=int, default=0, help="(internal) child mode of the CPU baseline's parallel paint")
+    ap.add_argument("--cpu-workers", type=int, default=16, help="processes of the CPU baseline's parallel paint")
     return ap.parse_args()
 
 
@@ -62,8 +64,8 @@ def cpu_baseline(sample, window, boxsize, dev=None):
     rfftn, FFTPower binning; float64 like the reference) on a bounded sample of the
     workload: sample^3 particles on a sample^3 grid.  `value` is the single-thread figure
     (how astrild runs: one MPI rank, FFTW without threads, numpy); `threaded` repeats the
-    FFT + binning with scipy.fft on every host core - the paint of the port
-    is numpy bincount and has no threaded form."""
+    FFT with scipy.fft on every host core and the paint as plane chunks of the
+    same numpy arithmetic in forked worker processes (cpu_parallel_paint)."""
     from oracle import mesh as omesh, fftpower as offt
     import scipy.fft
     ncpu = os.cpu_count() or 1
@@ -89,6 +91,9 @@ def cpu_baseline(sample, window, boxsize, dev=None):
                          "against that float64 device path on the same fp32-rounded positions (north_star: 1e-6)"}
         del p32
         torch.cuda.empty_cache()
+    workers = min(16, ncpu)            # (the GPU box hands one GPU's share of the host to this job: 16 cores)
+    par = cpu_parallel_paint(sample, window, boxsize, workers) if sample % 16 == 0 else {"error": "sample is not a multiple of the 16-plane chunk"}
+    par_ok = "paint_s" in par and np.allclose(par.get("moments", [0.0, 0.0]), _grid_moments(grid), rtol=1e-10, atol=0.0)
     t2b = time.perf_counter()
     spec = scipy.fft.rfftn(grid, workers=ncpu) / grid.size
     t3 = time.perf_counter()
@@ -102,14 +107,17 @@ def cpu_baseline(sample, window, boxsize, dev=None):
         "sample": f"{sample}^3 particles on a {sample}^3 grid, float64, numpy bincount paint {t1 - t0:.2f}s + "
                   f"numpy rfftn/shell binning {t2 - t1:.2f}s (1024^3 is not run: the numpy port's temporaries "
                   f"need > 100 GB of host RAM)",
-        "threaded": {"value": n / ((t1 - t0) + (t4 - t2b)), "cores": ncpu,
+        "threaded": {"value": n / ((par["paint_s"] if par_ok else (t1 - t0)) + (t4 - t2b)), "cores": ncpu,
                      "fft_s": round(t3 - t2b, 3), "binning_s": round(t4 - t3, 3), "paint_s_single_thread": round(t1 - t0, 3),
-                     "note": f"scipy.fft.rfftn(workers={ncpu}) + numpy shell binning; paint as in the single-thread leg"},
+                     "paint_s_parallel": round(par["paint_s"], 3) if par_ok else None, "paint_workers": workers if par_ok else 1,
+                     "paint_parallel_error": None if par_ok else par.get("error", "grid moments differ"),
+                     "note": f"paint: the same chunked numpy paint in {workers} forked processes of a child interpreter (even chunks, then "
+                             f"odd ones, into one shared grid); scipy.fft.rfftn(workers={ncpu}); numpy shell binning, single thread"},
         "cpu_model": _cpu_model(), "logical_cores": ncpu, "check": check,
         # the same port on the benchmark's own configuration, by particle count (its paint, binning and FFT are all
         # O(N) or O(N log N) in the 8x larger problem): a projection, not a measurement
         "projected_1024_cubed": {"seconds_single_thread": round(1024 ** 3 / (n / (t2 - t0)), 1),
-                                 "seconds_threaded_fft": round(1024 ** 3 / (n / ((t1 - t0) + (t4 - t2b))), 1),
+                                 "seconds_threaded": round(1024 ** 3 / (n / ((par["paint_s"] if par_ok else (t1 - t0)) + (t4 - t2b))), 1),
                                  "note": "particles of the 1024^3 workload / the sample's particles per second"},
     }
 
@@ -213,6 +221,63 @@ def cpu_baseline_chunked(sample, window, boxsize, planes=32, pad=6, pos=None, de
                          "note": f"scipy.fft.rfftn(workers={ncpu}); paint and binning as in the single-thread leg"},
             "seconds_single_thread": round(single, 1), "paint_s": round(t_paint, 1), "fft_s_single_thread": round(t_fft1, 1),
             "binning_s": round(t_bin, 1), "cpu_model": _cpu_model(), "logical_cores": ncpu}
+
+
+def cpu_parallel_paint_child(sample, window, boxsize, workers, planes=16, pad=6):
+    """Runs in a CHILD process of bench.py (`--cpu-paint-child`), which never touches the GPU: the chunked CPU paint of the
+    lattice set with `workers` forked processes writing into one shared grid - the chunks of a phase (even ones, then odd
+    ones) touch disjoint slabs of it (chunk + 2 pad planes < two chunks).  Prints one JSON line: paint seconds, grid sum."""
+    import multiprocessing as mp
+    from oracle import mesh as omesh
+    n = int(sample)
+    pos = omesh.lattice_particles(n, n, boxsize, seed=20240601)
+    shared = mp.RawArray("d", n * n * n)
+    grid = np.frombuffer(shared, dtype=np.float64).reshape(n, n, n)
+    per = n * n * planes
+
+    def work(c):
+        g = np.frombuffer(shared, dtype=np.float64).reshape(n, n, n)
+        _cpu_paint_chunk(pos[c * per:(c + 1) * per], c * planes, planes, pad, n, boxsize, window, g)
+        return c
+    chunks = list(range(n // planes))
+    ctx = mp.get_context("fork")
+    global _CPU_CHILD_WORK
+    _CPU_CHILD_WORK = work
+    t0 = time.perf_counter()
+    with ctx.Pool(processes=workers) as pool:
+        tail = [chunks.pop()] if len(chunks) % 2 and len(chunks) > 1 else []   # an odd count: the last chunk wraps onto chunk 0
+        pool.map(_cpu_child_call, chunks[0::2])
+        pool.map(_cpu_child_call, chunks[1::2])
+        pool.map(_cpu_child_call, tail)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"paint_s": dt, "workers": workers, "grid_sum": float(grid.sum()), "moments": _grid_moments(grid),
+                      "nparticles": int(pos.shape[0])}))
+
+
+def _grid_moments(grid):
+    """First moments of a grid along x and z: the fingerprint by which the parent compares the child's paint with its own."""
+    ramp = np.arange(1, grid.shape[0] + 1, dtype=np.float64)
+    return [float(grid.sum(axis=(1, 2)) @ ramp), float(grid.sum(axis=(0, 1)) @ ramp)]
+
+
+_CPU_CHILD_WORK = None
+
+
+def _cpu_child_call(c):
+    return _CPU_CHILD_WORK(c)
+
+
+def cpu_parallel_paint(sample, window, boxsize, workers):
+    """The threaded leg's paint: a child process (fresh interpreter, no GPU) paints the same sample with `workers` processes."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-paint-child", str(int(sample)), "--window", window,
+           "--cpu-workers", str(int(workers))]
+    try:
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"))
+        line = [ln for ln in res.stdout.decode().splitlines() if ln.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as exc:          # the baseline is a reported figure: a failure here must not take the bench line down
+        return {"error": repr(exc)}
 
 
 def subfind_leg(dev, nobj=2_000_000, nbins=512, boxsize=500.0, reps=5):
@@ -368,6 +433,9 @@ def launch_ranks(ngpus):
 
 def main():
     args = parse()
+    if args.cpu_paint_child:
+        cpu_parallel_paint_child(args.cpu_paint_child, args.window, 1000.0, args.cpu_workers)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus)
         return

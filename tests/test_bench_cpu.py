@@ -17,3 +17,15 @@ def test_chunked_cpu_paint_equals_the_oracle_paint(window):
     np.testing.assert_allclose(grid, ref, rtol=1e-13, atol=1e-13)
     res = bench.cpu_baseline_chunked(32, window, L, planes=8, pad=6)
     assert res["value"] > 0 and res["cores"] == 1 and res["kind"] == "port"
+
+
+def test_parallel_cpu_paint_child_paints_every_particle():
+    """The threaded leg's paint runs in a child interpreter with forked workers: same particles, same grid total."""
+    import bench
+    res = bench.cpu_parallel_paint(80, "cic", 1000.0, workers=2)       # 5 chunks: the odd-count path
+    assert "error" not in res, res
+    assert res["nparticles"] == 80 ** 3 and res["paint_s"] > 0
+    assert abs(res["grid_sum"] - 80 ** 3) < 1e-6 * 80 ** 3
+    from oracle import mesh as omesh
+    ref = omesh.paint(omesh.lattice_particles(80, 80, 1000.0, seed=20240601), None, 80, 1000.0, "cic")
+    np.testing.assert_allclose(res["moments"], bench._grid_moments(ref), rtol=1e-12)
