@@ -50,6 +50,7 @@ SIGNATURES = {
     "ast_route_count": (_i, [_vp, _i, _sz, _i, _d, _i, _i, _vp, _vp]),
     "ast_route_scatter": (_i, [_vp, _vp, _i, _sz, _i, _d, _i, _i, _vp, _vp, _vp, _vp]),
     "ast_accumulate": (_i, [_vp, _vp, _i, _sz, _vp]),
+    "ast_stream_copy": (_i, [_vp, _vp, _sz, _i, _vp]),
     "ast_fft_plan_create": (_i, [ct.POINTER(_vp), _i, _i, _i, ct.POINTER(_sz), _sz, _d, _i]),
     "ast_fft_plan_create_strided_1d": (_i, [ct.POINTER(_vp), _i, _i, _sz, _sz, _sz, _sz, _d]),
     "ast_fft_plan_create_general": (_i, [ct.POINTER(_vp), _i, _i, _i, ct.POINTER(_sz), ct.POINTER(_sz),

@@ -465,6 +465,66 @@ extern "C" int ast_add(const void* a, const void* b, void* out, int dtype, size_
     return AST_OK;
 }
 
+// The on-box streaming ceiling the roofline fractions are also quoted against ("also measure an on-box
+// streaming-copy kernel"): 16 bytes per lane and access, four accesses in flight per lane, consecutive workgroups on
+// consecutive 16-KB pieces.  mode 0 = copy (read + write), 1 = read only (the sum keeps the loads alive; one store per
+// workgroup that never happens: the guard value is not reachable), 2 = write only.
+typedef float vfloat4 __attribute__((ext_vector_type(4)));
+template <bool NTL, bool NTS, int U>
+__global__ void __launch_bounds__(256) stream_copy_kernel(vfloat4* __restrict__ dst, const vfloat4* __restrict__ src, size_t n16, int mode) {
+    const size_t per_block = 256 * U;
+    vfloat4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (size_t base = (size_t)blockIdx.x * per_block; base < n16; base += (size_t)gridDim.x * per_block) {
+        vfloat4 v[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const size_t i = base + (size_t)j * 256 + threadIdx.x;
+            v[j] = (mode != 2 && i < n16) ? (NTL ? __builtin_nontemporal_load(src + i) : src[i]) : vfloat4{1.f, 2.f, 3.f, 4.f};
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const size_t i = base + (size_t)j * 256 + threadIdx.x;
+            if (mode == 1) acc += v[j];
+            else if (i < n16) { if (NTS) __builtin_nontemporal_store(v[j], dst + i); else dst[i] = v[j]; }
+        }
+    }
+    if (mode == 1 && acc.x + acc.y + acc.z + acc.w == -1.2345e38f) dst[0] = acc;
+}
+
+// mode bits 0-1: 0 copy, 1 read, 2 write.  Tuning bits (scripts/micro/copy_rate.py; honoured when bit 8 is set): 4 plain
+// loads, 5 plain stores, 6 one piece per workgroup instead of a grid-stride loop, 7 eight accesses per lane instead of four.
+extern "C" int ast_stream_copy(void* dst, const void* src, size_t bytes, int mode, void* stream) {
+    // defaults = the fastest variant per operation on the MI355X (scripts/micro/copy_rate.py, 4 GiB): copy 5.78 TB/s with plain
+    // loads and stores, read 7.18 with nontemporal loads, write 6.18 with plain stores - one 16-KB piece per workgroup in all
+    // three (a grid-stride loop over 8192 workgroups: 5.2 / 7.0 / 5.7).  Bit 8 set: bits 4-7 choose the variant explicitly.
+    const int op = mode & 3, tune = (mode & 256) ? (mode >> 4) & 15 : (op == 1 ? 4 : 7);
+    AST_CHECK_ARG(dst != nullptr && (src != nullptr || op == 2));
+    AST_CHECK_ARG(mode >= 0 && mode < 512 && op <= 2 && (mode & 12) == 0 && ((mode & 256) || (mode & 240) == 0));
+    AST_CHECK_ARG(bytes % 16 == 0 && ((uintptr_t)dst % 16) == 0 && ((uintptr_t)src % 16) == 0);
+    if (bytes == 0) return AST_OK;
+    const int U = (tune & 8) ? 8 : 4;
+    const size_t n16 = bytes / 16, blocks = (n16 + 256 * U - 1) / (256 * U);
+    AST_CHECK_ARG(blocks < (1ull << 31));
+    const unsigned g = (tune & 4) ? (unsigned)blocks : (unsigned)(blocks < 256u * 32u ? blocks : 256u * 32u);
+    vfloat4* d = (vfloat4*)dst;
+    const vfloat4* sp = (const vfloat4*)src;
+    hipStream_t st = ast::as_stream(stream);
+#define AST_COPY_CASE(NTL, NTS, UU) stream_copy_kernel<NTL, NTS, UU><<<g, 256, 0, st>>>(d, sp, n16, op)
+    switch (tune & 11) {
+        case 0: AST_COPY_CASE(true, true, 4); break;
+        case 1: AST_COPY_CASE(false, true, 4); break;
+        case 2: AST_COPY_CASE(true, false, 4); break;
+        case 3: AST_COPY_CASE(false, false, 4); break;
+        case 8: AST_COPY_CASE(true, true, 8); break;
+        case 9: AST_COPY_CASE(false, true, 8); break;
+        case 10: AST_COPY_CASE(true, false, 8); break;
+        default: AST_COPY_CASE(false, false, 8); break;
+    }
+#undef AST_COPY_CASE
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+
 extern "C" int ast_accumulate(void* dst, const void* src, int dtype, size_t count, void* stream) {
     return ast_add(dst, src, dst, dtype, count, stream);
 }

@@ -280,6 +280,34 @@ def cpu_parallel_paint(sample, window, boxsize, workers):
         return {"error": repr(exc)}
 
 
+def stream_ceiling(dev, gib=4, reps=5):
+    """The on-box streaming rates: `ast_stream_copy` over `gib` GiB (far beyond the 256 MB Infinity Cache),
+    HIP events on the stream it is launched on, best of `reps`: copy (read + write bytes / time), read only, write only."""
+    from astrild_amd._lib import lib, check
+    nbytes = int(gib) << 30
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev.device()).fill_(1.0)
+    b = torch.empty_like(a)
+    out = {}
+    for name, mode, moved in (("copy", 0, 2 * nbytes), ("read", 1, nbytes), ("write", 2, nbytes)):
+        best = float("inf")
+        for _ in range(reps + 1):                      # (the first one warms up)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(lib().ast_stream_copy(dev.ptr(b), dev.ptr(a), nbytes, mode, dev.stream()), "ast_stream_copy")
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        out[name + "_GBps"] = round(moved / (best * 1e6), 1)
+    assert bool(torch.equal(a[:1 << 20], torch.ones(1 << 20, device=a.device)))
+    del a, b
+    torch.cuda.empty_cache()
+    out["buffer_GiB"] = gib
+    out["note"] = ("hand-written 16-byte-per-lane streaming kernel of this library on this GPU (the fastest of its 16 access variants "
+                   "per operation, scripts/micro/copy_rate.py), best of %d; the guide's figure for a float4 copy is 6290 GB/s "
+                   "(MI355X_MICROARCH.md)" % reps)
+    return out
+
+
 def subfind_leg(dev, nobj=2_000_000, nbins=512, boxsize=500.0, reps=5):
     """SubFind.power_spectrum's real shape (stats_subfind.py:109-153): 2e6 mass-weighted objects, TSC, nbins = 512,
     float64, through the Python API from host arrays - H2D copies, mass bound, paint, /dx^3, FFTPower.  The catalogue:
@@ -513,6 +541,16 @@ def main():
                    "parallelism": "single GPU" if not use_slab else f"axis-0 slabs x{world}, RCCL all-to-all transpose"},
         "roofline": roofline,
     }
+    if rank == 0 and not use_slab:
+        # every fraction above is of the data sheet's 8 TB/s; the same figures against what this GPU streams (measured here)
+        ceil = stream_ceiling(dev)
+        ceil["reading_the_fractions"] = ("frac_of_copy_rate = algorithmic GB/s / copy_GBps; a stage that moves fewer bytes than the "
+                                         "algorithmic count - the FFT passes pruned to the Nyquist disc - can read above 1")
+        roofline["streaming_ceiling"] = ceil
+        roofline["frac_of_copy_rate"] = round(roofline["achieved"] / ceil["copy_GBps"], 4)
+        roofline["end_to_end"]["frac_of_copy_rate"] = round(roofline["end_to_end"]["GBps"] / ceil["copy_GBps"], 4)
+        for st in roofline["stages"].values():
+            st["frac_of_copy_rate"] = round(st["GBps"] / ceil["copy_GBps"], 4)
     if "diag" in leg:
         out["multi_gpu"] = leg["diag"]
     if "paint_path" in leg:
@@ -567,6 +605,9 @@ def main():
             torch.cuda.empty_cache()
             from astrild_amd import lensing
             out["kappa"]["api"] = lensing.bench_kappa_api()
+            # the stack reads 64 planes for one map written: against the measured READ rate; the whole pipeline against the copy rate
+            out["kappa"]["stack"]["frac_of_read_rate"] = round(out["kappa"]["stack"]["GBps"] / ceil["read_GBps"], 4)
+            out["kappa"]["roofline"]["frac_of_copy_rate"] = round(out["kappa"]["roofline"]["achieved"] / ceil["copy_GBps"], 4)
     if use_slab and world > 1 and args.kappa:
         # config D on N GPUs: lens planes sharded over the ranks (every rank takes part)
         del leg

@@ -274,6 +274,11 @@ int ast_route_scatter(const void* pos_d, const void* mass_d, int dtype, size_t n
 
 /* dst[i] += src[i] — ghost-plane fold after a slab paint. */
 int ast_accumulate(void* dst_d, const void* src_d, int dtype, size_t count, void* stream);
+/* Measurement aid (SURVEY.md §8d "also measure an on-box streaming-copy kernel"): streams `bytes` (a multiple of 16,
+ * 16-byte aligned) with 16-byte accesses - mode 0 copy src -> dst, 1 read src only, 2 write dst only (the fastest access
+ * variant of each; mode | 256 | variant << 4 picks one explicitly, scripts/micro/copy_rate.py).  bench.py times it
+ * and quotes every roofline fraction against this ceiling beside the 8 TB/s of the data sheet.  No reference counterpart. */
+int ast_stream_copy(void* dst_d, const void* src_d, size_t bytes, int mode, void* stream);
 
 /* ------------------------------------------------------------- a-4: FFTs */
 
