@@ -428,6 +428,45 @@ def kappa_leg(dev, steps, warmup, group=None):
                                         group=group)
 
 
+def kappa_cpu_baseline(dev, nplanes=64, npix=4096, theta_deg=20.0, sigma_arcmin=1.0):
+    """The oracle (numpy port of rayramses.py:186-232 + sky_utils.py:318-339 + filters.py:181-225 + lensing_funcs.c:45-115 +
+    sky_array.py:428-433, float64, one thread) on ONE map of the kappa leg's own workload - the same 64 synthetic planes,
+    fetched from the device -, timed on the host; and its map and deflection field as the checker of the device's."""
+    from oracle import kappa as ok
+    from astrild_amd import lensing
+    planes_d = lensing.synth_kappa_planes(nplanes, npix)
+    wnum, wden = lensing.synth_plane_weights(nplanes)
+    bsz = np.deg2rad(theta_deg)
+    sigma_px = sigma_arcmin / 60.0 * npix / theta_deg
+    # the device's map first (its own code path, as in the timed leg)
+    out = lensing.kappa_stack(planes_d, wnum, wden)
+    lensing.convert_code_to_phy_units("kappa_2", out)
+    lensing.smooth_plan(npix).gaussian(out, sigma_px, "gaussianFFT")
+    a1_d, _ = lensing.lens_plan(npix, bsz).alphas(out)
+    kappa_d, a1_d = out.cpu().numpy(), a1_d.cpu().numpy()
+    planes = [p.cpu().numpy() for p in planes_d]
+    del planes_d, out
+    torch.cuda.empty_cache()
+    mid = (np.arange(nplanes) + 0.5) * (1000.0 / nplanes)
+    half = 0.5 * 1000.0 / nplanes
+    t0 = time.perf_counter()
+    total = ok.kappa_stack(planes, mid - half, mid + half, 1100.0, 1000.0)
+    t1 = time.perf_counter()
+    img = ok.gaussian_smooth(ok.convert_code_to_phy_units("kappa_2", total), theta_deg, sigma_arcmin, "gaussianFFT")
+    t2 = time.perf_counter()
+    a1, a2 = ok.kappa0_to_alphas(img, npix, bsz)
+    t3 = time.perf_counter()
+    ok.pdf(img, 100)
+    t4 = time.perf_counter()
+    scale_k, scale_a = float(np.abs(img).max()), float(np.abs(a1).max())
+    return {"value": 1.0 / (t4 - t0), "unit": "maps/s", "cores": 1, "kind": "port",
+            "sample": f"one map of the leg's own workload ({nplanes} planes x {npix}^2 float64): stack {t1 - t0:.2f}s + units and "
+                      f"Gaussian FFT smoothing {t2 - t1:.2f}s + kappa->alpha on the padded {2 * npix}^2 array {t3 - t2:.2f}s + PDF {t4 - t3:.2f}s",
+            "check": {"kappa_max_abs_over_max": float(np.abs(kappa_d - img).max() / scale_k),
+                      "alpha1_max_abs_over_max": float(np.abs(a1_d - a1).max() / scale_a),
+                      "note": "the device's smoothed map and alpha1 against the CPU leg's own, same planes"}}
+
+
 def _free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
@@ -605,6 +644,8 @@ def main():
             torch.cuda.empty_cache()
             from astrild_amd import lensing
             out["kappa"]["api"] = lensing.bench_kappa_api()
+            if args.cpu_sample:
+                out["kappa"]["cpu_baseline"] = kappa_cpu_baseline(dev)
             # the stack reads 64 planes for one map written: against the measured READ rate; the whole pipeline against the copy rate
             out["kappa"]["stack"]["frac_of_read_rate"] = round(out["kappa"]["stack"]["GBps"] / ceil["read_GBps"], 4)
             out["kappa"]["roofline"]["frac_of_copy_rate"] = round(out["kappa"]["roofline"]["achieved"] / ceil["copy_GBps"], 4)
