@@ -193,14 +193,22 @@ __device__ __noinline__ void place_run_slow(uint32_t key, uint32_t p1, uint32_t 
 // bound) 53 %, scatter of the parked codes (store-issue bound) 28 %, flush 12 %.
 // MODE 0: count (two-pass A1)   1: fill at exact offsets (two-pass A2)
 // MODE 2: single pass — tile t owns index[t*cap, (t+1)*cap); overflow goes to ovf[]
-template <typename T, int W, int MODE, bool PLAINX>
+// STRIDE = 4, np_dev: the "particles" are the {x, y, z, m} records of the scatter path's late list, as many as *np_dev says
+// (at most np; fewer than np_min: nothing to do here, the list is deposited with global atomics instead).
+template <typename T, int W, int MODE, bool PLAINX, int STRIDE = 3>
 __global__ void __launch_bounds__(256)
 tile_index_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t* __restrict__ tile_count,
                   const uint32_t* __restrict__ tile_off, uint32_t* __restrict__ tile_fill,
                   uint32_t* __restrict__ index, uint32_t cap, uint32_t* __restrict__ ovf,
                   unsigned long long* __restrict__ ovf_count, uint32_t* __restrict__ col_flags,
-                  unsigned long long* dropped) {
+                  unsigned long long* dropped, const unsigned long long* __restrict__ np_dev = nullptr,
+                  unsigned long long np_min = 0) {
     constexpr bool FILL = MODE != 0;
+    if (np_dev != nullptr) {                          // uniform, before any barrier
+        const unsigned long long nd = *np_dev;
+        if (nd < np_min || nd == 0) return;
+        np = nd < np ? (size_t)nd : np;
+    }
     // skey/scnt are re-armed by each thread as soon as it leaves the scatter loop, so the
     // scatter reads the interval's results from sdst/sroom, which only the next flush rewrites:
     // sdst = first index element of the slot's tile segment part, sroom = elements left in it
@@ -228,9 +236,9 @@ tile_index_kernel(const T* __restrict__ pos, size_t np, TileGeom g, uint32_t* __
             // unconditional (lanes past the end re-load the last particle): a predicated load
             // costs a branch and a full s_waitcnt each, i.e. IDX_UNROLL serial round trips
             const size_t p = min(pbase + (size_t)u * 256 + tid, np - 1);
-            x[u] = pos[3 * p + 0];
-            y[u] = pos[3 * p + 1];
-            z[u] = pos[3 * p + 2];
+            x[u] = pos[STRIDE * p + 0];
+            y[u] = pos[STRIDE * p + 1];
+            z[u] = pos[STRIDE * p + 2];
         }
     };
     auto place_run = [&](uint32_t key, uint32_t p1, uint32_t len) {
@@ -861,8 +869,10 @@ __device__ __noinline__ void deposit_record_global(T x, T y, T z, T m, const Til
 template <typename T, int W>
 __global__ void __launch_bounds__(256)
 late_deposit_kernel(const T* __restrict__ late_list, const unsigned long long* __restrict__ late, unsigned long long late_cap,
-                    TileGeom g, double scale, T* __restrict__ grid, unsigned long long* dropped, int x_lo, int x_hi) {
+                    TileGeom g, double scale, T* __restrict__ grid, unsigned long long* dropped, int x_lo, int x_hi,
+                    unsigned long long n_below = ~0ull) {
     const unsigned long long n = min(*late, late_cap);
+    if (n >= n_below) return;                         // a long list goes through LDS tiles (run_tiled, scattered branch)
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * blockDim.x)
         deposit_record_global<T, W>(late_list[4 * i], late_list[4 * i + 1], late_list[4 * i + 2], late_list[4 * i + 3], g, scale,
@@ -1057,23 +1067,27 @@ scan_add_kernel(uint32_t* out, const uint32_t* __restrict__ block_sums, uint32_t
     for (int i = 0; i < 4; ++i) if (base + i < n) out[base + i] += add;
 }
 
-template <typename T, int W>
+template <typename T, int W, int STRIDE = 3>
 __global__ void __launch_bounds__(256)
 tile_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileGeom g, double scale,
                     const uint32_t* __restrict__ index, const uint32_t* __restrict__ tile_off,
                     const uint32_t* __restrict__ tile_count, uint32_t cap, T* __restrict__ grid,
-                    unsigned long long* dropped) {
+                    unsigned long long* dropped, uint32_t ntiles_loop = 0) {
     constexpr int LX = TX + W - 1, LY = TY + W - 1, LZ = TZ + W - 1;
     constexpr int LO = Window<W>::LO;
     // ds_add_f32 retires ~0.33 lanes/clk/CU on gfx950 against ~7 for ds_add_f64
     // (scripts/micro/lds_atomics.hip), so the LDS tile accumulates in double for
     // both grid dtypes and is rounded to T once, at the flush.
     __shared__ double tile[LX * LY * LZ];
-    const uint32_t t = blockIdx.x;
+    // ntiles_loop = 0: tile = workgroup.  Otherwise the workgroups stride over the ntiles_loop tiles (the late list's
+    // deposit: nearly all tiles are empty there, and half a million workgroups that only find that out cost 0.1 ms)
+    const uint32_t t_end = ntiles_loop ? ntiles_loop : blockIdx.x + 1u;
+  for (uint32_t t = blockIdx.x; t < t_end; t += gridDim.x) {
     // cap != 0: single-pass layout (fixed segments, tile_count holds the slots REQUESTED)
     const uint32_t cnt = cap ? min(tile_count[t], cap) : tile_count[t];
-    if (cnt == 0) return;                       // uniform for the workgroup
+    if (cnt == 0) continue;                     // uniform for the workgroup
     const size_t off = cap ? (size_t)t * cap : (size_t)tile_off[t];
+    __syncthreads();                            // (the previous tile's flush has read the LDS tile)
     for (int i = threadIdx.x; i < LX * LY * LZ; i += 256) tile[i] = 0.0;
     __syncthreads();
 
@@ -1091,10 +1105,10 @@ tile_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileG
             const uint32_t i = i0 + u * 256 + threadIdx.x;
             on[u] = i < cnt;
             const size_t p = on[u] ? index[off + i] : 0;
-            px[u] = on[u] ? pos[3 * p + 0] : (T)0;
-            py[u] = on[u] ? pos[3 * p + 1] : (T)0;
-            pz[u] = on[u] ? pos[3 * p + 2] : (T)0;
-            pm[u] = (on[u] && mass) ? mass[p] : (T)1;
+            px[u] = on[u] ? pos[STRIDE * p + 0] : (T)0;
+            py[u] = on[u] ? pos[STRIDE * p + 1] : (T)0;
+            pz[u] = on[u] ? pos[STRIDE * p + 2] : (T)0;
+            pm[u] = STRIDE == 4 ? (on[u] ? pos[STRIDE * p + 3] : (T)1) : (on[u] && mass) ? mass[p] : (T)1;       // (records carry their mass)
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1127,7 +1141,7 @@ tile_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileG
         }
     }
     __syncthreads();
-    if (ablate & 1) return;
+    if (ablate & 1) continue;
 
     // flush: LDS cell (a, b, c) is buffer plane ox + a - LO, global (oy + b - LO, oz + c - LO)
     unsigned long long ndrop = 0;
@@ -1142,6 +1156,7 @@ tile_deposit_kernel(const T* __restrict__ pos, const T* __restrict__ mass, TileG
         atomicAdd(&grid[((size_t)px * g.n + gy) * g.n + gz], v);
     }
     if (dropped && ndrop) atomicAdd(dropped, ndrop);
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1861,6 +1876,7 @@ struct Workspace {
     void* staging;                   // [np] x {x, y, z, m}, bucket-major
     uint32_t tpb;                    // tiles per bucket (0: the scatter path does not apply)
     uint32_t nb;                     // buckets (scatter_buckets)
+    uint32_t* late_index;            // record numbers of the late list, tile-major (its deposit through LDS tiles)
     size_t bytes;
 };
 
@@ -1919,6 +1935,7 @@ Workspace carve(void* base, size_t np, uint32_t ntiles, uint32_t ncols, int flag
     w.strays = take((size_t)ntiles * w.scap * 4 * esz);
     w.staging = take(w.tpb ? (size_t)w.nb * SC_GROUPS * w.cap_bg * 4 * esz : 0);
     w.ovf = (uint32_t*)take(two_pass ? 0 : np * 4);
+    w.late_index = (uint32_t*)take(w.tpb ? np / 4 * sizeof(uint32_t) / esz * 4 : 0);      // one id per record the list has room for
     w.rec = take(rec_bytes);
     w.zrec = (unsigned long long*)take(zrec_bytes);
     w.bytes = off;
@@ -2155,8 +2172,35 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
         { const int rc = scatter_pass(); if (rc != AST_OK) return rc; }
         deposit_pass(nullptr, nullptr, 0);
         AST_PROF("paint_tiled.overflow", s);
-        late_deposit_kernel<T, W><<<1024, 256, 0, s>>>((const T*)w.ovf, w.late, np / 4 * sizeof(uint32_t) / sizeof(T), g, scale, grid,
-                                                       dropped, 0, g.nx_alloc);
+        // The late list (records whose tile - or bucket - segment was full).  A few stragglers: global atomics.  A long list
+        // (clustered input without order in memory: a tenth of the particles, in a few hundred hot tiles) is a small paint
+        // of its own - counted per tile, scanned, its record numbers filled tile-major, then ONE workgroup per tile adds its
+        // records up in LDS and flushes the tile onto the grid: the two-pass variant with the list's records as particles.
+        // The list's length stays on the device: all kernels are launched, each looks at the count.
+        const unsigned long long late_cap = np / 4 * sizeof(uint32_t) / sizeof(T);
+        const unsigned long long lds_min = getenv("AST_PAINT_LATE_LDS_MIN") ? strtoull(getenv("AST_PAINT_LATE_LDS_MIN"), nullptr, 10) : 262144ull;
+        late_deposit_kernel<T, W><<<1024, 256, 0, s>>>((const T*)w.ovf, w.late, late_cap, g, scale, grid, dropped, 0, g.nx_alloc, lds_min);
+        if (lds_min != ~0ull && late_cap > 0) {
+            const size_t lint = (late_cap + per_interval - 1) / per_interval;
+            const unsigned gl = (unsigned)(lint > 4096 ? 4096 : lint);
+            const uint32_t nblk = (ntiles + 1023) / 1024;
+            auto late_index_pass = [&](auto mode) {
+                constexpr int MODE = decltype(mode)::value;
+                if (plainx)
+                    tile_index_kernel<T, W, MODE, true, 4><<<gl, 256, 0, s>>>((const T*)w.ovf, (size_t)late_cap, g, w.tile_count, w.tile_off, w.tile_fill,
+                                                                              w.late_index, 0, nullptr, nullptr, w.col_flags, nullptr, w.late, lds_min);
+                else
+                    tile_index_kernel<T, W, MODE, false, 4><<<gl, 256, 0, s>>>((const T*)w.ovf, (size_t)late_cap, g, w.tile_count, w.tile_off, w.tile_fill,
+                                                                               w.late_index, 0, nullptr, nullptr, w.col_flags, nullptr, w.late, lds_min);
+            };
+            late_index_pass(std::integral_constant<int, 0>{});
+            scan_blocks_kernel<<<nblk, 256, 0, s>>>(w.tile_count, w.tile_off, w.block_sums, ntiles);
+            scan_sums_kernel<<<1, 256, 0, s>>>(w.block_sums, nblk);
+            scan_add_kernel<<<nblk, 256, 0, s>>>(w.tile_off, w.block_sums, ntiles);
+            late_index_pass(std::integral_constant<int, 1>{});
+            tile_deposit_kernel<T, W, 4><<<ntiles < 8192u ? ntiles : 8192u, 256, 0, s>>>((const T*)w.ovf, nullptr, g, scale, w.late_index, w.tile_off,
+                                                                                       w.tile_count, 0, grid, dropped, ntiles);
+        }
     } else if (overwrite) {
         // AST_PAINT_XSORTED: the particles come in ascending x (buffer planes).  They are grouped chunk by chunk
         // (plan.chunk_planes planes' worth each); a tile row is walked as soon as the chunks cover its planes plus a

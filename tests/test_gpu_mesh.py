@@ -432,7 +432,7 @@ def test_power_spectrum_3d_catalogue_branch(dev, tmp_path):
 
 
 @pytest.mark.parametrize("window,dtype", [("cic", np.float32), ("tsc", np.float64)])
-def test_scattered_path_two_level_bucket_scatter(dev, window, dtype):
+def test_scattered_path_two_level_bucket_scatter(dev, window, dtype, monkeypatch):
     """AST_PAINT_SCATTERED (hint="scattered"): count, scan, particle -> bucket staging, bucket -> tile stray segments,
     column walk over stray copies only.  Unordered uniform input with masses against the oracle; a clustered blob
     on top exercises the late list (tile segments full) and, through the API's retry, the exact two-pass variant."""
@@ -455,6 +455,20 @@ def test_scattered_path_two_level_bucket_scatter(dev, window, dtype):
     assert 0 < st["overflow"] < npart // 64                       # a few thousand records take the late list
     ref = omesh.paint(blob, None, n, L, window)
     np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * ref.max())
+    # a LONG late list is deposited through LDS tiles (counted per tile, scanned, filled, one workgroup per tile) instead of
+    # global atomics record by record: forced here for the short one, with and without masses
+    monkeypatch.setenv("AST_PAINT_LATE_LDS_MIN", "1")
+    st = {}
+    got = dev.paint(dev.as_device(blob), None, n, L, window, method="tiled", accumulate=False, hint="scattered",
+                    check_dropped=False, stats=st).cpu().numpy()
+    assert 0 < st["overflow"] < npart // 64
+    np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * ref.max())
+    bmass = rng.uniform(0.5, 2.0, size=npart).astype(dtype)
+    got = dev.paint(dev.as_device(blob), dev.as_device(bmass), n, L, window, method="tiled", accumulate=False, hint="scattered",
+                    check_dropped=False).cpu().numpy()
+    refm = omesh.paint(blob, bmass, n, L, window)
+    np.testing.assert_allclose(got, refm, rtol=tol, atol=tol * refm.max())
+    monkeypatch.delenv("AST_PAINT_LATE_LDS_MIN")
     heavy = np.concatenate([rng.normal(0.3 * L, 0.01 * L, size=(npart // 2, 3)), pos[: npart // 2]]).astype(dtype)
     rng.shuffle(heavy)
     got = dev.paint(dev.as_device(heavy), None, n, L, window, method="tiled", accumulate=False).cpu().numpy()   # retries
