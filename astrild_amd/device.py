@@ -223,6 +223,25 @@ def synth_clustered_particles(npside, nmesh, boxsize, seed=20240601, sigma_cells
     return pos
 
 
+def auto_paint_method(npart, n, nx, window, hint=None, accumulate=False):
+    """What ``paint(method="auto")`` runs (measured on the MI355X, scripts/perf_sparse.py: 256^3 and 512^3 grids, halo-like
+    catalogues of 1 ... 64 objects per 8 x 8 x 32-cell tile).  The tiled paint walks every column of the grid, so below ~16
+    (CIC) / ~8 (TSC) objects per tile - SubFind haloes on nbins = 1024 - global atomics on a zero-filled grid win:
+    "direct".  Above that, catalogues too small for the input probe (< 2^20 objects), or still sparse (< 64 per tile:
+    halo catalogues, stats_subfind.py:125-131, clumpy by nature), take the exact two-pass lists - as fast as the single
+    pass there and without its per-tile capacity (512^3, 32 per tile, TSC float64: direct 2.7 ms, tiled2 1.45; a clumpy
+    256^3 set at 64 per tile: single pass 1.0 ms through its overflow list, tiled2 0.2).  Dense input goes to "tiled",
+    where the probe picks single pass / scatter levels / two-pass from the input itself."""
+    per_tile = npart * 2048 / max(1, nx * n * n)
+    if accumulate:                                   # (adding onto a grid: index lists + atomic tile flush; the round-1 threshold)
+        return "tiled" if n % 32 == 0 and npart >= 65536 and per_tile >= 64 else "direct"
+    if n % 32 or npart < 65536 or per_tile < (8 if window.lower() == "tsc" else 16):
+        return "direct"
+    if hint is None and (npart < (1 << 20) or per_tile < 64):
+        return "tiled2"
+    return "tiled"
+
+
 def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="auto",
           x_start=0, nx_alloc=None, check_dropped=True, accumulate=None, defer_fold=False, offset=0.0,
           hint=None, stats=None, shift=0.0, offset_planes=None):
@@ -288,18 +307,19 @@ def paint(pos, mass, nmesh, boxsize, window="cic", scale=1.0, out=None, method="
         raise ValueError(hint)
     if hint == "clustered" and method in ("auto", "tiled"):
         method = "tiled2"
+    was_auto = method == "auto"
+    if was_auto and win != 0:
+        method = auto_paint_method(npart, n, nx, window, hint, accumulate)
     tflags = (1 if method == "tiled2" else 0) | (0 if accumulate else 2) | (4 if defer_fold else 0) | \
              (8 if hint == "scattered" and not accumulate and method != "tiled2" else 0) | \
              (16 if hint == "xsorted" and not accumulate and method != "tiled2" else 0)
     if method in ("auto", "tiled", "tiled2") and win != 0 and npart < 2**32 - 65:
         ws_bytes = int(L.ast_paint_tiled_workspace_bytes(win, code, npart, n, nx, tflags))
     if method in ("tiled", "tiled2") and ws_bytes == 0:
-        raise _lib.AstrildHipError("tiled paint needs a CIC/TSC window and nmesh a multiple of 32")
-    # "auto": the tiled paint walks every column of the grid and its workspace scales with the GRID, so it only pays
-    # when the tiles are reasonably full (>= 64 particles per 8 x 8 x 32 tile on average); sparse catalogues on big
-    # grids (SubFind haloes on nbins = 1024) take the direct atomic path
-    dense = npart >= 65536 and npart * 2048 >= 64 * nx * n * n
-    use_tiled = ws_bytes > 0 and (method in ("tiled", "tiled2") or dense)
+        if not was_auto:
+            raise _lib.AstrildHipError("tiled paint needs a CIC/TSC window and nmesh a multiple of 32")
+        method, tflags = "direct", 0                  # a buffer geometry the tiles do not cover
+    use_tiled = ws_bytes > 0 and method in ("tiled", "tiled2")      # ("auto" was resolved above: auto_paint_method)
     if defer_fold and not (use_tiled and not accumulate and x_start == 0 and nx == n):
         raise _lib.AstrildHipError("defer_fold needs the tiled overwrite paint of the whole periodic grid")
     if out is None:
@@ -711,29 +731,32 @@ def fused_power_supported(field):
         and bool(_lib.lib().ast_fft_tile_supported(F32, n))
 
 
-def paint_power_1d(pos, mass, nmesh, boxsize, window="cic", scale=1.0, binning=None, defer_fold64=True):
+def paint_power_1d(pos, mass, nmesh, boxsize, window="cic", scale=1.0, binning=None, defer_fold64=True, pos_scale=1.0):
     """``pm.paint(...)`` followed by ``FFTPower(ArrayMesh(grid), mode="1d")`` (stats_subfind.py:130-150)
-    as one pipeline: where the fused fp32 path applies, the paint's halo fold rides on the FFT's z pass."""
+    as one pipeline: where the fused fp32 path applies, the paint's halo fold rides on the FFT's z pass.
+    pos_scale: the positions are in units of 1 / pos_scale box units (``pos * pos_scale`` is what the reference paints,
+    stats_subfind.py:121-122: kpc -> Mpc/h): folded into the cell lookup - the catalogue is painted as it was read."""
     n = int(nmesh)
-    fast = pos.dtype == torch.float32 and n % 32 == 0 and pos.shape[0] >= 65536 \
-        and pos.shape[0] * 2048 >= 64 * n ** 3 and bool(_lib.lib().ast_fft_tile_supported(F32, n))     # tiles reasonably full
+    paint_box = float(boxsize) / float(pos_scale)
+    # which tiled variant (None: a catalogue too sparse for the tiles - global atomics, then the plain transform)
+    tiled = auto_paint_method(pos.shape[0], n, n, window) if n % 32 == 0 else "direct"
+    tiled = None if tiled == "direct" else tiled
+    fast = pos.dtype == torch.float32 and tiled is not None and bool(_lib.lib().ast_fft_tile_supported(F32, n))
     if fast:
         # the grid holds rho - mean (subtracted before the fp32 rounding): only the discarded DC mode differs
-        grid, halo = paint(pos, mass, n, boxsize, window, scale=scale, method="tiled", defer_fold=True,
+        grid, halo = paint(pos, mass, n, paint_box, window, scale=scale, method=tiled, defer_fold=True,
                            offset="mean")
         return finish_power(*power_sums_fused(grid, boxsize, halo=halo, binning=binning))
-    if pos.dtype == torch.float32 and n % 32 == 0 and pos.shape[0] >= 65536 and pos.shape[0] * 2048 >= 64 * n ** 3 \
-            and bool(_lib.lib().ast_fft64_supported(n)):
+    if pos.dtype == torch.float32 and tiled is not None and bool(_lib.lib().ast_fft64_supported(n)):
         # fp32 particles on a grid without fp32 tile passes (128^3, 2048^3): the grid holds rho - mean (only the discarded DC
         # mode differs), the transform runs in double straight from the fp32 grid
-        grid = paint(pos, mass, n, boxsize, window, scale=scale, method="tiled", offset="mean")
+        grid = paint(pos, mass, n, paint_box, window, scale=scale, method=tiled, offset="mean")
         return finish_power(*power_sums_fused64(grid, boxsize, binning=binning))
-    fast64 = pos.dtype == torch.float64 and n % 32 == 0 and pos.shape[0] >= 65536 \
-        and pos.shape[0] * 2048 >= 64 * n ** 3 and bool(_lib.lib().ast_fft64_supported(n))
+    fast64 = pos.dtype == torch.float64 and tiled is not None and bool(_lib.lib().ast_fft64_supported(n))
     if fast64 and defer_fold64:               # float64: the halo fold inside the double z pass (26.2 vs 26.5 ms at 1024^3)
-        grid, halo = paint(pos, mass, n, boxsize, window, scale=scale, method="tiled", defer_fold=True)
+        grid, halo = paint(pos, mass, n, paint_box, window, scale=scale, method=tiled, defer_fold=True)
         return finish_power(*power_sums_fused64(grid, boxsize, halo=halo, binning=binning))
-    return fftpower_1d(paint(pos, mass, n, boxsize, window, scale=scale), boxsize, binning=binning)
+    return fftpower_1d(paint(pos, mass, n, paint_box, window, scale=scale), boxsize, binning=binning)
 
 
 def fftpower_1d(field1, boxsize, field2=None, fused=True, binning=None):

@@ -17,17 +17,19 @@ class SubFind:
         ``.header.hubble/.boxsize`` like astrild's read_hdf5.snapshot."""
         if boxsize is None:
             boxsize = snapshot.header.boxsize / 1e3  # [Mpc/h]
-        if objects == "subhalo":
-            pos_field = snapshot.cat["SubhaloPos"][:] * snapshot.header.hubble / 1e3  # [Mpc/h]
-            mass_field = snapshot.cat["SubhaloMass"][:] * snapshot.header.hubble / 1e10
-        else:
+        if objects != "subhalo":
             raise ValueError(f"objects={objects!r} is not supported")
+        # The reference converts units on the host first (pos * h / 1e3 [Mpc/h], mass * h / 1e10: stats_subfind.py:121-122 -
+        # two numpy passes over the catalogue, 7.5 ms for 2e6 objects, more than everything the GPU does with it).  Here the
+        # catalogue goes to the device as it was read; the position factor rides on the cell lookup (pos_scale), the mass
+        # factor on the paint's scale.
+        h = float(snapshot.header.hubble)
         dx = boxsize / nbins
-        pos = dev.as_device(np.ascontiguousarray(pos_field), SubFind.dtype)
-        mass = dev.as_device(np.ascontiguousarray(mass_field), SubFind.dtype)
+        pos = dev.as_device(np.ascontiguousarray(snapshot.cat["SubhaloPos"][:]), SubFind.dtype)
+        mass = dev.as_device(np.ascontiguousarray(snapshot.cat["SubhaloMass"][:]), SubFind.dtype)
         # pm.paint(pos, mass=mass, resampler="tsc") / dx**3   (stats_subfind.py:130-132)
         # ... then FFTPower(ArrayMesh(value_map), mode="1d")                 (stats_subfind.py:134-150)
-        r = dev.paint_power_1d(pos, mass, nbins, boxsize, "tsc", scale=1.0 / dx ** 3)
+        r = dev.paint_power_1d(pos, mass, nbins, boxsize, "tsc", scale=(h / 1e10) / dx ** 3, pos_scale=h / 1e3)
         k = np.array(r["k"])
         Pk = np.array(r["power"] - r["shotnoise"])
         return k, Pk

@@ -127,6 +127,31 @@ def test_subfind_power_spectrum_tsc():
     npt.assert_allclose(p, pr, rtol=1e-9)
 
 
+def test_subfind_power_spectrum_clumpy_catalogue_on_the_tiles():
+    """A halo-like catalogue (Gaussian clumps, masses over three decades) dense enough for the LDS tiles (24 objects per
+    tile: the exact two-pass lists, `device.auto_paint_method`), through the API from raw catalogue units - the unit factors
+    ride on the paint (stats_subfind.py:121-122 converts on the host first) - against the oracle on converted arrays."""
+    from astrild_amd.particles.hutils import SubFind
+    from astrild_amd import device as dev
+    rng = np.random.default_rng(5)
+    nobj, nbins, box, h = 200000, 256, 500.0, 0.6774
+    assert dev.auto_paint_method(nobj, nbins, nbins, "tsc") == "tiled2"
+    assert dev.auto_paint_method(nobj // 4, nbins, nbins, "tsc") == "direct" and dev.auto_paint_method(1 << 24, nbins, nbins, "cic") == "tiled"
+    centres = rng.uniform(0.0, box, size=(512, 3))
+    which = rng.integers(0, 512, size=nobj)
+    pos = np.mod(centres[which] + rng.standard_normal((nobj, 3)) * rng.uniform(0.5, 4.0, size=512)[which][:, None], box)
+    mass = 10.0 ** rng.uniform(0.0, 3.0, size=nobj)
+    snap = types.SimpleNamespace(cat={"SubhaloPos": pos * 1e3 / h, "SubhaloMass": mass * 1e10 / h},
+                                 header=types.SimpleNamespace(hubble=h, boxsize=box * 1e3))
+    k, p = SubFind.power_spectrum(snap, nbins=nbins, boxsize=box)
+    pos_c = snap.cat["SubhaloPos"] * h / 1e3
+    mass_c = snap.cat["SubhaloMass"] * h / 1e10
+    grid = omesh.paint(pos_c, mass_c, nbins, box, "tsc") / (box / nbins) ** 3
+    kr, pr = offt.power_spectrum_3d(grid, box)
+    npt.assert_allclose(k, kr, rtol=1e-12)
+    npt.assert_allclose(p, pr, rtol=1e-9)
+
+
 @pytest.mark.parametrize("n,width", [(16, 1), (32, 3)])
 def test_bispectrum_3d_vs_oracle(tmp_path, n, width):
     from astrild_amd.bispectra import Bispectrum3D
