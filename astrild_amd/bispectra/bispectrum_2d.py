@@ -13,6 +13,13 @@ from .. import lensing
 from ..io import IO
 
 
+
+def _map_of(skymap, on):
+    """The map as it lives: the CUDA tensor of a SkyArray's resident map (no PCIe hop), else the array."""
+    dev_fn = getattr(skymap.data, "device", None)
+    return dev_fn(on) if dev_fn is not None else skymap.data[on]
+
+
 class Bispectrum2DWarning(BaseException):
     pass
 
@@ -29,7 +36,7 @@ class Bispectrum2D:
                     rtn: bool = False) -> "Bispectrum2D":
         if "kappa" not in skymap.quantity:
             raise Bispectrum2DWarning(f"no bispectrum for quantity {skymap.quantity!r} (the reference handles kappa only)")
-        l, B, ntri = lensing.flat_bispectrum_equilateral(skymap.data[on], skymap.opening_angle,
+        l, B, ntri = lensing.flat_bispectrum_equilateral(_map_of(skymap, on), skymap.opening_angle,
                                                          np.asarray(multipoles, dtype=np.float64))
         out = cls(l, B, skymap, on)
         out.ntri = ntri

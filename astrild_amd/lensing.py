@@ -613,3 +613,39 @@ def bench_kappa_api(nplanes=64, npix=4096, nz=8, one_by_one=2):
             "note": "z_src_shift as a sequence: planes uploaded once and resident in HBM, one pass of ast_kappa_stack per "
                     "source redshift, results copied back as numpy arrays; the loader returns arrays already in host memory"}
 
+
+
+def bench_skyarray_chain(npix=4096, reps=3):
+    """One map through the reference-shaped per-map API (rays/skys/sky_array.py): SkyArray.from_array(host map) ->
+    filter(Gaussian, 1 arcmin) -> convert_convergence_to_deflection(rtn=False) -> pdf -> wl_peak_counts -> the two deflection
+    maps read back as arrays.  Timed as the methods leave it (what they produce stays in HBM, rays/_resident.MapStore) and
+    with every intermediate map fetched between the methods (the reference's shape: numpy arrays in ``self.data``)."""
+    from .rays.skys import SkyArray
+    host = synth_kappa_planes(1, npix)[0].cpu().numpy()
+
+    def chain(fetch):
+        sky = SkyArray.from_array(host, opening_angle=20.0, quantity="kappa_2", dir_in="")
+        sky.filter({"gaussian": {"theta_i": 1.0, "abbrev": "g"}}, on="orig")
+        if fetch:
+            sky.data["orig_g"]
+        sky.convert_convergence_to_deflection(on="orig_g", rtn=False)
+        if fetch:
+            sky.data["defltx"], sky.data["deflty"]
+        pdf = sky.pdf(100, of="orig_g")
+        peaks = sky.wl_peak_counts(30, "", of="orig_g")
+        return sky.data["defltx"], sky.data["deflty"], pdf, peaks
+
+    out = {}
+    for name, fetch in (("resident", False), ("fetched_between_methods", True)):
+        chain(fetch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = chain(fetch)
+        torch.cuda.synchronize()
+        out[name] = {"ms_per_map": round((time.perf_counter() - t0) / reps * 1e3, 2)}
+        out[name + "_result"] = res
+    same = all(np.array_equal(a, b) for a, b in zip(out.pop("resident_result")[:2], out.pop("fetched_between_methods_result")[:2]))
+    return {"metric": f"one {npix}^2 float64 map through SkyArray: filter -> kappa->alpha -> pdf -> peak counts, host array in, deflection maps out",
+            "value": round(1e3 / out["resident"]["ms_per_map"], 2), "unit": "maps/s", **out, "bit_identical": bool(same),
+            "pcie_MB": {"resident": round(3 * npix * npix * 8 / 1e6), "fetched_between_methods": round(8 * npix * npix * 8 / 1e6)}}

@@ -12,6 +12,13 @@ import numpy as np
 from .. import lensing
 
 
+
+def _map_of(skymap, on):
+    """The map as it lives: the CUDA tensor of a SkyArray's resident map (no PCIe hop), else the array."""
+    dev_fn = getattr(skymap.data, "device", None)
+    return dev_fn(on) if dev_fn is not None else skymap.data[on]
+
+
 class PowerSpectrum2DWarning(BaseException):
     pass
 
@@ -25,5 +32,5 @@ class AngularPowerSpectrum:
     def from_array(cls, skymap, on: str,
                    multipoles: Union[List[float], np.array] = np.arange(200.0, 50000.0, 200.0)) -> "AngularPowerSpectrum":
         """``skymap``: a SkyArray (``.data[on]``, ``.opening_angle`` in degrees); ``multipoles``: bin edges."""
-        l, P = lensing.flat_power_spectrum(skymap.data[on], skymap.opening_angle, np.asarray(multipoles, dtype=np.float64))
+        l, P = lensing.flat_power_spectrum(_map_of(skymap, on), skymap.opening_angle, np.asarray(multipoles, dtype=np.float64))
         return cls(l, P)

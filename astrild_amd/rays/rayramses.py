@@ -25,7 +25,7 @@ import numpy as np
 import pandas as pd
 
 from .. import lensing
-from ..device import as_device
+from ..device import as_device, to_numpy
 
 
 def _shard_group(group):
@@ -64,7 +64,7 @@ class PlaneStacker:
     def _translate_redshift(self, quantity, z_near, z_far, z_src, z_src_shift):
         num, den = self._translate_redshift_weight(z_near, z_far, z_src, z_src_shift)
         t = as_device(np.ascontiguousarray(quantity, dtype=np.float64))
-        return lensing.kappa_stack([t], [num], [den]).cpu().numpy()
+        return to_numpy(lensing.kappa_stack([t], [num], [den]))
 
     @staticmethod
     def _z_next(table, box_nr, ray_nr):
@@ -95,9 +95,9 @@ class PlaneStacker:
     def _sum_planes(planes, wn, wd, group):
         """Device planes -> summed map as numpy; sharded over `group` when given (every rank gets the result)."""
         if group is None:
-            return lensing.kappa_stack(planes, wn, wd).cpu().numpy()
+            return to_numpy(lensing.kappa_stack(planes, wn, wd))
         from ..kappa_shard import kappa_stack_sharded
-        return kappa_stack_sharded(planes, wn, wd, group=group, all_ranks=True).cpu().numpy()
+        return to_numpy(kappa_stack_sharded(planes, wn, wd, group=group, all_ranks=True))
 
     @classmethod
     def _stack_columns(cls, frames, columns, weights, group=None, template=None):
@@ -131,7 +131,7 @@ class PlaneStacker:
                 if key not in done:
                     wn, wd = w if w is not None else (None, None)
                     done[key] = lensing.kappa_stack(planes, wn, wd)          # queued back to back: no host round trip between maps
-            host = {key: t.cpu().numpy() for key, t in done.items()}
+            host = {key: to_numpy(t) for key, t in done.items()}
             return [host[key] for key in keys]
         from ..kappa_shard import MapStream
         import torch.distributed as dist

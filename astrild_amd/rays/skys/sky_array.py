@@ -1,7 +1,10 @@
 """``SkyArray`` (src/astrild/rays/skys/sky_array.py) for the kappa-map hot path:
 unit conversion + reshape, PDF, filters, galaxy shape noise, kappa -> deflection,
-crop / division / merge.  ``self.data`` holds numpy arrays like the reference;
-the arithmetic runs on the GPU through libastrild_hip.so.
+crop / division / merge.  ``self.data`` hands out numpy arrays like the reference's dict;
+the arithmetic runs on the GPU through libastrild_hip.so, and what a method produces
+STAYS in HBM until somebody asks for the array (``rays/_resident.MapStore``): a chain
+filter -> kappa->alpha -> shear -> pdf makes one upload instead of a PCIe round trip
+per method (4096^2 float64: 134 MB each way, several times any of the kernels).
 
 Not carried over (out of scope): create_cmb (broken in the reference,
 sky_array.py:735-739)."""
@@ -13,6 +16,7 @@ import pandas as pd
 
 from ... import lensing
 from ...device import as_device
+from .._resident import MapStore, is_device_map, to_host
 from ..skyio import SkyIO
 from ..utils.filters import Filters
 from .sky_utils import SkyUtils
@@ -25,7 +29,7 @@ class SkyArrayWarning(BaseException):
 class SkyArray:
     def __init__(self, skymap: np.ndarray, opening_angle: float, quantity: str, dirs: Dict[str, str],
                  map_file: Optional[str] = None):
-        self.data = {"orig": skymap}
+        self.data = MapStore({"orig": skymap})
         self._npix = skymap.shape[0]
         self._opening_angle = opening_angle
         self.quantity = quantity
@@ -126,7 +130,7 @@ class SkyArray:
     def pdf(self, nbins: int, of: str = "orig") -> dict:
         """np.histogram(data, bins=nbins, density=True)  (sky_array.py:428-433)."""
         _pdf = {}
-        t = as_device(np.ascontiguousarray(self.data[of], dtype=np.float64))
+        t = self.data.device(of)
         _pdf["values"], _pdf["bins"] = lensing.histogram(t, nbins, density=True)
         return _pdf
 
@@ -138,8 +142,7 @@ class SkyArray:
         ``locatePeaks`` semantics: interior pixels, strictly larger than all 8 neighbours, thresholds[0] <= height
         < thresholds[-1].  ("normalize" subtracts the mean of the map itself; the reference reads a non-existent
         ``self.skymap`` there.)"""
-        data = np.ascontiguousarray(self.data[of], dtype=np.float64)
-        t = as_device(data)
+        t = self.data.device(of)
         if limits is None:
             lower_bound, upper_bound = lensing.percentile(t, [5, 95])
         else:
@@ -147,7 +150,8 @@ class SkyArray:
         map_bins = np.arange(lower_bound, upper_bound, (upper_bound - lower_bound) / nbins)
         heights, _ = lensing.peak_find(t)
         if field_conversion == "normalize":
-            heights = heights - np.mean(data)          # the peak heights of (map - mean): same subtraction, same operands
+            # the peak heights of (map - mean): same subtraction, same operands (numpy's mean of the host array)
+            heights = heights - np.mean(np.ascontiguousarray(self.data[of], dtype=np.float64))
         _kappa = heights[(heights >= map_bins[0]) & (heights < map_bins[-1])]
         _hist, _kappa = np.histogram(_kappa, bins=nbins, density=False)
         _kappa = (_kappa[1:] + _kappa[:-1]) / 2
@@ -160,11 +164,11 @@ class SkyArray:
         ``self.data[of]`` (it resizes ``img`` or fails on None, :491); here ``of`` alone selects the stored map."""
         if img is None and of is not None:
             assert of in list(self.data.keys()), "Map does not exist."
-            img = self.data[of]
+            img = self.data.device(of)
         img = self._manage_img_data(img, orig_data)
-        img = lensing.resize_antialiased(img, npix).cpu().numpy()
+        img = lensing.resize_antialiased(img, npix)
         if rtn:
-            return img
+            return to_host(img)
         self.data[of] = img
 
     def crop(self, xlimit, ylimit, of: Optional[str] = None, img: Optional[np.ndarray] = None,
@@ -231,7 +235,7 @@ class SkyArray:
         each entry is dispatched by name into :class:`Filters`."""
         if on:
             assert on in list(self.data.keys()), "Map does not exist."
-            img = self.data[on]
+            img = self.data.device(on)               # the kernels of the chain hand CUDA tensors to each other
             map_name = [on]
         else:
             map_name = [""]
@@ -245,7 +249,7 @@ class SkyArray:
             fct = getattr(Filters, filter_name)
             img = fct(img, self._opening_angle, **args)
         if rtn:
-            return img
+            return to_host(img)
         self.data[("_").join(map_name)] = img
 
     def create_galaxy_shape_noise(self, std: float, ngal: float, rnd_seed: Optional[int] = None) -> None:
@@ -263,9 +267,7 @@ class SkyArray:
     def add_galaxy_shape_noise(self, on: str = "orig") -> np.ndarray:
         """sky_array.py:693-706."""
         if "kappa" in self.quantity:
-            a = as_device(np.ascontiguousarray(self.data["orig"], dtype=np.float64))
-            b = as_device(np.ascontiguousarray(self.data["gsn"], dtype=np.float64))
-            self.data["orig_gsn"] = lensing.add(a, b).cpu().numpy()
+            self.data["orig_gsn"] = lensing.add(self.data.device("orig"), self.data.device("gsn"))
             return self.data["orig_gsn"]
         raise SkyArrayWarning(f"GSN should not be added to {self.quantity}")
 
@@ -276,7 +278,7 @@ class SkyArray:
         """sky_array.py:780-817.  Returns (alpha_2, alpha_1) — the reference's order."""
         assert self.quantity in ["kappa_1", "kappa_2"], "Deflection angle can only be calculated from the kappa map"
         if on:
-            img = self.data[on]
+            img = self.data.device(on) if self.data.resident(on) or not rtn else self.data[on]
         img = self._manage_img_data(img, orig_data)
         if npix is None:
             npix = self._npix
@@ -284,7 +286,7 @@ class SkyArray:
             opening_angle = self._opening_angle
         alpha_1, alpha_2 = SkyUtils.convert_convergence_to_deflection_ctypes(img, npix, opening_angle)
         if rtn:
-            return alpha_2, alpha_1
+            return to_host(alpha_2), to_host(alpha_1)
         self.data["defltx"] = alpha_2
         self.data["deflty"] = alpha_1
 
@@ -295,18 +297,20 @@ class SkyArray:
         here `img` / `on` name the pair (alpha_1, alpha_2), default the stored data["deflty"], data["defltx"]."""
         assert self.quantity in ["alpha"], "Shear can only be calculated from the deflection angle map"
         if on:
-            img = (self.data[on[0]], self.data[on[1]])
+            img = (self.data.device(on[0]), self.data.device(on[1]))
         if img is None:
-            img = (self.data["deflty"], self.data["defltx"])
+            img = (self.data.device("deflty"), self.data.device("defltx"))
         a1, a2 = (self._manage_img_data(m, orig_data) for m in img)
         gamma_1, gamma_2 = SkyUtils.convert_deflection_to_shear(a1, a2, self._npix, self._opening_angle)
         if rtn:
-            return gamma_2, gamma_1
+            return to_host(gamma_2), to_host(gamma_1)
         self.data["gammax"] = gamma_2
         self.data["gammay"] = gamma_1
 
     @staticmethod
     def _manage_img_data(img: np.ndarray, orig_data: str = None) -> np.ndarray:
+        if is_device_map(img):                       # (device operations never write into their input: a copy only on request)
+            return img.clone() if orig_data in ("shallow", "deep") else img
         if orig_data == "shallow":
             return copy.copy(img)
         elif orig_data == "deep":

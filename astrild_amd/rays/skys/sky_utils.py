@@ -10,7 +10,8 @@ from typing import Tuple
 import numpy as np
 
 from ... import _lib, lensing
-from ...device import as_device
+from ...device import as_device, to_numpy
+from .._resident import is_device_map, to_device
 from .._units import angle_value
 
 c_light = lensing.C_LIGHT_KMS
@@ -43,14 +44,14 @@ class SkyUtils:
         """Sum of the analytic NFW stamps of the selected halos (sky_utils.py:79-137): one GPU
         launch over all halos instead of a Python loop (and joblib batches) of numpy stamps."""
         sel = {key: np.asarray(val)[np.asarray(halo_idx)] for key, val in halo_cat.items()}
-        return lensing.nfw_paint(sel, extent, direction, suppress, suppression_R, npix, signal).cpu().numpy()
+        return to_numpy(lensing.nfw_paint(sel, extent, direction, suppress, suppression_R, npix, signal))
 
     @staticmethod
     def add_patch_to_map(limg: np.ndarray, simg: np.ndarray, cen_pix: tuple) -> np.ndarray:
         """sky_utils.py:140-173."""
         big = as_device(np.ascontiguousarray(limg, dtype=np.float64))
         small = as_device(np.ascontiguousarray(simg, dtype=np.float64))
-        return lensing.add_patch(big, small, cen_pix).cpu().numpy()
+        return to_numpy(lensing.add_patch(big, small, cen_pix))
 
     @staticmethod
     def _single_stamp(theta_200c, M_200c, c_200c, angu_diam_dist, npix, extent, direction, suppress,
@@ -60,7 +61,7 @@ class SkyUtils:
                "theta1_pix": [npix // 2], "theta2_pix": [npix // 2], "theta1_tv": [vel[0]], "theta2_tv": [vel[1]],
                "r200_pix": [(npix - 1) / (2.0 * extent)]}
         out = lensing.nfw_paint(cat, extent, direction, suppress, suppression_R, npix, signal)
-        return out.cpu().numpy()
+        return to_numpy(out)
 
     @staticmethod
     def NFW_deflection_angle_map(theta_200c, M_200c, c_200c, angu_diam_dist, npix: int = 100, extent: float = 1,
@@ -94,6 +95,10 @@ class SkyUtils:
                                                  ) -> Tuple[np.ndarray, np.ndarray]:
         """alpha1, alpha2 in units of opening_angle (sky_utils.py:366-385).
         opening_angle: astropy Quantity or degrees."""
+        if is_device_map(kappa):
+            # a map resident in HBM (SkyArray's MapStore): the same transform plan the host-pointer symbol above runs
+            # between its two PCIe copies, CUDA tensors in and out
+            return lensing.lens_plan(int(npix), angle_value(opening_angle, "rad", "deg")).alphas(to_device(kappa))
         return _call_alphas(kappa, npix, angle_value(opening_angle, "rad", "deg"))
 
     @staticmethod
@@ -104,7 +109,9 @@ class SkyUtils:
         (opening_angle: astropy Quantity or degrees), the unit convert_convergence_to_deflection_ctypes returns alpha in."""
         h = angle_value(opening_angle, "rad", "deg") / int(npix)
         g1, g2 = lensing.deflection_to_shear(alpha1, alpha2, h)
-        return g1.cpu().numpy(), g2.cpu().numpy()
+        if is_device_map(alpha1) and is_device_map(alpha2):
+            return g1, g2
+        return to_numpy(g1), to_numpy(g2)
 
     @staticmethod
     def convert_convergence_to_potential(kappa: np.ndarray, npix: int, opening_angle) -> np.ndarray:

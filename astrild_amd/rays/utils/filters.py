@@ -6,8 +6,14 @@ scipy ``gaussian_filter`` below 500 px, periodic FFT filter from 500 px on."""
 import numpy as np
 
 from ... import lensing
-from ...device import as_device
+from .._resident import is_device_map, to_device, to_host
 from .._units import angle_value
+
+
+def _out(t, like):
+    """A device result in the form of the input: CUDA tensor for a CUDA tensor (SkyArray's resident maps: no PCIe hop between
+    the kernels of a chain), numpy array otherwise."""
+    return t if is_device_map(like) else to_host(t)
 
 
 class Filters:
@@ -29,9 +35,9 @@ class Filters:
         npix = len(img)
         sigma_px = (sigma_i / 60.0) * npix / angle_value(theta, "deg", "deg")
         kind = "gaussian" if npix < 500 else "gaussianFFT"      # filters.py:215-224
-        t = as_device(np.array(img, dtype=np.float64))
+        t = to_device(img).clone() if is_device_map(img) else to_device(np.array(img, dtype=np.float64))     # (smoothed in place)
         lensing.smooth_plan(npix).gaussian(t, sigma_px, kind)
-        return t.cpu().numpy()
+        return _out(t, img)
 
     @staticmethod
     def gaussian_high_pass(img: np.ndarray, theta, theta_i=None, fwhm_i=None) -> np.ndarray:
@@ -46,14 +52,14 @@ class Filters:
         _npix = len(img)
         theta_deg = angle_value(theta, "deg", "deg")
         theta_i_pix = int(np.ceil(_npix * angle_value(theta_i, "deg", "deg") / theta_deg))
-        t = as_device(np.ascontiguousarray(img, dtype=np.float64))
+        t = to_device(img)
         out = torch.empty_like(t)
         work = torch.empty(2 * t.numel(), dtype=torch.float64, device=t.device)
         # theta_fov_deg / len(dist) with theta_fov_deg = theta * len(dist) / npix  (filters.py:349-354)
         h = (theta_deg * _npix / _npix) / _npix
         _lib.check(_lib.lib().ast_dgd_filter(ptr(t), ptr(out), ptr(work), _npix, float(theta_i_pix), h,
                                             int(direction), order, stream()), "ast_dgd_filter")
-        return out.cpu().numpy()
+        return _out(out, img)
 
     @staticmethod
     def gaussian_third_derivative(img: np.ndarray, theta, theta_i, direction: int) -> np.ndarray:
@@ -76,10 +82,10 @@ class Filters:
         from ... import _lib
         from ...device import ptr, stream
         import torch
-        t = as_device(np.ascontiguousarray(img, dtype=np.float64))
+        t = to_device(img)
         out = torch.empty_like(t)
         _lib.check(_lib.lib().ast_hann_apodize(ptr(t), ptr(out), len(img), stream()), "ast_hann_apodize")
-        return out.cpu().numpy()
+        return _out(out, img)
 
     @staticmethod
     def gaussian_third_derivative_convolution(img: np.ndarray, theta, theta_i, direction=1) -> np.ndarray:
@@ -93,7 +99,7 @@ class Filters:
         s_pix = int(np.ceil(_npix * angle_value(theta_i, "deg", "deg") / angle_value(theta, "deg", "deg")))
         order = 3 * np.asarray(direction)
         o0, o1 = (int(order), int(order)) if order.ndim == 0 else (int(order[0]), int(order[1]))
-        t = as_device(np.ascontiguousarray(img, dtype=np.float64))
+        t = to_device(img)
         acc = None
         for fac, sign in ((0.5, 1.0), (1.0, -1.0), (2.0, 1.0)):
             sigma = s_pix * fac
@@ -105,7 +111,7 @@ class Filters:
                                                            o0, o1, 1, stream()), "ast_gaussian_filter_order")
             # gauss_1 - gauss_2 + gauss_3 in that order
             acc = out if acc is None else (acc - out if sign < 0 else acc + out)
-        return acc.cpu().numpy()
+        return _out(acc, img)
 
     @staticmethod
     def gaussian_compensated(img: np.ndarray, theta, theta_i, theta_o) -> np.ndarray:
@@ -122,12 +128,12 @@ class Filters:
         xx, x_o = dist / t_i, t_o / t_i
         window = (np.exp(-xx ** 2.0) / (np.pi * t_i ** 2.0)) - ((1.0 - np.exp(-x_o ** 2.0)) / (np.pi * t_o ** 2.0))
         window[t_o < dist] = 0
-        t = as_device(np.ascontiguousarray(img, dtype=np.float64))
-        w = as_device(np.ascontiguousarray(window, dtype=np.float64))
+        t = to_device(img)
+        w = to_device(window)
         out = torch.empty_like(t)
         _lib.check(_lib.lib().ast_convolve2d(ptr(t), ptr(w), ptr(out), img.shape[0], w.shape[0], w.shape[1],
                                              stream()), "ast_convolve2d")
-        return out.cpu().numpy()
+        return _out(out, img)
 
     @staticmethod
     def aperture_photometry(img: np.ndarray, theta, alpha) -> np.ndarray:
@@ -139,11 +145,15 @@ class Filters:
         _npix = len(img)
         pix_per_deg = _npix / angle_value(theta, "deg", "deg")
         alpha_pix = int(np.ceil(angle_value(alpha, "deg", "deg") * pix_per_deg))
-        t = as_device(np.ascontiguousarray(img, dtype=np.float64))
+        t = to_device(img)
         work = torch.empty(2048, dtype=torch.float64, device=t.device)
         _lib.check(_lib.lib().ast_aperture_photometry(ptr(t), ptr(t), ptr(work), _npix, float(alpha_pix), stream()),
                    "ast_aperture_photometry")
-        res = t.cpu().numpy()
+        if is_device_map(img):                        # a resident float64 map is updated in place, like the array below
+            if t.data_ptr() != img.data_ptr():
+                img.copy_(t)
+            return img
+        res = to_host(t)
         if isinstance(img, np.ndarray) and img.dtype == np.float64:
             img[...] = res
             return img

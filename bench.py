@@ -646,6 +646,7 @@ def main():
             torch.cuda.empty_cache()
             from astrild_amd import lensing
             out["kappa"]["api"] = lensing.bench_kappa_api()
+            out["kappa"]["api_per_map_chain"] = lensing.bench_skyarray_chain()
             if args.cpu_sample:
                 out["kappa"]["cpu_baseline"] = kappa_cpu_baseline(dev)
             # the stack reads 64 planes for one map written: against the measured READ rate; the whole pipeline against the copy rate
