@@ -425,8 +425,13 @@ def synth_kappa_plane(p, npix, seed0=4242, rms=0.01, dtype=torch.float64):
 
 
 def synth_kappa_planes(nplanes, npix, seed0=4242, rms=0.01, dtype=torch.float64, ids=None):
-    """The planes `ids` (default: all) of the synthetic stack."""
-    return [synth_kappa_plane(p, npix, seed0, rms, dtype) for p in (range(nplanes) if ids is None else ids)]
+    """The planes `ids` (default: all) of the synthetic stack, as views into one allocation (device.upload_planes: the stack
+    reads one pixel of every plane at a time and runs 8-10 % faster over one large allocation than over separate blocks)."""
+    ids = list(range(nplanes) if ids is None else ids)
+    slab = torch.empty((len(ids), npix, npix), dtype=dtype, device="cuda")
+    for i, p in enumerate(ids):
+        slab[i].copy_(synth_kappa_plane(p, npix, seed0, rms, dtype))
+    return [slab[i] for i in range(len(ids))]
 
 
 def synth_plane_weights(nplanes):

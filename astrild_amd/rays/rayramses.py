@@ -25,7 +25,7 @@ import numpy as np
 import pandas as pd
 
 from .. import lensing
-from ..device import as_device, to_numpy
+from ..device import as_device, to_numpy, upload_planes
 
 
 def _shard_group(group):
@@ -178,14 +178,14 @@ class PlaneStacker:
 
     @classmethod
     def _stack_arrays_many(cls, arrays, weights_list, group=None, shape=None):
-        planes = [as_device(np.ascontiguousarray(a, dtype=np.float64)).reshape(-1) for a in arrays]
+        planes = upload_planes(arrays)                 # one device allocation, plane after plane
         maps = cls._stack_many(planes, weights_list, group)
         shape = np.shape(arrays[0]) if arrays else shape
         return [None if r is None else r.reshape(shape) for r in maps]
 
     @classmethod
     def _stack_arrays(cls, arrays, weights=None, group=None):
-        planes = [as_device(np.ascontiguousarray(a, dtype=np.float64)) for a in arrays]
+        planes = upload_planes(arrays, flat=False)
         wn, wd = weights if weights else (None, None)
         out = cls._sum_planes(planes, wn, wd, group)
         return out.reshape(np.shape(arrays[0])) if arrays else out

@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-LEG_STEPS, LEG_WARMUP = 5, 2    # the secondary legs (shuffled / TSC / float64): enough steps for figures that do not wander
+LEG_STEPS, LEG_WARMUP = 10, 2   # the secondary legs (shuffled / TSC / float64): as many timed steps as the headline (0.1-0.3 s each)
 
 
 def parse():
