@@ -24,12 +24,11 @@ namespace {
 #ifndef KSTACK_DEPTH
 #define KSTACK_DEPTH 4             // planes whose loads are issued before the first add
 #endif
-template <typename T, int V>
+template <typename T, int V, int D = KSTACK_DEPTH>
 __global__ void __launch_bounds__(256)
 kappa_stack_kernel(const T* const* __restrict__ planes, const double* __restrict__ wnum,
                    const double* __restrict__ wden, int nplanes, size_t count, T* __restrict__ out) {
     typedef T vec_t __attribute__((ext_vector_type(V)));
-    constexpr int D = KSTACK_DEPTH;
     const size_t nvec = count / V;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     auto load = [&](int p, size_t i) -> vec_t {
@@ -348,7 +347,12 @@ extern "C" int ast_kappa_stack(const void* const* planes, const double* wnum, co
         if (wide) kappa_stack_kernel<float, 4><<<g, 256, 0, s>>>((const float* const*)planes, wnum, wden, nplanes, count, (float*)out);
         else kappa_stack_kernel<float, 1><<<g, 256, 0, s>>>((const float* const*)planes, wnum, wden, nplanes, count, (float*)out);
     } else {
-        if (wide) kappa_stack_kernel<double, 2><<<g, 256, 0, s>>>((const double* const*)planes, wnum, wden, nplanes, count, (double*)out);
+        static const int depth = getenv("AST_KSTACK_DEPTH") ? atoi(getenv("AST_KSTACK_DEPTH")) : KSTACK_DEPTH;
+        static const int grid_env = getenv("AST_KSTACK_GRID") ? atoi(getenv("AST_KSTACK_GRID")) : 0;
+        if (grid_env > 0 && (unsigned)grid_env < g) g = (unsigned)grid_env;
+        if (wide && depth == 8) kappa_stack_kernel<double, 2, 8><<<g, 256, 0, s>>>((const double* const*)planes, wnum, wden, nplanes, count, (double*)out);
+        else if (wide && depth == 16) kappa_stack_kernel<double, 2, 16><<<g, 256, 0, s>>>((const double* const*)planes, wnum, wden, nplanes, count, (double*)out);
+        else if (wide) kappa_stack_kernel<double, 2><<<g, 256, 0, s>>>((const double* const*)planes, wnum, wden, nplanes, count, (double*)out);
         else kappa_stack_kernel<double, 1><<<g, 256, 0, s>>>((const double* const*)planes, wnum, wden, nplanes, count, (double*)out);
     }
     AST_CHECK_LAUNCH();
