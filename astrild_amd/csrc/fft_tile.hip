@@ -961,6 +961,15 @@ triangles_reduce_kernel(const double* __restrict__ partial, int nblocks, int nth
 // Deterministic (fixed summation trees).  The grid may hold rho or rho - mean: only the unused DC mode differs.
 constexpr int MLOW = 5;                  // shells 0..4 (|m| in [1, 6), by the binning rule) are taken from the double-precision sums
 constexpr int MBOX = MLOW + 1;           // modes |m_i| <= MBOX are evaluated: under the float64 rule a vector of norm exactly 6 may fall into shell 4
+// e^{-2 pi i r / 32} for odd r: (kC32o[r / 2], kS32o[r / 2]) - cos and -sin of pi r / 16
+__device__ constexpr double kC32o[16] = {0.98078528040323044, 0.83146961230254524, 0.55557023301960222, 0.19509032201612827,
+                                         -0.19509032201612827, -0.55557023301960222, -0.83146961230254524, -0.98078528040323044,
+                                         -0.98078528040323044, -0.83146961230254524, -0.55557023301960222, -0.19509032201612827,
+                                         0.19509032201612827, 0.55557023301960222, 0.83146961230254524, 0.98078528040323044};
+__device__ constexpr double kS32o[16] = {-0.19509032201612827, -0.55557023301960222, -0.83146961230254524, -0.98078528040323044,
+                                         -0.98078528040323044, -0.83146961230254524, -0.55557023301960222, -0.19509032201612827,
+                                         0.19509032201612827, 0.55557023301960222, 0.83146961230254524, 0.98078528040323044,
+                                         0.98078528040323044, 0.83146961230254524, 0.55557023301960222, 0.19509032201612827};
 // e^{-2 pi i r / 16} = (kC16[r], kS16[r])
 __device__ constexpr double kC16[16] = {1.0, 0.92387953251128674, 0.70710678118654752, 0.38268343236508977, 0.0,
                                         -0.38268343236508977, -0.70710678118654752, -0.92387953251128674, -1.0,
@@ -1032,13 +1041,23 @@ lowk_z_kernel(const float* __restrict__ grid, const float* __restrict__ rec, int
                 double re = 0.0, im = 0.0;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    constexpr int step = 16 / NJ;
-                    const int r = ((kz * j) % NJ) * step;    // e^{-2 pi i (kz j) / NJ}: a compile-time constant after unrolling
-                    if (r == 0) re += f[j];
-                    else if (r == 4) im -= f[j];
-                    else if (r == 8) re -= f[j];
-                    else if (r == 12) im += f[j];
-                    else { re += f[j] * kC16[r]; im += f[j] * kS16[r]; }
+                    if (NJ <= 16) {
+                        constexpr int step = NJ <= 16 ? 16 / NJ : 1;
+                        const int r = ((kz * j) % NJ) * step;    // e^{-2 pi i (kz j) / NJ}: a compile-time constant after unrolling
+                        if (r == 0) re += f[j];
+                        else if (r == 4) im -= f[j];
+                        else if (r == 8) re -= f[j];
+                        else if (r == 12) im += f[j];
+                        else { re += f[j] * kC16[r]; im += f[j] * kS16[r]; }
+                    } else {                                     // NJ = 32 (n = 2048): 32nd roots of unity
+                        const int r = (kz * j) % 32;
+                        if (r == 0) re += f[j];
+                        else if (r == 8) im -= f[j];
+                        else if (r == 16) re -= f[j];
+                        else if (r == 24) im += f[j];
+                        else if (r % 2 == 0) { re += f[j] * kC16[r / 2]; im += f[j] * kS16[r / 2]; }
+                        else { re += f[j] * kC32o[r / 2]; im += f[j] * kS32o[r / 2]; }
+                    }
                 }
                 v[rr * 14 + 2 * kz] = re * twc[kz] - im * tws[kz];
                 v[rr * 14 + 2 * kz + 1] = re * tws[kz] + im * twc[kz];
@@ -1741,6 +1760,7 @@ static int lowk_modes(const float* planes, const float* rec, int window, int n, 
         else lowk_z_kernel<NJ, 3><<<blocks, 256, 0, s>>>(planes, rec, n, nrows, lowz);
     };
     if (z_done) {}                                       // the FFT's z pass has left the z sums in `work`
+    else if (n == 2048) z(std::integral_constant<int, 32>{});
     else if (n == 1024) z(std::integral_constant<int, 16>{});
     else if (n == 512) z(std::integral_constant<int, 8>{});
     else z(std::integral_constant<int, 4>{});
@@ -1875,7 +1895,7 @@ extern "C" int ast_lowk_shell_count(void) { return MLOW; }
 extern "C" int ast_lowk_modes(const void* planes, int dtype, size_t n, size_t x0, size_t nx, int accumulate, void* modes,
                               void* work, size_t work_bytes, void* stream) {
     AST_CHECK_ARG(planes && modes && work && nx >= 1 && x0 + nx <= n && (nx * n) % 4 == 0);
-    AST_CHECK_ARG(ast_fft_tile_supported(dtype, n));
+    AST_CHECK_ARG(ast_fft_tile_supported(dtype, n) || (dtype == AST_F32 && n == 2048));      // (2048: the passes of lens_fft.hip's fp32 section)
     AST_CHECK_ARG(work_bytes >= ast_lowk_work_bytes(n, nx));
     hipStream_t s = ast::as_stream(stream);
     AST_PROF("fft_tile.lowk", s);

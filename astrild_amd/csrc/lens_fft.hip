@@ -63,23 +63,32 @@ __device__ constexpr double kC32odd[8] = {0.98078528040323044, 0.831469612302545
 __device__ constexpr double kS32odd[8] = {-0.19509032201612827, -0.55557023301960222, -0.83146961230254524, -0.98078528040323044,
                                           -0.98078528040323044, -0.83146961230254524, -0.55557023301960222, -0.19509032201612827};
 
+__device__ inline float2 cmul(float2 a, float2 w) {
+    return make_float2(fmaf(a.x, w.x, -a.y * w.y), fmaf(a.x, w.y, a.y * w.x));
+}
+template <typename V> struct ScalarOf;
+template <> struct ScalarOf<double2> { typedef double type; };
+template <> struct ScalarOf<float2> { typedef float type; };
+
 // forward FFT of R <= 32 points in registers, decimation in frequency: X[k] ends up in v[bitrev(k)]
-template <int R>
-__device__ inline void fft_reg(double2 (&v)[R]) {
+// (V = double2, or float2 for the single-precision passes of cubes of side 2048 at the end of this file)
+template <int R, typename V>
+__device__ inline void fft_reg(V (&v)[R]) {
+    typedef typename ScalarOf<V>::type S;
 #pragma unroll
     for (int h = R / 2; h >= 1; h /= 2) {
 #pragma unroll
         for (int blk = 0; blk < R; blk += 2 * h) {
 #pragma unroll
             for (int j = 0; j < h; ++j) {
-                const double2 a = v[blk + j], b = v[blk + j + h];
-                v[blk + j] = make_double2(a.x + b.x, a.y + b.y);
-                const double2 d = make_double2(a.x - b.x, a.y - b.y);
+                const V a = v[blk + j], b = v[blk + j + h];
+                v[blk + j] = V(a.x + b.x, a.y + b.y);
+                const V d = V(a.x - b.x, a.y - b.y);
                 const int t = j * (16 / h);                  // W_{2h}^j = W_32^{j * 32 / (2h)}, t < 16
                 if (t == 0) v[blk + j + h] = d;
-                else if (t == 8) v[blk + j + h] = make_double2(d.y, -d.x);          // * (-i)
-                else if (t % 2 == 0) v[blk + j + h] = cmul(d, make_double2(kC16[t / 2], kS16[t / 2]));
-                else v[blk + j + h] = cmul(d, make_double2(kC32odd[t / 2], kS32odd[t / 2]));
+                else if (t == 8) v[blk + j + h] = V(d.y, -d.x);          // * (-i)
+                else if (t % 2 == 0) v[blk + j + h] = cmul(d, V((S)kC16[t / 2], (S)kS16[t / 2]));
+                else v[blk + j + h] = cmul(d, V((S)kC32odd[t / 2], (S)kS32odd[t / 2]));
             }
         }
     }
@@ -308,14 +317,14 @@ struct RowGeo {
 
 // On entry (threads t < T1): va[a] = input[RB RC a + t].  On exit (threads t < T3, t = alpha * RB + beta): vc[bitrev(gamma)] =
 // output[alpha + RA beta + RA RB gamma].
-template <int RA, int RB, int RC>
-__device__ inline void three_stage(double2 (&va)[RA], double2 (&vc)[RC], double2* Y, const double2* __restrict__ twM, int t) {
+template <int RA, int RB, int RC, typename V>
+__device__ inline void three_stage(V (&va)[RA], V (&vc)[RC], V* Y, const V* __restrict__ twM, int t) {
     using G = RowGeo<RA, RB, RC>;
     if (t < G::T1) {
         fft_reg<RA>(va);
 #pragma unroll
         for (int al = 0; al < RA; ++al) {
-            double2 y = va[bitrev(al, ilog2(RA))];
+            V y = va[bitrev(al, ilog2(RA))];
             if (al != 0) y = cmul(y, twM[t * al]);
             Y[lds_pad(al * G::T1 + t)] = y;
         }
@@ -323,14 +332,14 @@ __device__ inline void three_stage(double2 (&va)[RA], double2 (&vc)[RC], double2
     __syncthreads();
     if (t < G::T2) {
         const int al = t / RC, c = t % RC;
-        double2 vb[RB];
+        V vb[RB];
 #pragma unroll
         for (int b = 0; b < RB; ++b) vb[b] = Y[lds_pad(al * G::T1 + RC * b + c)];
         fft_reg<RB>(vb);
         // the slots this thread read are the slots it writes: no barrier in between
 #pragma unroll
         for (int be = 0; be < RB; ++be) {
-            double2 y = vb[bitrev(be, ilog2(RB))];
+            V y = vb[bitrev(be, ilog2(RB))];
             if (be != 0 && c != 0) y = cmul(y, twM[RA * c * be]);
             Y[lds_pad(al * G::T1 + RC * be + c)] = y;
         }
@@ -1031,4 +1040,519 @@ extern "C" int ast_fft64_r2c_3d(const double* grid, void* spec_out, size_t n, do
     rc = col3_dispatch<false>(n, spec, twN, nz, nz, n, n * nz, 1.0, nullptr, 0.0, s);                      // y, per x plane
     if (rc != AST_OK) return rc;
     return col3_dispatch<false>(n, spec, twN, n * nz, nz, n, nz, scale, nullptr, 0.0, s);                 // x
+}
+
+// ================================================================== single-precision passes for cubes of side 2048
+// The fp32 tile passes of fft_tile.hip are two register FFTs per axis (R1 x R2 <= 32 x 32 = 1024 points).  A cube of side
+// 2048 - the largest whose fp32 grid (34 GB) and scratch spectrum (35 GB) one MI355X holds with room to spare - took the
+// double passes above, widened on load: twice the bytes on every pass.  These are the same three-stage passes in float:
+// z rows (half-length complex transform + untangling, the grid's mean subtracted as the rows are loaded), y pass, x pass
+// fused with FFTPower's shell sums (power_spectrum_3d.py:189-224).  The strided passes take EIGHT k_z columns per workgroup
+// (64-byte row pieces, the LDS of the double pass's four) and two columns per thread - one 16-byte access per row piece
+// and lane, 1024 threads.  The lowest shells are patched from the double-precision side channel by the caller
+// (ast_lowk_modes: fp32 round-off of an O(1) field on shells of a few dozen modes), as in the fp32 tile pipeline.
+namespace {
+__global__ void tw_table32_kernel(float2* out, int len) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    double sn, cs;
+    sincospi(-2.0 * (double)i / (double)len, &sn, &cs);
+    out[i] = make_float2((float)cs, (float)sn);
+}
+struct TwCache32 {
+    std::mutex m;
+    struct E { int dev, len; float2* d; };
+    std::vector<E> tabs;
+    const float2* get(int len, hipStream_t s) {
+        std::lock_guard<std::mutex> lock(m);
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+        for (auto& t : tabs) if (t.dev == dev && t.len == len) return t.d;
+        float2* d = nullptr;
+        if (hipMalloc(&d, (size_t)len * sizeof(float2)) != hipSuccess) return nullptr;
+        tw_table32_kernel<<<(len + 255) / 256, 256, 0, s>>>(d, len);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipFree(d); return nullptr; }
+        tabs.push_back({dev, len, d});
+        return d;
+    }
+} g_tw32;
+
+// one row per workgroup: 2 M reals -> M + 1 complex (lens_rows_forward_kernel without padding, fold or widening)
+template <int RA, int RB, int RC>
+__global__ void __launch_bounds__((RowGeo<RA, RB, RC>::NT))
+rows32_forward_kernel(const float* __restrict__ grid, size_t in_pitch, float2* __restrict__ spec, size_t pitch,
+                      const float2* __restrict__ twM, const float2* __restrict__ twL, float scale, float mean) {
+    using G = RowGeo<RA, RB, RC>;
+    constexpr int M = G::M;
+    extern __shared__ float2 Y32[];
+    const int t = threadIdx.x;
+    const size_t row = blockIdx.x;
+    const float2* z = reinterpret_cast<const float2*>(grid + row * in_pitch);
+    float2 va[RA], vc[RC];
+    if (t < G::T1) {
+#pragma unroll
+        for (int a = 0; a < RA; ++a) {
+            va[a] = z[G::T1 * a + t];
+            va[a].x -= mean;
+            va[a].y -= mean;
+        }
+    }
+    three_stage<RA, RB, RC>(va, vc, Y32, twM, t);
+    constexpr int IT = (M / 2) / G::NT;
+    static_assert(IT * G::NT == M / 2, "row length and thread count");
+    float2 wk[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) wk[it] = twL[t + it * G::NT];
+    __syncthreads();
+    if (t < G::T3) {
+#pragma unroll
+        for (int ga = 0; ga < RC; ++ga) Y32[lds_pad((t / RB) + RA * (t % RB) + RA * RB * ga)] = vc[bitrev(ga, ilog2(RC))];
+    }
+    __syncthreads();
+    float2* orow = spec + row * pitch;
+    auto emit = [&](int k, float2 w) {
+        const float2 zk = Y32[lds_pad(k)];
+        const float2 zm = Y32[lds_pad(M - k)];
+        const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+        const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
+        const float2 tt = cmul(o, w);
+        orow[k] = make_float2((e.x + tt.y) * scale, (e.y - tt.x) * scale);
+        orow[M - k] = make_float2((e.x - tt.y) * scale, (-e.y - tt.x) * scale);
+    };
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int k = t + it * G::NT;
+        if (k == 0) {
+            const float2 zk = Y32[lds_pad(0)];
+            orow[0] = make_float2((zk.x + zk.y) * scale, 0.0f);
+            orow[M] = make_float2((zk.x - zk.y) * scale, 0.0f);
+        } else {
+            emit(k, wk[it]);
+        }
+    }
+    if (t == 0) emit(M / 2, twL[M / 2]);
+}
+
+// strided pass over N = RA RB RC rows, 8 adjacent columns per workgroup, 2 per thread (col3_kernel in float)
+constexpr int C32 = 8, CT32 = 2;
+template <int RA, int RB, int RC, bool POWER>
+__global__ void __launch_bounds__(((C32 / CT32) * RowGeo<RA, RB, RC>::NT))
+col32_kernel(float2* __restrict__ data, const float2* __restrict__ twM, size_t elem_stride, size_t ncols, size_t batch_stride,
+             unsigned tiles_per_batch, float scale, double* __restrict__ partial, double kf_rule, int prune2) {
+    using G = RowGeo<RA, RB, RC>;
+    constexpr int N = G::M, NB = N / 2 - 1, LINE = N + N / 8, CS = C32 / CT32, NTH = CS * G::NT;
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    extern __shared__ float2 L32[];
+    double* shell = reinterpret_cast<double*>(L32 + C32 * LINE);          // [NB + 1] when POWER
+    const int cs = threadIdx.x % CS, t = threadIdx.x / CS;
+    // a workgroup touches HALF of every 128-byte line, the next tile the other half: both on one XCD (see col3_kernel)
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned full = gridDim.x / 16 * 16;
+        if (bid < full) {
+            const unsigned xcd = bid % 8, slot = bid / 8;
+            bid = ((slot >> 1) * 8 + xcd) * 2 + (slot & 1);
+        }
+    }
+    const unsigned tile = bid % tiles_per_batch, b = bid / tiles_per_batch;
+    const size_t c0 = (size_t)tile * C32;
+    if (prune2 > 0 && POWER) {
+        const int ky = (int)b > N / 2 ? (int)b - N : (int)b;
+        if (ky * ky + (int)(c0 * c0) > prune2) {                            // block-uniform, before any barrier
+            for (int i = threadIdx.x; i < NB; i += NTH) partial[(size_t)bid * NB + i] = 0.0;
+            return;
+        }
+    }
+    // columns c0 + 2 cs, c0 + 2 cs + 1 as ONE 16-byte access (the row pitch is even and the tile starts at a multiple of 8);
+    // a pair past the last column re-reads the last valid pair and is never stored or binned
+    const size_t cpair = c0 + (size_t)(CT32 * cs);
+    const size_t cload = cpair + 1 < ncols + (ncols & 1) ? cpair : ((ncols - 1) & ~(size_t)1);
+    float2* base = data + (size_t)b * batch_stride + cload;
+    const bool ok0 = cpair < ncols, ok1 = cpair + 1 < ncols;
+    float2* Y0 = L32 + (CT32 * cs) * LINE;
+    float2* Y1 = Y0 + LINE;
+    if (POWER)
+        for (int i = threadIdx.x; i <= NB; i += NTH) shell[i] = 0.0;
+    float2 va0[RA], va1[RA], vc0[RC], vc1[RC];
+    if (t < G::T1) {
+#pragma unroll
+        for (int a = 0; a < RA; ++a) {
+            const vf4 v = *reinterpret_cast<const vf4*>(base + (size_t)(G::T1 * a + t) * elem_stride);
+            va0[a] = make_float2(v.x, v.y);
+            va1[a] = make_float2(v.z, v.w);
+        }
+    }
+    // the two columns' stages between the same barriers
+    if (t < G::T1) {
+        fft_reg<RA>(va0);
+        fft_reg<RA>(va1);
+#pragma unroll
+        for (int al = 0; al < RA; ++al) {
+            float2 y0 = va0[bitrev(al, ilog2(RA))], y1 = va1[bitrev(al, ilog2(RA))];
+            if (al != 0) { const float2 w = twM[t * al]; y0 = cmul(y0, w); y1 = cmul(y1, w); }
+            Y0[lds_pad(al * G::T1 + t)] = y0;
+            Y1[lds_pad(al * G::T1 + t)] = y1;
+        }
+    }
+    __syncthreads();
+    if (t < G::T2) {
+        const int al = t / RC, c = t % RC;
+#pragma unroll
+        for (int j = 0; j < CT32; ++j) {
+            float2* Y = j ? Y1 : Y0;
+            float2 vb[RB];
+#pragma unroll
+            for (int bb = 0; bb < RB; ++bb) vb[bb] = Y[lds_pad(al * G::T1 + RC * bb + c)];
+            fft_reg<RB>(vb);
+#pragma unroll
+            for (int be = 0; be < RB; ++be) {
+                float2 y = vb[bitrev(be, ilog2(RB))];
+                if (be != 0 && c != 0) y = cmul(y, twM[RA * c * be]);
+                Y[lds_pad(al * G::T1 + RC * be + c)] = y;
+            }
+        }
+    }
+    __syncthreads();
+    if (t < G::T3) {
+#pragma unroll
+        for (int c = 0; c < RC; ++c) { vc0[c] = Y0[lds_pad(t * RC + c)]; vc1[c] = Y1[lds_pad(t * RC + c)]; }
+        fft_reg<RC>(vc0);
+        fft_reg<RC>(vc1);
+        const int al = t / RB, be = t % RB;
+        if (!POWER) {
+            if (ok0) {
+                const int room = prune2 > 0 ? prune2 - (int)(c0 * c0) : 0x7fffffff;        // rows are k_y: keep k_y^2 <= room
+#pragma unroll
+                for (int ga = 0; ga < RC; ++ga) {
+                    const float2 x0 = vc0[bitrev(ga, ilog2(RC))], x1 = vc1[bitrev(ga, ilog2(RC))];
+                    const int row = al + RA * be + RA * RB * ga, aky = RA * RB * ga >= N / 2 ? N - row : row;
+                    if (aky * aky <= room)
+                        *reinterpret_cast<vf4*>(base + (size_t)row * elem_stride) = vf4{x0.x * scale, x0.y * scale, x1.x * scale, x1.y * scale};
+                }
+            }
+        } else {
+            const int ky = (int)b > N / 2 ? (int)b - N : (int)b;
+#pragma unroll
+            for (int j = 0; j < CT32; ++j) {
+                if (!(j ? ok1 : ok0)) continue;
+                const int kz = (int)cpair + j;
+                const int m2yz = ky * ky + kz * kz;
+                const float w = (kz > 0 && kz < N / 2) ? 2.0f : 1.0f;
+#pragma unroll
+                for (int ga = 0; ga < RC; ++ga) {
+                    const float2 x = j ? vc1[bitrev(ga, ilog2(RC))] : vc0[bitrev(ga, ilog2(RC))];
+                    const int row = al + RA * be + RA * RB * ga;
+                    const int kx = row > N / 2 ? row - N : row;
+                    const int m2 = kx * kx + m2yz;
+                    int r = (int)__builtin_amdgcn_sqrtf((float)m2 + 0.5f);
+                    if (r * r > m2) --r;                                      // (N = 2048: beyond the exhaustively checked range)
+                    else if ((r + 1) * (r + 1) <= m2) ++r;
+                    if (kf_rule != 0.0 && r > 0 && r * r == m2) r = ast::float64_edge_norm(r, kx, ky, kz, kf_rule);
+                    // |delta_k|^2 in fp32 (one rounding per mode), accumulated in double - as in fft_tile.hip's binning pass
+                    if (r >= 1 && r <= NB) atomicAdd(&shell[r], (double)(fmaf(x.x, x.x, x.y * x.y) * w));
+                }
+            }
+        }
+    }
+    if (POWER) {
+        __syncthreads();
+        const double s2 = (double)scale * (double)scale;
+        for (int i = threadIdx.x; i < NB; i += NTH) partial[(size_t)bid * NB + i] = shell[i + 1] * s2;
+    }
+}
+
+template <int RA, int RB, int RC, bool POWER>
+int col32_launch(float2* data, const float2* tw, size_t elem_stride, size_t ncols, size_t batch, size_t batch_stride, float scale,
+                 double* partial, double kf_rule, hipStream_t s, int prune2) {
+    using G = RowGeo<RA, RB, RC>;
+    constexpr int LINE = G::M + G::M / 8;
+    const size_t lds = (size_t)C32 * LINE * sizeof(float2) + (POWER ? (G::M / 2) * sizeof(double) : 0);
+    static ast::PerDeviceOnce once;
+    if (once.need()) {
+        AST_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&col32_kernel<RA, RB, RC, POWER>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        once.mark();
+    }
+    const size_t tiles = (ncols + C32 - 1) / C32;
+    AST_CHECK_ARG(tiles * batch < 0x7fffffffull);
+    col32_kernel<RA, RB, RC, POWER><<<(unsigned)(tiles * batch), (C32 / CT32) * G::NT, lds, s>>>(data, tw, elem_stride, ncols, batch_stride,
+                                                                                             (unsigned)tiles, scale, partial, kf_rule, prune2);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
+}
+}  // namespace
+
+// ------------------------------------------------------------------ the lowest shells in double, for the passes above
+// A density painted from a lattice coarser than the grid carries O(1) power at the lattice's Bragg vectors and next to none
+// at low k (1024^3 particles on 2048^3 cells: P(shell 5) = 1.4e-6 of the box volume): the fp32 passes' round-off - white,
+// proportional to the field's rms - is 3e-6 of the signal at shell 5 and falls below 1e-6 only from shell 16 on (measured,
+// scripts/perf_big32.py).  So the shells |m| < 17 come from double-precision sums over the grid, as the fp32 tile pipeline
+// takes its five lowest (fft_tile.hip, MLOW) - with a box of |m_i| <= 17 instead of 6:
+//   z  one wave per grid row: lane l holds f[l + 64 j]; per k_z the lane's NJ-term sum times e^{-2 pi i k_z l / n}, the 64
+//      lanes' terms added in lane order through LDS                                   -> lowz[x][y][kz]
+//   y  one workgroup per x plane, direct sums over y                                  -> lowy[x][ky][kz]
+//   x  BIGLOW_XPARTS workgroups, each over its range of x, then the parts in order    -> modes[kx][ky][kz]
+//   shells: one thread per shell walks all modes in a fixed order (integer rule, or nbodykit's float64 edge rule).
+namespace {
+constexpr int BIGLOW = 16;                         // shells 0 .. 15 (|m| in [1, 17))
+constexpr int BIGBOX = BIGLOW + 1;                 // modes |m_i| <= 17: a vector of norm exactly 17 may fall into shell 15 (float64 rule)
+constexpr int BIGKZ = BIGBOX + 1, BIGK = 2 * BIGBOX + 1;
+constexpr int BIGLOW_MODES = BIGK * BIGK * BIGKZ;
+constexpr int BIGLOW_XPARTS = 256;
+
+template <int NJ>
+__global__ void __launch_bounds__(256)
+biglow_z_kernel(const float* __restrict__ grid, int n, size_t nrows, double mean, double2* __restrict__ out) {
+    __shared__ double part[4][2 * BIGKZ][65];                      // [wave][sum][lane] (65: the 36 readers on different banks)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double twc[BIGKZ], tws[BIGKZ];                                 // the lane's e^{-2 pi i kz lane / n}
+#pragma unroll
+    for (int kz = 0; kz < BIGKZ; ++kz) sincospi(-2.0 * (double)((kz * lane) % n) / (double)n, &tws[kz], &twc[kz]);
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    for (size_t row = (size_t)blockIdx.x * 4 + wave; row < nrows; row += nwaves) {
+        const float* in = grid + row * (size_t)n;
+        // the lane's NJ samples z = lane + 64 j through ONE NJ-point register FFT (all NJ outputs for the price of the few
+        // needed: 80 butterflies at NJ = 32 against 18 x 32 multiply-adds in a dependent chain, 105 ms -> ... at side 2048)
+        double2 v[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) v[j] = make_double2((double)in[lane + 64 * j] - mean, 0.0);
+        fft_reg<NJ>(v);
+#pragma unroll
+        for (int kz = 0; kz < BIGKZ; ++kz) {
+            const double2 x = v[bitrev(kz % NJ, ilog2(NJ))];
+            part[wave][2 * kz][lane] = x.x * twc[kz] - x.y * tws[kz];
+            part[wave][2 * kz + 1][lane] = x.x * tws[kz] + x.y * twc[kz];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 2 * BIGKZ) {                                    // the 64 lanes' terms in a fixed order, eight sums in flight
+            double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int l = 0; l < 64; ++l) acc[l & 7] += part[wave][lane][l];
+            reinterpret_cast<double*>(out)[row * (size_t)(2 * BIGKZ) + lane] =
+                ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// out[(outer * nparts + part) * BIGK + (k + BIGBOX)][i] = sum over the part's t of in[(outer * nt + t) * inner + i] e^{-2 pi i k (t0 + t) / n}
+__global__ void __launch_bounds__(256)
+biglow_axis_kernel(const double2* __restrict__ in, int n, int nt, int inner, double2* __restrict__ out) {
+    extern __shared__ double2 lds64[];
+    double2* tw = lds64;                                            // e^{-2 pi i t / n}
+    for (int t = threadIdx.x; t < n; t += 256) {
+        double sn, cs;
+        sincospi(-2.0 * (double)t / (double)n, &sn, &cs);
+        tw[t] = make_double2(cs, sn);
+    }
+    __syncthreads();
+    const size_t outer = blockIdx.x;
+    const int nparts = gridDim.y, part = blockIdx.y;
+    const int per = (nt + nparts - 1) / nparts, ta = part * per, tb = min(nt, ta + per);
+    const int nout = BIGK * inner;
+    for (int o = threadIdx.x; o < nout; o += 256) {
+        const int k = o / inner - BIGBOX, i = o % inner;
+        double re[4] = {0.0, 0.0, 0.0, 0.0}, im[4] = {0.0, 0.0, 0.0, 0.0};      // four loads in flight; added up in a fixed order
+        for (int tq = ta; tq < tb; tq += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = tq + q < tb ? tq + q : tb - 1;          // unconditional load; the duplicate is not added
+                const double2 v = in[(outer * nt + t) * inner + i];
+                const double2 w = tw[(unsigned)(k * t) & (unsigned)(n - 1)];          // n is a power of two
+                if (tq + q < tb) {
+                    re[q] += v.x * w.x - v.y * w.y;
+                    im[q] += v.x * w.y + v.y * w.x;
+                }
+            }
+        }
+        out[((outer * nparts + part) * BIGK + k + BIGBOX) * inner + i] = make_double2((re[0] + re[1]) + (re[2] + re[3]), (im[0] + im[1]) + (im[2] + im[3]));
+    }
+}
+
+// the y sums of one x plane: lowz[x][y][kz] -> lowy[x][ky][kz].  The plane's rows come through LDS 32 at a time (whole lines,
+// read once); a thread owns up to three (ky, kz) outputs.  (The generic kernel above took 5.8 ms here: every term a
+// dependent global load.)
+__global__ void __launch_bounds__(256)
+biglow_y_kernel(const double2* __restrict__ lowz, int n, double2* __restrict__ lowy) {
+    extern __shared__ double2 lds64[];
+    double2* tw = lds64;                                            // e^{-2 pi i t / n}
+    double2* chunk = lds64 + n;                                     // [32][BIGKZ]
+    constexpr int TC = 32, NOUT = BIGK * BIGKZ, PER = (NOUT + 255) / 256;
+    for (int t = threadIdx.x; t < n; t += 256) {
+        double sn, cs;
+        sincospi(-2.0 * (double)t / (double)n, &sn, &cs);
+        tw[t] = make_double2(cs, sn);
+    }
+    const double2* plane = lowz + (size_t)blockIdx.x * n * BIGKZ;
+    double re[PER], im[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { re[q] = 0.0; im[q] = 0.0; }
+    for (int t0 = 0; t0 < n; t0 += TC) {
+        __syncthreads();                                            // (the table; the previous chunk's readers)
+        for (int e = threadIdx.x; e < TC * BIGKZ; e += 256) chunk[e] = plane[(size_t)t0 * BIGKZ + e];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int o = threadIdx.x + 256 * q;
+            if (o < NOUT) {
+                const int k = o / BIGKZ - BIGBOX, i = o % BIGKZ;
+#pragma unroll 8
+                for (int tt = 0; tt < TC; ++tt) {
+                    const double2 v = chunk[tt * BIGKZ + i];
+                    const double2 w = tw[(unsigned)(k * (t0 + tt)) & (unsigned)(n - 1)];
+                    re[q] += v.x * w.x - v.y * w.y;
+                    im[q] += v.x * w.y + v.y * w.x;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int o = threadIdx.x + 256 * q;
+        if (o < NOUT) lowy[(size_t)blockIdx.x * NOUT + o] = make_double2(re[q], im[q]);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+biglow_parts_kernel(const double2* __restrict__ parts, int nparts, int count, double2* __restrict__ modes) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= count) return;
+    double re = 0.0, im = 0.0;
+    for (int p = 0; p < nparts; ++p) { re += parts[(size_t)p * count + o].x; im += parts[(size_t)p * count + o].y; }
+    modes[o] = make_double2(re, im);
+}
+
+// psum[shell] += norm * sum over the box's modes of the shell of w |mode|^2, shells 0 .. BIGLOW - 1; modes[kx][ky][kz].
+// 256 threads take the modes in turn, every thread its own 16 sums; thread `shell` then adds the 256 in thread order.
+__global__ void __launch_bounds__(256)
+biglow_shell_kernel(const double2* __restrict__ modes, double norm, double kf_rule, double* __restrict__ psum) {
+    __shared__ double part[BIGLOW][257];
+    double acc[BIGLOW];
+#pragma unroll
+    for (int sh = 0; sh < BIGLOW; ++sh) acc[sh] = 0.0;
+    for (int o = threadIdx.x; o < BIGLOW_MODES; o += 256) {
+        const int kz = o % BIGKZ, ky = (o / BIGKZ) % BIGK - BIGBOX, kx = o / (BIGKZ * BIGK) - BIGBOX;
+        const int m2 = kx * kx + ky * ky + kz * kz;
+        if (m2 == 0) continue;
+        int r = (int)__builtin_amdgcn_sqrtf((float)m2 + 0.5f);       // m2 <= 3 * 17^2: exact after the repair step
+        if (r * r > m2) --r;
+        else if ((r + 1) * (r + 1) <= m2) ++r;
+        if (kf_rule != 0.0 && r * r == m2) r = ast::float64_edge_norm(r, kx, ky, kz, kf_rule);
+        const int shell = r - 1;
+        if (shell < 0 || shell >= BIGLOW) continue;
+        const double2 v = modes[o];
+        const double p = (v.x * v.x + v.y * v.y) * (kz > 0 ? 2.0 : 1.0);
+#pragma unroll
+        for (int sh = 0; sh < BIGLOW; ++sh) acc[sh] += sh == shell ? p : 0.0;
+    }
+#pragma unroll
+    for (int sh = 0; sh < BIGLOW; ++sh) part[sh][threadIdx.x] = acc[sh];
+    __syncthreads();
+    if (threadIdx.x < BIGLOW) {
+        double total = 0.0;
+        for (int t = 0; t < 256; ++t) total += part[threadIdx.x][t];
+        psum[threadIdx.x] += norm * total;
+    }
+}
+
+// the fp32 passes' sums for the shells from `first` on (the ones below come from the double-precision box)
+__global__ void __launch_bounds__(256)
+power32_stage2_kernel(const double* __restrict__ part, int nb, int first, double pnorm, double* __restrict__ psum) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nb || i < first) return;
+    double acc = 0.0;
+    for (int r = 0; r < REDUCE64; ++r) acc += part[(size_t)r * nb + i];
+    psum[i] += pnorm * acc;
+}
+
+size_t biglow_bytes(size_t n) {
+    return (n * n * BIGKZ + n * BIGK * BIGKZ + (size_t)(BIGLOW_XPARTS + 1) * BIGLOW_MODES) * sizeof(double2);
+}
+}  // namespace
+
+// 2048 is what these passes are for; 256 (covered by the fp32 tile passes in production) is there so that the same kernels
+// can be checked against the CPU oracle at a size it finishes in seconds
+extern "C" int ast_fft32_big_supported(size_t n) { return n == 2048 || n == 256; }
+static size_t fft32_pitch(size_t n) { return (n / 2 + 1 + 15) / 16 * 16; }        // complex64 elements: whole 128-byte lines
+extern "C" size_t ast_fft32_big_power_scratch_bytes(size_t n) {
+    const size_t nzp = fft32_pitch(n), tiles = (n / 2 + 1 + C32 - 1) / C32, nb = n / 2 - 1;
+    return n * n * nzp * sizeof(float2) + n * tiles * nb * sizeof(double) + (size_t)REDUCE64 * nb * sizeof(double) + biglow_bytes(n);
+}
+
+// psum_d[shell] += L^3 sum over the shell's modes of w |delta_k|^2, delta_k = rfftn(grid - mean) / n^3, for an (n, n, n)
+// float grid of side 2048: all passes in single precision, the shells |m| < 17 from double-precision sums over the grid
+// (see the two section headers).  grid_d is not modified.
+extern "C" int ast_fft32_big_power_3d(const float* grid, void* scratch, size_t scratch_bytes, size_t n, double boxsize, int binning,
+                                      double mean, double* psum, void* stream) {
+    AST_CHECK_ARG(grid != nullptr && scratch != nullptr && psum != nullptr && boxsize > 0.0);
+    AST_CHECK_ARG(ast_fft32_big_supported(n) && scratch_bytes >= ast_fft32_big_power_scratch_bytes(n));
+    AST_CHECK_ARG(binning == AST_BIN_INTEGER || binning == AST_BIN_FLOAT64);
+    AST_CHECK_ARG(((uintptr_t)grid & 7) == 0 && ((uintptr_t)scratch & 15) == 0);
+    hipStream_t s = ast::as_stream(stream);
+    const size_t nz = n / 2 + 1, nzp = fft32_pitch(n), tiles = (nz + C32 - 1) / C32, nb = n / 2 - 1;
+    float2* spec = (float2*)scratch;
+    double* partial = (double*)((char*)scratch + n * n * nzp * sizeof(float2));
+    double* part2 = partial + n * tiles * nb;
+    const float2* twH = g_tw32.get((int)(n / 2), s);
+    const float2* twN = g_tw32.get((int)n, s);
+    if (!twH || !twN) { ast::set_error("ast_fft32_big_power_3d: twiddle table allocation failed"); return AST_ERR_HIP; }
+    const int prune2 = getenv("AST_FFT_NO_PRUNE") ? 0 : (int)((n / 2) * (n / 2));
+    AST_CHECK_ARG(n * n < 0x7fffffffull);
+    const float inv_ng = (float)(1.0 / ((double)n * (double)n * (double)n));
+    const double kf_rule = binning == AST_BIN_FLOAT64 ? 2.0 * M_PI / boxsize : 0.0;
+    int rc = AST_OK;
+    auto passes = [&](auto ra, auto rb, auto rcc, auto ha, auto hb, auto hc) -> int {        // (RA, RB, RC) of the axis, of the half-length rows
+        constexpr int A = decltype(ra)::value, B = decltype(rb)::value, Cc = decltype(rcc)::value;
+        constexpr int HA = decltype(ha)::value, HB = decltype(hb)::value, HC = decltype(hc)::value;
+        {
+            AST_PROF("fft32big.rows_r2c", s);
+            using G = RowGeo<HA, HB, HC>;
+            const size_t lds = (size_t)(G::M + G::M / 8) * sizeof(float2);
+            rows32_forward_kernel<HA, HB, HC><<<(unsigned)(n * n), G::NT, lds, s>>>(grid, n, spec, nzp, twH, twN, 1.0f, (float)mean);
+            AST_CHECK_LAUNCH();
+        }
+        {
+            AST_PROF("fft32big.cols", s);
+            LENS_FWD((col32_launch<A, B, Cc, false>(spec, twN, nzp, nz, n, n * nzp, 1.0f, nullptr, 0.0, s, prune2)));           // y, per x plane
+        }
+        AST_PROF("fft32big.cols_power", s);
+        return col32_launch<A, B, Cc, true>(spec, twN, n * nzp, nz, n, nzp, inv_ng, partial, kf_rule, s, prune2);
+    };
+    using I4 = std::integral_constant<int, 4>;
+    using I8 = std::integral_constant<int, 8>;
+    using I16 = std::integral_constant<int, 16>;
+    if (n == 2048) rc = passes(I16{}, I16{}, I8{}, I16{}, I8{}, I8{});
+    else rc = passes(I8{}, I8{}, I4{}, I8{}, I4{}, I4{});
+    if (rc != AST_OK) return rc;
+    {
+        AST_PROF("fft32big.shell_reduce", s);
+        power64_stage1_kernel<<<REDUCE64, 256, 0, s>>>(partial, n * tiles, (int)nb, part2);
+        power32_stage2_kernel<<<(unsigned)((nb + 255) / 256), 256, 0, s>>>(part2, (int)nb, BIGLOW, boxsize * boxsize * boxsize, psum);
+        AST_CHECK_LAUNCH();
+    }
+    double2* lowz = (double2*)(part2 + (size_t)REDUCE64 * nb);
+    double2* lowy = lowz + n * n * BIGKZ;
+    double2* parts = lowy + n * BIGK * BIGKZ;
+    double2* modes = parts + (size_t)BIGLOW_XPARTS * BIGLOW_MODES;
+    const unsigned zblocks = (unsigned)std::min<size_t>((n * n + 3) / 4, (size_t)256 * 8);
+    {
+        AST_PROF("fft32big.lowk_z", s);
+        if (n == 2048) biglow_z_kernel<32><<<zblocks, 256, 0, s>>>(grid, (int)n, n * n, mean, lowz);
+        else biglow_z_kernel<4><<<zblocks, 256, 0, s>>>(grid, (int)n, n * n, mean, lowz);
+    }
+    const size_t lds = n * sizeof(double2);
+    {
+        AST_PROF("fft32big.lowk_y", s);
+        biglow_y_kernel<<<(unsigned)n, 256, lds + 32 * BIGKZ * sizeof(double2), s>>>(lowz, (int)n, lowy);                  // y, per x plane
+    }
+    {
+        AST_PROF("fft32big.lowk_x", s);
+        biglow_axis_kernel<<<dim3(1, BIGLOW_XPARTS), 256, lds, s>>>(lowy, (int)n, (int)n, BIGK * BIGKZ, parts);            // x, in parts
+    }
+    AST_PROF("fft32big.lowk_shells", s);
+    biglow_parts_kernel<<<(BIGLOW_MODES + 255) / 256, 256, 0, s>>>(parts, BIGLOW_XPARTS, BIGLOW_MODES, modes);
+    const double ng = (double)n * (double)n * (double)n;
+    biglow_shell_kernel<<<1, 256, 0, s>>>(modes, boxsize * boxsize * boxsize / (ng * ng), kf_rule, psum);
+    AST_CHECK_LAUNCH();
+    return AST_OK;
 }

@@ -728,19 +728,37 @@ def fused_power64_supported(field, allow_f32=False):
         and bool(_lib.lib().ast_fft64_supported(n))
 
 
-def power_sums_fused64(field, boxsize, psum=None, binning=None, halo=None):
-    """(ksum, psum, nmodes) of the auto power of a float64 cube of side 256/512/1024 through the hand-written
-    double-precision passes (ast_fft64_power_3d): one pass per axis, the last one fused with the shell binning."""
+def power_sums_fused64(field, boxsize, psum=None, binning=None, halo=None, mean=None):
+    """(ksum, psum, nmodes) of the auto power of a float64 cube of side 128 ... 2048 through the hand-written
+    double-precision passes (ast_fft64_power_3d): one pass per axis, the last one fused with the shell binning.  fp32 cubes
+    of the sides the fp32 tile passes do not cover take the same passes, widened on load - or, at side 2048 and with the
+    grid's ``mean`` given (0.0 for a grid that holds rho - mean), single-precision passes of their own
+    (ast_fft32_big_power_3d)."""
+    import os
     n = field.shape[0]
     L = _lib.lib()
+    if psum is None:
+        psum = torch.zeros(n // 2 - 1, dtype=torch.float64, device=field.device)
+    ksum, nmodes = shell_geometry(n, boxsize, binning=binning)
+    if field.dtype == torch.float32 and mean is not None and bool(L.ast_fft32_big_supported(n)) \
+            and not os.environ.get("ASTRILD_FFT32_BIG_OFF"):
+        # side 2048: single-precision passes (half the bytes of the double route below); the grid's mean leaves as the rows
+        # are loaded and the sixteen lowest shells come from double-precision sums over the grid (inside the call) - fp32
+        # round-off of an O(1) field on shells of little power - as the fp32 tile pipeline takes its five lowest
+        assert halo is None
+        key32 = (torch.cuda.current_device(), n, "f32big")
+        scratch = _power_scratch.get(key32)
+        if scratch is None:
+            _power_scratch.clear()
+            scratch = _power_scratch[key32] = torch.empty(int(L.ast_fft32_big_power_scratch_bytes(n)), dtype=torch.uint8, device=field.device)
+        check(L.ast_fft32_big_power_3d(ptr(field), ptr(scratch), scratch.numel(), n, float(boxsize), _bin_code(binning), float(mean),
+                                       ptr(psum), stream()), "ast_fft32_big_power_3d")
+        return ksum, psum, nmodes
     key = (torch.cuda.current_device(), n, "f64")
     scratch = _power_scratch.get(key)
     if scratch is None:
         _power_scratch.clear()
         scratch = _power_scratch[key] = torch.empty(int(L.ast_fft64_power_scratch_bytes(n)), dtype=torch.uint8, device=field.device)
-    if psum is None:
-        psum = torch.zeros(n // 2 - 1, dtype=torch.float64, device=field.device)
-    ksum, nmodes = shell_geometry(n, boxsize, binning=binning)
     if field.dtype == torch.float32:          # an fp32 grid through the double passes (sizes without fp32 tile passes)
         assert halo is None
         check(L.ast_fft64_power_3d_f32(ptr(field), ptr(scratch), scratch.numel(), n, float(boxsize), _bin_code(binning), ptr(psum),
@@ -781,7 +799,7 @@ def paint_power_1d(pos, mass, nmesh, boxsize, window="cic", scale=1.0, binning=N
         # fp32 particles on a grid without fp32 tile passes (128^3, 2048^3): the grid holds rho - mean (only the discarded DC
         # mode differs), the transform runs in double straight from the fp32 grid
         grid = paint(pos, mass, n, paint_box, window, scale=scale, method=tiled, offset="mean")
-        return finish_power(*power_sums_fused64(grid, boxsize, binning=binning))
+        return finish_power(*power_sums_fused64(grid, boxsize, binning=binning, mean=0.0))
     fast64 = pos.dtype == torch.float64 and tiled is not None and bool(_lib.lib().ast_fft64_supported(n))
     if fast64 and defer_fold64:               # float64: the halo fold inside the double z pass (26.2 vs 26.5 ms at 1024^3)
         grid, halo = paint(pos, mass, n, paint_box, window, scale=scale, method=tiled, defer_fold=True)
@@ -802,7 +820,8 @@ def fftpower_1d(field1, boxsize, field2=None, fused=True, binning=None):
     if fused and field2 is None and fused_power64_supported(field1, allow_f32=True):
         # float64 cubes of side 128 ... 2048 - and fp32 cubes of the sides the fp32 tile passes do not cover (128, 2048),
         # transformed in double without a float64 copy of the grid
-        return finish_power(*power_sums_fused64(field1, boxsize, binning=binning))
+        mean = total_mass(field1.reshape(-1), 0) / float(field1.numel()) if field1.dtype == torch.float32 else None
+        return finish_power(*power_sums_fused64(field1, boxsize, binning=binning, mean=mean))
     if field1.dtype == torch.float32:
         # fp32 grids that do not take the fused path above - cross spectra, sizes the tile FFT does not cover: an fp32
         # transform would carry the O(1) mean's round-off into the low shells (2e-6 and worse: only the fused path

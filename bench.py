@@ -678,7 +678,7 @@ def _stage_table(prof, steps, npart_rank, ng_rank, esz, fused_bin, concurrent=()
     on a second stream beside the stage's other kernels - listed, but their time is not added to the stage's."""
     stage_sites = {
         "paint": [k for k in prof if k.startswith("paint")],
-        "fft": [k for k in prof if k.startswith("rocfft") or k.startswith("fft_tile") or k.startswith("fft64") or k.startswith("slab.")],
+        "fft": [k for k in prof if k.startswith("rocfft") or k.startswith("fft_tile") or k.startswith("fft64") or k.startswith("fft32big") or k.startswith("slab.")],
         "power_bin": [k for k in prof if k == "power_bin"],        # absent when fused into the last FFT pass
     }
     stage_bytes = {
@@ -743,8 +743,9 @@ def power_leg(dev, n, npside, L, window, order, dtype, method, steps, warmup, cl
     dev.shell_geometry(n, L)          # data independent, cached like the FFT plan
     fused = dev.fused_power_supported(grid)
     fused64 = dev.fused_power64_supported(grid) and not os.environ.get("ASTRILD_BENCH_ROCFFT64")
-    # fp32 grids of the sides the fp32 tile passes do not cover (128, 2048): painted as rho - mean, transformed in DOUBLE straight
-    # from the fp32 grid (ast_fft64_power_3d_f32) - the stage table still prices the FFT at the grid's 4 bytes per cell
+    # fp32 grids of the sides the fp32 tile passes do not cover (128, 2048): painted as rho - mean; side 128 transformed in DOUBLE
+    # straight from the fp32 grid (ast_fft64_power_3d_f32), side 2048 by three-stage single-precision passes
+    # (ast_fft32_big_power_3d) with the lowest shells from the double-precision side channel
     f32_via_double = dtype == "f32" and not fused and dev.fused_power64_supported(grid, allow_f32=True)
     spec = None
     if not fused and not fused64 and not f32_via_double:
@@ -780,7 +781,7 @@ def power_leg(dev, n, npside, L, window, order, dtype, method, steps, warmup, cl
             dev.paint(pos, None, n, L, window, out=grid, method="tiled", check_dropped=False, accumulate=False, offset=mean, hint=hint,
                       stats=collect[0])
             psum.zero_()
-            return dev.power_sums_fused64(grid, L, psum=psum)
+            return dev.power_sums_fused64(grid, L, psum=psum, mean=0.0)      # (rho - mean: side 2048 takes its fp32 passes + low-k patch)
         if fused64 and method in ("auto", "tiled"):     # float64: the halo fold rides on the double z pass too
             _, halo = dev.paint(pos, None, n, L, window, out=grid, method="tiled", check_dropped=False,
                                 accumulate=False, defer_fold=True, hint=hint, stats=collect[0])
@@ -813,7 +814,7 @@ def power_leg(dev, n, npside, L, window, order, dtype, method, steps, warmup, cl
     assert np.isfinite(res["power"]).all() and res["power"][-1] > 0
     overlapped = ("paint_tiled.fill", "paint_tiled.deposit") if "paint_tiled.pipeline" in prof else ()
     stages, stage_sites, stage_bytes = _stage_table(prof, steps, npart_total, n ** 3, esz, fused_bin=True,
-                                                    concurrent=("fft_tile.lowk",) + overlapped)
+                                                    concurrent=(("fft_tile.lowk",) if fused else ()) + overlapped)
     dom = max(stages, key=lambda k: stages[k]["ms"])
     traffic, source = (None, None)
     if dom == "paint" and n == 1024 and npside == 1024 and window == "cic" and dtype == "f32" and order == "natural":

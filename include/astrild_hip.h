@@ -580,6 +580,15 @@ int ast_fft64_power_3d(const double* grid_d, void* scratch_d, size_t scratch_byt
  * cubes the fp32 tile passes do not cover (n = 128, 2048) without a float64 copy of the grid.  Same scratch. */
 int ast_fft64_power_3d_f32(const float* grid_d, void* scratch_d, size_t scratch_bytes, size_t n, double boxsize, int binning,
                            double* psum_d, void* stream);
+/* The same shell sums for a SINGLE-precision cube of side 2048 with every pass in single precision (three register FFTs
+ * per axis; the fp32 tile passes end at 1024): psum_d[shell] += L^3 sum w |rfftn(grid - mean) / n^3|^2, FFTPower's sums
+ * (power_spectrum_3d.py:189-224).  `mean` is subtracted as the rows are loaded (only the discarded DC mode sees it).  The
+ * lowest shells carry fp32 round-off; callers patch them from ast_lowk_modes / ast_lowk_shell_sums (device.py does).
+ * Half the bytes of ast_fft64_power_3d_f32 on every pass. */
+int ast_fft32_big_supported(size_t n);
+size_t ast_fft32_big_power_scratch_bytes(size_t n);
+int ast_fft32_big_power_3d(const float* grid_d, void* scratch_d, size_t scratch_bytes, size_t n, double boxsize, int binning,
+                           double mean, double* psum_d, void* stream);
 /* spec_d (n, n, n / 2 + 1) complex double, contiguous = rfftn(grid_d) * scale (pmesh's r2c with scale = 1 / n^3) through
  * the same passes; grid_d is not modified */
 int ast_fft64_r2c_3d(const double* grid_d, void* spec_d, size_t n, double scale, void* stream);

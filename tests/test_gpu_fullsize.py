@@ -242,3 +242,30 @@ def test_config_b_512_against_the_oracle(dev, window, shuffle):
     r32 = dev.finish_power(*dev.power_sums_fused(grid, L, halo=halo))
     np.testing.assert_array_equal(r32["modes"], ref["modes"])
     np.testing.assert_allclose(r32["power"], ref["power"].real, rtol=1e-6)
+
+
+def test_side_2048_single_precision_passes_against_the_double_passes(dev, monkeypatch):
+    """1024^3 lattice particles on a 2048^3 fp32 grid (the largest cube one GPU holds; domain_level is arbitrary in the
+    reference, power_spectrum_3d.py:183-188): the three-stage single-precision passes + double-precision low-k patch
+    (ast_fft32_big_power_3d) against the double passes over the same fp32 grid (ast_fft64_power_3d_f32) - every shell
+    within 1e-6 (north_star), mode counts equal - and through paint_power_1d."""
+    n, npside, L = 2048, 1024, 1000.0
+    pos = dev.synth_lattice_particles(npside, n, L, seed=20240601, dtype=torch.float32)
+    grid = dev.paint(pos, None, n, L, "cic", method="tiled", offset="mean", check_dropped=False)
+    fast = dev.finish_power(*dev.power_sums_fused64(grid, L, mean=0.0))
+    torch.cuda.synchronize()
+    dev._power_scratch.clear()
+    torch.cuda.empty_cache()
+    monkeypatch.setenv("ASTRILD_FFT32_BIG_OFF", "1")
+    ref = dev.finish_power(*dev.power_sums_fused64(grid, L, mean=0.0))
+    monkeypatch.delenv("ASTRILD_FFT32_BIG_OFF")
+    dev._power_scratch.clear()
+    del grid
+    torch.cuda.empty_cache()
+    assert np.array_equal(fast["modes"], ref["modes"])
+    rel = np.abs(fast["power"] / ref["power"] - 1.0)
+    assert rel.max() < 1e-6, (int(rel.argmax()), float(rel.max()))
+    whole = dev.paint_power_1d(pos, None, n, L, "cic")
+    np.testing.assert_allclose(whole["power"], ref["power"], rtol=1e-6)
+    dev._power_scratch.clear()
+    torch.cuda.empty_cache()
