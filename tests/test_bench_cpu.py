@@ -29,3 +29,19 @@ def test_parallel_cpu_paint_child_paints_every_particle():
     from oracle import mesh as omesh
     ref = omesh.paint(omesh.lattice_particles(80, 80, 1000.0, seed=20240601), None, 80, 1000.0, "cic")
     np.testing.assert_allclose(res["moments"], bench._grid_moments(ref), rtol=1e-12)
+
+
+def test_auto_paint_method_thresholds():
+    """device.auto_paint_method is plain arithmetic (no GPU): direct atomics for sparse catalogues, two-pass lists for small or
+    clumpy-sparse ones, the probe-driven tiled paths for dense input; accumulate keeps round 1's threshold."""
+    from astrild_amd.device import auto_paint_method as m
+    n = 512
+    per_tile = n ** 3 // 2048
+    assert m(7 * per_tile, n, n, "tsc") == "direct" and m(8 * per_tile, n, n, "tsc") == "tiled2"
+    assert m(15 * per_tile, n, n, "cic") == "direct" and m(16 * per_tile, n, n, "cic") == "tiled2"
+    assert m(63 * per_tile, n, n, "cic") == "tiled2" and m(64 * per_tile, n, n, "cic") == "tiled"       # (>= 2^20 objects: the probe decides)
+    assert m(1 << 19, 128, 128, "cic") == "tiled2"                                                       # dense but too small for the probe
+    assert m(1 << 24, 256, 256, "cic", hint="scattered") == "tiled" and m(1 << 24, 256, 256, "cic") == "tiled"
+    assert m(40 * per_tile, n, n, "cic", accumulate=True) == "direct" and m(64 * per_tile, n, n, "cic", accumulate=True) == "tiled"
+    assert m(10 ** 7, 100, 100, "cic") == "direct"                                                       # nmesh not a multiple of 32
+    assert m(1000, n, n, "cic") == "direct"
