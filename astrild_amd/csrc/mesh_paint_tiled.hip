@@ -1930,6 +1930,17 @@ Workspace carve(void* base, size_t np, uint32_t ntiles, uint32_t ncols, int flag
     w.cap = two_pass ? 0 : tile_capacity(np, ntiles);
     w.rcap = compact && !w.tpb ? (w.cap + MINPOP - 1) / MINPOP : 0;       // the scatter path writes stray copies only
     w.scap = compact ? ((flags & AST_PAINT_SCATTERED) ? w.cap : (w.cap + 3) / 4) : 0;
+    {   // At 1024^3 a tile's record segment is 512 x 8 bytes and its stray segment 1024 x 12: strides of 4 KB and 12 KB, so every
+        // segment starts at the same offset inside a 4-KB block and the grouping kernel's stores crowd a few channels - how
+        // badly depends on where the workspace's pages lie (the step's 12.6-13.1 ms spread).  16 records / 32 copies more per
+        // segment make the strides odd multiples of 128 bytes: grouping 3.61 -> 3.46 ms, step 12.95 -> 12.79 (means over ten
+        // placements each, scripts/micro/placement_step.py; AST_PAINT_SEG_SKEW=0 restores the old strides).
+        static const int skew = getenv("AST_PAINT_SEG_SKEW") ? atoi(getenv("AST_PAINT_SEG_SKEW")) : 1;
+        if (skew && w.rcap) w.rcap += 16 * skew;
+        if (skew && w.scap) w.scap += 32 * skew;
+        // (the scatter path: level B's stores into the stray segments 5.7 -> 5.5 ms; level A's staging segments - 3 MB apart -
+        // measured worse with such a skew, 6.6 -> 6.8, and keep their stride)
+    }
     w.index = (uint32_t*)take(two_pass ? np * 4 : compact ? 0 : (size_t)ntiles * w.cap * 4);
     w.recs = (GroupRec*)take((size_t)ntiles * w.rcap * sizeof(GroupRec));
     w.strays = take((size_t)ntiles * w.scap * 4 * esz);
