@@ -1197,7 +1197,7 @@ __device__ inline unsigned long long column_line_dest(int a, int b, int col, int
     if (RM::owned(a, TX) && RM::owned(b, TY))
         return px < g.nx_alloc ? ((unsigned long long)(grid + ((size_t)px * g.n + oy + b - LO) * g.n) |
                                   (px >= g.off_lo && px < g.off_hi ? 2ull : 0ull)) : 0ull;
-    unsigned long long d = (unsigned long long)(rec + ((size_t)col * RM::COUNT + RM::cell(a, b)) * g.n);
+    unsigned long long d = (unsigned long long)(rec + ((size_t)col * RM::COUNT + RM::cell(a, b)) * ast::rec_pitch((size_t)g.n));
     if (g.nx_alloc != g.n && (px < 0 || px >= g.nx_alloc)) d |= 1ull;
     return d;
 }
@@ -1746,7 +1746,7 @@ column_fold_kernel(const T* __restrict__ rec, TileGeom g, T* __restrict__ grid, 
                     if (x_periodic) ntx = ast::wrap1(ntx, g.ntx);
                     else if (ntx < 0 || ntx >= g.ntx) continue;
                     const int nty_ = ast::wrap1(ty + dy, g.nty);
-                    if (ns < 3) src[ns++] = (unsigned long long)(rec + ((size_t)(ntx * g.nty + nty_) * RM::COUNT + RM::cell(a, b)) * g.n);
+                    if (ns < 3) src[ns++] = (unsigned long long)(rec + ((size_t)(ntx * g.nty + nty_) * RM::COUNT + RM::cell(a, b)) * ast::rec_pitch((size_t)g.n));
                 }
             }
         }
@@ -1976,7 +1976,7 @@ inline size_t seam_bytes(int window, const TileGeom& g, size_t np, size_t esz, i
 inline size_t record_bytes(int window, const TileGeom& g, size_t esz, int flags) {
     if (!(flags & AST_PAINT_OVERWRITE)) return 0;
     const size_t ring = window == AST_WIN_TSC ? RingMap<3>::COUNT : RingMap<2>::COUNT;
-    return (size_t)g.ntx * g.nty * ring * (size_t)g.n * esz;
+    return (size_t)g.ntx * g.nty * ring * ast::rec_pitch((size_t)g.n) * esz;
 }
 
 template <typename T, int W>

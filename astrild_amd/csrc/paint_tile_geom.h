@@ -12,6 +12,14 @@ namespace ast {
 #endif
 constexpr int TX = TILE_TX, TY = TILE_TY, TZ = TILE_TZ;   // owned cells per tile
 
+// Pitch (elements) of a halo-record z line: n.  (Every line then starts at a multiple of 4 KB for fp32 and n = 1024, like
+// the tile segments of the paint workspace before their strides were skewed - but here a pitch of n + 32 measured no
+// better: step 12.79 / 12.86 against 12.73 / 12.81 ms, scripts/micro/ab_rec_skew.sh.  -DREC_LINE_SKEW=32 for A/B builds.)
+#ifndef REC_LINE_SKEW
+#define REC_LINE_SKEW 0
+#endif
+__host__ __device__ inline size_t rec_pitch(size_t n) { return n + REC_LINE_SKEW; }
+
 // halo ring of one (LX x LY) plane of the LDS tile: the cells a column deposits for its x / y
 // neighbours, kept as z lines of the column's halo record [column][ring cell][z]
 template <int W> struct RingMap {
@@ -48,7 +56,7 @@ __device__ inline int halo_sources(const T* rec, int x, int y, int n, int ntx, i
             if (a < 0 || a >= RM::LX || b < 0 || b >= RM::LY) continue;
             if (!x_periodic && (tx + dx < 0 || tx + dx >= ntx)) continue;
             const int ntx_ = x_periodic ? wrap1(tx + dx, ntx) : tx + dx, nty_ = wrap1(ty + dy, nty);
-            const T* p = rec + ((size_t)(ntx_ * nty + nty_) * RM::COUNT + RM::cell(a, b)) * (size_t)n;
+            const T* p = rec + ((size_t)(ntx_ * nty + nty_) * RM::COUNT + RM::cell(a, b)) * rec_pitch((size_t)n);
             s0 = ns == 0 ? p : s0;
             s1 = ns == 1 ? p : s1;
             s2 = ns == 2 ? p : s2;
