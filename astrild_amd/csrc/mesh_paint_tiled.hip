@@ -430,7 +430,8 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
                   unsigned long long* __restrict__ fill64, GroupRec* __restrict__ recs, uint32_t rcap,
                   T* __restrict__ strays, uint32_t scap, uint32_t* __restrict__ ovf,
                   unsigned long long* __restrict__ ovf_count, uint32_t* __restrict__ col_flags,
-                  unsigned long long* dropped, uint32_t closed_lo, uint32_t closed_n, uint32_t closed_mod = 0u) {
+                  unsigned long long* dropped, uint32_t closed_lo, uint32_t closed_n, uint32_t closed_mod = 0u,
+                  uint32_t xcd_map = 0u) {
     __shared__ uint32_t skey[AGG_SLOTS], srun[AGG_SLOTS], sstray[AGG_SLOTS], sroom_run[AGG_SLOTS], sroom_stray[AGG_SLOTS];
     __shared__ unsigned long long sdst_run[AGG_SLOTS], sdst_stray[AGG_SLOTS];
     // group records: first, mask, tile key (phase 2 turns the key into slot << 16 | offset, DST_NONE = placed already)
@@ -478,8 +479,13 @@ tile_group_kernel(const T* __restrict__ pos, const T* __restrict__ mass, size_t 
     };
     static_assert(AGG_TRIPS % 2 == 0, "two register sets");
     T xa[IDX_UNROLL], ya[IDX_UNROLL], za[IDX_UNROLL], xb[IDX_UNROLL], yb[IDX_UNROLL], zb[IDX_UNROLL];
-    if ((size_t)blockIdx.x < nintervals) fetch(p_begin + (size_t)blockIdx.x * per_interval, xa, ya, za);
-    for (size_t interval = blockIdx.x; interval < nintervals; interval += gridDim.x) {
+    // xcd_map: workgroup b runs on XCD b mod 8 (round-robin dispatch: observed, nothing depends on it for correctness); with
+    // the map each XCD takes a CONTIGUOUS eighth of the intervals, so that the workgroups which append to one tile's
+    // segments - neighbouring intervals, and the same rows 256 intervals later, plane after plane - share an L2
+    size_t vb = blockIdx.x;
+    if (xcd_map && gridDim.x % 8u == 0u) vb = (size_t)(blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u;
+    if (vb < nintervals) fetch(p_begin + vb * per_interval, xa, ya, za);
+    for (size_t interval = vb; interval < nintervals; interval += gridDim.x) {
         const size_t p0 = p_begin + interval * per_interval;
         const bool full = p0 + per_interval <= np;
         const uint32_t p0_32 = (uint32_t)p0, left = (uint32_t)min(np - p0, per_interval);      // particle ids fit 32 bits (checked by the host)
@@ -2090,13 +2096,15 @@ int run_tiled(const T* pos, const T* mass, size_t np, TileGeom g, uint32_t ntile
     auto group_pass = [&](size_t pb, size_t pe, uint32_t closed_lo, uint32_t closed_n, uint32_t closed_mod = 0u) {
         AST_PROF("paint_tiled.fill", s);
         const size_t nint = (pe - pb + per_interval - 1) / per_interval;
-        const unsigned gg = (unsigned)(nint > want ? want : nint);
+        static const unsigned xcd_map = getenv("AST_PAINT_GROUP_XCD") ? (unsigned)atoi(getenv("AST_PAINT_GROUP_XCD")) : 0u;
+        unsigned gg = (unsigned)(nint > want ? want : nint);
+        if (xcd_map && nint <= want && nint >= 64) gg = (gg + 7u) / 8u * 8u;          // (the map needs a multiple of 8; the surplus workgroups find no interval)
         if (plainx)
             tile_group_kernel<T, W, true><<<gg, 256, 0, s>>>(pos, mass, pb, pe, g, w.fill64, w.recs, w.rcap, (T*)w.strays, w.scap,
-                                                             w.ovf, w.ovf_count, w.col_flags, dropped, closed_lo, closed_n);
+                                                             w.ovf, w.ovf_count, w.col_flags, dropped, closed_lo, closed_n, 0u, xcd_map);
         else
             tile_group_kernel<T, W, false><<<gg, 256, 0, s>>>(pos, mass, pb, pe, g, w.fill64, w.recs, w.rcap, (T*)w.strays, w.scap,
-                                                              w.ovf, w.ovf_count, w.col_flags, dropped, closed_lo, closed_n, closed_mod);
+                                                              w.ovf, w.ovf_count, w.col_flags, dropped, closed_lo, closed_n, closed_mod, xcd_map);
     };
     if (sel.stage != AST_PAINT_STAGE_ALL) {
         // the single-pass overwrite paint in three parts, so that a caller can interleave tile rows with what consumes
