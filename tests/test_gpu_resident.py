@@ -102,3 +102,28 @@ def test_map_store_is_the_reference_dict():
     s["c"] = torch.ones(2, device="cuda", dtype=torch.float64)
     d = copy.deepcopy(s)
     assert d.resident("c") and np.array_equal(d["c"], np.ones(2)) and s.resident("c")
+
+
+def test_upload_planes_one_allocation_and_fallbacks(hip):
+    """device.upload_planes: equal-sized host arrays become views into ONE device allocation (plane after plane, float64);
+    mixed sizes, a single array and an empty list fall back to one allocation each; values and order are kept, and the
+    stack over the views equals the stack over separately uploaded planes bit for bit."""
+    from astrild_amd import device as dev, lensing
+    torch.cuda.set_device(0)
+    rng = np.random.default_rng(3)
+    arrays = [rng.normal(size=(64, 64)) for _ in range(5)] + [rng.normal(size=(64, 64)).astype(np.float32)]
+    planes = dev.upload_planes(arrays)
+    assert len(planes) == 6 and all(p.is_cuda and p.dtype == torch.float64 and p.shape == (64 * 64,) for p in planes)
+    assert all(planes[i + 1].data_ptr() - planes[i].data_ptr() == 64 * 64 * 8 for i in range(5))          # one slab
+    for p, a in zip(planes, arrays):
+        assert np.array_equal(p.cpu().numpy(), np.asarray(a, dtype=np.float64).reshape(-1))
+    shaped = dev.upload_planes(arrays, flat=False)
+    assert all(p.shape == (64, 64) for p in shaped)
+    sep = [dev.as_device(np.asarray(a, dtype=np.float64)) for a in arrays]
+    assert torch.equal(lensing.kappa_stack(shaped), lensing.kappa_stack(sep))
+    mixed = dev.upload_planes([np.ones((4, 4)), np.ones((2, 2))])
+    assert [p.numel() for p in mixed] == [16, 4]
+    assert dev.upload_planes([]) == [] and dev.upload_planes([np.ones(3)])[0].shape == (3,)
+    big = dev.to_numpy(torch.arange(1 << 18, dtype=torch.float64, device="cuda"))                           # >= 1 MiB: page-locked
+    small = dev.to_numpy(torch.arange(8, dtype=torch.float64, device="cuda"))
+    assert np.array_equal(big, np.arange(1 << 18)) and np.array_equal(small, np.arange(8)) and big.flags.writeable
