@@ -113,6 +113,7 @@ SIGNATURES = {
     "ast_fft32_big_supported": (_i, [_sz]),
     "ast_fft32_big_power_scratch_bytes": (_sz, [_sz]),
     "ast_fft32_big_power_3d": (_i, [_vp, _vp, _sz, _sz, _d, _i, _d, _vp, _vp]),
+    "ast_fft32_big_power_3d_halo": (_i, [_vp, _vp, _i, _vp, _sz, _sz, _d, _i, _d, _vp, _vp]),
     "ast_fft64_power_3d_halo": (_i, [_vp, _vp, _i, _vp, _sz, _sz, _d, _i, _vp, _vp]),
     "ast_lens_cols_supported": (_i, [_sz]),
     "ast_lens_rows_supported": (_i, [_sz]),

@@ -1078,10 +1078,14 @@ struct TwCache32 {
 } g_tw32;
 
 // one row per workgroup: 2 M reals -> M + 1 complex (lens_rows_forward_kernel without padding, fold or widening)
-template <int RA, int RB, int RC>
+// FOLDW = 2 / 3 (CIC / TSC): the grid is what a deferred-fold paint left and `rec` its halo records; the up to three record
+// lines that end in a border row are added as the row is loaded - records first, then onto the row, the order of the paint's
+// own fold kernel (as in the double row kernel above and fft_tile.hip's).
+template <int RA, int RB, int RC, int FOLDW = 0>
 __global__ void __launch_bounds__((RowGeo<RA, RB, RC>::NT))
 rows32_forward_kernel(const float* __restrict__ grid, size_t in_pitch, float2* __restrict__ spec, size_t pitch,
-                      const float2* __restrict__ twM, const float2* __restrict__ twL, float scale, float mean) {
+                      const float2* __restrict__ twM, const float2* __restrict__ twL, float scale, float mean,
+                      const float* __restrict__ rec = nullptr) {
     using G = RowGeo<RA, RB, RC>;
     constexpr int M = G::M;
     extern __shared__ float2 Y32[];
@@ -1089,10 +1093,33 @@ rows32_forward_kernel(const float* __restrict__ grid, size_t in_pitch, float2* _
     const size_t row = blockIdx.x;
     const float2* z = reinterpret_cast<const float2*>(grid + row * in_pitch);
     float2 va[RA], vc[RC];
+    const float* src[3] = {nullptr, nullptr, nullptr};
+    int ns = 0;
+    if (FOLDW != 0) {
+        constexpr int W = FOLDW != 0 ? FOLDW : 2;
+        const int ng = 2 * M;
+        ns = ast::halo_sources<float, W>(rec, (int)(row / ng), (int)(row % ng), ng, ng / ast::TX, ng / ast::TY, src);
+    }
     if (t < G::T1) {
 #pragma unroll
+        for (int a = 0; a < RA; ++a) va[a] = z[G::T1 * a + t];
+        if (FOLDW != 0 && ns > 0) {
+            float2 h[RA];
+#pragma unroll
+            for (int a = 0; a < RA; ++a) h[a] = reinterpret_cast<const float2*>(src[0])[G::T1 * a + t];
+            if (ns > 1) {
+#pragma unroll
+                for (int a = 0; a < RA; ++a) { const float2 g2 = reinterpret_cast<const float2*>(src[1])[G::T1 * a + t]; h[a].x += g2.x; h[a].y += g2.y; }
+            }
+            if (ns > 2) {
+#pragma unroll
+                for (int a = 0; a < RA; ++a) { const float2 g3 = reinterpret_cast<const float2*>(src[2])[G::T1 * a + t]; h[a].x += g3.x; h[a].y += g3.y; }
+            }
+#pragma unroll
+            for (int a = 0; a < RA; ++a) { va[a].x += h[a].x; va[a].y += h[a].y; }
+        }
+#pragma unroll
         for (int a = 0; a < RA; ++a) {
-            va[a] = z[G::T1 * a + t];
             va[a].x -= mean;
             va[a].y -= mean;
         }
@@ -1300,9 +1327,10 @@ constexpr int BIGKZ = BIGBOX + 1, BIGK = 2 * BIGBOX + 1;
 constexpr int BIGLOW_MODES = BIGK * BIGK * BIGKZ;
 constexpr int BIGLOW_XPARTS = 256;
 
-template <int NJ>
+template <int NJ, int FOLDW = 0>
 __global__ void __launch_bounds__(256)
-biglow_z_kernel(const float* __restrict__ grid, int n, size_t nrows, double mean, double2* __restrict__ out) {
+biglow_z_kernel(const float* __restrict__ grid, int n, size_t nrows, double mean, double2* __restrict__ out,
+                const float* __restrict__ rec = nullptr) {
     __shared__ double part[4][2 * BIGKZ][65];                      // [wave][sum][lane] (65: the 36 readers on different banks)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double twc[BIGKZ], tws[BIGKZ];                                 // the lane's e^{-2 pi i kz lane / n}
@@ -1313,9 +1341,32 @@ biglow_z_kernel(const float* __restrict__ grid, int n, size_t nrows, double mean
         const float* in = grid + row * (size_t)n;
         // the lane's NJ samples z = lane + 64 j through ONE NJ-point register FFT (all NJ outputs for the price of the few
         // needed: 80 butterflies at NJ = 32 against 18 x 32 multiply-adds in a dependent chain, 105 ms -> ... at side 2048)
+        float fr[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fr[j] = in[lane + 64 * j];
+        if (FOLDW != 0) {                                  // the fp32 value the z rows see: records first, then onto the row
+            constexpr int W = FOLDW != 0 ? FOLDW : 2;
+            const float* src[3];
+            const int ns = ast::halo_sources<float, W>(rec, (int)(row / n), (int)(row % n), n, n / ast::TX, n / ast::TY, src);
+            if (ns > 0) {
+                float h[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) h[j] = src[0][lane + 64 * j];
+                if (ns > 1) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) h[j] += src[1][lane + 64 * j];
+                }
+                if (ns > 2) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) h[j] += src[2][lane + 64 * j];
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fr[j] += h[j];
+            }
+        }
         double2 v[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) v[j] = make_double2((double)in[lane + 64 * j] - mean, 0.0);
+        for (int j = 0; j < NJ; ++j) v[j] = make_double2((double)fr[j] - mean, 0.0);
         fft_reg<NJ>(v);
 #pragma unroll
         for (int kz = 0; kz < BIGKZ; ++kz) {
@@ -1482,8 +1533,21 @@ extern "C" size_t ast_fft32_big_power_scratch_bytes(size_t n) {
 // psum_d[shell] += L^3 sum over the shell's modes of w |delta_k|^2, delta_k = rfftn(grid - mean) / n^3, for an (n, n, n)
 // float grid of side 2048: all passes in single precision, the shells |m| < 17 from double-precision sums over the grid
 // (see the two section headers).  grid_d is not modified.
+static int fft32_big_impl(const float* grid, const float* rec, int window, void* scratch, size_t scratch_bytes, size_t n,
+                          double boxsize, int binning, double mean, double* psum, void* stream);
 extern "C" int ast_fft32_big_power_3d(const float* grid, void* scratch, size_t scratch_bytes, size_t n, double boxsize, int binning,
                                       double mean, double* psum, void* stream) {
+    return fft32_big_impl(grid, nullptr, 0, scratch, scratch_bytes, n, boxsize, binning, mean, psum, stream);
+}
+// The same for a grid painted with AST_PAINT_OVERWRITE | AST_PAINT_DEFER_FOLD: halo_rec_d (ast_paint_tiled_halo) is folded
+// into the border rows as the z rows - and the low-k sums - load them.
+extern "C" int ast_fft32_big_power_3d_halo(const float* grid, const float* halo_rec, int window, void* scratch, size_t scratch_bytes,
+                                           size_t n, double boxsize, int binning, double mean, double* psum, void* stream) {
+    AST_CHECK_ARG(halo_rec != nullptr && (window == AST_WIN_CIC || window == AST_WIN_TSC));
+    return fft32_big_impl(grid, halo_rec, window, scratch, scratch_bytes, n, boxsize, binning, mean, psum, stream);
+}
+static int fft32_big_impl(const float* grid, const float* rec, int window, void* scratch, size_t scratch_bytes, size_t n,
+                          double boxsize, int binning, double mean, double* psum, void* stream) {
     AST_CHECK_ARG(grid != nullptr && scratch != nullptr && psum != nullptr && boxsize > 0.0);
     AST_CHECK_ARG(ast_fft32_big_supported(n) && scratch_bytes >= ast_fft32_big_power_scratch_bytes(n));
     AST_CHECK_ARG(binning == AST_BIN_INTEGER || binning == AST_BIN_FLOAT64);
@@ -1508,7 +1572,9 @@ extern "C" int ast_fft32_big_power_3d(const float* grid, void* scratch, size_t s
             AST_PROF("fft32big.rows_r2c", s);
             using G = RowGeo<HA, HB, HC>;
             const size_t lds = (size_t)(G::M + G::M / 8) * sizeof(float2);
-            rows32_forward_kernel<HA, HB, HC><<<(unsigned)(n * n), G::NT, lds, s>>>(grid, n, spec, nzp, twH, twN, 1.0f, (float)mean);
+            if (rec == nullptr) rows32_forward_kernel<HA, HB, HC, 0><<<(unsigned)(n * n), G::NT, lds, s>>>(grid, n, spec, nzp, twH, twN, 1.0f, (float)mean);
+            else if (window == AST_WIN_CIC) rows32_forward_kernel<HA, HB, HC, 2><<<(unsigned)(n * n), G::NT, lds, s>>>(grid, n, spec, nzp, twH, twN, 1.0f, (float)mean, rec);
+            else rows32_forward_kernel<HA, HB, HC, 3><<<(unsigned)(n * n), G::NT, lds, s>>>(grid, n, spec, nzp, twH, twN, 1.0f, (float)mean, rec);
             AST_CHECK_LAUNCH();
         }
         {
@@ -1537,8 +1603,14 @@ extern "C" int ast_fft32_big_power_3d(const float* grid, void* scratch, size_t s
     const unsigned zblocks = (unsigned)std::min<size_t>((n * n + 3) / 4, (size_t)256 * 8);
     {
         AST_PROF("fft32big.lowk_z", s);
-        if (n == 2048) biglow_z_kernel<32><<<zblocks, 256, 0, s>>>(grid, (int)n, n * n, mean, lowz);
-        else biglow_z_kernel<4><<<zblocks, 256, 0, s>>>(grid, (int)n, n * n, mean, lowz);
+        auto lowz_launch = [&](auto nj) {
+            constexpr int NJ = decltype(nj)::value;
+            if (rec == nullptr) biglow_z_kernel<NJ, 0><<<zblocks, 256, 0, s>>>(grid, (int)n, n * n, mean, lowz);
+            else if (window == AST_WIN_CIC) biglow_z_kernel<NJ, 2><<<zblocks, 256, 0, s>>>(grid, (int)n, n * n, mean, lowz, rec);
+            else biglow_z_kernel<NJ, 3><<<zblocks, 256, 0, s>>>(grid, (int)n, n * n, mean, lowz, rec);
+        };
+        if (n == 2048) lowz_launch(std::integral_constant<int, 32>{});
+        else lowz_launch(std::integral_constant<int, 4>{});
     }
     const size_t lds = n * sizeof(double2);
     {

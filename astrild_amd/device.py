@@ -745,14 +745,18 @@ def power_sums_fused64(field, boxsize, psum=None, binning=None, halo=None, mean=
         # side 2048: single-precision passes (half the bytes of the double route below); the grid's mean leaves as the rows
         # are loaded and the sixteen lowest shells come from double-precision sums over the grid (inside the call) - fp32
         # round-off of an O(1) field on shells of little power - as the fp32 tile pipeline takes its five lowest
-        assert halo is None
         key32 = (torch.cuda.current_device(), n, "f32big")
         scratch = _power_scratch.get(key32)
         if scratch is None:
             _power_scratch.clear()
             scratch = _power_scratch[key32] = torch.empty(int(L.ast_fft32_big_power_scratch_bytes(n)), dtype=torch.uint8, device=field.device)
-        check(L.ast_fft32_big_power_3d(ptr(field), ptr(scratch), scratch.numel(), n, float(boxsize), _bin_code(binning), float(mean),
-                                       ptr(psum), stream()), "ast_fft32_big_power_3d")
+        if halo is not None:                  # grid from paint(..., defer_fold=True): the fold rides on the z rows
+            check(L.ast_fft32_big_power_3d_halo(ptr(field), halo.rec_ptr, halo.window_code, ptr(scratch), scratch.numel(), n,
+                                                float(boxsize), _bin_code(binning), float(mean), ptr(psum), stream()),
+                  "ast_fft32_big_power_3d_halo")
+        else:
+            check(L.ast_fft32_big_power_3d(ptr(field), ptr(scratch), scratch.numel(), n, float(boxsize), _bin_code(binning), float(mean),
+                                           ptr(psum), stream()), "ast_fft32_big_power_3d")
         return ksum, psum, nmodes
     key = (torch.cuda.current_device(), n, "f64")
     scratch = _power_scratch.get(key)
@@ -798,6 +802,9 @@ def paint_power_1d(pos, mass, nmesh, boxsize, window="cic", scale=1.0, binning=N
     if pos.dtype == torch.float32 and tiled is not None and bool(_lib.lib().ast_fft64_supported(n)):
         # fp32 particles on a grid without fp32 tile passes (128^3, 2048^3): the grid holds rho - mean (only the discarded DC
         # mode differs), the transform runs in double straight from the fp32 grid
+        # (side 2048 takes its fp32 passes.  Their z rows could fold the halo records on load - power_sums_fused64(halo=) -
+        # but TWO kernels read every row there, the transform and the low-k sums, and both would fetch the 9 GB of records:
+        # 86.6 ms against 83.5 with the paint's own fold kernel, so the grid is folded here)
         grid = paint(pos, mass, n, paint_box, window, scale=scale, method=tiled, offset="mean")
         return finish_power(*power_sums_fused64(grid, boxsize, binning=binning, mean=0.0))
     fast64 = pos.dtype == torch.float64 and tiled is not None and bool(_lib.lib().ast_fft64_supported(n))

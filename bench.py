@@ -781,7 +781,7 @@ def power_leg(dev, n, npside, L, window, order, dtype, method, steps, warmup, cl
             dev.paint(pos, None, n, L, window, out=grid, method="tiled", check_dropped=False, accumulate=False, offset=mean, hint=hint,
                       stats=collect[0])
             psum.zero_()
-            return dev.power_sums_fused64(grid, L, psum=psum, mean=0.0)      # (rho - mean: side 2048 takes its fp32 passes + low-k patch)
+            return dev.power_sums_fused64(grid, L, psum=psum, mean=0.0)      # (rho - mean: side 2048 takes its fp32 passes + low-k box; 128 the double passes)
         if fused64 and method in ("auto", "tiled"):     # float64: the halo fold rides on the double z pass too
             _, halo = dev.paint(pos, None, n, L, window, out=grid, method="tiled", check_dropped=False,
                                 accumulate=False, defer_fold=True, hint=hint, stats=collect[0])

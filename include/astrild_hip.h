@@ -589,6 +589,10 @@ int ast_fft32_big_supported(size_t n);
 size_t ast_fft32_big_power_scratch_bytes(size_t n);
 int ast_fft32_big_power_3d(const float* grid_d, void* scratch_d, size_t scratch_bytes, size_t n, double boxsize, int binning,
                            double mean, double* psum_d, void* stream);
+/* ... of a grid painted with AST_PAINT_OVERWRITE | AST_PAINT_DEFER_FOLD: halo_rec_d (ast_paint_tiled_halo) is folded into the
+ * border rows as the z rows and the low-k sums load them (the paint's fold kernel - 5 ms at side 2048 - is not run) */
+int ast_fft32_big_power_3d_halo(const float* grid_d, const float* halo_rec_d, int window, void* scratch_d, size_t scratch_bytes,
+                                size_t n, double boxsize, int binning, double mean, double* psum_d, void* stream);
 /* spec_d (n, n, n / 2 + 1) complex double, contiguous = rfftn(grid_d) * scale (pmesh's r2c with scale = 1 / n^3) through
  * the same passes; grid_d is not modified */
 int ast_fft64_r2c_3d(const double* grid_d, void* spec_d, size_t n, double scale, void* stream);

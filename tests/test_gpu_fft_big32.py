@@ -55,3 +55,18 @@ def test_big32_rejects_what_it_does_not_cover(dev):
     g = torch.zeros((256, 256, 256), dtype=torch.float32, device="cuda")
     ps = torch.zeros(127, dtype=torch.float64, device="cuda")
     assert lib().ast_fft32_big_power_3d(dev.ptr(g), dev.ptr(scratch), scratch.numel(), 256, 100.0, 0, 0.0, dev.ptr(ps), dev.stream()) != 0   # scratch too small
+
+
+@pytest.mark.parametrize("window", ["cic", "tsc"])
+def test_big32_fold_on_load_equals_the_folded_grid(dev, window):
+    """A grid painted with defer_fold=True: its halo records are folded as the z rows - and the double-precision low-k sums -
+    load the border rows (ast_fft32_big_power_3d_halo), in the fold kernel's own order: the same shell sums as over the grid
+    the paint folded itself."""
+    n, L = 256, 1000.0
+    pos = dev.synth_lattice_particles(n, n, L, seed=9, dtype=torch.float32)
+    folded = dev.paint(pos, None, n, L, window, method="tiled", offset="mean", check_dropped=False)
+    ref = dev.power_sums_fused64(folded, L, mean=0.0)[1].clone()
+    grid, halo = dev.paint(pos, None, n, L, window, method="tiled", offset="mean", defer_fold=True, check_dropped=False)
+    assert not torch.equal(grid, folded)                    # the deferred grid alone is incomplete
+    got = dev.power_sums_fused64(grid, L, mean=0.0, halo=halo)[1]
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-12)
