@@ -88,13 +88,19 @@ class PowerSpectrum3D:
         q = None if cross else quantity
         self._files_per_job = max((len(paths) for _, paths in jobs), default=1)
 
-        def load(paths):
-            return [self._load_host(p, q) for p in paths]
+        def load(tickets):
+            return [self._fill_host(t) for t in tickets]
+
+        def submit(pool, paths):
+            # the page-locked staging buffers are taken HERE, on the calling thread: the loader thread only reads files and
+            # copies bytes - it never enters the GPU runtime (a pinned allocation from a second thread beside the first GPU
+            # calls of the process is the one thing this loop did there; the suite once aborted at exactly that point)
+            return pool.submit(load, [self._open_host(p, q) for p in paths])
         with ThreadPoolExecutor(max_workers=1) as pool:
-            fut = pool.submit(load, jobs[0][1]) if jobs else None
+            fut = submit(pool, jobs[0][1]) if jobs else None
             for i, (snap_nr, paths) in enumerate(jobs):
                 loaded = fut.result()
-                fut = pool.submit(load, jobs[i + 1][1]) if i + 1 < len(jobs) else None
+                fut = submit(pool, jobs[i + 1][1]) if i + 1 < len(jobs) else None
                 maps = [self._to_device(item) for item in loaded]
                 if maps[0].dim() != 3:
                     raise PowerSpectrum3DWarning(f"{maps[0].dim()}D is not supported :-(")
@@ -117,23 +123,38 @@ class PowerSpectrum3D:
         return self._to_device(self._load_host(file_in, quantity))
 
     def _load_host(self, file_in: str, quantity=None):
-        """The disk -> host half of _read_data (safe to run in the loader thread: no GPU call): the DataFrame columns of
-        an .h5 file, or a .npy grid copied into a page-locked buffer (two rotate) so that its upload can run
-        asynchronously."""
+        """The disk -> host half of _read_data: the DataFrame columns of an .h5 file, or a .npy grid copied into a page-locked
+        buffer (two rotate) so that its upload can run asynchronously."""
+        return self._fill_host(self._open_host(file_in, quantity))
+
+    def _open_host(self, file_in: str, quantity=None):
+        """What the CALLING thread does of _load_host: the .npy header (a memory map) and the page-locked staging buffer the
+        grid will be read into - everything that enters the GPU runtime."""
         if ".h5" in file_in:
-            fields = pd.read_hdf(file_in, key="df")
-            column = quantity[0] if isinstance(quantity, (list, tuple)) else quantity
-            return ("frame", tuple(np.ascontiguousarray(fields[c].values) for c in ("x", "y", "z", column)))
+            return ("frame", file_in, quantity)
         elif ".npy" in file_in:
             arr = np.load(file_in, mmap_mode="r")
-            if not torch.cuda.is_available():
-                return ("array", torch.from_numpy(np.ascontiguousarray(arr)))
-            pinned = self._pinned(arr.shape, arr.dtype)
-            pinned.numpy()[...] = arr                    # the disk read itself, straight into page-locked memory
-            return ("array", pinned)
+            pinned = self._pinned(arr.shape, arr.dtype) if torch.cuda.is_available() else None
+            return ("array", arr, pinned)
         elif file_in.endswith((".a_den", ".a_vel", ".a_velDiv", ".den", ".dtfe")):
             return ("density_file", file_in)
         return ("zeros", None)
+
+    @staticmethod
+    def _fill_host(ticket):
+        """What the loader thread does: file reads and host copies only (no GPU call of any kind)."""
+        if ticket[0] == "frame":
+            _, file_in, quantity = ticket
+            fields = pd.read_hdf(file_in, key="df")
+            column = quantity[0] if isinstance(quantity, (list, tuple)) else quantity
+            return ("frame", tuple(np.ascontiguousarray(fields[c].values) for c in ("x", "y", "z", column)))
+        if ticket[0] == "array":
+            _, arr, pinned = ticket
+            if pinned is None:
+                return ("array", torch.from_numpy(np.ascontiguousarray(arr)))
+            pinned.numpy()[...] = arr                    # the disk read itself, straight into page-locked memory
+            return ("array", pinned)
+        return ticket
 
     def _pinned(self, shape, dtype):
         """One of the rotating page-locked staging buffers of this shape: two per file of a job (the loader fills the next
