@@ -129,7 +129,11 @@ def read_density_grid(path: str, to_device: bool = True, dtype=None):
 def write_density_grid(path: str, grid, box_size: float, file_type: int = 1, redshift: float = 0.0, **extra) -> None:
     """One-file density binary in the same framing (``writeDensityData``); ``grid``: numpy array or tensor,
     ``(gx, gy, gz[, components])``."""
-    arr = grid.cpu().numpy() if hasattr(grid, "cpu") else np.asarray(grid)
+    if hasattr(grid, "is_cuda") and grid.is_cuda:
+        from .device import to_numpy
+        arr = to_numpy(grid)                       # through page-locked memory (a pageable destination: a tenth of the rate)
+    else:
+        arr = grid.cpu().numpy() if hasattr(grid, "cpu") else np.asarray(grid)
     kind, comps = _FILE_TYPES.get(int(file_type), ("f4", 1))
     if (arr.ndim == 4) != (comps > 1) or (arr.ndim == 4 and arr.shape[3] != comps):
         raise DensityFileError(f"file type {file_type} stores {comps} component(s) per grid point")
